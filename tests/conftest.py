@@ -1,0 +1,29 @@
+import os
+import sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+    import goldenio
+    return goldenio.load('ref_vectors.json.gz')
+
+
+@pytest.fixture(scope='session')
+def testdata():
+    import goldenio
+    return goldenio.load('ref_testdata.json.gz')
+
+
+@pytest.fixture(scope='session')
+def oracle():
+    import oracle_py
+    return oracle_py.load()
