@@ -1,0 +1,75 @@
+/*
+ * nbls.h -- C ABI of the MI355X batched BLS12-381 pairing engine (libnbls.so).
+ *
+ * This is the drop-in boundary beneath the reference's exported TypeScript API (paulmillr/noble-bls12-381 v1.4.0).
+ * The reference has no native/FFI layer; every entry point below replaces the part of a reference function that
+ * runs between decoding its arguments and encoding its result, and names that function (file:line in the reference).
+ * INTEGRATION.md shows the N-API / ctypes stubs that bind these symbols behind noble's names.
+ *
+ * Conventions
+ *  - Wire format = the reference's own byte encodings: field elements are 48-byte big-endian (Fp.toBytes,
+ *    math.ts:284-290); Fp2 = c0||c1 (math.ts:540-549); Fp12 = 576 bytes in Fp12.toBytes order (math.ts:875-884).
+ *    G1 affine = x||y (96 B); G2 affine = x.c0||x.c1||y.c0||y.c1 (192 B).
+ *  - All buffers are caller-owned and contiguous; the library keeps no pointer after a call returns.
+ *  - Functions return 0 or a negative NBLS_E* code and never throw or abort.  Per-item `status` (may be NULL):
+ *    0 ok, 1 point at infinity, 2 not on curve, 3 not in the prime-order subgroup, 4 bad encoding;
+ *    +10 when the offending point is the G2 argument of a pairing.
+ *  - `*_dev` variants take DEVICE pointers (HIP) and a hipStream_t (as void*); they enqueue work and do not synchronise.
+ *  - A context is bound to one GPU; calls on one context are serialised internally (thread-safe per context).
+ */
+#ifndef NBLS_H
+#define NBLS_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nbls_ctx nbls_ctx;
+
+#define NBLS_OK 0
+#define NBLS_EINVAL (-1)      /* bad argument */
+#define NBLS_EHIP (-2)        /* HIP runtime error (nbls_last_hip_error) */
+#define NBLS_ENOSUP (-3)      /* not implemented in this build */
+#define NBLS_ENOGPU (-4)      /* no usable gfx950 device */
+
+/* Create / destroy an engine context on HIP device `device_id` (compiles the step programs, uploads them). */
+int nbls_init(int device_id, nbls_ctx** out);
+void nbls_destroy(nbls_ctx* ctx);
+const char* nbls_strerror(int code);
+int nbls_last_hip_error(nbls_ctx* ctx);
+
+/* pairing(P, Q, withFinalExponent) for n independent pairs -- reference index.ts:715-722.
+ * validate != 0 reproduces P.assertValidity()/Q.assertValidity() (index.ts:383-388, 633-638) and the infinity
+ * check (index.ts:716) as per-item status; items with a non-zero status get an all-zero output. */
+int nbls_pairing_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, const uint8_t* g2_aff, int with_final_exp, int validate,
+                       uint8_t* out_fp12, int8_t* status);
+int nbls_pairing_batch_dev(nbls_ctx* ctx, size_t n, const void* d_g1_aff, const void* d_g2_aff, int with_final_exp,
+                           void* d_out_fp12, void* stream);
+
+/* prod_i millerLoop(P_i, Q_i), optionally followed by ONE shared finalExponentiate -- the core of verify
+ * (index.ts:763-766) and verifyBatch (index.ts:811-816). */
+int nbls_miller_product(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, const uint8_t* g2_aff, int final_exp, int validate,
+                        uint8_t* out_fp12, int8_t* status);
+int nbls_miller_product_dev(nbls_ctx* ctx, size_t n, const void* d_g1_aff, const void* d_g2_aff, int final_exp, void* d_out_fp12, void* stream);
+
+/* Fp12.finalExponentiate for n elements -- reference math.ts:856-874. */
+int nbls_final_exp_batch(nbls_ctx* ctx, size_t n, const uint8_t* in_fp12, uint8_t* out_fp12);
+int nbls_final_exp_batch_dev(nbls_ctx* ctx, size_t n, const void* d_in_fp12, void* d_out_fp12, void* stream);
+
+/* Raw device partial product for multi-GPU reductions: prod_i millerLoop(P_i,Q_i) WITHOUT final exponentiation as
+ * 576 wire bytes on the device (one per rank; ranks exchange them and finish with nbls_fp12_product_final_dev). */
+int nbls_fp12_product_final_dev(nbls_ctx* ctx, size_t n, const void* d_in_fp12, int final_exp, void* d_out_fp12, void* stream);
+
+/* Introspection for the benchmark / tests. */
+int nbls_program_stats(nbls_ctx* ctx, int prog, uint32_t* out8);   /* steps, mul_steps, lin_steps, mul_ops, lin_ops, lin_terms, slots, lds_bytes */
+int nbls_device_synchronize(nbls_ctx* ctx);
+/* Per-kernel HIP-event timing (benchmark roofline leg): ms[i]/counts[i] for program i, last entry = inversion kernel. */
+#define NBLS_N_PROGRAMS 8
+int nbls_timing_enable(nbls_ctx* ctx, int on);
+int nbls_timing_read(nbls_ctx* ctx, float* ms /*[NBLS_N_PROGRAMS+1]*/, uint32_t* counts /*[NBLS_N_PROGRAMS+1]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

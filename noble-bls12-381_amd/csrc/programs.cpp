@@ -1,0 +1,162 @@
+// programs.cpp -- the step programs of the pairing path, traced from the tower formulas (tower.h).
+//
+// Buffer conventions (KernelArgs.bufs index):
+//   0  G1 affine points, 96 B/item  (x||y, big-endian)                    reference wire format
+//   1  G2 affine points, 192 B/item (x.c0||x.c1||y.c0||y.c1)
+//   2  Fp12 wire bytes, 576 B/item (Fp12.toBytes order, math.ts:875-884)  outputs / final_exp input
+//   3  F  : raw Montgomery Fp12 scratch, 576 B/item (12 x 12 words)
+//   4  N  : raw Fp scratch, 48 B/item (norm to invert / its inverse)
+//   5  F' : second raw Fp12 scratch (product reduction output)
+#include "programs.h"
+#include <mutex>
+#include "tower.h"
+
+namespace nbls {
+
+// ---------------------------------------------------------------- Miller loop (math.ts:1331-1388, fused)
+// calcPairingPrecomputes and millerLoop are fused: line coefficients are produced and consumed on the fly.  The
+// R-point update and the line coefficients are the reference's polynomials in (Rx, Ry, Rz, Qx, Qy); `.div(2n)` is
+// realised by the halve LIN post-op (x/2 mod p is the same field element as x * 2^-1).
+static SFp12 trace_miller(const SFp& Px, const SFp& Py, const SFp2& Qx, const SFp2& Qy) {
+  SFp2 Rx = Qx, Ry = Qy, Rz = fp2_one();
+  SFp12 f = fp12_one();
+  for (int i = 62; i >= 0; i--) {
+    // doubling step, math.ts:1339-1351
+    SFp2 t0 = sqr(Ry), t1 = sqr(Rz);
+    SFp2 t2 = mat(mul_by_b(scale(t1, 3)));
+    SFp2 t3 = scale(t2, 3);
+    SFp2 t4 = mat(sqr(Ry + Rz) - t1 - t0);
+    SFp2 e0 = t2 - t0, e1 = scale(sqr(Rx), 3), e2 = -t4;
+    SFp2 nRx = mul(halve(t0 - t3), mul(Rx, Ry));       // ((T0 - T3) * Rx * Ry) / 2
+    SFp2 nRy = sqr(halve(t0 + t3)) - scale(sqr(t2), 3);  // ((T0 + T3)/2)^2 - 3 T2^2
+    SFp2 nRz = mul(t0, t4);
+    Rx = mat(nRx); Ry = mat(nRy); Rz = mat(nRz);
+    f = mat(mul_by_014(f, e0, mul_fp(e1, Px), mul_fp(e2, Py)));   // math.ts:1379
+    if ((NBLS_X >> i) & 1) {
+      // addition step, math.ts:1353-1367
+      SFp2 a0 = mat(Ry - mul(Qy, Rz)), a1 = mat(Rx - mul(Qx, Rz));
+      SFp2 g0 = mul(a0, Qx) - mul(a1, Qy), g1 = -a0, g2 = a1;
+      SFp2 a2 = mat(sqr(a1)), a3 = mat(mul(a2, a1)), a4 = mat(mul(a2, Rx));
+      SFp2 a5 = mat(a3 - scale(a4, 2) + mul(sqr(a0), Rz));
+      nRx = mul(a1, a5);
+      nRy = mul(a4 - a5, a0) - mul(a3, Ry);
+      nRz = mul(Rz, a3);
+      Rx = mat(nRx); Ry = mat(nRy); Rz = mat(nRz);
+      f = mat(mul_by_014(f, g0, mul_fp(g1, Px), mul_fp(g2, Py)));   // math.ts:1383
+    }
+    if (i != 0) f = mat(sqr(f));
+  }
+  return conj(f);
+}
+
+// ---------------------------------------------------------------- Fp12 inversion split around the one Fp inversion
+// Fp12.invert (math.ts:793-797) -> Fp6.invert (672-680) -> Fp2.invert (522-526) -> Fp.invert.  Everything except
+// the Fp inversion is recomputed on both sides of the inversion kernel (cheap: ~90 Fp products).
+struct InvChain { SFp6 t; SFp2 T0, T1, T2, d; SFp n; };
+static InvChain inv_chain(const SFp12& f) {
+  InvChain c;
+  c.t = mat(sqr(f.c0) - mulnr(sqr(f.c1)));                      // c0^2 - c1^2 * v
+  c.T0 = mat(sqr(c.t.c0) - mulnr(mul(c.t.c2, c.t.c1)));
+  c.T1 = mat(mulnr(sqr(c.t.c2)) - mul(c.t.c0, c.t.c1));
+  c.T2 = mat(sqr(c.t.c1) - mul(c.t.c0, c.t.c2));
+  c.d = mat(mulnr(mul(c.t.c2, c.T1) + mul(c.t.c1, c.T2)) + mul(c.t.c0, c.T0));
+  c.n = sqr(c.d.c0) + sqr(c.d.c1);
+  return c;
+}
+static SFp12 inv_finish(const SFp12& f, const InvChain& c, const SFp& ninv) {
+  SFp2 dinv = {mul(c.d.c0, ninv), -mul(c.d.c1, ninv)};
+  SFp6 tinv = mat(SFp6{mul(dinv, c.T0), mul(dinv, c.T1), mul(dinv, c.T2)});
+  return {mul(f.c0, tinv), -mul(f.c1, tinv)};
+}
+
+// ---------------------------------------------------------------- final exponentiation (math.ts:856-874)
+static SFp12 trace_final_exp(const SFp12& f, const SFp12& finv) {
+  SFp12 t0 = mat(mul(frob(f, 6), finv));
+  SFp12 t1 = mat(mul(frob(t0, 2), t0));
+  SFp12 t2 = conj(cyclotomic_exp_x(t1));
+  SFp12 t3 = mat(mul(conj(cyclotomic_sqr(t1)), t2));
+  SFp12 t4 = conj(cyclotomic_exp_x(t3));
+  SFp12 t5 = conj(cyclotomic_exp_x(t4));
+  SFp12 t6 = mat(mul(conj(cyclotomic_exp_x(t5)), cyclotomic_sqr(t2)));
+  SFp12 t7 = conj(cyclotomic_exp_x(t6));
+  SFp12 a = mat(frob(mul(t2, t5), 2));
+  SFp12 b = mat(frob(mul(t4, t1), 3));
+  SFp12 c = mat(frob(mul(t6, conj(t1)), 1));
+  SFp12 d = mat(mul(mat(mul(t7, conj(t3))), t1));
+  return mul(mat(mul(mat(mul(a, b)), c)), d);
+}
+
+static void load_points(SFp& Px, SFp& Py, SFp2& Qx, SFp2& Qy) {
+  Px = input(0, 0); Py = input(0, 48);
+  Qx = input_fp2(1, 0); Qy = input_fp2(1, 96);
+}
+
+static Program build(ProgId id) {
+  Builder B;
+  switch (id) {
+    case P_MILLER_BYTES: {
+      SFp Px, Py; SFp2 Qx, Qy; load_points(Px, Py, Qx, Qy);
+      output_fp12(trace_miller(Px, Py, Qx, Qy), 2, 0);
+      return B.compile("miller_bytes", 64);
+    }
+    case P_MILLER_RAW: {
+      SFp Px, Py; SFp2 Qx, Qy; load_points(Px, Py, Qx, Qy);
+      outputw_fp12(trace_miller(Px, Py, Qx, Qy), 3, 0);
+      return B.compile("miller_raw", 64);
+    }
+    case P_MILLER_FE: {
+      SFp Px, Py; SFp2 Qx, Qy; load_points(Px, Py, Qx, Qy);
+      SFp12 f = mat(trace_miller(Px, Py, Qx, Qy));
+      outputw_fp12(f, 3, 0);
+      outputw(inv_chain(f).n, 4, 0);
+      return B.compile("miller_fe", 64);
+    }
+    case P_NORM_RAW: {
+      SFp12 f = inputw_fp12(3, 0);
+      outputw(inv_chain(f).n, 4, 0);
+      return B.compile("norm_raw", 32);
+    }
+    case P_NORM_BYTES: {
+      SFp12 f = mat(input_fp12(2, 0));
+      outputw_fp12(f, 3, 0);
+      outputw(inv_chain(f).n, 4, 0);
+      return B.compile("norm_bytes", 32);
+    }
+    case P_FE_HARD: {
+      SFp12 f = inputw_fp12(3, 0);
+      SFp ninv = inputw(4, 0);
+      InvChain c = inv_chain(f);
+      SFp12 finv = mat(inv_finish(f, c, ninv));
+      output_fp12(trace_final_exp(f, finv), 2, 0);
+      return B.compile("fe_hard", 21);
+    }
+    case P_MUL2: {
+      SFp12 a = inputw_fp12(3, 0), b = inputw_fp12(3, 576);
+      outputw_fp12(mul(a, b), 5, 0);
+      return B.compile("fp12_mul2", 64);
+    }
+    case P_RAW_TO_BYTES: {
+      output_fp12(inputw_fp12(3, 0), 2, 0);
+      return B.compile("raw_to_bytes", 16);
+    }
+    default: break;
+  }
+  return Program();
+}
+
+const Program& get_program(ProgId id) {
+  static Program cache[P_COUNT];
+  static bool built[P_COUNT];
+  static std::mutex mu;
+  std::lock_guard<std::mutex> g(mu);
+  if (!built[id]) { cache[id] = build(id); built[id] = true; }
+  return cache[id];
+}
+
+void print_stats(const Program& p) {
+  printf("%-14s W=%2u G=%u steps=%5zu (mul %4u, lin %4u, other %3u)  mul_ops=%6u (fill %.2f)  lin_ops=%6u terms=%7u  slots=%4u  lds=%6u B  descs=%zu KB\n",
+         p.name.c_str(), p.W, p.G, p.steps.size(), p.n_mul_steps, p.n_lin_steps, p.n_other_steps, p.n_mul_ops,
+         p.n_mul_steps ? (double)p.n_mul_ops / (p.n_mul_steps * p.W) : 0.0, p.n_lin_ops, p.n_lin_terms, p.slots, p.lds_bytes(), p.descs.size() * 4 / 1024);
+}
+
+}  // namespace nbls

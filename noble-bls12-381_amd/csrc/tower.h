@@ -1,0 +1,137 @@
+// tower.h -- Fp2 / Fp6 / Fp12 / curve arithmetic over symbolic Fp values (trace.h).
+// Each routine states which reference routine it is algebraically identical to (math.ts line numbers); the way
+// an individual product is evaluated is free (field elements are unique), but wherever the reference's result
+// depends on a projective representative (Miller-loop point R and its line coefficients) the same polynomial
+// formulas are used so that pairing(P, Q, false) is bit-exact too.
+#pragma once
+#include "trace.h"
+#include "consts_gen.h"
+
+namespace nbls {
+
+struct SFp2 { SFp c0, c1; };
+struct SFp6 { SFp2 c0, c1, c2; };
+struct SFp12 { SFp6 c0, c1; };
+
+static inline SFp fp_const(const u32* m) { return constant(m); }
+static inline SFp2 fp2_const(const u32 m[2][12]) { return {constant(m[0]), constant(m[1])}; }
+static inline SFp fp_one() { return constant(NBLS_R1); }
+static inline SFp2 fp2_one() { return {fp_one(), SFp()}; }
+static inline SFp2 fp2_zero() { return {SFp(), SFp()}; }
+
+
+// ---- Fp2 (math.ts:403-550)
+static inline SFp2 operator+(const SFp2& a, const SFp2& b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
+static inline SFp2 operator-(const SFp2& a, const SFp2& b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
+static inline SFp2 operator-(const SFp2& a) { return {-a.c0, -a.c1}; }
+static inline SFp2 scale(const SFp2& a, int k) { return {scale(a.c0, k), scale(a.c1, k)}; }
+static inline SFp2 mul(const SFp2& a, const SFp2& b) {            // math.ts:451-462 (Karatsuba)
+  SFp t1 = mul(a.c0, b.c0), t2 = mul(a.c1, b.c1), m = mul(a.c0 + a.c1, b.c0 + b.c1);
+  return {t1 - t2, m - t1 - t2};
+}
+static inline SFp2 sqr(const SFp2& a) {                           // math.ts:477-484
+  return {mul(a.c0 + a.c1, a.c0 - a.c1), mul(scale(a.c0, 2), a.c1)};
+}
+static inline SFp2 mul_fp(const SFp2& a, const SFp& k) { return {mul(a.c0, k), mul(a.c1, k)}; }
+static inline SFp2 mulnr(const SFp2& a) { return {a.c0 - a.c1, a.c0 + a.c1}; }              // * (u+1), math.ts:471-475
+static inline SFp2 mul_by_b(const SFp2& a) { return scale(mulnr(a), 4); }                   // * 4(1+u), math.ts:532-539
+static inline SFp2 conj(const SFp2& a) { return {a.c0, -a.c1}; }
+static inline SFp2 halve(const SFp2& a) { return {halve(a.c0), halve(a.c1)}; }
+static inline SFp2 frob(const SFp2& a, int power) { return (power & 1) ? conj(a) : a; }    // math.ts:529-531
+static inline SFp2 mat(const SFp2& a) { return {SFp(materialize(a.c0)), SFp(materialize(a.c1))}; }
+
+// ---- Fp6 (math.ts:554-700)
+static inline SFp6 operator+(const SFp6& a, const SFp6& b) { return {a.c0 + b.c0, a.c1 + b.c1, a.c2 + b.c2}; }
+static inline SFp6 operator-(const SFp6& a, const SFp6& b) { return {a.c0 - b.c0, a.c1 - b.c1, a.c2 - b.c2}; }
+static inline SFp6 operator-(const SFp6& a) { return {-a.c0, -a.c1, -a.c2}; }
+static inline SFp6 mul(const SFp6& a, const SFp6& b) {            // math.ts:601-618
+  SFp2 t0 = mul(a.c0, b.c0), t1 = mul(a.c1, b.c1), t2 = mul(a.c2, b.c2);
+  return {t0 + mulnr(mul(a.c1 + a.c2, b.c1 + b.c2) - (t1 + t2)),
+          mul(a.c0 + a.c1, b.c0 + b.c1) - (t0 + t1) + mulnr(t2),
+          t1 + (mul(a.c0 + a.c2, b.c0 + b.c2) - (t0 + t2))};
+}
+static inline SFp6 mulnr(const SFp6& a) { return {mulnr(a.c2), a.c0, a.c1}; }               // * v, math.ts:627-629
+static inline SFp6 mul_by_1(const SFp6& a, const SFp2& b1) {      // math.ts:631-637
+  return {mulnr(mul(a.c2, b1)), mul(a.c0, b1), mul(a.c1, b1)};
+}
+static inline SFp6 mul_by_01(const SFp6& a, const SFp2& b0, const SFp2& b1) {   // math.ts:639-651
+  SFp2 t0 = mul(a.c0, b0), t1 = mul(a.c1, b1);
+  return {mulnr(mul(a.c1 + a.c2, b1) - t1) + t0,
+          mul(b0 + b1, a.c0 + a.c1) - t0 - t1,
+          mul(a.c0 + a.c2, b0) - t0 + t1};
+}
+static inline SFp6 mul_by_fp2(const SFp6& a, const SFp2& k) { return {mul(a.c0, k), mul(a.c1, k), mul(a.c2, k)}; }
+static inline SFp6 sqr(const SFp6& a) {                           // math.ts:658-670
+  SFp2 t0 = sqr(a.c0), t1 = scale(mul(a.c0, a.c1), 2), t3 = scale(mul(a.c1, a.c2), 2), t4 = sqr(a.c2);
+  return {mulnr(t3) + t0, mulnr(t4) + t1, t1 + sqr(a.c0 - a.c1 + a.c2) + t3 - t0 - t4};
+}
+static inline SFp6 frob(const SFp6& a, int power) {               // math.ts:682-688
+  return {frob(a.c0, power), mul(frob(a.c1, power), fp2_const(NBLS_FROB6_1[power % 6])), mul(frob(a.c2, power), fp2_const(NBLS_FROB6_2[power % 6]))};
+}
+static inline SFp6 mat(const SFp6& a) { return {mat(a.c0), mat(a.c1), mat(a.c2)}; }
+
+// ---- Fp12 (math.ts:705-885)
+static inline SFp12 fp12_one() { return {{fp2_one(), fp2_zero(), fp2_zero()}, {fp2_zero(), fp2_zero(), fp2_zero()}}; }
+static inline SFp12 mul(const SFp12& a, const SFp12& b) {         // math.ts:748-759
+  SFp6 t1 = mul(a.c0, b.c0), t2 = mul(a.c1, b.c1);
+  return {t1 + mulnr(t2), mul(a.c0 + a.c1, b.c0 + b.c1) - (t1 + t2)};
+}
+static inline SFp12 mul_by_014(const SFp12& a, const SFp2& o0, const SFp2& o1, const SFp2& o4) {   // math.ts:768-777
+  SFp6 t0 = mul_by_01(a.c0, o0, o1), t1 = mul_by_1(a.c1, o4);
+  return {mulnr(t1) + t0, mul_by_01(a.c1 + a.c0, o0, o1 + o4) - t0 - t1};
+}
+static inline SFp12 sqr(const SFp12& a) {                         // math.ts:783-791
+  SFp6 ab = mul(a.c0, a.c1);
+  return {mul(mulnr(a.c1) + a.c0, a.c0 + a.c1) - ab - mulnr(ab), ab + ab};
+}
+static inline SFp12 conj(const SFp12& a) { return {a.c0, -a.c1}; }                             // math.ts:799-801
+static inline SFp12 frob(const SFp12& a, int power) {             // math.ts:804-809
+  return {frob(a.c0, power), mul_by_fp2(frob(a.c1, power), fp2_const(NBLS_FROB12[power % 12]))};
+}
+static inline SFp12 mat(const SFp12& a) { return {mat(a.c0), mat(a.c1)}; }
+static inline void fp4_square(const SFp2& a, const SFp2& b, SFp2& first, SFp2& second) {   // math.ts:811-818
+  SFp2 a2 = sqr(a), b2 = sqr(b);
+  first = mulnr(b2) + a2;
+  second = sqr(a + b) - a2 - b2;
+}
+static inline SFp12 cyclotomic_sqr(const SFp12& x) {              // math.ts:824-843
+  SFp2 t3, t4, t5, t6, t7, t8;
+  fp4_square(x.c0.c0, x.c1.c1, t3, t4);
+  fp4_square(x.c1.c0, x.c0.c2, t5, t6);
+  fp4_square(x.c0.c1, x.c1.c2, t7, t8);
+  SFp2 t9 = mulnr(t8);
+  return {{scale(t3 - x.c0.c0, 2) + t3, scale(t5 - x.c0.c1, 2) + t5, scale(t7 - x.c0.c2, 2) + t7},
+          {scale(t9 + x.c1.c0, 2) + t9, scale(t4 + x.c1.c1, 2) + t4, scale(t6 + x.c1.c2, 2) + t6}};
+}
+// z^|x| for unitary z (math.ts:845-852).  The reference starts from ONE and squares through all 64 bits; the
+// leading squarings of ONE are identities, so starting at the top set bit gives the same element.
+static inline SFp12 cyclotomic_exp_x(const SFp12& a) {
+  SFp12 z = a;   // after bit 63
+  for (int i = 62; i >= 0; i--) {
+    z = mat(cyclotomic_sqr(z));
+    if ((NBLS_X >> i) & 1) z = mat(mul(z, a));
+  }
+  return z;
+}
+
+// I/O helpers: Fp12 in the reference's toBytes order (math.ts:875-884)
+static inline SFp2 input_fp2(int buf, int off) { return {input(buf, off), input(buf, off + 48)}; }
+static inline SFp12 input_fp12(int buf, int off) {
+  SFp2 c[6]; for (int i = 0; i < 6; i++) c[i] = input_fp2(buf, off + 96 * i);
+  return {{c[0], c[1], c[2]}, {c[3], c[4], c[5]}};
+}
+static inline void output_fp2(const SFp2& a, int buf, int off) { output(a.c0, buf, off); output(a.c1, buf, off + 48); }
+static inline void output_fp12(const SFp12& a, int buf, int off) {
+  const SFp2* c[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};
+  for (int i = 0; i < 6; i++) output_fp2(*c[i], buf, off + 96 * i);
+}
+static inline SFp12 inputw_fp12(int buf, int off) {
+  SFp2 c[6]; for (int i = 0; i < 6; i++) c[i] = {inputw(buf, off + 96 * i), inputw(buf, off + 96 * i + 48)};
+  return {{c[0], c[1], c[2]}, {c[3], c[4], c[5]}};
+}
+static inline void outputw_fp12(const SFp12& a, int buf, int off) {
+  const SFp2* c[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};
+  for (int i = 0; i < 6; i++) { outputw(c[i]->c0, buf, off + 96 * i); outputw(c[i]->c1, buf, off + 96 * i + 48); }
+}
+
+}  // namespace nbls

@@ -1,0 +1,61 @@
+// vm.h -- program format of the wavefront Fp engine ("wave VM").
+//
+// Design: the pairing path is straight-line arithmetic over Fp with a fixed control flow
+// (the bits of the BLS parameter x).  The host traces the tower formulas symbolically (trace.h), schedules the
+// resulting DAG of Fp operations into wave-wide STEPS (<= W lane-operations each, one kind per step) and
+// allocates LDS slots.  One wavefront executes the step list for G = 64/W work items ("instances") at once:
+// every lane performs one complete 12x32-bit Montgomery multiplication (or one linear combination) per step,
+// operands and results live in LDS slots (48 B each), values are kept in the redundant range [0, 2p).
+// Within one wavefront LDS operations execute in order, so no barriers are needed anywhere.
+#pragma once
+#include <stdint.h>
+
+namespace nbls {
+
+enum StepKind : uint8_t {
+  K_LOAD = 0,    // slot <- 48 big-endian bytes of an input buffer (raw integer, < 2^384)
+  K_MUL = 1,     // slot <- mont((a0 [+|-] a1) * (b0 [+|-] b1)), result in [0,2p)
+  K_LIN = 2,     // slot <- sum of +-slots, reduced to [0,2p)
+  K_STORE = 3,   // 48 big-endian bytes of an output buffer <- canonical(slot)   (slot must hold value/R already)
+  K_LOADW = 4,   // slot <- 12 raw little-endian words of a scratch buffer
+  K_STOREW = 5,  // scratch buffer <- 12 raw words of slot
+  K_ISZ = 6,     // slot <- (value == 0 mod p) ? 1 : 0   (raw integer flag)
+  K_SEL = 7,     // slot <- flag ? a : b
+  K_STATUS = 8,  // int8 status[item] <- first code whose flag is 0, else 0
+  K_CANON = 9,   // slot <- canonical representative in [0,p)
+  K_CMP = 10,    // flag slot <- predicate on raw integers: p0 = 0: a > b ; 1: a is odd
+  K_FLAG = 11,   // flag slot <- boolean op of two flags: p0 = 0 and, 1 or, 2 xor, 3 and-not (a & !b)
+};
+
+struct Step {
+  uint8_t kind;
+  uint8_t nlanes;     // active lanes per instance (<= W)
+  uint8_t p0, p1;     // kind-specific (MUL: bit0 any a1, bit1 any b1; LIN: p0 = max terms, p1 = reduce stages)
+  uint32_t desc_off;  // word offset of this step's descriptors
+  uint32_t stride;    // words per lane descriptor
+  uint32_t pad;
+};
+
+// operand encoding (16 bit): bits 0..12 slot index, bit 13 = constant region, bits 14..15 = mode
+static const uint32_t OP_SLOT_MASK = 0x1fff;
+static const uint32_t OP_CONST = 0x2000;
+static const uint32_t OP_MODE_SHIFT = 14;   // second operand of MUL: 0 none, 1 add, 2 sub ; LIN term: 1 = negative
+static const int MAX_LIN_TERMS = 14;   // header word + 7 words of 2 terms (stride 8)
+static const int MAX_BUFS = 8;
+
+struct IOBuf { uint8_t* ptr; uint64_t stride; };
+
+struct KernelArgs {
+  const Step* steps;
+  const uint32_t* descs;
+  const uint32_t* consts;   // nconst * 12 words followed by the PM2 table (17 * 16 words)
+  uint32_t nsteps, nconst;
+  uint32_t W, G;            // lanes per instance, instances per wave (G * W <= 64)
+  uint32_t slots;           // LDS slots per instance
+  uint32_t n_items;
+  IOBuf bufs[MAX_BUFS];
+};
+
+static inline uint32_t lds_words(uint32_t nconst, uint32_t G, uint32_t slots) { return nconst * 12 + 17 * 16 + G * slots * 12; }
+
+}  // namespace nbls

@@ -1,0 +1,51 @@
+// vm_kernel.hip -- the gfx950 wave-VM kernel: one wavefront (= one workgroup of 64 lanes) interprets a compiled
+// step list for G work items at once; see vm.h / vm_exec.h.  Integer VALU work (v_mad_u64_u32 + carry chains):
+// no MFMA by construction (independent 381-bit products are not a dense contraction).
+#include <hip/hip_runtime.h>
+#include "vm_exec.h"
+
+namespace nbls {
+
+extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel(KernelArgs ka) {
+  extern __shared__ __attribute__((aligned(16))) u32 smem[];
+  const u32 lane = threadIdx.x;
+  const u32 shared_words = ka.nconst * 12 + 17 * 16;
+  for (u32 i = lane; i < shared_words; i += 64) smem[i] = ka.consts[i];
+  const u32 W = ka.W;
+  const u32 inst_id = lane / W;
+  const u32 lane_in = (inst_id < ka.G) ? (lane - inst_id * W) : 0xffffu;
+  LaneCtx cx;
+  cx.pm2 = ka.nconst * 12;
+  cx.inst = shared_words + inst_id * ka.slots * 12;
+  cx.item = blockIdx.x * ka.G + inst_id;
+  cx.live = inst_id < ka.G && cx.item < ka.n_items;
+  __syncthreads();   // single wave: orders the constant fill before first use
+  for (u32 s = 0; s < ka.nsteps; s++) {
+    const Step st = ka.steps[s];
+    if (lane_in < st.nlanes) {
+      const u32* d = ka.descs + st.desc_off + lane_in * st.stride;
+      u32 res[12];
+      u32 dst = exec_lane(st, d, smem, cx, ka.bufs, res);
+      if (dst != 0xffffffffu) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) smem[dst + i] = res[i];
+      }
+    }
+  }
+}
+
+}  // namespace nbls
+
+// host-side launcher (C linkage, used by nbls_api.cpp)
+extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream) {
+  using namespace nbls;
+  if (ka->n_items == 0) return 0;
+  unsigned blocks = (ka->n_items + ka->G - 1) / ka->G;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)nbls_vm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(nbls_vm_kernel, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, *ka);
+  return (int)hipGetLastError();
+}

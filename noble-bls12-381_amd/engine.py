@@ -1,0 +1,124 @@
+"""ctypes binding of libnbls.so (include/nbls.h).  Mirrors the reference's batched entry points:
+pairing (index.ts:715), the Miller-product core of verify/verifyBatch (index.ts:763-766, 811-816) and
+Fp12.finalExponentiate (math.ts:856)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PROGRAMS = ['miller_bytes', 'miller_raw', 'miller_fe', 'norm_raw', 'norm_bytes', 'fe_hard', 'fp12_mul2', 'raw_to_bytes']
+
+
+class NblsError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, 'libnbls.so')
+
+
+def load_library():
+    p = lib_path()
+    if not os.path.exists(p):
+        raise NblsError('libnbls.so is not built (run __graft_entry__.build() or make -C noble-bls12-381_amd/csrc)')
+    lib = C.CDLL(p)
+    lib.nbls_strerror.restype = C.c_char_p
+    vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
+    lib.nbls_init.argtypes = [i32, C.POINTER(vp)]
+    lib.nbls_destroy.argtypes = [vp]
+    lib.nbls_last_hip_error.argtypes = [vp]
+    lib.nbls_device_synchronize.argtypes = [vp]
+    lib.nbls_pairing_batch.argtypes = [vp, sz, vp, vp, i32, i32, vp, vp]
+    lib.nbls_pairing_batch_dev.argtypes = [vp, sz, vp, vp, i32, vp, vp]
+    lib.nbls_miller_product.argtypes = [vp, sz, vp, vp, i32, i32, vp, vp]
+    lib.nbls_miller_product_dev.argtypes = [vp, sz, vp, vp, i32, vp, vp]
+    lib.nbls_final_exp_batch.argtypes = [vp, sz, vp, vp]
+    lib.nbls_final_exp_batch_dev.argtypes = [vp, sz, vp, vp, vp]
+    lib.nbls_fp12_product_final_dev.argtypes = [vp, sz, vp, i32, vp, vp]
+    lib.nbls_program_stats.argtypes = [vp, i32, C.POINTER(C.c_uint32)]
+    lib.nbls_timing_enable.argtypes = [vp, i32]
+    lib.nbls_timing_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+    return lib
+
+
+class Engine:
+    """One engine context = one GPU."""
+
+    def __init__(self, device_id=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        r = self.lib.nbls_init(device_id, C.byref(h))
+        if r != 0:
+            raise NblsError('nbls_init failed: %s (code %d)' % (self.lib.nbls_strerror(r).decode(), r))
+        self.h = h
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.nbls_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, r):
+        if r != 0:
+            raise NblsError('%s (code %d, hip %d)' % (self.lib.nbls_strerror(r).decode(), r, self.lib.nbls_last_hip_error(self.h)))
+
+    # ---- host-buffer entry points (bytes in, bytes out)
+    def pairing_batch(self, g1_aff, g2_aff, with_final_exp=True, validate=False):
+        n = len(g1_aff) // 96
+        assert len(g1_aff) == 96 * n and len(g2_aff) == 192 * n
+        out = C.create_string_buffer(576 * n)
+        st = C.create_string_buffer(max(n, 1))
+        self._chk(self.lib.nbls_pairing_batch(self.h, n, g1_aff, g2_aff, int(with_final_exp), int(validate), out, st))
+        return out.raw, st.raw[:n]
+
+    def miller_product(self, g1_aff, g2_aff, final_exp=True, validate=False):
+        n = len(g1_aff) // 96
+        out = C.create_string_buffer(576)
+        st = C.create_string_buffer(max(n, 1))
+        self._chk(self.lib.nbls_miller_product(self.h, n, g1_aff, g2_aff, int(final_exp), int(validate), out, st))
+        return out.raw, st.raw[:n]
+
+    def final_exp_batch(self, fp12s):
+        n = len(fp12s) // 576
+        out = C.create_string_buffer(576 * max(n, 1))
+        self._chk(self.lib.nbls_final_exp_batch(self.h, n, fp12s, out))
+        return out.raw[:576 * n]
+
+    # ---- device-pointer entry points (torch uint8 CUDA tensors); enqueue on `stream` (int handle) or the context stream
+    def pairing_batch_dev(self, n, d_g1, d_g2, d_out, with_final_exp=True, stream=None):
+        self._chk(self.lib.nbls_pairing_batch_dev(self.h, n, d_g1, d_g2, int(with_final_exp), d_out, stream))
+
+    def miller_product_dev(self, n, d_g1, d_g2, d_out, final_exp=True, stream=None):
+        self._chk(self.lib.nbls_miller_product_dev(self.h, n, d_g1, d_g2, int(final_exp), d_out, stream))
+
+    def final_exp_batch_dev(self, n, d_in, d_out, stream=None):
+        self._chk(self.lib.nbls_final_exp_batch_dev(self.h, n, d_in, d_out, stream))
+
+    def fp12_product_final_dev(self, n, d_in, d_out, final_exp=True, stream=None):
+        self._chk(self.lib.nbls_fp12_product_final_dev(self.h, n, d_in, int(final_exp), d_out, stream))
+
+    def synchronize(self):
+        self._chk(self.lib.nbls_device_synchronize(self.h))
+
+    def program_stats(self, name):
+        o = (C.c_uint32 * 8)()
+        self._chk(self.lib.nbls_program_stats(self.h, PROGRAMS.index(name), o))
+        keys = ['steps', 'mul_steps', 'lin_steps', 'mul_ops', 'lin_ops', 'lin_terms', 'slots', 'lds_bytes']
+        return dict(zip(keys, list(o)))
+
+    def timing_enable(self, on=True):
+        self._chk(self.lib.nbls_timing_enable(self.h, int(on)))
+
+    def timing_read(self):
+        """-> {kernel name: (total ms, launches)} since timing_enable(True)"""
+        n = len(PROGRAMS) + 1
+        ms = (C.c_float * n)()
+        cnt = (C.c_uint32 * n)()
+        self._chk(self.lib.nbls_timing_read(self.h, ms, cnt))
+        names = PROGRAMS + ['fp_inv']
+        return {names[i]: (ms[i], cnt[i]) for i in range(n) if cnt[i]}

@@ -1,0 +1,105 @@
+"""GPU parity tests: the HIP engine through the C ABI (libnbls.so) vs the CPU oracle and the golden vectors."""
+import hashlib
+import importlib
+import os
+import pytest
+from goldenio import hx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    pkg = importlib.import_module('noble-bls12-381_amd')
+    return pkg.Engine(0)
+
+
+def _rand_points(oracle, n, seed):
+    g1, g2 = oracle.g1_generator(), oracle.g2_generator()
+    G1, G2 = [], []
+    for i in range(n):
+        a = int.from_bytes(hashlib.sha256(b'nbls-test-%d-%d-a' % (seed, i)).digest(), 'big') % (2**250) + 1
+        b = int.from_bytes(hashlib.sha256(b'nbls-test-%d-%d-b' % (seed, i)).digest(), 'big') % (2**250) + 1
+        G1.append(oracle.g1_mul(g1, a)[1])
+        G2.append(oracle.g2_mul(g2, b)[1])
+    return b''.join(G1), b''.join(G2)
+
+
+def test_golden_pairs(eng, golden):
+    g1 = b''.join(hx(v['g1']) for v in golden['pairs'])
+    g2 = b''.join(hx(v['g2']) for v in golden['pairs'])
+    n = len(golden['pairs'])
+    out, st = eng.pairing_batch(g1, g2, True, False)
+    ml, _ = eng.pairing_batch(g1, g2, False, False)
+    for i, v in enumerate(golden['pairs']):
+        assert out[576 * i:576 * (i + 1)] == hx(v['pairing']), i
+        assert ml[576 * i:576 * (i + 1)] == hx(v['miller']), i
+
+
+def test_reference_kats(eng, oracle, testdata):
+    out, _ = eng.pairing_batch(oracle.g1_generator(), oracle.g2_generator(), True, False)
+    assert out == hx(testdata['e_G1_G2'])                                   # test/pairing.test.ts:46-64
+    assert eng.final_exp_batch(hx(testdata['finalexp_in'])) == hx(testdata['finalexp_out'])   # test/pairing.test.ts:65-96
+
+
+def test_kilic_vectors(eng, oracle, testdata):
+    """test/deterministic.test.ts:34-46: e(i*G1, i*G2), first 128 of the 1000 kilic vectors."""
+    g1, g2 = oracle.g1_generator(), oracle.g2_generator()
+    n = 128
+    G1 = b''.join(oracle.g1_mul(g1, i)[1] for i in range(1, n + 1))
+    G2 = b''.join(oracle.g2_mul(g2, i)[1] for i in range(1, n + 1))
+    out, _ = eng.pairing_batch(G1, G2, True, False)
+    for i in range(n):
+        assert out[576 * i:576 * (i + 1)] == hx(testdata['pairing_iG1_iG2'][i]), i
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 63, 64, 65, 200])
+def test_random_batches_vs_oracle(eng, oracle, n):
+    G1, G2 = _rand_points(oracle, n, n)
+    out, _ = eng.pairing_batch(G1, G2, True, False)
+    ref, _ = oracle.pairing_batch(G1, G2, True, False, threads=16)
+    assert out == ref
+    out, _ = eng.pairing_batch(G1, G2, False, False)
+    ref, _ = oracle.pairing_batch(G1, G2, False, False, threads=16)
+    assert out == ref
+
+
+def test_empty_batch(eng):
+    out, st = eng.pairing_batch(b'', b'', True, False)
+    assert out == b'' and st == b''
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 5, 8, 33])
+def test_miller_product(eng, oracle, golden, n):
+    G1, G2 = _rand_points(oracle, n, 1000 + n)
+    for fe in (False, True):
+        out, _ = eng.miller_product(G1, G2, fe, False)
+        assert out == oracle.miller_product(G1, G2, fe)
+
+
+def test_product_golden(eng, golden):
+    p = golden['product']
+    out, _ = eng.miller_product(hx(''.join(p['g1'])), hx(''.join(p['g2'])), True, False)
+    assert out == hx(p['result'])
+    out, _ = eng.miller_product(hx(''.join(p['g1'])), hx(''.join(p['g2'])), False, False)
+    assert out == hx(p['miller_product'])
+
+
+def test_final_exp_batch(eng, oracle, golden):
+    ins = b''.join(hx(v['a']) for v in golden['fp12'])
+    out = eng.final_exp_batch(ins)
+    for i, v in enumerate(golden['fp12']):
+        assert out[576 * i:576 * (i + 1)] == hx(v['finalexp'])
+
+
+def test_batch_4096_properties(eng, oracle):
+    """BASELINE config 2 size: 4096 pairings.  Full comparison against the multi-threaded oracle, plus bilinearity as a
+    size-independent property: prod_i e(P_i, Q_i) * e(-P_i, Q_i) == 1 via the shared-final-exponentiation path."""
+    n = 4096
+    base1, base2 = _rand_points(oracle, 64, 77)
+    G1 = base1 * (n // 64)
+    G2 = b''.join(base2[192 * ((i * 7 + i // 64) % 64):192 * ((i * 7 + i // 64) % 64 + 1)] for i in range(n))
+    out, _ = eng.pairing_batch(G1, G2, True, False)
+    ref, _ = oracle.pairing_batch(G1, G2, True, False, threads=min(64, os.cpu_count() or 8))
+    assert hashlib.sha256(out).hexdigest() == hashlib.sha256(ref).hexdigest()
+    assert out == ref
