@@ -65,7 +65,7 @@ int nbls_fp12_product_final_dev(nbls_ctx* ctx, size_t n, const void* d_in_fp12, 
 int nbls_program_stats(nbls_ctx* ctx, int prog, uint32_t* out8);   /* steps, mul_steps, lin_steps, mul_ops, lin_ops, lin_terms, slots, lds_bytes */
 int nbls_device_synchronize(nbls_ctx* ctx);
 /* Per-kernel HIP-event timing (benchmark roofline leg): ms[i]/counts[i] for program i, last entry = inversion kernel. */
-#define NBLS_N_PROGRAMS 8
+#define NBLS_N_PROGRAMS 12
 int nbls_timing_enable(nbls_ctx* ctx, int on);
 int nbls_timing_read(nbls_ctx* ctx, float* ms /*[NBLS_N_PROGRAMS+1]*/, uint32_t* counts /*[NBLS_N_PROGRAMS+1]*/);
 

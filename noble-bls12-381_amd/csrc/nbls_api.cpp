@@ -9,9 +9,10 @@
 #include "nbls.h"
 #include "programs.h"
 #include "consts_gen.h"
+#include "fp_inv.h"
 
 extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream);
-extern "C" int nbls_fp_inv_launch(unsigned n, const void* in, void* out, void* stream);
+extern "C" int nbls_fp_inv_launch(unsigned n, const void* in, void* out, const void* table, void* stream);
 
 using namespace nbls;
 
@@ -28,7 +29,8 @@ struct nbls_ctx {
   std::mutex mu;
   DevProgram prog[P_COUNT];
   // scratch (device)
-  uint8_t *F = nullptr, *F2 = nullptr, *N = nullptr, *NI = nullptr, *io_g1 = nullptr, *io_g2 = nullptr, *io_f12 = nullptr, *one12 = nullptr;
+  uint8_t *F = nullptr, *F2 = nullptr, *N = nullptr, *NI = nullptr, *io_g1 = nullptr, *io_g2 = nullptr, *io_f12 = nullptr, *one12 = nullptr, *inv_table = nullptr;
+  uint8_t* T[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // t1..t7 of the final exponentiation, raw Fp12
   size_t cap_F = 0, cap_io = 0;
   int last_hip = 0;
   // optional per-kernel timing (HIP events on the launch stream); slot P_COUNT = inversion kernel
@@ -69,7 +71,7 @@ static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pa
 static int run_inv(nbls_ctx* ctx, size_t n, hipStream_t s) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s); }
-  int e = nbls_fp_inv_launch((unsigned)n, ctx->N, ctx->NI, s);
+  int e = nbls_fp_inv_launch((unsigned)n, ctx->N, ctx->NI, ctx->inv_table, s);
   if (ctx->timing) { hipEventRecord(e1, s); ctx->tev.push_back({(int)P_COUNT, {e0, e1}}); }
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
   return NBLS_OK;
@@ -78,12 +80,13 @@ static int run_inv(nbls_ctx* ctx, size_t n, hipStream_t s) {
 static int ensure_scratch(nbls_ctx* ctx, size_t n) {
   if (n <= ctx->cap_F) return NBLS_OK;
   size_t cap = n + n / 8 + 64;
-  if (ctx->F) { hipFree(ctx->F); hipFree(ctx->F2); hipFree(ctx->N); hipFree(ctx->NI); }
+  if (ctx->F) { hipFree(ctx->F); hipFree(ctx->F2); hipFree(ctx->N); hipFree(ctx->NI); for (auto& t : ctx->T) hipFree(t); }
   ctx->cap_F = 0;
   HIPCHK(hipMalloc(&ctx->F, (cap + 2) * 576));
   HIPCHK(hipMalloc(&ctx->F2, (cap / 2 + 2) * 576));
   HIPCHK(hipMalloc(&ctx->N, cap * 48));
   HIPCHK(hipMalloc(&ctx->NI, cap * 48));
+  for (auto& t : ctx->T) HIPCHK(hipMalloc(&t, cap * 576));
   ctx->cap_F = cap;
   return NBLS_OK;
 }
@@ -114,13 +117,27 @@ static int reduce_product(nbls_ctx* ctx, size_t n, uint8_t** result, hipStream_t
   *result = src;
   return NBLS_OK;
 }
+// n raw Fp12 in `f_raw` (norms already in ctx->N) -> finalExponentiate -> wire bytes at d_out (math.ts:856-874)
+static int final_exp_pipeline(nbls_ctx* ctx, size_t n, uint8_t* f_raw, void* d_out, hipStream_t s) {
+  int r;
+  uint8_t** T = ctx->T;
+  if ((r = run_inv(ctx, n, s))) return r;
+  if ((r = run(ctx, P_FE_EASY, n, {B(3, f_raw, 576), B(4, ctx->NI, 48), B(5, T[0], 576)}, s))) return r;
+  if ((r = run(ctx, P_EXPX, n, {B(3, T[0], 576), B(5, T[1], 576)}, s))) return r;                       // t2
+  if ((r = run(ctx, P_FE_MID1, n, {B(3, T[0], 576), B(5, T[1], 576), B(6, T[2], 576)}, s))) return r;   // t3
+  if ((r = run(ctx, P_EXPX, n, {B(3, T[2], 576), B(5, T[3], 576)}, s))) return r;                       // t4
+  if ((r = run(ctx, P_EXPX, n, {B(3, T[3], 576), B(5, T[4], 576)}, s))) return r;                       // t5
+  if ((r = run(ctx, P_EXPX, n, {B(3, T[4], 576), B(5, T[6], 576)}, s))) return r;                       // t6' (parked in T7's buffer)
+  if ((r = run(ctx, P_FE_MID2, n, {B(3, T[6], 576), B(5, T[1], 576), B(6, T[5], 576)}, s))) return r;   // t6
+  if ((r = run(ctx, P_EXPX, n, {B(3, T[5], 576), B(5, T[6], 576)}, s))) return r;                       // t7
+  return run(ctx, P_FE_FINAL, n, {B(0, T[0], 576), B(1, T[1], 576), B(2, T[2], 576), B(3, T[3], 576), B(4, T[4], 576), B(5, T[5], 576), B(6, T[6], 576), B(7, d_out, 576)}, s);
+}
 // one raw Fp12 -> final exponentiation (or plain encoding) -> wire bytes on device
 static int finish_single(nbls_ctx* ctx, uint8_t* f_raw, int final_exp, void* d_out, hipStream_t s) {
   int r;
   if (!final_exp) return run(ctx, P_RAW_TO_BYTES, 1, {B(3, f_raw, 576), B(2, d_out, 576)}, s);
   if ((r = run(ctx, P_NORM_RAW, 1, {B(3, f_raw, 576), B(4, ctx->N, 48)}, s))) return r;
-  if ((r = run_inv(ctx, 1, s))) return r;
-  return run(ctx, P_FE_HARD, 1, {B(3, f_raw, 576), B(4, ctx->NI, 48), B(2, d_out, 576)}, s);
+  return final_exp_pipeline(ctx, 1, f_raw, d_out, s);
 }
 
 EXPORT int nbls_init(int device_id, nbls_ctx** out) {
@@ -135,6 +152,10 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
   // Montgomery one as a raw Fp12 (pads odd-sized product reductions)
   u32 one[144]; memset(one, 0, sizeof one); memcpy(one, NBLS_R1, 48);
   if (hipMalloc(&ctx->one12, 576) != hipSuccess || hipMemcpy(ctx->one12, one, 576, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
+  {
+    std::vector<u32> tab(382 * 12); make_inv_table(tab.data());
+    if (hipMalloc(&ctx->inv_table, tab.size() * 4) != hipSuccess || hipMemcpy(ctx->inv_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
+  }
   for (int i = 0; i < P_COUNT; i++) { int r = upload(ctx, (ProgId)i); if (r) { int e = ctx->last_hip; (void)e; nbls_destroy(ctx); return r; } }
   *out = ctx;
   return NBLS_OK;
@@ -144,7 +165,8 @@ EXPORT void nbls_destroy(nbls_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   for (auto& d : ctx->prog) { if (d.steps) hipFree(d.steps); if (d.descs) hipFree(d.descs); if (d.consts) hipFree(d.consts); }
-  for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12}) if (p) hipFree(p);
+  for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->inv_table}) if (p) hipFree(p);
+  for (uint8_t* p : ctx->T) if (p) hipFree(p);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -172,8 +194,7 @@ EXPORT int nbls_pairing_batch_dev(nbls_ctx* ctx, size_t n, const void* d_g1, con
   if (!with_final_exp) return run(ctx, P_MILLER_BYTES, n, {B(0, d_g1, 96), B(1, d_g2, 192), B(2, d_out, 576)}, s);
   if ((r = ensure_scratch(ctx, n))) return r;
   if ((r = run(ctx, P_MILLER_FE, n, {B(0, d_g1, 96), B(1, d_g2, 192), B(3, ctx->F, 576), B(4, ctx->N, 48)}, s))) return r;
-  if ((r = run_inv(ctx, n, s))) return r;
-  return run(ctx, P_FE_HARD, n, {B(3, ctx->F, 576), B(4, ctx->NI, 48), B(2, d_out, 576)}, s);
+  return final_exp_pipeline(ctx, n, ctx->F, d_out, s);
 }
 
 EXPORT int nbls_pairing_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2, int with_final_exp, int validate, uint8_t* out, int8_t* status) {
@@ -242,8 +263,7 @@ EXPORT int nbls_final_exp_batch_dev(nbls_ctx* ctx, size_t n, const void* d_in, v
   int r;
   if ((r = ensure_scratch(ctx, n))) return r;
   if ((r = run(ctx, P_NORM_BYTES, n, {B(2, d_in, 576), B(3, ctx->F, 576), B(4, ctx->N, 48)}, s))) return r;
-  if ((r = run_inv(ctx, n, s))) return r;
-  return run(ctx, P_FE_HARD, n, {B(3, ctx->F, 576), B(4, ctx->NI, 48), B(2, d_out, 576)}, s);
+  return final_exp_pipeline(ctx, n, ctx->F, d_out, s);
 }
 
 EXPORT int nbls_final_exp_batch(nbls_ctx* ctx, size_t n, const uint8_t* in, uint8_t* out) {

@@ -70,15 +70,21 @@ static SFp12 inv_finish(const SFp12& f, const InvChain& c, const SFp& ninv) {
 }
 
 // ---------------------------------------------------------------- final exponentiation (math.ts:856-874)
-static SFp12 trace_final_exp(const SFp12& f, const SFp12& finv) {
+// Split into phase programs chained through raw Fp12 scratch buffers in HBM (576 B per value per item): the long-lived
+// intermediates t1..t7 would otherwise pin ~300 LDS slots per instance and starve occupancy.  One EXPX program is reused
+// for all five cyclotomic exponentiations.
+//   t0 = f^(p^6) / f ; t1 = t0^(p^2) * t0                      FE_EASY
+//   t2 = conj(t1^x)                                             EXPX
+//   t3 = conj(cycsqr(t1)) * t2                                  FE_MID1
+//   t4 = conj(t3^x) ; t5 = conj(t4^x) ; t6' = conj(t5^x)        EXPX x3
+//   t6 = t6' * cycsqr(t2)                                       FE_MID2
+//   t7 = conj(t6^x)                                             EXPX
+//   (t2 t5)^(p^2) * (t4 t1)^(p^3) * (t6 conj(t1))^p * t7 conj(t3) t1     FE_FINAL
+static SFp12 trace_fe_easy(const SFp12& f, const SFp12& finv) {
   SFp12 t0 = mat(mul(frob(f, 6), finv));
-  SFp12 t1 = mat(mul(frob(t0, 2), t0));
-  SFp12 t2 = conj(cyclotomic_exp_x(t1));
-  SFp12 t3 = mat(mul(conj(cyclotomic_sqr(t1)), t2));
-  SFp12 t4 = conj(cyclotomic_exp_x(t3));
-  SFp12 t5 = conj(cyclotomic_exp_x(t4));
-  SFp12 t6 = mat(mul(conj(cyclotomic_exp_x(t5)), cyclotomic_sqr(t2)));
-  SFp12 t7 = conj(cyclotomic_exp_x(t6));
+  return mul(frob(t0, 2), t0);
+}
+static SFp12 trace_fe_final(const SFp12& t1, const SFp12& t2, const SFp12& t3, const SFp12& t4, const SFp12& t5, const SFp12& t6, const SFp12& t7) {
   SFp12 a = mat(frob(mul(t2, t5), 2));
   SFp12 b = mat(frob(mul(t4, t1), 3));
   SFp12 c = mat(frob(mul(t6, conj(t1)), 1));
@@ -122,13 +128,32 @@ static Program build(ProgId id) {
       outputw(inv_chain(f).n, 4, 0);
       return B.compile("norm_bytes", 32);
     }
-    case P_FE_HARD: {
+    case P_FE_EASY: {
       SFp12 f = inputw_fp12(3, 0);
       SFp ninv = inputw(4, 0);
       InvChain c = inv_chain(f);
       SFp12 finv = mat(inv_finish(f, c, ninv));
-      output_fp12(trace_final_exp(f, finv), 2, 0);
-      return B.compile("fe_hard", 21);
+      outputw_fp12(trace_fe_easy(f, finv), 5, 0);
+      return B.compile("fe_easy", 32);
+    }
+    case P_EXPX: {
+      outputw_fp12(conj(cyclotomic_exp_x(inputw_fp12(3, 0))), 5, 0);
+      return B.compile("expx", 21);
+    }
+    case P_FE_MID1: {
+      SFp12 a = inputw_fp12(3, 0), b = inputw_fp12(5, 0);
+      outputw_fp12(mul(conj(mat(cyclotomic_sqr(a))), b), 6, 0);
+      return B.compile("fe_mid1", 32);
+    }
+    case P_FE_MID2: {
+      SFp12 a = inputw_fp12(3, 0), b = inputw_fp12(5, 0);
+      outputw_fp12(mul(a, mat(cyclotomic_sqr(b))), 6, 0);
+      return B.compile("fe_mid2", 32);
+    }
+    case P_FE_FINAL: {
+      SFp12 t[7]; for (int i = 0; i < 7; i++) t[i] = inputw_fp12(i, 0);
+      output_fp12(trace_fe_final(t[0], t[1], t[2], t[3], t[4], t[5], t[6]), 7, 0);
+      return B.compile("fe_final", 64);
     }
     case P_MUL2: {
       SFp12 a = inputw_fp12(3, 0), b = inputw_fp12(3, 576);

@@ -127,7 +127,7 @@ NBLS_HD void ld12(u32* x, LDSP lds, u32 off) {
 }
 
 template <typename LDSP>
-NBLS_HD u32 exec_lane(const Step& st, const u32* __restrict__ d, LDSP lds, const LaneCtx& cx, const IOBuf* bufs, u32* res) {
+NBLS_HD u32 exec_lane(const Step& st, const u32* d /* 8 descriptor words, already loaded */, LDSP lds, const LaneCtx& cx, const IOBuf* bufs, u32* res) {
   const u32 P[12] = NBLS_P32;
   const u32 P2[12] = NBLS_2P32;
   switch (st.kind) {
@@ -143,16 +143,7 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* __restrict__ d, LDSP lds, const
       return slot_addr(w2 & 0xffff, cx.inst);
     }
     case K_LIN: {
-      u32 w[8];
-#pragma unroll
-      for (int i = 0; i < 4; i++) w[i] = d[i];
-      if (st.stride > 4) {
-#pragma unroll
-        for (int i = 4; i < 8; i++) w[i] = d[i];
-      } else {
-#pragma unroll
-        for (int i = 4; i < 8; i++) w[i] = 0;
-      }
+      const u32* w = d;
       u32 nt = (w[0] >> 16) & 0xff, nneg = 0;
       u32 acc[13];
 #pragma unroll

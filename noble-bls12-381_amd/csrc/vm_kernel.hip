@@ -20,10 +20,27 @@ extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel(KernelArgs ka) {
   cx.item = blockIdx.x * ka.G + inst_id;
   cx.live = inst_id < ka.G && cx.item < ka.n_items;
   __syncthreads();   // single wave: orders the constant fill before first use
+  // Software-pipelined interpreter loop: the step header (scalar) and this lane's descriptor words for step s+1 are
+  // requested before step s executes, so the L2 latency of the descriptor fetch overlaps the arithmetic.
+  const uint4* descs4 = (const uint4*)ka.descs;
+  Step st = ka.steps[0];
+  uint4 d0 = make_uint4(0, 0, 0, 0), d1 = make_uint4(0, 0, 0, 0);
+  if (lane_in < st.nlanes) {
+    const u32 o = (st.desc_off + lane_in * st.stride) >> 2;
+    d0 = descs4[o];
+    if (st.stride > 4) d1 = descs4[o + 1];
+  }
   for (u32 s = 0; s < ka.nsteps; s++) {
-    const Step st = ka.steps[s];
+    const u32 sn = (s + 1 < ka.nsteps) ? s + 1 : s;
+    const Step nst = ka.steps[sn];
+    uint4 n0 = make_uint4(0, 0, 0, 0), n1 = make_uint4(0, 0, 0, 0);
+    if (lane_in < nst.nlanes) {
+      const u32 o = (nst.desc_off + lane_in * nst.stride) >> 2;
+      n0 = descs4[o];
+      if (nst.stride > 4) n1 = descs4[o + 1];
+    }
     if (lane_in < st.nlanes) {
-      const u32* d = ka.descs + st.desc_off + lane_in * st.stride;
+      u32 d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
       u32 res[12];
       u32 dst = exec_lane(st, d, smem, cx, ka.bufs, res);
       if (dst != 0xffffffffu) {
@@ -31,6 +48,7 @@ extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel(KernelArgs ka) {
         for (int i = 0; i < 12; i++) smem[dst + i] = res[i];
       }
     }
+    st = nst; d0 = n0; d1 = n1;
   }
 }
 

@@ -8,6 +8,7 @@
 #include "programs.h"
 #include "vm_exec.h"
 #include "consts_gen.h"
+#include "fp_inv.h"
 
 using namespace nbls;
 
@@ -29,7 +30,9 @@ static void sim_run(const Program& p, unsigned n_items, const IOBuf* bufs) {
         if (lane_in >= st.nlanes) continue;
         LaneCtx cx; cx.pm2 = p.nconst * 12; cx.inst = shared + inst * p.slots * 12; cx.item = blk * p.G + inst; cx.live = cx.item < n_items;
         Pending pd;
-        pd.dst = exec_lane(st, p.descs.data() + st.desc_off + lane_in * st.stride, lds.data(), cx, bufs, pd.v);
+        u32 dw[8] = {0};
+        memcpy(dw, p.descs.data() + st.desc_off + lane_in * st.stride, st.stride * 4);
+        pd.dst = exec_lane(st, dw, lds.data(), cx, bufs, pd.v);
         if (pd.dst != 0xffffffffu) pend.push_back(pd);
       }
       for (auto& pd : pend) memcpy(&lds[pd.dst], pd.v, 48);
@@ -46,20 +49,11 @@ __attribute__((visibility("default"))) int nbls_sim_run(int prog, unsigned n_ite
   sim_run(get_program((ProgId)prog), n_items, b);
   return 0;
 }
-// out = in^(p-2) on raw Montgomery limbs (stands in for the fp inversion kernel)
+// out = in^-1 on raw Montgomery limbs: the same fp_mont_inverse routine the inversion kernel runs per lane
 __attribute__((visibility("default"))) void nbls_sim_fp_inv(unsigned n, const u32* in, u32* out) {
-  const u32 P2[12] = NBLS_2P32;
-  const u32 P1[12] = NBLS_P32;
-  for (unsigned k = 0; k < n; k++) {
-    u32 acc[12], x[12];
-    memcpy(x, in + 12 * k, 48); memcpy(acc, NBLS_R1, 48);
-    for (int i = NBLS_P_MINUS_2_BITS - 1; i >= 0; i--) {
-      u32 t[12]; mont_mul12(t, acc, acc); csub<12>(t, P2); memcpy(acc, t, 48);
-      if ((NBLS_EXP_P_MINUS_2[i >> 6] >> (i & 63)) & 1) { mont_mul12(t, acc, x); csub<12>(t, P2); memcpy(acc, t, 48); }
-    }
-    (void)P1;
-    memcpy(out + 12 * k, acc, 48);
-  }
+  static std::vector<u32> table;
+  if (table.empty()) { table.resize(382 * 12); make_inv_table(table.data()); }
+  for (unsigned k = 0; k < n; k++) fp_mont_inverse(out + 12 * k, in + 12 * k, table.data());
 }
 __attribute__((visibility("default"))) void nbls_sim_stats() { for (int i = 0; i < P_COUNT; i++) print_stats(get_program((ProgId)i)); }
 }

@@ -30,11 +30,9 @@ def test_full_pairing_pipeline(sim, oracle, golden):
     g1, g2 = _points(golden, n)
     F = C.create_string_buffer(576 * n)
     N = C.create_string_buffer(48 * n)
-    NI = C.create_string_buffer(48 * n)
     out = C.create_string_buffer(576 * n)
     vmsim_py.run(sim, 'MILLER_FE', n, {0: (C.create_string_buffer(g1, len(g1)), 96), 1: (C.create_string_buffer(g2, len(g2)), 192), 3: (F, 576), 4: (N, 48)})
-    sim.nbls_sim_fp_inv(C.c_uint(n), N, NI)
-    vmsim_py.run(sim, 'FE_HARD', n, {3: (F, 576), 4: (NI, 48), 2: (out, 576)})
+    vmsim_py.final_exp(sim, n, F, N, out)
     for i in range(n):
         assert out.raw[576 * i:576 * (i + 1)] == hx(golden['pairs'][i]['pairing']), i
 
@@ -43,11 +41,10 @@ def test_final_exp_and_product(sim, oracle, golden, testdata):
     # final_exp_batch path: wire bytes -> F, N -> inverse -> hard part
     fin = hx(testdata['finalexp_in']) + hx(golden['fp12'][0]['a'])
     n = 2
-    F = C.create_string_buffer(576 * n); N = C.create_string_buffer(48 * n); NI = C.create_string_buffer(48 * n)
+    F = C.create_string_buffer(576 * n); N = C.create_string_buffer(48 * n)
     out = C.create_string_buffer(576 * n)
     vmsim_py.run(sim, 'NORM_BYTES', n, {2: (C.create_string_buffer(fin, len(fin)), 576), 3: (F, 576), 4: (N, 48)})
-    sim.nbls_sim_fp_inv(C.c_uint(n), N, NI)
-    vmsim_py.run(sim, 'FE_HARD', n, {3: (F, 576), 4: (NI, 48), 2: (out, 576)})
+    vmsim_py.final_exp(sim, n, F, N, out)
     assert out.raw[:576] == hx(testdata['finalexp_out'])
     assert out.raw[576:] == hx(golden['fp12'][0]['finalexp'])
     # product of two Miller values then shared final exponentiation (golden 'product')
@@ -58,8 +55,7 @@ def test_final_exp_and_product(sim, oracle, golden, testdata):
     vmsim_py.run(sim, 'MUL2', 1, {3: (F2, 1152), 5: (Fp, 576)})
     vmsim_py.run(sim, 'RAW_TO_BYTES', 1, {3: (Fp, 576), 2: (outb, 576)})
     assert outb.raw == hx(p['miller_product'])
-    N1 = C.create_string_buffer(48); NI1 = C.create_string_buffer(48)
+    N1 = C.create_string_buffer(48)
     vmsim_py.run(sim, 'NORM_RAW', 1, {3: (Fp, 576), 4: (N1, 48)})
-    sim.nbls_sim_fp_inv(C.c_uint(1), N1, NI1)
-    vmsim_py.run(sim, 'FE_HARD', 1, {3: (Fp, 576), 4: (NI1, 48), 2: (outb, 576)})
+    vmsim_py.final_exp(sim, 1, Fp, N1, outb)
     assert outb.raw == hx(p['result'])
