@@ -306,7 +306,7 @@ EXPORT int nbls_program_stats(nbls_ctx* ctx, int prog, uint32_t* o) {
   (void)ctx;
   if (prog < 0 || prog >= P_COUNT || !o) return NBLS_EINVAL;
   const Program& p = get_program((ProgId)prog);
-  o[0] = (uint32_t)p.steps.size(); o[1] = p.n_mul_steps; o[2] = p.n_lin_steps; o[3] = p.n_mul_ops; o[4] = p.n_lin_ops; o[5] = p.n_lin_terms; o[6] = p.slots; o[7] = p.lds_bytes();
+  o[0] = (uint32_t)p.steps.size(); o[1] = p.n_dot_steps; o[2] = p.n_lin_steps; o[3] = p.n_dot_ops; o[4] = p.n_products; o[5] = p.n_lin_ops; o[6] = p.slots; o[7] = p.lds_bytes();
   return NBLS_OK;
 }
 

@@ -97,36 +97,41 @@ static void load_points(SFp& Px, SFp& Py, SFp2& Qx, SFp2& Qy) {
   Qx = input_fp2(1, 0); Qy = input_fp2(1, 96);
 }
 
+// lanes per work item (instances per wave = 64 / W): an Fp12 lane-op step has 12 heavy lanes
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
+static const int MILLER_W = env_int("NBLS_MILLER_W", 16);
+static const int EXPX_W = env_int("NBLS_EXPX_W", 16);
+
 static Program build(ProgId id) {
   Builder B;
   switch (id) {
     case P_MILLER_BYTES: {
       SFp Px, Py; SFp2 Qx, Qy; load_points(Px, Py, Qx, Qy);
       output_fp12(trace_miller(Px, Py, Qx, Qy), 2, 0);
-      return B.compile("miller_bytes", 64);
+      return B.compile("miller_bytes", MILLER_W);
     }
     case P_MILLER_RAW: {
       SFp Px, Py; SFp2 Qx, Qy; load_points(Px, Py, Qx, Qy);
       outputw_fp12(trace_miller(Px, Py, Qx, Qy), 3, 0);
-      return B.compile("miller_raw", 64);
+      return B.compile("miller_raw", MILLER_W);
     }
     case P_MILLER_FE: {
       SFp Px, Py; SFp2 Qx, Qy; load_points(Px, Py, Qx, Qy);
       SFp12 f = mat(trace_miller(Px, Py, Qx, Qy));
       outputw_fp12(f, 3, 0);
       outputw(inv_chain(f).n, 4, 0);
-      return B.compile("miller_fe", 64);
+      return B.compile("miller_fe", MILLER_W);
     }
     case P_NORM_RAW: {
       SFp12 f = inputw_fp12(3, 0);
       outputw(inv_chain(f).n, 4, 0);
-      return B.compile("norm_raw", 32);
+      return B.compile("norm_raw", 16);
     }
     case P_NORM_BYTES: {
       SFp12 f = mat(input_fp12(2, 0));
       outputw_fp12(f, 3, 0);
       outputw(inv_chain(f).n, 4, 0);
-      return B.compile("norm_bytes", 32);
+      return B.compile("norm_bytes", 16);
     }
     case P_FE_EASY: {
       SFp12 f = inputw_fp12(3, 0);
@@ -134,31 +139,31 @@ static Program build(ProgId id) {
       InvChain c = inv_chain(f);
       SFp12 finv = mat(inv_finish(f, c, ninv));
       outputw_fp12(trace_fe_easy(f, finv), 5, 0);
-      return B.compile("fe_easy", 32);
+      return B.compile("fe_easy", 16);
     }
     case P_EXPX: {
       outputw_fp12(conj(cyclotomic_exp_x(inputw_fp12(3, 0))), 5, 0);
-      return B.compile("expx", 21);
+      return B.compile("expx", EXPX_W);
     }
     case P_FE_MID1: {
       SFp12 a = inputw_fp12(3, 0), b = inputw_fp12(5, 0);
       outputw_fp12(mul(conj(mat(cyclotomic_sqr(a))), b), 6, 0);
-      return B.compile("fe_mid1", 32);
+      return B.compile("fe_mid1", 16);
     }
     case P_FE_MID2: {
       SFp12 a = inputw_fp12(3, 0), b = inputw_fp12(5, 0);
       outputw_fp12(mul(a, mat(cyclotomic_sqr(b))), 6, 0);
-      return B.compile("fe_mid2", 32);
+      return B.compile("fe_mid2", 16);
     }
     case P_FE_FINAL: {
       SFp12 t[7]; for (int i = 0; i < 7; i++) t[i] = inputw_fp12(i, 0);
       output_fp12(trace_fe_final(t[0], t[1], t[2], t[3], t[4], t[5], t[6]), 7, 0);
-      return B.compile("fe_final", 64);
+      return B.compile("fe_final", 32);
     }
     case P_MUL2: {
       SFp12 a = inputw_fp12(3, 0), b = inputw_fp12(3, 576);
       outputw_fp12(mul(a, b), 5, 0);
-      return B.compile("fp12_mul2", 64);
+      return B.compile("fp12_mul2", 16);
     }
     case P_RAW_TO_BYTES: {
       output_fp12(inputw_fp12(3, 0), 2, 0);
@@ -179,9 +184,9 @@ const Program& get_program(ProgId id) {
 }
 
 void print_stats(const Program& p) {
-  printf("%-14s W=%2u G=%u steps=%5zu (mul %4u, lin %4u, other %3u)  mul_ops=%6u (fill %.2f)  lin_ops=%6u terms=%7u  slots=%4u  lds=%6u B  descs=%zu KB\n",
-         p.name.c_str(), p.W, p.G, p.steps.size(), p.n_mul_steps, p.n_lin_steps, p.n_other_steps, p.n_mul_ops,
-         p.n_mul_steps ? (double)p.n_mul_ops / (p.n_mul_steps * p.W) : 0.0, p.n_lin_ops, p.n_lin_terms, p.slots, p.lds_bytes(), p.descs.size() * 4 / 1024);
+  printf("%-14s W=%2u G=%u steps=%5zu (dot %4u, lin %4u, other %3u)  dot_ops=%6u products=%6u (product-slot fill %.2f)  lin_ops=%6u terms=%6u  slots=%4u  lds=%6u B  descs=%zu KB\n",
+         p.name.c_str(), p.W, p.G, p.steps.size(), p.n_dot_steps, p.n_lin_steps, p.n_other_steps, p.n_dot_ops, p.n_products,
+         p.n_prod_slots ? (double)p.n_products / p.n_prod_slots : 0.0, p.n_lin_ops, p.n_lin_terms, p.slots, p.lds_bytes(), p.descs.size() * 4 / 1024);
 }
 
 }  // namespace nbls

@@ -20,14 +20,13 @@ static inline SFp2 fp2_one() { return {fp_one(), SFp()}; }
 static inline SFp2 fp2_zero() { return {SFp(), SFp()}; }
 
 
-// ---- Fp2 (math.ts:403-550)
+// ---- Fp2 (math.ts:403-550).  Products stay pending (lazy); an output coefficient is evaluated by one DOT lane-op.
 static inline SFp2 operator+(const SFp2& a, const SFp2& b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
 static inline SFp2 operator-(const SFp2& a, const SFp2& b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
 static inline SFp2 operator-(const SFp2& a) { return {-a.c0, -a.c1}; }
 static inline SFp2 scale(const SFp2& a, int k) { return {scale(a.c0, k), scale(a.c1, k)}; }
-static inline SFp2 mul(const SFp2& a, const SFp2& b) {            // math.ts:451-462 (Karatsuba)
-  SFp t1 = mul(a.c0, b.c0), t2 = mul(a.c1, b.c1), m = mul(a.c0 + a.c1, b.c0 + b.c1);
-  return {t1 - t2, m - t1 - t2};
+static inline SFp2 mul(const SFp2& a, const SFp2& b) {            // = math.ts:451-462 (schoolbook; same element as Karatsuba)
+  return {mul(a.c0, b.c0) - mul(a.c1, b.c1), mul(a.c0, b.c1) + mul(a.c1, b.c0)};
 }
 static inline SFp2 sqr(const SFp2& a) {                           // math.ts:477-484
   return {mul(a.c0 + a.c1, a.c0 - a.c1), mul(scale(a.c0, 2), a.c1)};
@@ -40,30 +39,28 @@ static inline SFp2 halve(const SFp2& a) { return {halve(a.c0), halve(a.c1)}; }
 static inline SFp2 frob(const SFp2& a, int power) { return (power & 1) ? conj(a) : a; }    // math.ts:529-531
 static inline SFp2 mat(const SFp2& a) { return {SFp(materialize(a.c0)), SFp(materialize(a.c1))}; }
 
-// ---- Fp6 (math.ts:554-700)
+// ---- Fp6 (math.ts:554-700).  Schoolbook over Fp2 with the non-residue folded into an operand: xi*(x*y) = (xi*x)*y and
+// xi*x = (x.c0 - x.c1, x.c0 + x.c1) is a fused pre-addition, so every output coefficient is a sum of 3 Fp2 products.
 static inline SFp6 operator+(const SFp6& a, const SFp6& b) { return {a.c0 + b.c0, a.c1 + b.c1, a.c2 + b.c2}; }
 static inline SFp6 operator-(const SFp6& a, const SFp6& b) { return {a.c0 - b.c0, a.c1 - b.c1, a.c2 - b.c2}; }
 static inline SFp6 operator-(const SFp6& a) { return {-a.c0, -a.c1, -a.c2}; }
-static inline SFp6 mul(const SFp6& a, const SFp6& b) {            // math.ts:601-618
-  SFp2 t0 = mul(a.c0, b.c0), t1 = mul(a.c1, b.c1), t2 = mul(a.c2, b.c2);
-  return {t0 + mulnr(mul(a.c1 + a.c2, b.c1 + b.c2) - (t1 + t2)),
-          mul(a.c0 + a.c1, b.c0 + b.c1) - (t0 + t1) + mulnr(t2),
-          t1 + (mul(a.c0 + a.c2, b.c0 + b.c2) - (t0 + t2))};
+static inline SFp6 scale(const SFp6& a, int k) { return {scale(a.c0, k), scale(a.c1, k), scale(a.c2, k)}; }
+static inline SFp6 mul(const SFp6& a, const SFp6& b) {            // = math.ts:601-618
+  SFp2 xa1 = mulnr(a.c1), xa2 = mulnr(a.c2);
+  return {mul(a.c0, b.c0) + mul(xa1, b.c2) + mul(xa2, b.c1),
+          mul(a.c0, b.c1) + mul(a.c1, b.c0) + mul(xa2, b.c2),
+          mul(a.c0, b.c2) + mul(a.c1, b.c1) + mul(a.c2, b.c0)};
 }
 static inline SFp6 mulnr(const SFp6& a) { return {mulnr(a.c2), a.c0, a.c1}; }               // * v, math.ts:627-629
-static inline SFp6 mul_by_1(const SFp6& a, const SFp2& b1) {      // math.ts:631-637
-  return {mulnr(mul(a.c2, b1)), mul(a.c0, b1), mul(a.c1, b1)};
+static inline SFp6 mul_by_1(const SFp6& a, const SFp2& b1) {      // = math.ts:631-637
+  return {mul(mulnr(a.c2), b1), mul(a.c0, b1), mul(a.c1, b1)};
 }
-static inline SFp6 mul_by_01(const SFp6& a, const SFp2& b0, const SFp2& b1) {   // math.ts:639-651
-  SFp2 t0 = mul(a.c0, b0), t1 = mul(a.c1, b1);
-  return {mulnr(mul(a.c1 + a.c2, b1) - t1) + t0,
-          mul(b0 + b1, a.c0 + a.c1) - t0 - t1,
-          mul(a.c0 + a.c2, b0) - t0 + t1};
+static inline SFp6 mul_by_01(const SFp6& a, const SFp2& b0, const SFp2& b1) {   // = math.ts:639-651
+  return {mul(a.c0, b0) + mul(mulnr(a.c2), b1), mul(a.c0, b1) + mul(a.c1, b0), mul(a.c1, b1) + mul(a.c2, b0)};
 }
 static inline SFp6 mul_by_fp2(const SFp6& a, const SFp2& k) { return {mul(a.c0, k), mul(a.c1, k), mul(a.c2, k)}; }
-static inline SFp6 sqr(const SFp6& a) {                           // math.ts:658-670
-  SFp2 t0 = sqr(a.c0), t1 = scale(mul(a.c0, a.c1), 2), t3 = scale(mul(a.c1, a.c2), 2), t4 = sqr(a.c2);
-  return {mulnr(t3) + t0, mulnr(t4) + t1, t1 + sqr(a.c0 - a.c1 + a.c2) + t3 - t0 - t4};
+static inline SFp6 sqr(const SFp6& a) {                           // = math.ts:658-670
+  return {sqr(a.c0) + scale(mul(mulnr(a.c1), a.c2), 2), scale(mul(a.c0, a.c1), 2) + mulnr(sqr(a.c2)), sqr(a.c1) + scale(mul(a.c0, a.c2), 2)};
 }
 static inline SFp6 frob(const SFp6& a, int power) {               // math.ts:682-688
   return {frob(a.c0, power), mul(frob(a.c1, power), fp2_const(NBLS_FROB6_1[power % 6])), mul(frob(a.c2, power), fp2_const(NBLS_FROB6_2[power % 6]))};
@@ -72,27 +69,30 @@ static inline SFp6 mat(const SFp6& a) { return {mat(a.c0), mat(a.c1), mat(a.c2)}
 
 // ---- Fp12 (math.ts:705-885)
 static inline SFp12 fp12_one() { return {{fp2_one(), fp2_zero(), fp2_zero()}, {fp2_zero(), fp2_zero(), fp2_zero()}}; }
-static inline SFp12 mul(const SFp12& a, const SFp12& b) {         // math.ts:748-759
-  SFp6 t1 = mul(a.c0, b.c0), t2 = mul(a.c1, b.c1);
-  return {t1 + mulnr(t2), mul(a.c0 + a.c1, b.c0 + b.c1) - (t1 + t2)};
+static inline SFp12 mat(const SFp12& a) { return {mat(a.c0), mat(a.c1)}; }
+static inline SFp12 mul(const SFp12& a, const SFp12& b) {         // math.ts:748-759 (Karatsuba over Fp6, three 18-lane products)
+  SFp6 t1 = mat(mul(a.c0, b.c0)), t2 = mat(mul(a.c1, b.c1));
+  SFp6 sa = mat(a.c0 + a.c1), sb = mat(b.c0 + b.c1);
+  SFp6 v = mul(sa, sb);
+  return {t1 + mulnr(t2), v - (t1 + t2)};
 }
-static inline SFp12 mul_by_014(const SFp12& a, const SFp2& o0, const SFp2& o1, const SFp2& o4) {   // math.ts:768-777
-  SFp6 t0 = mul_by_01(a.c0, o0, o1), t1 = mul_by_1(a.c1, o4);
-  return {mulnr(t1) + t0, mul_by_01(a.c1 + a.c0, o0, o1 + o4) - t0 - t1};
+// f * (o0 + o1 v + o4 v w): every output coefficient is 3 Fp2 products of f with the line  (= math.ts:768-777)
+static inline SFp12 mul_by_014(const SFp12& a, const SFp2& o0, const SFp2& o1, const SFp2& o4) {
+  const SFp6 &x = a.c0, &y = a.c1;
+  SFp2 xx2 = mulnr(x.c2), xy1 = mulnr(y.c1), xy2 = mulnr(y.c2);
+  return {{mul(x.c0, o0) + mul(xx2, o1) + mul(xy1, o4), mul(x.c0, o1) + mul(x.c1, o0) + mul(xy2, o4), mul(x.c1, o1) + mul(x.c2, o0) + mul(y.c0, o4)},
+          {mul(y.c0, o0) + mul(xy2, o1) + mul(xx2, o4), mul(y.c0, o1) + mul(y.c1, o0) + mul(x.c0, o4), mul(y.c1, o1) + mul(y.c2, o0) + mul(x.c1, o4)}};
 }
-static inline SFp12 sqr(const SFp12& a) {                         // math.ts:783-791
-  SFp6 ab = mul(a.c0, a.c1);
-  return {mul(mulnr(a.c1) + a.c0, a.c0 + a.c1) - ab - mulnr(ab), ab + ab};
+static inline SFp12 sqr(const SFp12& a) {                         // = math.ts:783-791: (c0^2 + v c1^2, 2 c0 c1)
+  return {sqr(a.c0) + mulnr(sqr(a.c1)), scale(mul(a.c0, a.c1), 2)};
 }
 static inline SFp12 conj(const SFp12& a) { return {a.c0, -a.c1}; }                             // math.ts:799-801
 static inline SFp12 frob(const SFp12& a, int power) {             // math.ts:804-809
   return {frob(a.c0, power), mul_by_fp2(frob(a.c1, power), fp2_const(NBLS_FROB12[power % 12]))};
 }
-static inline SFp12 mat(const SFp12& a) { return {mat(a.c0), mat(a.c1)}; }
-static inline void fp4_square(const SFp2& a, const SFp2& b, SFp2& first, SFp2& second) {   // math.ts:811-818
-  SFp2 a2 = sqr(a), b2 = sqr(b);
-  first = mulnr(b2) + a2;
-  second = sqr(a + b) - a2 - b2;
+static inline void fp4_square(const SFp2& a, const SFp2& b, SFp2& first, SFp2& second) {   // = math.ts:811-818
+  first = mulnr(sqr(b)) + sqr(a);
+  second = scale(mul(a, b), 2);       // (a + b)^2 - a^2 - b^2
 }
 static inline SFp12 cyclotomic_sqr(const SFp12& x) {              // math.ts:824-843
   SFp2 t3, t4, t5, t6, t7, t8;

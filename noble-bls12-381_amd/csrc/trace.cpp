@@ -1,10 +1,22 @@
-// trace.cpp -- scheduler, slot allocator and descriptor emitter of the wave VM (see trace.h).
+// trace.cpp -- form materialisation, scheduler, slot allocator and descriptor emitter of the wave VM (see trace.h).
 #include "trace.h"
 #include <cassert>
+#include <cmath>
 #include <queue>
 #include "consts_gen.h"
 
 namespace nbls {
+
+static const double P_OVER_R = 0.10158;   // p / 2^384, rounded up
+
+static void add_mod_p(u32* x, const u32* y) {
+  uint64_t c = 0;
+  for (int i = 0; i < 12; i++) { uint64_t s = (uint64_t)x[i] + y[i] + c; x[i] = (u32)s; c = s >> 32; }
+  // conditional subtract p (values stay < 2p < 2^384, so no carry-out)
+  u32 d[12]; uint64_t br = 0;
+  for (int i = 0; i < 12; i++) { uint64_t t = (uint64_t)x[i] - NBLS_P[i] - br; d[i] = (u32)t; br = (t >> 63) & 1; }
+  if (!br) memcpy(x, d, 48);
+}
 
 Builder::Builder() {
   cur() = this;
@@ -15,25 +27,146 @@ Builder::Builder() {
   rawone_atom = const_atom(NBLS_RAW_ONE);
 }
 
+int Builder::small_const(int c) {
+  assert(c > 0 && c < 4096);
+  auto it = small_consts.find(c);
+  if (it != small_consts.end()) return it->second;
+  u32 acc[12] = {0}, dbl[12];
+  memcpy(dbl, NBLS_R1, 48);
+  for (int k = c; k; k >>= 1) { if (k & 1) add_mod_p(acc, dbl); u32 t[12]; memcpy(t, dbl, 48); add_mod_p(dbl, t); }
+  int id = const_atom(acc);
+  small_consts[c] = id;
+  return id;
+}
+
 SFp input(int buf, int off) {
   Builder* B = Builder::cur();
-  Node n; n.kind = K_LOAD; n.buf = buf; n.off = off;
+  Node n; n.kind = K_LOAD; n.buf = buf; n.off = off; n.raw = true;
   int raw = B->add_node(n);
-  Node m; m.kind = K_MUL; m.a0 = raw; m.b0 = B->r2_atom;       // x * R^2 / R = x R : to Montgomery form (any x < 2^384)
-  return SFp(B->add_node(m));
+  // x * R^2 / R = x R : to Montgomery form (valid for any x < 2^384)
+  Operand a; a.s0 = raw; Operand b; b.s0 = B->r2_atom;
+  SFp r; r.f.push_back({PROD_BASE + B->product(a, b), 1});
+  return SFp(materialize(r));
 }
 void output(const SFp& x, int buf, int off) {
   Builder* B = Builder::cur();
-  Node m; m.kind = K_MUL; m.a0 = materialize(x); m.b0 = B->rawone_atom;   // x / R : out of Montgomery form
-  int v = B->add_node(m);
-  Node n; n.kind = K_STORE; n.a0 = v; n.buf = buf; n.off = off; n.live = true;
+  Operand a; a.s0 = materialize(x); Operand b; b.s0 = B->rawone_atom;      // x / R : out of Montgomery form
+  SFp r; r.f.push_back({PROD_BASE + B->product(a, b), 1});
+  Node n; n.kind = K_STORE; n.a0 = materialize(r); n.buf = buf; n.off = off; n.live = true;
   B->add_node(n);
+}
+
+static int stages_for(double total_bound_p) {   // reduce [0, total) to [0, 2p) by conditional subtractions of 2p << s
+  int s = 0; while (2.0 * (1 << s) < total_bound_p) s++;
+  return s;
+}
+
+// Emit one DOT node for (prods, lin) -- caller guarantees the limits.
+static int emit_dot(Builder* B, const std::vector<DotProduct>& prods, int mult, const std::vector<std::pair<int, int>>& lin, bool halve_it) {
+  Node n; n.kind = K_DOT; n.prods = prods; n.mult = mult; n.lin = lin; n.halve = halve_it;
+  double V = 0; for (auto& p : prods) V += B->operand_bound(p.a) * B->operand_bound(p.b);
+  double D = prods.empty() ? 0.0 : V * P_OVER_R + 1.0;
+  double T = mult * D + 2.0 * lin.size();
+  n.stages = stages_for(T);
+  assert(n.stages <= 4);
+  return B->add_node(n);
+}
+static int emit_lin(Builder* B, std::vector<std::pair<int, int>> terms, bool halve_it) {
+  while ((int)terms.size() > MAX_LIN_TERMS) {
+    Node n; n.kind = K_LIN; n.lin.assign(terms.begin(), terms.begin() + MAX_LIN_TERMS);
+    int id = B->add_node(n);
+    terms.erase(terms.begin(), terms.begin() + MAX_LIN_TERMS);
+    terms.insert(terms.begin(), {id, 1});
+  }
+  Node n; n.kind = K_LIN; n.lin = terms; n.halve = halve_it;
+  return B->add_node(n);
+}
+
+int materialize(const SFp& x, bool halve_it) {
+  Builder* B = Builder::cur();
+  if (x.f.empty()) return B->zero_atom;
+  if (!halve_it && x.f.size() == 1 && x.f[0].second == 1 && x.f[0].first < PROD_BASE) return (int)x.f[0].first;
+  auto& cse = halve_it ? B->halve_cse : B->mat_cse;
+  auto it = cse.find(x.f);
+  if (it != cse.end()) return it->second;
+
+  std::vector<std::pair<int, int>> prods;   // (product id, coef)
+  std::vector<std::pair<int, int>> atoms;   // (atom, coef)
+  for (auto& t : x.f) {
+    if (t.first >= PROD_BASE) prods.push_back({(int)(t.first - PROD_BASE), t.second});
+    else if (std::abs(t.second) > 3) {
+      // large integer multiple of an atom: multiply by the constant inside the dot product instead of repeated addition
+      Operand a; a.s0 = (int)t.first; Operand c; c.s0 = B->small_const(std::abs(t.second));
+      prods.push_back({B->product(a, c), t.second > 0 ? 1 : -1});
+    } else atoms.push_back({(int)t.first, t.second});
+  }
+  // common multiplier m of the products: every |coef| / m must be 1, or 2 with one single-atom operand (2x = x + x)
+  int g = 0; for (auto& p : prods) { int a = std::abs(p.second), b = g; while (b) { int t = a % b; a = b; b = t; } g = a; }
+  int mult = 1;
+  for (int m = 4; m >= 1; m--) {
+    if (g % m) continue;
+    bool ok = true;
+    for (auto& p : prods) {
+      int q = std::abs(p.second) / m; const ProdKey& k = B->prods[p.first];
+      if (!(q == 1 || (q == 2 && (k.a.s1 < 0 || k.b.s1 < 0)))) { ok = false; break; }
+    }
+    if (ok) { mult = m; break; }
+  }
+  std::vector<DotProduct> dps;
+  for (auto& p : prods) {
+    ProdKey k = B->prods[p.first];
+    int q = std::abs(p.second) / mult; bool neg = p.second < 0;
+    if (q == 2 && k.a.s1 < 0) { k.a.s1 = k.a.s0; k.a.n1 = false; q = 1; }
+    else if (q == 2 && k.b.s1 < 0) { k.b.s1 = k.b.s0; k.b.n1 = false; q = 1; }
+    if (q == 1) dps.push_back({k.a, k.b, neg});
+    else {
+      // awkward coefficient: evaluate the product on its own, then use it as a linear term
+      SFp one; one.f.push_back({PROD_BASE + p.first, 1});
+      int a = materialize(one);
+      int c = p.second;
+      if (std::abs(c) > 3) { Operand oa; oa.s0 = a; Operand oc; oc.s0 = B->small_const(std::abs(c)); dps.push_back({oa, oc, c < 0}); assert(mult == 1); }
+      else atoms.push_back({a, c});
+    }
+  }
+  if (mult > 1) for (auto& d : dps) (void)d;
+  std::vector<std::pair<int, int>> lin;
+  for (auto& a : atoms) for (int k = 0; k < std::abs(a.second); k++) lin.push_back({a.first, a.second > 0 ? 1 : -1});
+
+  int id;
+  if (dps.empty()) {
+    id = emit_lin(B, lin, halve_it);
+  } else {
+    if ((int)lin.size() > MAX_DOT_LINEAR) { int a = emit_lin(B, lin, false); lin.clear(); lin.push_back({a, 1}); }
+    // chunk the products so that every lane-op respects k <= 8, REDC bound <= 9p and total bound <= 32p
+    for (;;) {
+      double V = 0; size_t take = 0;
+      while (take < dps.size() && take < (size_t)MAX_DOT_PRODUCTS) {
+        double v = B->operand_bound(dps[take].a) * B->operand_bound(dps[take].b);
+        double D = (V + v) * P_OVER_R + 1.0;
+        if (mult * D + 2.0 * (lin.size() + 1) > 32.0) break;
+        V += v; take++;
+      }
+      assert(take > 0);
+      if (take == dps.size()) break;
+      std::vector<DotProduct> chunk(dps.begin(), dps.begin() + take);
+      int a = emit_dot(B, chunk, mult, {}, false);
+      dps.erase(dps.begin(), dps.begin() + take);
+      if ((int)lin.size() >= MAX_DOT_LINEAR) { int l = emit_lin(B, lin, false); lin.clear(); lin.push_back({l, 1}); }
+      lin.push_back({a, 1});
+    }
+    id = emit_dot(B, dps, mult, lin, halve_it);
+  }
+  cse[x.f] = id;
+  return id;
 }
 
 static void node_deps(const Node& n, std::vector<int>& d) {
   d.clear();
   switch (n.kind) {
-    case K_MUL: d = {n.a0, n.a1, n.b0, n.b1}; break;
+    case K_DOT:
+      for (auto& p : n.prods) { d.push_back(p.a.s0); d.push_back(p.a.s1); d.push_back(p.b.s0); d.push_back(p.b.s1); }
+      for (auto& t : n.lin) d.push_back(t.first);
+      break;
     case K_LIN: for (auto& t : n.lin) d.push_back(t.first); break;
     case K_STORE: case K_STOREW: case K_ISZ: case K_CANON: d = {n.a0}; break;
     case K_SEL: d = {n.b0, n.a0, n.a1}; break;
@@ -73,7 +206,7 @@ Program Builder::compile(const std::string& name, int W) {
     for (int x : d) if (nodes[x].kind != 0xff) { nodes[x].users.push_back(i); n.ndeps++; }
   }
   // 3. heights (critical path to a sink)
-  auto cost = [&](const Node& n) { return n.kind == K_MUL ? 20 : n.kind == K_LIN ? 3 + (int)n.lin.size() / 3 : 2; };
+  auto cost = [&](const Node& n) { return n.kind == K_DOT ? 8 + 14 * (int)n.prods.size() : n.kind == K_LIN ? 3 + (int)n.lin.size() / 3 : 2; };
   for (int i = N - 1; i >= 0; i--) {
     Node& n = nodes[i];
     if (!n.live || n.kind == 0xff) continue;
@@ -81,7 +214,9 @@ Program Builder::compile(const std::string& name, int W) {
     n.height = h + cost(n);
   }
   // 4. list scheduling.  Ready queues per (kind, p0).
-  auto qkey = [&](const Node& n) { return (int)n.kind * 256 + ((n.kind == K_CMP || n.kind == K_FLAG) ? n.p0 : 0); };
+  // DOT lane-ops are bucketed by weight class so that a step's lanes do similar amounts of work (step time = max k)
+  auto dot_class = [&](const Node& n) { size_t k = n.prods.size(); return k <= 2 ? 0 : 1; };
+  auto qkey = [&](const Node& n) { return (int)n.kind * 256 + ((n.kind == K_CMP || n.kind == K_FLAG) ? n.p0 : n.kind == K_DOT ? dot_class(n) : 0); };
   auto cmp = [&](int a, int b) { return nodes[a].height < nodes[b].height || (nodes[a].height == nodes[b].height && a > b); };
   typedef std::priority_queue<int, std::vector<int>, decltype(cmp)> PQ;
   std::map<int, PQ> ready;
@@ -93,24 +228,35 @@ Program Builder::compile(const std::string& name, int W) {
     if (n.ndeps == 0) ready.emplace(qkey(n), PQ(cmp)).first->second.push(i);
   }
   std::vector<std::vector<int>> step_nodes;
-  const int MULKEY = K_MUL * 256;
+  const int DOTKEY = K_DOT * 256;
   while (remaining > 0) {
     int key = -1;
-    auto itm = ready.find(MULKEY);
-    size_t nmul = itm == ready.end() ? 0 : itm->second.size();
-    if (nmul >= (size_t)W) key = MULKEY;
-    else {
+    // a full DOT step of one class is always worth issuing; otherwise drain the cheap kinds first, then issue the DOT
+    // class that holds the most urgent (highest critical path) ready lane-op
+    int best_dot = -1, best_h = -1;
+    for (int c = 1; c >= 0; c--) {
+      auto itq = ready.find(DOTKEY + c);
+      if (itq == ready.end() || itq->second.empty()) continue;
+      if (itq->second.size() >= (size_t)W) { key = DOTKEY + c; break; }
+      int h = nodes[itq->second.top()].height;
+      if (h > best_h) { best_h = h; best_dot = DOTKEY + c; }
+    }
+    if (key < 0) {
       static const int order[] = {K_LOAD, K_LOADW, K_LIN, K_ISZ, K_FLAG, K_CMP, K_CANON, K_SEL, K_STOREW, K_STORE, K_STATUS};
       for (int k : order) {
         for (auto& kv : ready) if (kv.first / 256 == k && !kv.second.empty()) { key = kv.first; break; }
         if (key >= 0) break;
       }
-      if (key < 0) key = MULKEY;
+      if (key < 0) key = best_dot;
     }
     PQ& q = ready.find(key)->second;
     assert(!q.empty());
     std::vector<int> chosen;
     while (!q.empty() && (int)chosen.size() < W) { chosen.push_back(q.top()); q.pop(); }
+    if (key == DOTKEY + 1) {   // heavy DOT step: light lane-ops ride along in the free lanes at no cost
+      auto itl = ready.find(DOTKEY);
+      if (itl != ready.end()) while (!itl->second.empty() && (int)chosen.size() < W) { chosen.push_back(itl->second.top()); itl->second.pop(); }
+    }
     int sidx = (int)step_nodes.size();
     for (size_t l = 0; l < chosen.size(); l++) { nodes[chosen[l]].step = sidx; nodes[chosen[l]].lane = (int)l; }
     step_nodes.push_back(chosen);
@@ -137,9 +283,14 @@ Program Builder::compile(const std::string& name, int W) {
   auto op = [&](int atom) -> u32 {
     if (atom < 0) return OP_CONST | 0;   // const slot 0 is zero
     const Node& n = nodes[atom];
-    if (n.kind == 0xff) return OP_CONST | (u32)n.const_idx;
+    if (n.kind == 0xff) { assert(n.const_idx < (int)OP_SLOT_MASK); return OP_CONST | (u32)n.const_idx; }
     assert(n.slot >= 0);
     return (u32)n.slot;
+  };
+  auto enc_operand = [&](const Operand& o, bool negate) -> u32 {
+    u32 e0 = op(o.s0) | (negate ? OP_NEG : 0u);
+    u32 e1 = o.s1 >= 0 ? (op(o.s1) | ((o.n1 != negate) ? OP_NEG : 0u) | OP_PRESENT) : 0u;
+    return e0 | (e1 << 16);
   };
   for (size_t s = 0; s < step_nodes.size(); s++) {
     const std::vector<int>& L = step_nodes[s];
@@ -153,9 +304,12 @@ Program Builder::compile(const std::string& name, int W) {
       int stages = 0; while ((1u << stages) < mx) stages++;
       st.p1 = (uint8_t)stages;
       P.n_lin_steps++; P.n_lin_ops += (u32)L.size();
-    } else if (n0.kind == K_MUL) {
-      for (int c : L) { if (nodes[c].a1 >= 0) st.p0 |= 1; if (nodes[c].b1 >= 0) st.p0 |= 2; }
-      P.n_mul_steps++; P.n_mul_ops += (u32)L.size();
+    } else if (n0.kind == K_DOT) {
+      size_t mk = 0, ml = 0; int stg = 0;
+      for (int c : L) { mk = std::max(mk, nodes[c].prods.size()); ml = std::max(ml, nodes[c].lin.size()); stg = std::max(stg, nodes[c].stages); P.n_products += (u32)nodes[c].prods.size(); }
+      st.p0 = (uint8_t)mk; st.p1 = (uint8_t)stg; st.pad = (u32)ml;
+      st.stride = (u32)((4 + 2 * mk + 3) / 4 * 4);
+      P.n_dot_steps++; P.n_dot_ops += (u32)L.size(); P.n_prod_slots += (u32)(mk * W);
     } else {
       st.p0 = n0.p0; P.n_other_steps++;
       if (n0.kind == K_STATUS) st.stride = 8;
@@ -164,10 +318,14 @@ Program Builder::compile(const std::string& name, int W) {
       const Node& n = nodes[c];
       std::vector<u32> w(st.stride, 0);
       switch (n.kind) {
-        case K_MUL:
-          w[0] = op(n.a0) | ((n.a1 >= 0 ? (op(n.a1) | ((u32)n.am << OP_MODE_SHIFT)) : 0u) << 16);
-          w[1] = op(n.b0) | ((n.b1 >= 0 ? (op(n.b1) | ((u32)n.bm << OP_MODE_SHIFT)) : 0u) << 16);
-          w[2] = (u32)n.slot;
+        case K_DOT:
+          assert(n.prods.size() <= (size_t)MAX_DOT_PRODUCTS && n.lin.size() <= (size_t)MAX_DOT_LINEAR && n.mult >= 1 && n.mult <= 4);
+          w[0] = (u32)n.slot | ((u32)n.prods.size() << 16) | ((u32)n.lin.size() << 20) | ((u32)n.mult << 24) | (n.halve ? (1u << 27) : 0u);
+          for (size_t t = 0; t < n.lin.size(); t++) {
+            u32 term = op(n.lin[t].first) | (n.lin[t].second < 0 ? (1u << OP_MODE_SHIFT) : 0u);
+            w[2 + t / 2] |= term << (16 * (t & 1));
+          }
+          for (size_t i = 0; i < n.prods.size(); i++) { w[4 + 2 * i] = enc_operand(n.prods[i].a, n.prods[i].neg); w[5 + 2 * i] = enc_operand(n.prods[i].b, false); }
           break;
         case K_LIN:
           w[0] = (u32)n.slot | ((u32)n.lin.size() << 16) | (n.halve ? (1u << 24) : 0u);

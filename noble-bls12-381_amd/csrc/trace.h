@@ -1,18 +1,23 @@
-// trace.h -- host-side "compiler" of the wave VM: symbolic Fp values, lazy linear forms, DAG construction,
+// trace.h -- host-side "compiler" of the wave VM: symbolic Fp values, lazy bilinear forms, DAG construction,
 // list scheduling into wave-wide steps and LDS slot allocation.  Runs once per program at nbls_init().
 //
-// A symbolic Fp value (SFp) is a linear form  sum coef_i * atom_i  over ATOMS = values that live in an LDS slot
-// (inputs, constants, products, materialised sums, select results).  Additions, subtractions, negations and
-// multiplications by small integers only edit the form; a form is materialised by a K_LIN lane-op when it is
-// needed as a multiplication operand with more than two terms, as an output, or when it grows past TMAX terms.
-// Every atom is kept in [0,2p); a MUL operand may be (x) or (x +- y) -- the pre-addition is fused into the
-// multiplication lane-op.
+// A symbolic Fp value (SFp) is a lazy form
+//        sum_i c_i * atom_i  +  sum_j d_j * (A_j x B_j)
+// over ATOMS (values that live in an LDS slot: inputs, constants, results of earlier lane-ops) and PENDING PRODUCTS
+// whose operands A_j, B_j are (+-atom) or (+-atom +- atom).  Additions, subtractions, negations and multiplications by
+// small integers only edit the form; multiplying two forms yields a one-product form.  A form is materialised -- turned
+// into ONE lane-op -- only when it is needed as a multiplication operand that is not of the (x) / (x +- y) shape, as an
+// output, or when it outgrows a lane-op.  The lane-op (K_DOT) evaluates  m * REDC(sum_j A_j * B_j) +- atoms  with a
+// single Montgomery reduction, so the Karatsuba / tower recombination of Fp2, Fp6 and Fp12 arithmetic costs no extra
+// steps: an Fp12 coefficient is produced directly from the operand slots.  Every atom is kept in [0, 2p).
 #pragma once
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 #include "vm.h"
 
@@ -27,21 +32,36 @@ struct Program {
   std::vector<u32> consts;   // nconst*12 words + PM2 table (17*16 words)
   u32 nconst = 0, W = 64, G = 1, slots = 0;
   // statistics
-  u32 n_mul_steps = 0, n_lin_steps = 0, n_other_steps = 0, n_mul_ops = 0, n_lin_ops = 0, n_lin_terms = 0;
+  u32 n_dot_steps = 0, n_lin_steps = 0, n_other_steps = 0, n_dot_ops = 0, n_products = 0, n_prod_slots = 0, n_lin_ops = 0, n_lin_terms = 0;
   u32 lds_bytes() const { return lds_words(nconst, G, slots) * 4; }
 };
 
-typedef std::vector<std::pair<int, int>> Form;   // (atom, coef), sorted by atom, no zero coefs
+// operand of a pending product: s0 (never negated after canonicalisation) and optional s1 with sign
+struct Operand {
+  int s0 = -1, s1 = -1; bool n1 = false;
+  bool operator<(const Operand& o) const { return std::tie(s0, s1, n1) < std::tie(o.s0, o.s1, o.n1); }
+  bool operator==(const Operand& o) const { return s0 == o.s0 && s1 == o.s1 && n1 == o.n1; }
+};
+struct ProdKey { Operand a, b; bool operator<(const ProdKey& o) const { return std::tie(a, b) < std::tie(o.a, o.b); } };
+
+typedef long long TermKey;                         // atom id, or PROD_BASE + product id
+static const TermKey PROD_BASE = 1LL << 40;
+typedef std::vector<std::pair<TermKey, int>> Form;   // sorted by key, no zero coefficients
+
+struct DotProduct { Operand a, b; bool neg; };       // neg: the product enters with a minus sign
 
 struct Node {
   uint8_t kind = 0;        // StepKind, or 0xff for constants
   uint8_t p0 = 0;
-  bool halve = false;       // LIN: divide the reduced sum by two (mod p)
-  int a0 = -1, a1 = -1, am = 0, b0 = -1, b1 = -1, bm = 0;   // MUL operands / generic sources (a0 = src, a1 = second src, b0 = flag)
-  std::vector<std::pair<int, int>> lin;                    // LIN terms (atom, sign)
+  bool halve = false;      // DOT/LIN: divide the reduced result by two (mod p)
+  bool raw = false;        // K_LOAD result: any 384-bit integer (not < 2p)
+  int a0 = -1, a1 = -1, b0 = -1;                           // generic sources (a0 = src, a1 = second src, b0 = flag)
+  std::vector<DotProduct> prods; int mult = 1;             // DOT
+  std::vector<std::pair<int, int>> lin;                    // DOT / LIN linear terms (atom, sign)
   std::vector<std::pair<int, int>> stat;                   // STATUS (flag atom, code)
   int buf = 0, off = 0;
   int const_idx = -1;
+  int stages = 0;
   // scheduling state
   bool live = false;
   int step = -1, lane = 0, slot = -1, last_use = -1, height = 0, ndeps = 0;
@@ -53,10 +73,12 @@ struct Builder {
   std::vector<Node> nodes;
   std::vector<u32> const_words;                      // 12 words per constant
   std::map<std::vector<u32>, int> const_map;         // limbs -> node id
-  std::map<std::vector<int>, int> mul_cse;
-  std::map<Form, int> lin_cse, halve_cse;
+  std::vector<ProdKey> prods;
+  std::map<ProdKey, int> prod_map;
+  std::map<Form, int> mat_cse, halve_cse;
+  std::map<int, int> small_consts;                   // integer -> constant atom (Montgomery form)
   int zero_atom = -1, one_atom = -1, r2_atom = -1, rawone_atom = -1;
-  int TMAX = 10;
+  int TMAX = 12;         // soft cap on the size of a lazy form
   static Builder*& cur() { static thread_local Builder* b = nullptr; return b; }
   Builder();
   ~Builder() { if (cur() == this) cur() = nullptr; }
@@ -70,6 +92,16 @@ struct Builder {
     const_words.insert(const_words.end(), key.begin(), key.end());
     int id = add_node(n); const_map[key] = id; return id;
   }
+  int small_const(int c);                            // Montgomery form of a small positive integer
+  int product(const Operand& a, const Operand& b) {
+    ProdKey k{a, b}; if (k.b < k.a) std::swap(k.a, k.b);
+    auto it = prod_map.find(k); if (it != prod_map.end()) return it->second;
+    prods.push_back(k); prod_map[k] = (int)prods.size() - 1; return (int)prods.size() - 1;
+  }
+  bool is_const(int atom) const { return nodes[atom].kind == 0xff; }
+  // magnitude bound of an atom in units of p
+  double atom_bound(int atom) const { const Node& n = nodes[atom]; return n.kind == 0xff ? 1.0 : n.raw ? 9.85 : 2.0; }
+  double operand_bound(const Operand& o) const { return atom_bound(o.s0) + (o.s1 >= 0 ? atom_bound(o.s1) : 0.0); }
   Program compile(const std::string& name, int W);
 };
 
@@ -77,9 +109,10 @@ struct Builder {
 struct SFp {
   Form f;
   SFp() {}
-  explicit SFp(int atom) { f.push_back({atom, 1}); }
+  explicit SFp(int atom) { f.push_back({(TermKey)atom, 1}); }
   bool is_zero() const { return f.empty(); }
-  int weight() const { int w = 0; for (auto& t : f) w += std::abs(t.second); return w; }
+  int weight() const { return (int)f.size(); }
+  bool pure_atoms() const { for (auto& t : f) if (t.first >= PROD_BASE) return false; return true; }
 };
 
 static inline Form form_add(const Form& a, const Form& b, int sb) {
@@ -93,13 +126,12 @@ static inline Form form_add(const Form& a, const Form& b, int sb) {
   return r;
 }
 
-int materialize(const SFp& x);
+int materialize(const SFp& x, bool halve_it = false);
 
 static inline SFp lin_combine(SFp a, SFp b, int sb) {
   Builder* B = Builder::cur();
   SFp r; r.f = form_add(a.f, b.f, sb);
   if (r.weight() > B->TMAX) {
-    // keep forms small: put the heavier operand into a slot first
     if (a.weight() >= b.weight() && a.weight() > 1) a = SFp(materialize(a)); else if (b.weight() > 1) b = SFp(materialize(b));
     r.f = form_add(a.f, b.f, sb);
     if (r.weight() > B->TMAX) {
@@ -113,88 +145,37 @@ static inline SFp lin_combine(SFp a, SFp b, int sb) {
 static inline SFp operator+(const SFp& a, const SFp& b) { return lin_combine(a, b, 1); }
 static inline SFp operator-(const SFp& a, const SFp& b) { return lin_combine(a, b, -1); }
 static inline SFp operator-(const SFp& a) { SFp r = a; for (auto& t : r.f) t.second = -t.second; return r; }
-static inline SFp scale(const SFp& a, int k) {
-  Builder* B = Builder::cur();
-  SFp x = a;
-  if (std::abs(k) * x.weight() > B->TMAX && x.weight() > 1) x = SFp(materialize(x));
-  SFp r; if (k == 0) return r;
-  r = x; for (auto& t : r.f) t.second *= k; return r;
-}
+static inline SFp scale(const SFp& a, int k) { SFp r; if (k == 0) return r; r = a; for (auto& t : r.f) t.second *= k; return r; }
+static inline SFp halve(const SFp& x) { if (x.f.empty()) return SFp(); return SFp(materialize(x, true)); }
 
-inline int materialize(const SFp& x) {
-  Builder* B = Builder::cur();
-  if (x.f.empty()) return B->zero_atom;
-  if (x.f.size() == 1 && x.f[0].second == 1) return x.f[0].first;
-  auto it = B->lin_cse.find(x.f);
-  if (it != B->lin_cse.end()) return it->second;
-  // expand coefficients into repeated terms; split when too many
-  std::vector<std::pair<int, int>> terms;
-  for (auto& t : x.f) for (int k = 0; k < std::abs(t.second); k++) terms.push_back({t.first, t.second > 0 ? 1 : -1});
-  while ((int)terms.size() > MAX_LIN_TERMS) {
-    // fold the first chunk into its own LIN atom
-    Node n; n.kind = K_LIN; n.lin.assign(terms.begin(), terms.begin() + (MAX_LIN_TERMS));
-    int id = B->add_node(n);
-    terms.erase(terms.begin(), terms.begin() + (MAX_LIN_TERMS));
-    terms.insert(terms.begin(), {id, 1});
+// Turn a form into a product operand: returns the integer factor pulled out (may be negative).  The form must
+// consist of one or two atoms with equal |coefficient|; anything else is materialised first.
+static inline int as_operand(const SFp& x, Operand& o) {
+  const Form& f = x.f;
+  bool ok = x.pure_atoms() && (f.size() == 1 || (f.size() == 2 && std::abs(f[0].second) == std::abs(f[1].second)));
+  if (!ok) { o.s0 = materialize(x); o.s1 = -1; o.n1 = false; return 1; }
+  int g = std::abs(f[0].second);
+  if (f.size() == 1) {
+    if (g % 2 == 0) { o.s0 = o.s1 = (int)f[0].first; o.n1 = false; return f[0].second / 2; }   // 2x = x + x in the pre-addition
+    o.s0 = (int)f[0].first; o.s1 = -1; o.n1 = false; return f[0].second;
   }
-  Node n; n.kind = K_LIN; n.lin = terms;
-  int id = B->add_node(n);
-  B->lin_cse[x.f] = id;
-  return id;
-}
-
-// x/2 mod p of a linear form, as one LIN lane-op with the halve flag
-static inline SFp halve(const SFp& x) {
-  Builder* B = Builder::cur();
-  if (x.f.empty()) return SFp();
-  auto it = B->halve_cse.find(x.f);
-  if (it != B->halve_cse.end()) return SFp(it->second);
-  SFp y = x;
-  if (y.weight() > MAX_LIN_TERMS) y = SFp(materialize(y));
-  Node n; n.kind = K_LIN; n.halve = true;
-  for (auto& t : y.f) for (int k = 0; k < std::abs(t.second); k++) n.lin.push_back({t.first, t.second > 0 ? 1 : -1});
-  int id = B->add_node(n);
-  B->halve_cse[x.f] = id;
-  return SFp(id);
-}
-
-struct MulOperand { int sign, a0, a1, mode; };
-static inline int igcd(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
-// `sign` carries an integer factor pulled out of the operand: (g * form) * y = g * (form * y)
-static inline MulOperand mul_operand(const SFp& x) {
-  Form f = x.f;
-  int g = 0; for (auto& t : f) g = igcd(g, std::abs(t.second));
-  if (f.size() == 1 && g == 2) g = 1;            // 2x is served by the fused pre-addition x + x
-  if (g > 1) for (auto& t : f) t.second /= g;
-  if (f.size() == 1 && std::abs(f[0].second) == 1) return {g * f[0].second, f[0].first, -1, 0};
-  if (f.size() == 1 && std::abs(f[0].second) == 2) return {f[0].second / 2, f[0].first, f[0].first, 1};
-  if (f.size() == 2 && std::abs(f[0].second) == 1 && std::abs(f[1].second) == 1) {
-    if (f[0].second == 1) return {g, f[0].first, f[1].first, f[1].second == 1 ? 1 : 2};
-    if (f[1].second == 1) return {g, f[1].first, f[0].first, 2};
-    return {-g, f[0].first, f[1].first, 1};
-  }
-  SFp y; y.f = f;
-  return {g, materialize(y), -1, 0};
+  int c0 = f[0].second / g, c1 = f[1].second / g;
+  if (c0 == 1) { o.s0 = (int)f[0].first; o.s1 = (int)f[1].first; o.n1 = c1 < 0; return g; }
+  if (c1 == 1) { o.s0 = (int)f[1].first; o.s1 = (int)f[0].first; o.n1 = true; return g; }
+  o.s0 = (int)f[0].first; o.s1 = (int)f[1].first; o.n1 = false; return -g;
 }
 
 static inline SFp mul(const SFp& a, const SFp& b) {
   Builder* B = Builder::cur();
   if (a.is_zero() || b.is_zero()) return SFp();
-  MulOperand A = mul_operand(a), Bo = mul_operand(b);
-  // multiplication by the constant one
-  if (A.a1 < 0 && A.a0 == B->one_atom) { SFp r = b; if (A.sign < 0) r = -r; return r; }
-  if (Bo.a1 < 0 && Bo.a0 == B->one_atom) { SFp r = a; if (Bo.sign < 0) r = -r; return r; }
-  std::vector<int> ka = {A.a0, A.a1, A.mode}, kb = {Bo.a0, Bo.a1, Bo.mode};
-  if (kb < ka) { std::swap(ka, kb); std::swap(A, Bo); }
-  std::vector<int> key = ka; key.insert(key.end(), kb.begin(), kb.end());
-  int id;
-  auto it = B->mul_cse.find(key);
-  if (it != B->mul_cse.end()) id = it->second;
-  else {
-    Node n; n.kind = K_MUL; n.a0 = A.a0; n.a1 = A.a1; n.am = A.mode; n.b0 = Bo.a0; n.b1 = Bo.a1; n.bm = Bo.mode;
-    id = B->add_node(n); B->mul_cse[key] = id;
-  }
-  SFp r(id); r.f[0].second = A.sign * Bo.sign; return r;
+  Operand A, Bo;
+  int ga = as_operand(a, A), gb = as_operand(b, Bo);
+  if (A.s1 < 0 && A.s0 == B->one_atom) return scale(b, ga);
+  if (Bo.s1 < 0 && Bo.s0 == B->one_atom) return scale(a, gb);
+  if (A.s1 < 0 && A.s0 == B->zero_atom) return SFp();
+  if (Bo.s1 < 0 && Bo.s0 == B->zero_atom) return SFp();
+  SFp r; r.f.push_back({PROD_BASE + B->product(A, Bo), ga * gb});
+  return r;
 }
 static inline SFp sqr(const SFp& a) { return mul(a, a); }
 

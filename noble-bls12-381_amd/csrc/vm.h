@@ -25,12 +25,15 @@ enum StepKind : uint8_t {
   K_CANON = 9,   // slot <- canonical representative in [0,p)
   K_CMP = 10,    // flag slot <- predicate on raw integers: p0 = 0: a > b ; 1: a is odd
   K_FLAG = 11,   // flag slot <- boolean op of two flags: p0 = 0 and, 1 or, 2 xor, 3 and-not (a & !b)
+  K_DOT = 12,    // slot <- m * mont(sum_i A_i * B_i) +- up to 4 slots, ONE Montgomery reduction for the whole sum;
+                 //         every A_i, B_i is (+-x) or (+-x +- y).  Subsumes Fp2/Fp6/Fp12 recombination
 };
 
 struct Step {
   uint8_t kind;
   uint8_t nlanes;     // active lanes per instance (<= W)
-  uint8_t p0, p1;     // kind-specific (MUL: bit0 any a1, bit1 any b1; LIN: p0 = max terms, p1 = reduce stages)
+  uint8_t p0, p1;     // kind-specific (MUL: bit0 any a1, bit1 any b1; LIN: p0 = max terms, p1 = reduce stages;
+                      //                DOT: p0 = max products, p1 = reduce stages, pad = max linear terms)
   uint32_t desc_off;  // word offset of this step's descriptors
   uint32_t stride;    // words per lane descriptor
   uint32_t pad;
@@ -42,6 +45,12 @@ static const uint32_t OP_CONST = 0x2000;
 static const uint32_t OP_MODE_SHIFT = 14;   // second operand of MUL: 0 none, 1 add, 2 sub ; LIN term: 1 = negative
 static const int MAX_LIN_TERMS = 14;   // header word + 7 words of 2 terms (stride 8)
 static const int MAX_BUFS = 8;
+// K_DOT lane descriptor: w0 = dst | k<<16 | L<<20 | m<<24 | halve<<27 ; w1 reserved ; w2,w3 = 4 linear terms (u16: slot|const|neg<<14)
+//   then per product 2 words: (a0 | a1<<16), (b0 | b1<<16); operand u16 = slot | const<<13 | neg<<14 | present<<15 (a1/b1 only)
+static const int MAX_DOT_PRODUCTS = 8;
+static const int MAX_DOT_LINEAR = 4;
+static const uint32_t OP_NEG = 0x4000;
+static const uint32_t OP_PRESENT = 0x8000;
 
 struct IOBuf { uint8_t* ptr; uint64_t stride; };
 

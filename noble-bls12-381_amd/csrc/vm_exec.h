@@ -88,6 +88,78 @@ NBLS_HD void pre_add(u32* A, const u32* a1, u32 mode) {
   for (int i = 0; i < 12; i++) A[i] = addc(A[i], P2[i] & mask, c, &c);
 }
 
+// operand of a DOT product: (+-x) or (+-x +- y), plus 2p per negated term; result in (0, 4p)
+template <typename LDSP>
+NBLS_HD void dot_operand(u32* A, u32 enc, LDSP lds, u32 inst) {
+  const u32 P2[12] = NBLS_2P32;
+  const u32 e0 = enc & 0xffff, e1 = enc >> 16;
+  const u32 o0 = ((e0 & OP_CONST) ? 0u : inst) + (e0 & OP_SLOT_MASK) * 12u;
+#pragma unroll
+  for (int i = 0; i < 12; i++) A[i] = lds[o0 + i];
+  if ((enc & (OP_NEG | (OP_PRESENT << 16))) == 0) return;   // plain slot: the common case
+  if (e0 & OP_NEG) {   // 2p - x
+    u32 br = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) A[i] = subb(P2[i], A[i], br, &br);
+  }
+  if (e1 & OP_PRESENT) {
+    const u32 o1 = ((e1 & OP_CONST) ? 0u : inst) + (e1 & OP_SLOT_MASK) * 12u;
+    u32 m1 = (e1 & OP_NEG) ? 0xffffffffu : 0u, c = m1 & 1u;
+#pragma unroll
+    for (int i = 0; i < 12; i++) A[i] = addc(A[i], lds[o1 + i] ^ m1, c, &c);
+    if (m1) {
+      c = 0;
+#pragma unroll
+      for (int i = 0; i < 12; i++) A[i] = addc(A[i], P2[i], c, &c);
+    }
+  }
+}
+
+// acc (25 words) += a * b  (full 24-word product, then one 25-word addition)
+NBLS_HD void wide_mac(u32* acc, const u32* a, const u32* b) {
+  u32 t[24];
+#pragma unroll
+  for (int i = 0; i < 24; i++) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    u32 lo[12], hi[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) { u64 x = (u64)a[j] * b[i] + t[i + j]; lo[j] = (u32)x; hi[j] = (u32)(x >> 32); }
+    u32 c = 0;
+    t[i] = lo[0];
+#pragma unroll
+    for (int j = 1; j < 12; j++) t[i + j] = addc(lo[j], hi[j - 1], c, &c);
+    t[i + 12] = hi[11] + c;   // fresh word: the partial product of rows 0..i is < 2^(32(i+13))
+  }
+  u32 c = 0;
+#pragma unroll
+  for (int i = 0; i < 24; i++) acc[i] = addc(acc[i], t[i], c, &c);
+  acc[24] += c;
+}
+
+// Montgomery reduction of a 25-word accumulator V: r (13 words) = V / R mod-ish, r < V/R + p
+NBLS_HD void wide_redc(u32* r, u32* acc) {
+  const u32 P[12] = NBLS_P32;
+  u32 carry = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    u32 m = acc[i] * NBLS_N0INV;
+    u32 lo[12], hi[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) { u64 x = (u64)m * P[j] + acc[i + j]; lo[j] = (u32)x; hi[j] = (u32)(x >> 32); }
+    u32 c = 0;
+#pragma unroll
+    for (int j = 1; j < 12; j++) acc[i + j] = addc(lo[j], hi[j - 1], c, &c);
+    u32 c1, c2;
+    u32 w = addc(acc[i + 12], hi[11], c, &c1);
+    acc[i + 12] = addc(w, carry, 0, &c2);
+    carry = c1 + c2;
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) r[i] = acc[12 + i];
+  r[12] = acc[24] + carry;
+}
+
 NBLS_HD u32 bswap32(u32 x) { return (x >> 24) | ((x >> 8) & 0xff00u) | ((x << 8) & 0xff0000u) | (x << 24); }
 
 NBLS_HD bool is_zero_mod_p(const u32* x) {   // x in [0,2p)
@@ -127,7 +199,8 @@ NBLS_HD void ld12(u32* x, LDSP lds, u32 off) {
 }
 
 template <typename LDSP>
-NBLS_HD u32 exec_lane(const Step& st, const u32* d /* 8 descriptor words, already loaded */, LDSP lds, const LaneCtx& cx, const IOBuf* bufs, u32* res) {
+NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, already loaded */, const u32* __restrict__ gd /* this lane's descriptor in global memory */,
+                      LDSP lds, const LaneCtx& cx, const IOBuf* bufs, u32* res) {
   const u32 P[12] = NBLS_P32;
   const u32 P2[12] = NBLS_2P32;
   switch (st.kind) {
@@ -141,6 +214,79 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* 8 descriptor words, alread
       mont_mul12(res, A, B);
       csub<12>(res, P2);
       return slot_addr(w2 & 0xffff, cx.inst);
+    }
+    case K_DOT: {
+      const u32 w0 = d[0];
+      const u32 k = (w0 >> 16) & 0xf, L = (w0 >> 20) & 0xf, mult = (w0 >> 24) & 0x7;
+      u32 r[13];
+      if (st.p0 > 0) {   // uniform
+        u32 acc[25];
+#pragma unroll
+        for (int i = 0; i < 25; i++) acc[i] = 0;
+        u32 na = d[4], nb = d[5];
+        for (u32 i = 0; i < st.p0; i++) {   // uniform trip count; next product's operand words are fetched ahead
+          const u32 ea = na, eb = nb;
+          if (i + 1 < st.p0) { na = gd[6 + 2 * i]; nb = gd[7 + 2 * i]; }
+          if (i < k) {
+            u32 A[12], B[12];
+            dot_operand(A, ea, lds, cx.inst);
+            dot_operand(B, eb, lds, cx.inst);
+            wide_mac(acc, A, B);
+          }
+        }
+        wide_redc(r, acc);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 13; i++) r[i] = 0;
+      }
+      if (mult > 1) {   // m * dot, m <= 4
+        u32 t[13];
+#pragma unroll
+        for (int i = 0; i < 13; i++) t[i] = r[i];
+        for (u32 j = 1; j < mult; j++) {
+          u32 c = 0;
+#pragma unroll
+          for (int i = 0; i < 13; i++) r[i] = addc(r[i], t[i], c, &c);
+        }
+      }
+      u32 nneg = 0;
+#pragma unroll
+      for (int t = 0; t < MAX_DOT_LINEAR; t++) {
+        if (t < (int)st.pad) {   // uniform
+          u32 term = (d[2 + t / 2] >> (16 * (t & 1))) & 0xffff;
+          if ((u32)t < L) {
+            u32 neg = (term >> OP_MODE_SHIFT) & 1, mask = neg ? 0xffffffffu : 0u, c = neg;
+            u32 X[12];
+            ld12(X, lds, slot_addr(term, cx.inst));
+#pragma unroll
+            for (int i = 0; i < 12; i++) r[i] = addc(r[i], X[i] ^ mask, c, &c);
+            r[12] = r[12] + mask + c;
+            nneg += neg;
+          }
+        }
+      }
+      if (st.pad > 0) {
+        u32 c = 0, off = cx.pm2 + nneg * 16;
+#pragma unroll
+        for (int i = 0; i < 13; i++) r[i] = addc(r[i], lds[off + i], c, &c);
+      }
+      for (int s = (int)st.p1 - 1; s >= 0; s--) {
+        u32 M[13], off = cx.pm2 + (16u << s);
+#pragma unroll
+        for (int i = 0; i < 13; i++) M[i] = lds[off + i];
+        csub<13>(r, M);
+      }
+      if (w0 & (1u << 27)) {   // halve
+        u32 mask = (r[0] & 1) ? 0xffffffffu : 0u, c = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) r[i] = addc(r[i], P[i] & mask, c, &c);
+#pragma unroll
+        for (int i = 0; i < 11; i++) r[i] = (r[i] >> 1) | (r[i + 1] << 31);
+        r[11] >>= 1;
+      }
+#pragma unroll
+      for (int i = 0; i < 12; i++) res[i] = r[i];
+      return slot_addr(w0 & 0xffff, cx.inst);
     }
     case K_LIN: {
       const u32* w = d;

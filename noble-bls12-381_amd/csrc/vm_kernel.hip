@@ -42,7 +42,7 @@ extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel(KernelArgs ka) {
     if (lane_in < st.nlanes) {
       u32 d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
       u32 res[12];
-      u32 dst = exec_lane(st, d, smem, cx, ka.bufs, res);
+      u32 dst = exec_lane(st, d, ka.descs + st.desc_off + lane_in * st.stride, smem, cx, ka.bufs, res);
       if (dst != 0xffffffffu) {
 #pragma unroll
         for (int i = 0; i < 12; i++) smem[dst + i] = res[i];

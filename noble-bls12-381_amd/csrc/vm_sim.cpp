@@ -31,8 +31,9 @@ static void sim_run(const Program& p, unsigned n_items, const IOBuf* bufs) {
         LaneCtx cx; cx.pm2 = p.nconst * 12; cx.inst = shared + inst * p.slots * 12; cx.item = blk * p.G + inst; cx.live = cx.item < n_items;
         Pending pd;
         u32 dw[8] = {0};
-        memcpy(dw, p.descs.data() + st.desc_off + lane_in * st.stride, st.stride * 4);
-        pd.dst = exec_lane(st, dw, lds.data(), cx, bufs, pd.v);
+        const u32* gd = p.descs.data() + st.desc_off + lane_in * st.stride;
+        memcpy(dw, gd, (st.stride < 8 ? st.stride : 8) * 4);
+        pd.dst = exec_lane(st, dw, gd, lds.data(), cx, bufs, pd.v);
         if (pd.dst != 0xffffffffu) pend.push_back(pd);
       }
       for (auto& pd : pend) memcpy(&lds[pd.dst], pd.v, 48);

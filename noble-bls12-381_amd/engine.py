@@ -108,7 +108,7 @@ class Engine:
     def program_stats(self, name):
         o = (C.c_uint32 * 8)()
         self._chk(self.lib.nbls_program_stats(self.h, PROGRAMS.index(name), o))
-        keys = ['steps', 'mul_steps', 'lin_steps', 'mul_ops', 'lin_ops', 'lin_terms', 'slots', 'lds_bytes']
+        keys = ['steps', 'dot_steps', 'lin_steps', 'dot_ops', 'products', 'lin_ops', 'slots', 'lds_bytes']
         return dict(zip(keys, list(o)))
 
     def timing_enable(self, on=True):
