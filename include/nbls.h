@@ -32,6 +32,7 @@ typedef struct nbls_ctx nbls_ctx;
 #define NBLS_EHIP (-2)        /* HIP runtime error (nbls_last_hip_error) */
 #define NBLS_ENOSUP (-3)      /* not implemented in this build */
 #define NBLS_ENOGPU (-4)      /* no usable gfx950 device */
+#define NBLS_EDECODE (-5)     /* an input point failed to decode where the reference throws (see per-item status) */
 
 /* Create / destroy an engine context on HIP device `device_id` (compiles the step programs, uploads them). */
 int nbls_init(int device_id, nbls_ctx** out);
@@ -61,11 +62,37 @@ int nbls_final_exp_batch_dev(nbls_ctx* ctx, size_t n, const void* d_in_fp12, voi
  * 576 wire bytes on the device (one per rank; ranks exchange them and finish with nbls_fp12_product_final_dev). */
 int nbls_fp12_product_final_dev(nbls_ctx* ctx, size_t n, const void* d_in_fp12, int final_exp, void* d_out_fp12, void* stream);
 
+/* P.assertValidity() for affine points -- reference index.ts:383-388 (G1), 633-638 (G2): status 0 / 2 / 3. */
+int nbls_g1_validate_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, int8_t* status);
+int nbls_g2_validate_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, int8_t* status);
+
+/* PointG1.fromHex for 48-byte compressed keys (index.ts:298-327) and PointG2.fromSignature for 96-byte compressed
+ * signatures (index.ts:500-530): affine output + status (0 ok, 1 zero point, 3 not in subgroup, 4 no square root). */
+int nbls_g1_decompress_batch(nbls_ctx* ctx, size_t n, const uint8_t* in48, uint8_t* out96, int8_t* status);
+int nbls_g2_decompress_batch(nbls_ctx* ctx, size_t n, const uint8_t* in96, uint8_t* out192, int8_t* status);
+
+/* PointG2.hashToCurve(msg, {DST}) for n messages (index.ts:481-490): msgs are concatenated, message i = msgs[offsets[i] ..
+ * offsets[i+1]); SHA-256 expand_message_xmd runs on the host cores, everything after it on the GPU. */
+int nbls_hash_to_g2_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len, uint8_t* out192);
+
+/* Sum of n affine points: the reduce step of aggregatePublicKeys / aggregateSignatures (index.ts:771-788). *status = 1 when
+ * the sum is the zero point (output then all-zero). */
+int nbls_g1_sum(nbls_ctx* ctx, size_t n, const uint8_t* pts96, uint8_t* out96, int8_t* status);
+int nbls_g2_sum(nbls_ctx* ctx, size_t n, const uint8_t* pts192, uint8_t* out192, int8_t* status);
+
+/* verifyBatch(signature, messages, publicKeys) on wire inputs -- reference index.ts:792-821 with every message distinct.
+ * *ok = 1/0; returns NBLS_EDECODE where the reference throws while decoding its arguments. */
+int nbls_verify_batch(nbls_ctx* ctx, size_t n, const uint8_t* sig96, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
+                      const uint8_t* dst, size_t dst_len, int* ok);
+/* Same, inputs already in HBM: signature, 256-byte expand_message_xmd outputs, compressed keys.  Synchronises (returns *ok). */
+int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_sig96, const void* d_uniform256, const void* d_pk48, int* ok,
+                                 int8_t* pk_status /* n, may be NULL */, void* stream);
+
 /* Introspection for the benchmark / tests. */
 int nbls_program_stats(nbls_ctx* ctx, int prog, uint32_t* out8);   /* steps, mul_steps, lin_steps, mul_ops, lin_ops, lin_terms, slots, lds_bytes */
 int nbls_device_synchronize(nbls_ctx* ctx);
 /* Per-kernel HIP-event timing (benchmark roofline leg): ms[i]/counts[i] for program i, last entry = inversion kernel. */
-#define NBLS_N_PROGRAMS 12
+#define NBLS_N_PROGRAMS 33
 int nbls_timing_enable(nbls_ctx* ctx, int on);
 int nbls_timing_read(nbls_ctx* ctx, float* ms /*[NBLS_N_PROGRAMS+1]*/, uint32_t* counts /*[NBLS_N_PROGRAMS+1]*/);
 

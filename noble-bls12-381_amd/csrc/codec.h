@@ -1,0 +1,166 @@
+// codec.h -- symbolic restatements of the reference's point decoders and hash-to-G2 map (everything between the
+// wire bytes and an affine curve point), for the wave VM.  Data-dependent choices are expressed with flag / select lane-ops.
+#pragma once
+#include "curve.h"
+
+namespace nbls {
+
+static inline SFp2 select2(const SFp& f, const SFp2& a, const SFp2& b) { return {select(f, a.c0, b.c0), select(f, a.c1, b.c1)}; }
+// x (Montgomery form) -> canonical standard integer x/R mod p, for comparisons on the true value
+static inline SFp std_canon(const SFp& x) {
+  Builder* B = Builder::cur();
+  Operand a; a.s0 = materialize(x); Operand b; b.s0 = B->rawone_atom;
+  SFp r; r.f.push_back({PROD_BASE + B->product(a, b), 1});
+  return canon(SFp(materialize(r)));
+}
+// floor(2 v / p) == 1  <=>  v > (p-1)/2      ("(y.value * 2n) / P", index.ts:314, 524-525)
+static inline SFp gt_half(const SFp& v_std) { return cmp_gt(v_std, raw_const(NBLS_HALF_P_RAW)); }
+static inline SFp2 fp2_b() { return {scale(fp_one(), 4), scale(fp_one(), 4)}; }
+static inline SFp2 mul_i(const SFp2& a) { return {-a.c1, a.c0}; }
+
+// ---------------------------------------------------------------- PointG1.fromHex, 48-byte compressed (index.ts:301-315, 325)
+// phase A: x and x^3 + 4;  [kernel: (x^3+4)^((p+1)/4)];  phase B: check, sign, validity
+static inline void g1_decompress_A(int in_buf, int x_buf, int rhs_buf) {
+  SFp z = input_raw(in_buf, 0);
+  SFp x = to_mont(bit_and(z, raw_const(NBLS_MASK381_RAW)));           // x = value mod 2^381 (reduced mod p by the Fp constructor)
+  outputw(x, x_buf, 0);
+  outputw(mul(mat(sqr(x)), x) + scale(fp_one(), 4), rhs_buf, 0);
+}
+static inline void g1_decompress_B(int in_buf, int x_buf, int rhs_buf, int cand_buf, int out_buf, int status_buf) {
+  SFp z = input_raw(in_buf, 0);
+  SFp inf = bit_flag(z, 382), aflag = bit_flag(z, 381);               // bflag / aflag (index.ts:305, 313)
+  SFp x = inputw(x_buf, 0), rhs = inputw(rhs_buf, 0), y = inputw(cand_buf, 0);
+  SFp ok = is_zero(sqr(y) - rhs);                                     // Fp.sqrt: root^2 == a (math.ts:262)
+  SFp flip = f_xor(gt_half(std_canon(y)), aflag);
+  SFp ysel = select(flip, -y, y);
+  SFp oc, sg; g1_validity_flags(x, ysel, oc, sg);
+  SFp not_inf = f_not(inf);
+  status_out({{not_inf, 1}, {ok, 4}, {sg, 3}}, status_buf);
+  SFp good = f_and(f_and(not_inf, ok), sg);
+  output(select(good, x, SFp()), out_buf, 0);
+  output(select(good, ysel, SFp()), out_buf, 48);
+}
+
+// ---------------------------------------------------------------- PointG2.fromSignature, 96-byte compressed (index.ts:500-530)
+static inline void g2_decompress_A(int in_buf, int x_buf, int rhs_buf) {
+  SFp z1 = input_raw(in_buf, 0), z2 = input_raw(in_buf, 48);
+  SFp2 x = {to_mont(z2), to_mont(bit_and(z1, raw_const(NBLS_MASK381_RAW)))};   // x = Fp2(z2, z1 mod 2^381)
+  outputw(x.c0, x_buf, 0); outputw(x.c1, x_buf, 48);
+  SFp2 rhs = mul(mat(sqr(x)), x) + fp2_b();
+  outputw(rhs.c0, rhs_buf, 0); outputw(rhs.c1, rhs_buf, 48);
+}
+// Fp2.sqrt (math.ts:486-507) given cand = a^((p^2+7)/16): returns the chosen root and the `found` flag
+static inline SFp2 fp2_sqrt_finish(const SFp2& a, const SFp2& cand, SFp& found) {
+  SFp2 c2 = mat(sqr(cand));
+  SFp2 ia = mul_i(a);
+  SFp f0 = eq_zero(c2 - a), f1 = eq_zero(c2 - ia), f2 = eq_zero(c2 + a), f3 = eq_zero(c2 + ia);   // cand^2 / a in {1, i, -1, -i}
+  found = f_or(f_or(f0, f1), f_or(f2, f3));
+  SFp2 x1_1 = mat(mul(cand, fp2_const(NBLS_ROOTS8_INV[1]))), x1_2 = mat(mul(cand, fp2_const(NBLS_ROOTS8_INV[2]))), x1_3 = mat(mul(cand, fp2_const(NBLS_ROOTS8_INV[3])));
+  SFp2 x1 = select2(f0, cand, select2(f1, x1_1, select2(f2, x1_2, x1_3)));
+  SFp2 x2 = mat(-x1);
+  SFp re1 = std_canon(x1.c0), im1 = std_canon(x1.c1), re2 = std_canon(x2.c0), im2 = std_canon(x2.c1);
+  SFp choose1 = f_or(cmp_gt(im1, im2), f_and(is_zero(x1.c1), cmp_gt(re1, re2)));     // im1 > im2 || (im1 == im2 && re1 > re2)
+  return select2(choose1, x1, x2);
+}
+static inline void g2_decompress_B(int in_buf, int x_buf, int rhs_buf, int cand_buf, int out_buf, int status_buf) {
+  SFp z1 = input_raw(in_buf, 0);
+  SFp inf = bit_flag(z1, 382), aflag = bit_flag(z1, 381);
+  SFp2 x = {inputw(x_buf, 0), inputw(x_buf, 48)}, rhs = {inputw(rhs_buf, 0), inputw(rhs_buf, 48)}, cand = {inputw(cand_buf, 0), inputw(cand_buf, 48)};
+  SFp found; SFp2 y = fp2_sqrt_finish(rhs, cand, found);
+  SFp y1nz = f_not(is_zero(y.c1));
+  SFp big1 = gt_half(std_canon(y.c1)), big0 = gt_half(std_canon(y.c0));
+  SFp neg = f_or(f_and(y1nz, f_xor(big1, aflag)), f_and(f_not(y1nz), f_xor(big0, aflag)));   // isGreater || isZero (index.ts:524-526)
+  SFp2 ysel = select2(neg, mat(-y), y);
+  SFp oc, sg; g2_validity_flags(x, ysel, oc, sg);
+  SFp not_inf = f_not(inf);
+  status_out({{not_inf, 1}, {found, 4}, {sg, 3}}, status_buf);
+  SFp good = f_and(f_and(not_inf, found), sg);
+  SFp2 zero = fp2_zero();
+  output_fp2(select2(good, x, zero), out_buf, 0);
+  output_fp2(select2(good, ysel, zero), out_buf, 96);
+}
+
+// ---------------------------------------------------------------- hash_to_field tail + SWU + isogeny + cofactor (index.ts:256-263, 481-490)
+// os2ip(64 bytes) mod p: v = top16 * 2^384 + low48  ->  Montgomery form  top16 * R^2 + low48 * R  =  REDC(top16 * R^3 + low48 * R^2)
+static inline SFp field_elem_from_64(int buf, int off) {
+  Builder* B = Builder::cur();
+  Operand t; t.s0 = materialize(input_raw(buf, off, 16)); Operand r3; r3.s0 = B->const_atom(NBLS_R3);
+  Operand l; l.s0 = materialize(input_raw(buf, off + 16, 48)); Operand r2; r2.s0 = B->r2_atom;
+  SFp f; f.f = form_add({{PROD_BASE + B->product(t, r3), 1}}, {{PROD_BASE + B->product(l, r2), 1}}, 1);
+  return SFp(materialize(f));
+}
+struct SwuState { SFp2 t, zt2, num, den, v, u, uv7, uv15; };
+// map_to_curve_simple_swu_9mod16 up to the exponentiation input (math.ts:1220-1241, 1196-1198)
+static inline SwuState swu_prepare(const SFp2& t) {
+  SwuState s; s.t = t;
+  SFp2 Z = fp2_const(NBLS_SWU_Z), A = fp2_const(NBLS_SWU_A), Bc = fp2_const(NBLS_SWU_B);
+  SFp2 t2 = mat(sqr(t));
+  s.zt2 = mat(mul(Z, t2));
+  SFp2 ztzt = mat(s.zt2 + sqr(s.zt2));
+  SFp2 den0 = mat(-mul(A, ztzt));
+  s.num = mat(mul(Bc, ztzt + fp2_one()));
+  SFp dz = eq_zero(den0);
+  s.den = select2(dz, mat(mul(Z, A)), den0);                                  // exceptional case (math.ts:1233)
+  SFp2 den2 = mat(sqr(s.den));
+  s.v = mat(mul(den2, s.den));
+  SFp2 num2 = mat(sqr(s.num));
+  s.u = mat(mul(num2, s.num) + mul(mat(mul(A, s.num)), den2) + mul(Bc, s.v));
+  SFp2 v2 = mat(sqr(s.v)), v4 = mat(sqr(v2)), v3 = mat(mul(v2, s.v)), v7 = mat(mul(v4, v3));
+  s.uv7 = mat(mul(s.u, v7));
+  s.uv15 = mat(mul(s.uv7, mat(mul(v7, s.v))));
+  return s;
+}
+// sgn0_fp2 (math.ts:1179-1185) on Montgomery values
+static inline SFp sgn0(const SFp2& x) {
+  SFp s0 = is_odd(std_canon(x.c0)), z0 = is_zero(x.c0), s1 = is_odd(std_canon(x.c1));
+  return f_or(s0, f_and(z0, s1));
+}
+// rest of map_to_curve_simple_swu_9mod16 (math.ts:1199-1266) given gp = uv15^((p^2-9)/16); returns the point projectively (X : Y : Z) = (num : y den : den)
+static inline Pt<SFp2> swu_finish(const SwuState& s, const SFp2& gp) {
+  SFp2 gamma = mat(mul(gp, s.uv7));
+  SFp ok[4]; SFp2 cand[4];
+  for (int k = 0; k < 4; k++) { cand[k] = k == 0 ? gamma : mat(mul(fp2_const(NBLS_ROOTS8[k]), gamma)); ok[k] = eq_zero(mul(mat(sqr(cand[k])), s.v) - s.u); }
+  SFp success = f_or(f_or(ok[0], ok[1]), f_or(ok[2], ok[3]));
+  SFp2 res = select2(ok[0], cand[0], select2(ok[1], cand[1], select2(ok[2], cand[2], select2(ok[3], cand[3], gamma))));
+  SFp2 t3 = mat(mul(mat(sqr(s.t)), s.t));
+  SFp2 x1c = mat(mul(res, t3));                                               // sqrt_candidate(x1) = sqrt_candidate(x0) * t^3
+  SFp2 zt2_3 = mat(mul(mat(sqr(s.zt2)), s.zt2));
+  SFp2 u2 = mat(mul(zt2_3, s.u));                                             // u(x1) = Z^3 t^6 u(x0)
+  SFp ok2[4]; SFp2 ec[4];
+  for (int k = 0; k < 4; k++) { ec[k] = mat(mul(fp2_const(NBLS_ETAS[k]), x1c)); ok2[k] = eq_zero(mul(mat(sqr(ec[k])), s.v) - u2); }
+  SFp2 y2 = select2(ok2[0], ec[0], select2(ok2[1], ec[1], select2(ok2[2], ec[2], ec[3])));
+  SFp2 y = select2(success, res, y2);
+  SFp2 num = select2(success, s.num, mat(mul(s.num, s.zt2)));                   // success2: numerator *= Z t^2
+  SFp flip = f_xor(sgn0(s.t), sgn0(y));
+  y = select2(flip, mat(-y), y);
+  return pt_mat<SFp2>({num, mul(y, s.den), s.den});
+}
+// isogenyMapG2 (math.ts:1315-1325) on a projective point (X : Y : Z): homogenised Horner evaluation, no inversion
+static inline Pt<SFp2> isogeny_g2_proj(const Pt<SFp2>& p) {
+  SFp2 Z2 = mat(sqr(p.z)), Z3 = mat(mul(Z2, p.z));
+  auto horner = [&](const u32 c[4][2][12]) {
+    // sum_i c[i] X^(3-i) Z^i  (coefficient lists are highest degree first)
+    SFp2 X2 = mat(sqr(p.x)), X3 = mat(mul(X2, p.x));
+    return mat(mul(fp2_const(c[0]), X3) + mul(fp2_const(c[1]), mat(mul(X2, p.z))) + mul(fp2_const(c[2]), mat(mul(p.x, Z2))) + mul(fp2_const(c[3]), Z3));
+  };
+  SFp2 xn = horner(NBLS_ISO_XNUM), xd = horner(NBLS_ISO_XDEN), yn = horner(NBLS_ISO_YNUM), yd = horner(NBLS_ISO_YDEN);
+  // x' = xn/xd, y' = (Y/Z) yn/yd  (all four polynomials carry the same factor Z^3)
+  SFp2 zxd = mat(mul(p.z, xd));
+  return pt_mat<SFp2>({mul(mat(mul(xn, yd)), p.z), mul(mat(mul(p.y, yn)), xd), mul(zxd, yd)});
+}
+static inline Pt<SFp2> psi_proj(const Pt<SFp2>& p) { return pt_mat<SFp2>({mul(conj(p.x), fp2_const(NBLS_PSI_X)), mul(conj(p.y), fp2_const(NBLS_PSI_Y)), conj(p.z)}); }
+static inline Pt<SFp2> psi2_proj(const Pt<SFp2>& p) { return pt_mat<SFp2>({mul_fp(p.x, fp_const(NBLS_PSI2_C1)), -p.y, p.z}); }
+// PointG2.clearCofactor (index.ts:659-672)
+static inline Pt<SFp2> clear_cofactor_g2(const Pt<SFp2>& P) {
+  Pt<SFp2> t1 = pt_neg(pt_mul_u64(P, NBLS_X));           // [-x]P
+  Pt<SFp2> t2 = psi_proj(P);
+  Pt<SFp2> t3 = psi2_proj(pt_dbl(P));
+  t3 = pt_add(t3, pt_neg(t2));
+  t2 = pt_add(t1, t2);
+  t2 = pt_neg(pt_mul_u64(t2, NBLS_X));
+  t3 = pt_add(t3, t2);
+  t3 = pt_add(t3, pt_neg(t1));
+  return pt_add(t3, pt_neg(P));
+}
+
+}  // namespace nbls

@@ -1,0 +1,97 @@
+// curve.h -- G1 / G2 point arithmetic over symbolic field values, for the validity checks, point sums, cofactor clearing.
+// Points that cross the C ABI are affine, so any exact group law reproduces the reference's results; we use the COMPLETE
+// projective formulas of Renes-Costello-Batina (2016, algorithms 7 and 9 for a = 0) because they need no data-dependent
+// branches: both curves (E/Fp and E'/Fp2) have odd order, so the formulas are valid for every pair of inputs including
+// P = Q, P = -Q and the identity (0 : 1 : 0).  The reference's ProjectivePoint.add/double (math.ts:974-1025) branch on those
+// cases instead; the group elements produced are the same.
+#pragma once
+#include "tower.h"
+
+namespace nbls {
+
+static inline SFp mat(const SFp& a) { return SFp(materialize(a)); }
+// b3 = 3b: G1 b = 4, G2 b = 4(1+u)
+static inline SFp mul_b3(const SFp& a) { return scale(a, 12); }
+static inline SFp2 mul_b3(const SFp2& a) { return scale(mulnr(a), 12); }
+static inline SFp f_zero(const SFp*) { return SFp(); }
+static inline SFp2 f_zero(const SFp2*) { return fp2_zero(); }
+static inline SFp f_one(const SFp*) { return fp_one(); }
+static inline SFp2 f_one(const SFp2*) { return fp2_one(); }
+
+template <class F> struct Pt { F x, y, z; };
+template <class F> static inline Pt<F> pt_identity() { return {f_zero((F*)0), f_one((F*)0), f_zero((F*)0)}; }
+template <class F> static inline Pt<F> pt_affine(const F& x, const F& y) { return {x, y, f_one((F*)0)}; }
+template <class F> static inline Pt<F> pt_neg(const Pt<F>& p) { return {p.x, -p.y, p.z}; }
+template <class F> static inline Pt<F> pt_mat(const Pt<F>& p) { return {mat(p.x), mat(p.y), mat(p.z)}; }
+
+// RCB16 algorithm 7 (complete addition, a = 0), regrouped into sums of products
+template <class F> static inline Pt<F> pt_add(const Pt<F>& p, const Pt<F>& q) {
+  F t0 = mat(mul(p.x, q.x)), t1 = mat(mul(p.y, q.y)), t2 = mat(mul(p.z, q.z));
+  F t3 = mat(mul(p.x, q.y) + mul(q.x, p.y));
+  F t4 = mat(mul(p.y, q.z) + mul(q.y, p.z));
+  F ty = mat(mul(p.x, q.z) + mul(q.x, p.z));
+  F b2 = mat(mul_b3(t2));
+  F z3 = mat(t1 + b2), s1 = mat(t1 - b2), y3 = mat(mul_b3(ty)), x0 = mat(scale(t0, 3));
+  return pt_mat<F>({mul(t3, s1) - mul(t4, y3), mul(s1, z3) + mul(y3, x0), mul(z3, t4) + mul(x0, t3)});
+}
+// add-1998-cmo-2 exactly as the reference's ProjectivePoint.add generic branch (math.ts:1008-1024): valid on ANY short
+// Weierstrass curve (no curve coefficient appears), used for the one addition on the isogenous curve E' in hash-to-G2.
+// The equal / opposite / zero branches of the reference (math.ts:1000-1013) are not reproduced: for two independent
+// SWU outputs they are cryptographically unreachable.
+template <class F> static inline Pt<F> pt_add_generic(const Pt<F>& p1, const Pt<F>& p2) {
+  F U1 = mat(mul(p2.y, p1.z)), U2 = mat(mul(p1.y, p2.z)), V1 = mat(mul(p2.x, p1.z)), V2 = mat(mul(p1.x, p2.z));
+  F U = mat(U1 - U2), V = mat(V1 - V2);
+  F VV = mat(sqr(V)), W = mat(mul(p1.z, p2.z));
+  F VVV = mat(mul(VV, V)), V2VV = mat(mul(V2, VV));
+  F A = mat(mul(mat(sqr(U)), W) - VVV - scale(V2VV, 2));
+  return pt_mat<F>({mul(V, A), mul(U, V2VV - A) - mul(VVV, U2), mul(VVV, W)});
+}
+// RCB16 algorithm 9 (complete doubling, a = 0)
+template <class F> static inline Pt<F> pt_dbl(const Pt<F>& p) {
+  F t0 = mat(sqr(p.y)), t1 = mat(mul(p.y, p.z)), t2 = mat(mul_b3(sqr(p.z))), xy = mat(mul(p.x, p.y));
+  F a = mat(t0 - scale(t2, 3)), b = mat(t0 + t2);
+  return pt_mat<F>({scale(mul(a, xy), 2), mul(a, b) + scale(mul(t0, t2), 8), scale(mul(t0, t1), 8)});
+}
+// [k]P for a public 64-bit constant k, MSB-first double-and-add (the reference's multiplyUnsafe, math.ts:1048-1058, is
+// LSB-first; the group element is the same)
+template <class F> static inline Pt<F> pt_mul_u64(const Pt<F>& p, uint64_t k) {
+  Pt<F> r = p; int top = 63; while (top > 0 && !((k >> top) & 1)) top--;
+  for (int i = top - 1; i >= 0; i--) { r = pt_dbl(r); if ((k >> i) & 1) r = pt_add(r, p); }
+  return r;
+}
+// projective equality flags (math.ts:915-927): X1 Z2 == X2 Z1 and Y1 Z2 == Y2 Z1
+static inline SFp eq_zero(const SFp& d) { return is_zero(d); }
+static inline SFp eq_zero(const SFp2& d) { return f_and(is_zero(d.c0), is_zero(d.c1)); }
+template <class F> static inline SFp pt_equal(const Pt<F>& a, const Pt<F>& b) {
+  return f_and(eq_zero(mul(a.x, b.z) - mul(b.x, a.z)), eq_zero(mul(a.y, b.z) - mul(b.y, a.z)));
+}
+static inline SFp pt_is_identity(const Pt<SFp>& a) { return is_zero(a.z); }
+static inline SFp pt_is_identity(const Pt<SFp2>& a) { return eq_zero(a.z); }
+
+// ---- reference validity checks on affine inputs
+// PointG1.isOnCurve / isTorsionFree (index.ts:408-448): y^2 = x^3 + 4 ;  -[x^2]P == phi(P), phi(x,y) = (beta x, y)
+static inline void g1_validity_flags(const SFp& x, const SFp& y, SFp& on_curve, SFp& in_subgroup) {
+  SFp x2 = mat(sqr(x));
+  on_curve = is_zero(sqr(y) - mul(x2, x) - scale(fp_one(), 4));
+  Pt<SFp> P = pt_affine(x, y);
+  Pt<SFp> xP = pt_neg(pt_mul_u64(P, NBLS_X));           // mulCurveX
+  Pt<SFp> u2P = pt_mul_u64(xP, NBLS_X);                 // mulCurveMinusX
+  Pt<SFp> phi = pt_affine(mat(mul(x, fp_const(NBLS_BETA))), y);
+  in_subgroup = pt_equal(u2P, phi);
+}
+// psi on an affine point (math.ts:1398-1403), reduced to conj(x) * PSI_X, conj(y) * PSI_Y (tools/gen_consts.py)
+static inline void psi_affine(const SFp2& x, const SFp2& y, SFp2& px, SFp2& py) {
+  px = mat(mul(conj(x), fp2_const(NBLS_PSI_X))); py = mat(mul(conj(y), fp2_const(NBLS_PSI_Y)));
+}
+// PointG2.isOnCurve / isTorsionFree (index.ts:675-690): y^2 = x^3 + 4(1+u) ;  [-x]P == psi(P)
+static inline void g2_validity_flags(const SFp2& x, const SFp2& y, SFp& on_curve, SFp& in_subgroup) {
+  SFp2 x2 = mat(sqr(x));
+  SFp2 four = {scale(fp_one(), 4), scale(fp_one(), 4)};
+  on_curve = eq_zero(sqr(y) - mul(x2, x) - four);
+  Pt<SFp2> P = pt_affine(x, y);
+  Pt<SFp2> xP = pt_neg(pt_mul_u64(P, NBLS_X));
+  SFp2 px, py; psi_affine(x, y, px, py);
+  in_subgroup = pt_equal(xP, pt_affine(px, py));
+}
+
+}  // namespace nbls

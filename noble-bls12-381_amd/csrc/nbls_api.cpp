@@ -10,9 +10,12 @@
 #include "programs.h"
 #include "consts_gen.h"
 #include "fp_inv.h"
+#include "sha256.h"
+#include <thread>
 
 extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream);
 extern "C" int nbls_fp_inv_launch(unsigned n, const void* in, void* out, const void* table, void* stream);
+extern "C" int nbls_fp_pow_launch(unsigned n, const void* in, void* out, const void* nibbles, int nnib, void* scratch, int is_fp2, void* stream);
 
 using namespace nbls;
 
@@ -31,6 +34,12 @@ struct nbls_ctx {
   // scratch (device)
   uint8_t *F = nullptr, *F2 = nullptr, *N = nullptr, *NI = nullptr, *io_g1 = nullptr, *io_g2 = nullptr, *io_f12 = nullptr, *one12 = nullptr, *inv_table = nullptr;
   uint8_t* T[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // t1..t7 of the final exponentiation, raw Fp12
+  // general scratch pool for the codec / hash / sum pipelines (grown on demand)
+  static const int NSB = 12;
+  uint8_t* sb[NSB] = {nullptr}; size_t sb_cap[NSB] = {0};
+  uint8_t* nib[3] = {nullptr, nullptr, nullptr}; int nnib[3] = {0, 0, 0};   // exponent nibbles: (p+1)/4, (p^2+7)/16, (p^2-9)/16
+  uint8_t* neg_g1 = nullptr;    // -G1 generator, affine wire bytes (verify: e(-G, S))
+  uint8_t* ident_g1 = nullptr; uint8_t* ident_g2 = nullptr;   // projective identity (0 : 1 : 0), raw
   size_t cap_F = 0, cap_io = 0;
   int last_hip = 0;
   // optional per-kernel timing (HIP events on the launch stream); slot P_COUNT = inversion kernel
@@ -102,6 +111,30 @@ static int ensure_io(nbls_ctx* ctx, size_t n) {
   return NBLS_OK;
 }
 
+static int need(nbls_ctx* ctx, int i, size_t bytes, uint8_t** out) {
+  if (bytes > ctx->sb_cap[i]) {
+    if (ctx->sb[i]) hipFree(ctx->sb[i]);
+    ctx->sb[i] = nullptr; ctx->sb_cap[i] = 0;
+    size_t cap = bytes + bytes / 8 + 4096;
+    HIPCHK(hipMalloc(&ctx->sb[i], cap));
+    ctx->sb_cap[i] = cap;
+  }
+  *out = ctx->sb[i];
+  return NBLS_OK;
+}
+static int run_pow(nbls_ctx* ctx, int which, size_t n, const void* in, void* out, hipStream_t s) {
+  int is_fp2 = which != 0;
+  uint8_t* scratch; int r = need(ctx, 11, n * 16 * (is_fp2 ? 96 : 48), &scratch); if (r) return r;
+  int e = nbls_fp_pow_launch((unsigned)n, in, out, ctx->nib[which], ctx->nnib[which], scratch, is_fp2, s);
+  if (e) { ctx->last_hip = e; return NBLS_EHIP; }
+  return NBLS_OK;
+}
+static int run_inv_buf(nbls_ctx* ctx, size_t n, const void* in, void* out, hipStream_t s) {
+  int e = nbls_fp_inv_launch((unsigned)n, in, out, ctx->inv_table, s);
+  if (e) { ctx->last_hip = e; return NBLS_EHIP; }
+  return NBLS_OK;
+}
+
 typedef std::pair<int, std::pair<const void*, size_t>> BufArg;
 static inline BufArg B(int idx, const void* p, size_t stride) { return {idx, {p, stride}}; }
 
@@ -156,6 +189,24 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
     std::vector<u32> tab(382 * 12); make_inv_table(tab.data());
     if (hipMalloc(&ctx->inv_table, tab.size() * 4) != hipSuccess || hipMemcpy(ctx->inv_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   }
+  {
+    const uint64_t* exps[3] = {NBLS_EXP_P_PLUS_1_DIV_4, NBLS_EXP_P2_PLUS_7_DIV_16, NBLS_EXP_P2_MINUS_9_DIV_16};
+    const int bits[3] = {NBLS_P_PLUS_1_DIV_4_BITS, NBLS_P2_PLUS_7_DIV_16_BITS, NBLS_P2_MINUS_9_DIV_16_BITS};
+    for (int k = 0; k < 3; k++) {
+      int nn = (bits[k] + 3) / 4; std::vector<uint8_t> nb(nn);
+      for (int j = 0; j < nn; j++) { int lo = 4 * (nn - 1 - j); uint8_t d = 0; for (int b = 3; b >= 0; b--) { int bit = lo + b; d = (uint8_t)((d << 1) | (bit < bits[k] ? (exps[k][bit >> 6] >> (bit & 63)) & 1 : 0)); } nb[j] = d; }
+      ctx->nnib[k] = nn;
+      if (hipMalloc(&ctx->nib[k], nn) != hipSuccess || hipMemcpy(ctx->nib[k], nb.data(), nn, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
+    }
+    // -G1 in wire form: x || (p - y)   (standard integers, big-endian)
+    uint8_t ng[96];
+    auto be = [](uint8_t* o, const u32* w) { for (int i = 0; i < 12; i++) { u32 v = w[11 - i]; o[4 * i] = v >> 24; o[4 * i + 1] = v >> 16; o[4 * i + 2] = v >> 8; o[4 * i + 3] = v; } };
+    be(ng, NBLS_G1X_RAW); be(ng + 48, NBLS_NEG_G1Y_RAW);
+    u32 id1[36] = {0}, id2[72] = {0}; memcpy(id1 + 12, NBLS_R1, 48); memcpy(id2 + 24, NBLS_R1, 48);
+    if (hipMalloc(&ctx->neg_g1, 96) != hipSuccess || hipMemcpy(ctx->neg_g1, ng, 96, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc(&ctx->ident_g1, 144) != hipSuccess || hipMemcpy(ctx->ident_g1, id1, 144, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc(&ctx->ident_g2, 288) != hipSuccess || hipMemcpy(ctx->ident_g2, id2, 288, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
+  }
   for (int i = 0; i < P_COUNT; i++) { int r = upload(ctx, (ProgId)i); if (r) { int e = ctx->last_hip; (void)e; nbls_destroy(ctx); return r; } }
   *out = ctx;
   return NBLS_OK;
@@ -167,6 +218,9 @@ EXPORT void nbls_destroy(nbls_ctx* ctx) {
   for (auto& d : ctx->prog) { if (d.steps) hipFree(d.steps); if (d.descs) hipFree(d.descs); if (d.consts) hipFree(d.consts); }
   for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->inv_table}) if (p) hipFree(p);
   for (uint8_t* p : ctx->T) if (p) hipFree(p);
+  for (uint8_t* p : ctx->sb) if (p) hipFree(p);
+  for (uint8_t* p : ctx->nib) if (p) hipFree(p);
+  for (uint8_t* p : {ctx->neg_g1, ctx->ident_g1, ctx->ident_g2}) if (p) hipFree(p);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -178,6 +232,7 @@ EXPORT const char* nbls_strerror(int code) {
     case NBLS_EHIP: return "HIP runtime error";
     case NBLS_ENOSUP: return "not supported in this build";
     case NBLS_ENOGPU: return "no usable GPU";
+    case NBLS_EDECODE: return "input point failed to decode";
     default: return "unknown error";
   }
 }
@@ -199,9 +254,13 @@ EXPORT int nbls_pairing_batch_dev(nbls_ctx* ctx, size_t n, const void* d_g1, con
 
 EXPORT int nbls_pairing_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2, int with_final_exp, int validate, uint8_t* out, int8_t* status) {
   if (!ctx || (n && (!g1 || !g2 || !out))) return NBLS_EINVAL;
-  if (validate) return NBLS_ENOSUP;
   if (n == 0) return NBLS_OK;
   int r;
+  std::vector<int8_t> st1, st2;
+  if (validate) {   // P.assertValidity(); Q.assertValidity()  (index.ts:717-718)
+    st1.resize(n); st2.resize(n);
+    if ((r = nbls_g1_validate_batch(ctx, n, g1, st1.data())) || (r = nbls_g2_validate_batch(ctx, n, g2, st2.data()))) return r;
+  }
   {
     std::lock_guard<std::mutex> g(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
@@ -214,6 +273,10 @@ EXPORT int nbls_pairing_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1, const 
   HIPCHK(hipMemcpyAsync(out, ctx->io_f12, n * 576, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (status) memset(status, 0, n);
+  if (validate) for (size_t i = 0; i < n; i++) {
+    int8_t c = st1[i] ? st1[i] : (st2[i] ? (int8_t)(10 + st2[i]) : 0);
+    if (c) { memset(out + 576 * i, 0, 576); if (status) status[i] = c; }
+  }
   return NBLS_OK;
 }
 
@@ -235,8 +298,13 @@ EXPORT int nbls_miller_product_dev(nbls_ctx* ctx, size_t n, const void* d_g1, co
 
 EXPORT int nbls_miller_product(nbls_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2, int final_exp, int validate, uint8_t* out, int8_t* status) {
   if (!ctx || !out || (n && (!g1 || !g2))) return NBLS_EINVAL;
-  if (validate) return NBLS_ENOSUP;
   int r;
+  if (validate && n) {
+    std::vector<int8_t> st1(n), st2(n); bool bad = false;
+    if ((r = nbls_g1_validate_batch(ctx, n, g1, st1.data())) || (r = nbls_g2_validate_batch(ctx, n, g2, st2.data()))) return r;
+    for (size_t i = 0; i < n; i++) { int8_t c = st1[i] ? st1[i] : (st2[i] ? (int8_t)(10 + st2[i]) : 0); if (status) status[i] = c; bad = bad || c; }
+    if (bad) { memset(out, 0, 576); return NBLS_EDECODE; }
+  }
   {
     std::lock_guard<std::mutex> g(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
@@ -330,5 +398,177 @@ EXPORT int nbls_timing_read(nbls_ctx* ctx, float* ms, uint32_t* counts) {
     hipEventDestroy(t.second.first); hipEventDestroy(t.second.second);
   }
   ctx->tev.clear();
+  return NBLS_OK;
+}
+
+// ================================================================================================================
+// Validity, decoders, hash-to-G2, point sums, verifyBatch.  Device-side pipelines (dev_*) work on device pointers and
+// enqueue on `s`; the exported wrappers stage host buffers.
+// ================================================================================================================
+static int dev_validate(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, void* d_status, hipStream_t s) {
+  return g2 ? run(ctx, P_G2_VALIDATE, n, {B(1, d_pts, 192), B(7, d_status, 1)}, s) : run(ctx, P_G1_VALIDATE, n, {B(0, d_pts, 96), B(7, d_status, 1)}, s);
+}
+// PointG1.fromHex (48 B) / PointG2.fromSignature (96 B): compressed -> affine wire bytes + status
+static int dev_decompress(nbls_ctx* ctx, bool g2, size_t n, const void* d_in, void* d_out, void* d_status, hipStream_t s) {
+  const size_t e = g2 ? 96 : 48;
+  uint8_t *X, *R, *Cd; int r;
+  if ((r = need(ctx, 0, n * e, &X)) || (r = need(ctx, 1, n * e, &R)) || (r = need(ctx, 2, n * e, &Cd))) return r;
+  if ((r = run(ctx, g2 ? P_G2_DEC_A : P_G1_DEC_A, n, {B(0, d_in, e), B(3, X, e), B(4, R, e)}, s))) return r;
+  if ((r = run_pow(ctx, g2 ? 1 : 0, n, R, Cd, s))) return r;
+  return run(ctx, g2 ? P_G2_DEC_B : P_G1_DEC_B, n, {B(0, d_in, e), B(3, X, e), B(4, R, e), B(5, Cd, e), B(6, d_out, 2 * e), B(7, d_status, 1)}, s);
+}
+// 256 uniform bytes per message (expand_message_xmd output) -> hash point, affine wire bytes (PointG2.hashToCurve, index.ts:481-490)
+static int dev_hash_to_g2(nbls_ctx* ctx, size_t n, const void* d_uniform, void* d_out, hipStream_t s) {
+  uint8_t *T, *E, *Pw, *Q, *N, *NI, *st; int r;
+  if ((r = need(ctx, 0, n * 192, &T)) || (r = need(ctx, 1, n * 192, &E)) || (r = need(ctx, 2, n * 192, &Pw)) || (r = need(ctx, 3, n * 288, &Q)) ||
+      (r = need(ctx, 4, n * 48, &N)) || (r = need(ctx, 5, n * 48, &NI)) || (r = need(ctx, 6, n, &st))) return r;
+  if ((r = run(ctx, P_H2C_A, n, {B(0, d_uniform, 256), B(3, T, 192), B(4, E, 192)}, s))) return r;
+  if ((r = run_pow(ctx, 2, 2 * n, E, Pw, s))) return r;
+  if ((r = run(ctx, P_H2C_B, n, {B(3, T, 192), B(5, Pw, 192), B(6, Q, 288), B(7, N, 48)}, s))) return r;
+  if ((r = run_inv_buf(ctx, n, N, NI, s))) return r;
+  return run(ctx, P_G2_TO_AFFINE, n, {B(3, Q, 288), B(4, NI, 48), B(2, d_out, 192), B(7, st, 1)}, s);
+}
+// sum of n affine points (left fold of add == tree of complete additions): affine wire bytes + status (1 = sum is the zero point)
+static int dev_point_sum(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, void* d_out, void* d_status, hipStream_t s) {
+  const size_t a = g2 ? 192 : 96, p = g2 ? 288 : 144;
+  uint8_t *A, *Bf, *N, *NI; int r;
+  if ((r = need(ctx, 0, (n + 2) * p, &A)) || (r = need(ctx, 1, (n / 2 + 2) * p, &Bf)) || (r = need(ctx, 4, 48, &N)) || (r = need(ctx, 5, 48, &NI))) return r;
+  uint8_t* ident = g2 ? ctx->ident_g2 : ctx->ident_g1;
+  if (n == 0) { HIPCHK(hipMemcpyAsync(A, ident, p, hipMemcpyDeviceToDevice, s)); }
+  else if ((r = run(ctx, g2 ? P_G2_TO_PROJ : P_G1_TO_PROJ, n, {B(g2 ? 1 : 0, d_pts, a), B(3, A, p)}, s))) return r;
+  uint8_t *src = A, *dst = Bf; size_t m = n ? n : 1;
+  while (m > 1) {
+    if (m & 1) { HIPCHK(hipMemcpyAsync(src + m * p, ident, p, hipMemcpyDeviceToDevice, s)); m++; }
+    if ((r = run(ctx, g2 ? P_G2_ADD2 : P_G1_ADD2, m / 2, {B(3, src, 2 * p), B(5, dst, p)}, s))) return r;
+    std::swap(src, dst); m /= 2;
+  }
+  if ((r = run(ctx, g2 ? P_G2_NORM : P_G1_NORM, 1, {B(3, src, p), B(4, N, 48)}, s))) return r;
+  if ((r = run_inv_buf(ctx, 1, N, NI, s))) return r;
+  return run(ctx, g2 ? P_G2_TO_AFFINE : P_G1_TO_AFFINE, 1, {B(3, src, p), B(4, NI, 48), B(2, d_out, a), B(7, d_status, 1)}, s);
+}
+
+// ---- host-buffer wrappers ------------------------------------------------------------------------------------
+struct HostIO {   // staging buffers on the device for one call
+  nbls_ctx* ctx; std::vector<void*> bufs;
+  ~HostIO() { for (void* p : bufs) hipFree(p); }
+  void* alloc(size_t n) { void* p = nullptr; if (hipMalloc(&p, n ? n : 1) != hipSuccess) return nullptr; bufs.push_back(p); return p; }
+};
+#define LOCKED(ctx) std::lock_guard<std::mutex> g_((ctx)->mu); HIPCHK(hipSetDevice((ctx)->device)); hipStream_t s = (ctx)->stream
+
+EXPORT int nbls_g1_validate_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, int8_t* status) {
+  if (!ctx || (n && (!g1_aff || !status))) return NBLS_EINVAL; if (!n) return NBLS_OK;
+  LOCKED(ctx); HostIO io{ctx}; void *d = io.alloc(n * 96), *st = io.alloc(n); if (!d || !st) return NBLS_EHIP;
+  HIPCHK(hipMemcpyAsync(d, g1_aff, n * 96, hipMemcpyHostToDevice, s));
+  int r = dev_validate(ctx, false, n, d, st, s); if (r) return r;
+  HIPCHK(hipMemcpyAsync(status, st, n, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); return NBLS_OK;
+}
+EXPORT int nbls_g2_validate_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, int8_t* status) {
+  if (!ctx || (n && (!g2_aff || !status))) return NBLS_EINVAL; if (!n) return NBLS_OK;
+  LOCKED(ctx); HostIO io{ctx}; void *d = io.alloc(n * 192), *st = io.alloc(n); if (!d || !st) return NBLS_EHIP;
+  HIPCHK(hipMemcpyAsync(d, g2_aff, n * 192, hipMemcpyHostToDevice, s));
+  int r = dev_validate(ctx, true, n, d, st, s); if (r) return r;
+  HIPCHK(hipMemcpyAsync(status, st, n, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); return NBLS_OK;
+}
+static int decompress_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* in, uint8_t* out, int8_t* status) {
+  if (!ctx || (n && (!in || !out))) return NBLS_EINVAL; if (!n) return NBLS_OK;
+  const size_t e = g2 ? 96 : 48;
+  LOCKED(ctx); HostIO io{ctx}; void *d = io.alloc(n * e), *o = io.alloc(n * 2 * e), *st = io.alloc(n); if (!d || !o || !st) return NBLS_EHIP;
+  HIPCHK(hipMemcpyAsync(d, in, n * e, hipMemcpyHostToDevice, s));
+  int r = dev_decompress(ctx, g2, n, d, o, st, s); if (r) return r;
+  HIPCHK(hipMemcpyAsync(out, o, n * 2 * e, hipMemcpyDeviceToHost, s));
+  std::vector<int8_t> tmp(n); HIPCHK(hipMemcpyAsync(tmp.data(), st, n, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+  if (status) memcpy(status, tmp.data(), n);
+  return NBLS_OK;
+}
+EXPORT int nbls_g1_decompress_batch(nbls_ctx* ctx, size_t n, const uint8_t* in48, uint8_t* out96, int8_t* status) { return decompress_host(ctx, false, n, in48, out96, status); }
+EXPORT int nbls_g2_decompress_batch(nbls_ctx* ctx, size_t n, const uint8_t* in96, uint8_t* out192, int8_t* status) { return decompress_host(ctx, true, n, in96, out192, status); }
+
+// expand_message_xmd for all messages on the host cores (SHA-256 is not the data-parallel part of this path)
+static bool expand_all(size_t n, const uint8_t* msgs, const uint32_t* offs, const uint8_t* dst, size_t dst_len, std::vector<uint8_t>& uni) {
+  uni.resize(n * 256);
+  unsigned nt = std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::max<size_t>(1, n / 256)); if (nt > 32) nt = 32;
+  std::vector<std::thread> th; std::vector<char> ok(nt, 1);
+  for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t] {
+    for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) if (!expand_message_xmd(msgs + offs[i], offs[i + 1] - offs[i], dst, dst_len, &uni[256 * i], 256)) ok[t] = 0;
+  });
+  for (auto& x : th) x.join();
+  for (char c : ok) if (!c) return false;
+  return true;
+}
+EXPORT int nbls_hash_to_g2_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len, uint8_t* out192) {
+  if (!ctx || (n && (!offsets || !out192 || !dst))) return NBLS_EINVAL; if (!n) return NBLS_OK;
+  std::vector<uint8_t> uni; if (!expand_all(n, msgs, offsets, dst, dst_len, uni)) return NBLS_EINVAL;
+  LOCKED(ctx); HostIO io{ctx}; void *d = io.alloc(n * 256), *o = io.alloc(n * 192); if (!d || !o) return NBLS_EHIP;
+  HIPCHK(hipMemcpyAsync(d, uni.data(), n * 256, hipMemcpyHostToDevice, s));
+  int r = dev_hash_to_g2(ctx, n, d, o, s); if (r) return r;
+  HIPCHK(hipMemcpyAsync(out192, o, n * 192, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); return NBLS_OK;
+}
+static int sum_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* pts, uint8_t* out, int8_t* status) {
+  if (!ctx || !out || (n && !pts)) return NBLS_EINVAL;
+  const size_t a = g2 ? 192 : 96;
+  LOCKED(ctx); HostIO io{ctx}; void *d = io.alloc(n * a), *o = io.alloc(a), *st = io.alloc(1); if (!d || !o || !st) return NBLS_EHIP;
+  if (n) HIPCHK(hipMemcpyAsync(d, pts, n * a, hipMemcpyHostToDevice, s));
+  int r = dev_point_sum(ctx, g2, n, d, o, st, s); if (r) return r;
+  int8_t z = 0; HIPCHK(hipMemcpyAsync(out, o, a, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(&z, st, 1, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+  if (status) *status = z;
+  return NBLS_OK;
+}
+EXPORT int nbls_g1_sum(nbls_ctx* ctx, size_t n, const uint8_t* pts96, uint8_t* out96, int8_t* status) { return sum_host(ctx, false, n, pts96, out96, status); }
+EXPORT int nbls_g2_sum(nbls_ctx* ctx, size_t n, const uint8_t* pts192, uint8_t* out192, int8_t* status) { return sum_host(ctx, true, n, pts192, out192, status); }
+
+// verifyBatch(signature, messages, publicKeys) on wire inputs (index.ts:792-821): every message hashes to its own point
+// (hex inputs are distinct objects in the reference), n pairings e(pk_i, H(m_i)) times e(-G, sig), one final exponentiation.
+//   *ok = 1 / 0.  Return code: NBLS_OK, or NBLS_EDECODE when the reference would throw while decoding (before its try block):
+//   invalid signature or public key encoding / subgroup.  A zero public key or zero signature gives *ok = 0 (pairing throws
+//   inside the try block, index.ts:716, 818-820).
+EXPORT int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_sig96, const void* d_uniform, const void* d_pk48, int* ok, int8_t* pk_status, void* stream);
+EXPORT int nbls_verify_batch(nbls_ctx* ctx, size_t n, const uint8_t* sig96, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48, const uint8_t* dst, size_t dst_len, int* ok) {
+  if (!ctx || !ok || !n || !sig96 || !offsets || !pk48 || !dst) return NBLS_EINVAL;
+  std::vector<uint8_t> uni; if (!expand_all(n, msgs, offsets, dst, dst_len, uni)) return NBLS_EINVAL;
+  void *d_sig, *d_uni, *d_pk;
+  {
+    LOCKED(ctx);
+    uint8_t *a, *b, *c; int r;
+    if ((r = need(ctx, 7, 96, &a)) || (r = need(ctx, 8, n * 256, &b)) || (r = need(ctx, 9, n * 48, &c))) return r;
+    HIPCHK(hipMemcpyAsync(a, sig96, 96, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(b, uni.data(), n * 256, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c, pk48, n * 48, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    d_sig = a; d_uni = b; d_pk = c;
+  }
+  return nbls_verify_batch_dev_inputs(ctx, n, d_sig, d_uni, d_pk, ok, nullptr, nullptr);
+}
+// Same with inputs resident in HBM: signature (96 B), expand_message_xmd outputs (256 B per message), public keys (48 B each).
+EXPORT int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_sig96, const void* d_uniform, const void* d_pk48, int* ok, int8_t* pk_status, void* stream) {
+  if (!ctx || !ok || !n || !d_sig96 || !d_uniform || !d_pk48) return NBLS_EINVAL;
+  std::vector<int8_t> st(n + 1);
+  uint8_t out[576];
+  {
+    std::lock_guard<std::mutex> g_(ctx->mu); HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    uint8_t *G1, *G2, *ST, *O; int r;
+    if ((r = need(ctx, 10, (n + 1) * (96 + 192) + (n + 1) + 576 + 64, &G1))) return r;
+    G2 = G1 + (n + 1) * 96; O = G2 + (n + 1) * 192; ST = O + 576;
+    if ((r = dev_decompress(ctx, false, n, d_pk48, G1, ST, s))) return r;                       // normP1: PointG1.fromHex
+    if ((r = dev_hash_to_g2(ctx, n, d_uniform, G2, s))) return r;                               // normP2Hash: PointG2.hashToCurve
+    if ((r = dev_decompress(ctx, true, 1, d_sig96, G2 + n * 192, ST + n, s))) return r;         // normP2: PointG2.fromSignature
+    HIPCHK(hipMemcpyAsync(G1 + n * 96, ctx->neg_g1, 96, hipMemcpyDeviceToDevice, s));           // PointG1.BASE.negate()
+    HIPCHK(hipMemcpyAsync(st.data(), ST, n + 1, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  if (pk_status) memcpy(pk_status, st.data(), n);
+  for (size_t i = 0; i <= n; i++) if (st[i] > 1) return NBLS_EDECODE;       // the reference throws before its try block
+  for (size_t i = 0; i <= n; i++) if (st[i] == 1) { *ok = 0; return NBLS_OK; }   // zero point -> pairing() throws -> false
+  {
+    uint8_t* base = ctx->sb[10];
+    int r = nbls_miller_product_dev(ctx, n + 1, base, base + (n + 1) * 96, 1, base + (n + 1) * 288, stream);
+    if (r) return r;
+    std::lock_guard<std::mutex> g_(ctx->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    HIPCHK(hipMemcpyAsync(out, base + (n + 1) * 288, 576, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  bool one = out[47] == 1; for (int i = 0; i < 576 && one; i++) if (i != 47 && out[i]) one = false;   // exp.equals(Fp12.ONE)
+  *ok = one ? 1 : 0;
   return NBLS_OK;
 }

@@ -10,6 +10,8 @@
 #include "programs.h"
 #include <mutex>
 #include "tower.h"
+#include "curve.h"
+#include "codec.h"
 
 namespace nbls {
 
@@ -168,6 +170,92 @@ static Program build(ProgId id) {
     case P_RAW_TO_BYTES: {
       output_fp12(inputw_fp12(3, 0), 2, 0);
       return B.compile("raw_to_bytes", 16);
+    }
+    case P_G1_VALIDATE: {
+      SFp x = input(0, 0), y = input(0, 48), oc, sg;
+      g1_validity_flags(x, y, oc, sg);
+      status_out({{oc, 2}, {sg, 3}}, 7);
+      return B.compile("g1_validate", 8);
+    }
+    case P_G2_VALIDATE: {
+      SFp2 x = input_fp2(1, 0), y = input_fp2(1, 96); SFp oc, sg;
+      g2_validity_flags(x, y, oc, sg);
+      status_out({{oc, 2}, {sg, 3}}, 7);
+      return B.compile("g2_validate", 8);
+    }
+    case P_G1_DEC_A: g1_decompress_A(0, 3, 4); return B.compile("g1_dec_a", 4);
+    case P_G1_DEC_B: g1_decompress_B(0, 3, 4, 5, 6, 7); return B.compile("g1_dec_b", 8);
+    case P_G2_DEC_A: g2_decompress_A(0, 3, 4); return B.compile("g2_dec_a", 4);
+    case P_G2_DEC_B: g2_decompress_B(0, 3, 4, 5, 6, 7); return B.compile("g2_dec_b", 8);
+    case P_H2C_A: {
+      for (int k = 0; k < 2; k++) {
+        SFp2 t = {field_elem_from_64(0, 128 * k), field_elem_from_64(0, 128 * k + 64)};
+        outputw(t.c0, 3, 96 * k); outputw(t.c1, 3, 96 * k + 48);
+        SwuState s = swu_prepare(t);
+        outputw(s.uv15.c0, 4, 96 * k); outputw(s.uv15.c1, 4, 96 * k + 48);
+      }
+      return B.compile("h2c_a", 8);
+    }
+    case P_H2C_B: {
+      Pt<SFp2> pts[2];
+      for (int k = 0; k < 2; k++) {
+        SFp2 t = {inputw(3, 96 * k), inputw(3, 96 * k + 48)};
+        SFp2 gp = {inputw(5, 96 * k), inputw(5, 96 * k + 48)};
+        pts[k] = swu_finish(swu_prepare(t), gp);
+      }
+      Pt<SFp2> q = clear_cofactor_g2(isogeny_g2_proj(pt_add_generic(pts[0], pts[1])));   // index.ts:487-489
+      outputw(q.x.c0, 6, 0); outputw(q.x.c1, 6, 48); outputw(q.y.c0, 6, 96); outputw(q.y.c1, 6, 144); outputw(q.z.c0, 6, 192); outputw(q.z.c1, 6, 240);
+      outputw(sqr(q.z.c0) + sqr(q.z.c1), 7, 0);
+      return B.compile("h2c_b", 8);
+    }
+    case P_G1_TO_PROJ: {
+      outputw(input(0, 0), 3, 0); outputw(input(0, 48), 3, 48); outputw(fp_one(), 3, 96);
+      return B.compile("g1_to_proj", 4);
+    }
+    case P_G1_ADD2: {
+      Pt<SFp> a = {inputw(3, 0), inputw(3, 48), inputw(3, 96)}, b = {inputw(3, 144), inputw(3, 192), inputw(3, 240)};
+      Pt<SFp> r = pt_add(a, b);
+      outputw(r.x, 5, 0); outputw(r.y, 5, 48); outputw(r.z, 5, 96);
+      return B.compile("g1_add2", 4);
+    }
+    case P_G1_NORM: { outputw(inputw(3, 96), 4, 0); return B.compile("g1_norm", 1); }
+    case P_G1_TO_AFFINE: {
+      SFp X = inputw(3, 0), Y = inputw(3, 48), Z = inputw(3, 96), zi = inputw(4, 0);
+      status_out({{f_not(is_zero(Z)), 1}}, 7);
+      output(mul(X, zi), 2, 0); output(mul(Y, zi), 2, 48);
+      return B.compile("g1_to_affine", 4);
+    }
+    case P_G2_TO_PROJ: {
+      for (int k = 0; k < 4; k++) outputw(input(1, 48 * k), 3, 48 * k);
+      outputw(fp_one(), 3, 192); outputw(SFp(), 3, 240);
+      return B.compile("g2_to_proj", 8);
+    }
+    case P_G2_ADD2: {
+      auto ld = [&](int off) { return Pt<SFp2>{{inputw(3, off), inputw(3, off + 48)}, {inputw(3, off + 96), inputw(3, off + 144)}, {inputw(3, off + 192), inputw(3, off + 240)}}; };
+      Pt<SFp2> r = pt_add(ld(0), ld(288));
+      outputw(r.x.c0, 5, 0); outputw(r.x.c1, 5, 48); outputw(r.y.c0, 5, 96); outputw(r.y.c1, 5, 144); outputw(r.z.c0, 5, 192); outputw(r.z.c1, 5, 240);
+      return B.compile("g2_add2", 8);
+    }
+    case P_G2_NORM: { SFp z0 = inputw(3, 192), z1 = inputw(3, 240); outputw(sqr(z0) + sqr(z1), 4, 0); return B.compile("g2_norm", 2); }
+    case P_G2_TO_AFFINE: {
+      SFp2 X = {inputw(3, 0), inputw(3, 48)}, Y = {inputw(3, 96), inputw(3, 144)}, Z = {inputw(3, 192), inputw(3, 240)};
+      SFp ni = inputw(4, 0);
+      SFp2 zi = mat(SFp2{mul(Z.c0, ni), -mul(Z.c1, ni)});          // Fp2.invert (math.ts:522-526)
+      status_out({{f_not(eq_zero(Z)), 1}}, 7);
+      output_fp2(mul(X, zi), 2, 0); output_fp2(mul(Y, zi), 2, 96);
+      return B.compile("g2_to_affine", 8);
+    }
+    case P_T_SWU: {
+      SFp2 t = {inputw(3, 0), inputw(3, 48)}, gp = {inputw(5, 0), inputw(5, 48)};
+      Pt<SFp2> q = swu_finish(swu_prepare(t), gp);
+      outputw(q.x.c0, 6, 0); outputw(q.x.c1, 6, 48); outputw(q.y.c0, 6, 96); outputw(q.y.c1, 6, 144); outputw(q.z.c0, 6, 192); outputw(q.z.c1, 6, 240);
+      return B.compile("t_swu", 8);
+    }
+    case P_T_ISO: case P_T_CLEAR: {
+      Pt<SFp2> p = {{inputw(3, 0), inputw(3, 48)}, {inputw(3, 96), inputw(3, 144)}, {inputw(3, 192), inputw(3, 240)}};
+      Pt<SFp2> q = id == P_T_ISO ? isogeny_g2_proj(p) : clear_cofactor_g2(p);
+      outputw(q.x.c0, 6, 0); outputw(q.x.c1, 6, 48); outputw(q.y.c0, 6, 96); outputw(q.y.c1, 6, 144); outputw(q.z.c0, 6, 192); outputw(q.z.c1, 6, 240);
+      return B.compile(id == P_T_ISO ? "t_iso" : "t_clear", 8);
     }
     default: break;
   }

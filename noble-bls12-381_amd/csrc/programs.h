@@ -15,6 +15,17 @@ enum ProgId {
   P_FE_FINAL,          // t1..t7 -> final product as wire bytes                    (math.ts:868-873)
   P_MUL2,              // F[2i] * F[2i+1] -> F'[i]
   P_RAW_TO_BYTES,      // F -> wire bytes
+  P_G1_VALIDATE,       // G1 affine (buf 0) -> int8 status (buf 7): 0 ok, 2 not on curve, 3 not in subgroup   (index.ts:383-388)
+  P_G2_VALIDATE,       // G2 affine (buf 1) -> int8 status (buf 7)                                           (index.ts:633-638)
+  P_G1_DEC_A,          // 48 B compressed G1 (buf 0) -> x (3), x^3+4 (4)                                       (index.ts:301-310)
+  P_G1_DEC_B,          // compressed (0), x (3), rhs (4), rhs^((p+1)/4) (5) -> affine bytes (6), status (7)     (index.ts:311-326)
+  P_G2_DEC_A,          // 96 B compressed G2 signature (buf 0) -> x (3), x^3+b (4)                             (index.ts:500-515)
+  P_G2_DEC_B,          // compressed (0), x (3), rhs (4), rhs^((p^2+7)/16) (5) -> affine bytes (6), status (7)  (index.ts:516-529)
+  P_H2C_A,             // 256 uniform bytes (buf 0) -> u0,u1 (3), SWU exponentiation inputs (4)                 (index.ts:256-263, math.ts:1220-1241)
+  P_H2C_B,             // u0,u1 (3), powers (5) -> projective hash point (6), norm of Z (7)                     (math.ts:1243-1266, index.ts:487-489, 659-672)
+  P_G1_TO_PROJ, P_G1_ADD2, P_G1_NORM, P_G1_TO_AFFINE,     // point sums: aggregatePublicKeys (index.ts:771-778)
+  P_G2_TO_PROJ, P_G2_ADD2, P_G2_NORM, P_G2_TO_AFFINE,     // aggregateSignatures (index.ts:781-788), hash-to-G2 output
+  P_T_SWU, P_T_ISO, P_T_CLEAR,   // test-only pieces of hash-to-G2 (unit parity against golden vectors): SWU map, 3-isogeny, cofactor clearing
   P_COUNT
 };
 const Program& get_program(ProgId id);

@@ -48,6 +48,17 @@ SFp input(int buf, int off) {
   SFp r; r.f.push_back({PROD_BASE + B->product(a, b), 1});
   return SFp(materialize(r));
 }
+SFp input_raw(int buf, int off, int nbytes) {
+  Node n; n.kind = K_LOAD; n.buf = buf; n.off = off; n.raw = true; n.p0 = (uint8_t)(nbytes == 48 ? 0 : nbytes);
+  return SFp(Builder::cur()->add_node(n));
+}
+SFp to_mont(const SFp& raw) {
+  Builder* B = Builder::cur();
+  Operand a; a.s0 = materialize(raw); Operand b; b.s0 = B->r2_atom;
+  SFp r; r.f.push_back({PROD_BASE + B->product(a, b), 1});
+  return SFp(materialize(r));
+}
+SFp raw_const(const u32* limbs) { return SFp(Builder::cur()->const_atom(limbs)); }
 void output(const SFp& x, int buf, int off) {
   Builder* B = Builder::cur();
   Operand a; a.s0 = materialize(x); Operand b; b.s0 = B->rawone_atom;      // x / R : out of Montgomery form
@@ -170,7 +181,8 @@ static void node_deps(const Node& n, std::vector<int>& d) {
     case K_LIN: for (auto& t : n.lin) d.push_back(t.first); break;
     case K_STORE: case K_STOREW: case K_ISZ: case K_CANON: d = {n.a0}; break;
     case K_SEL: d = {n.b0, n.a0, n.a1}; break;
-    case K_CMP: case K_FLAG: d = {n.a0, n.a1}; break;
+    case K_CMP: case K_FLAG: case K_BITAND: d = {n.a0, n.a1}; break;
+    case K_BIT: d = {n.a0}; break;
     case K_STATUS: for (auto& t : n.stat) d.push_back(t.first); break;
     default: break;
   }
@@ -216,7 +228,7 @@ Program Builder::compile(const std::string& name, int W) {
   // 4. list scheduling.  Ready queues per (kind, p0).
   // DOT lane-ops are bucketed by weight class so that a step's lanes do similar amounts of work (step time = max k)
   auto dot_class = [&](const Node& n) { size_t k = n.prods.size(); return k <= 2 ? 0 : 1; };
-  auto qkey = [&](const Node& n) { return (int)n.kind * 256 + ((n.kind == K_CMP || n.kind == K_FLAG) ? n.p0 : n.kind == K_DOT ? dot_class(n) : 0); };
+  auto qkey = [&](const Node& n) { return (int)n.kind * 256 + ((n.kind == K_CMP || n.kind == K_FLAG || n.kind == K_LOAD) ? n.p0 : n.kind == K_DOT ? dot_class(n) : 0); };
   auto cmp = [&](int a, int b) { return nodes[a].height < nodes[b].height || (nodes[a].height == nodes[b].height && a > b); };
   typedef std::priority_queue<int, std::vector<int>, decltype(cmp)> PQ;
   std::map<int, PQ> ready;
@@ -242,7 +254,7 @@ Program Builder::compile(const std::string& name, int W) {
       if (h > best_h) { best_h = h; best_dot = DOTKEY + c; }
     }
     if (key < 0) {
-      static const int order[] = {K_LOAD, K_LOADW, K_LIN, K_ISZ, K_FLAG, K_CMP, K_CANON, K_SEL, K_STOREW, K_STORE, K_STATUS};
+      static const int order[] = {K_LOAD, K_LOADW, K_BIT, K_BITAND, K_LIN, K_ISZ, K_FLAG, K_CMP, K_CANON, K_SEL, K_STOREW, K_STORE, K_STATUS};
       for (int k : order) {
         for (auto& kv : ready) if (kv.first / 256 == k && !kv.second.empty()) { key = kv.first; break; }
         if (key >= 0) break;
@@ -339,7 +351,8 @@ Program Builder::compile(const std::string& name, int W) {
         case K_STORE: case K_STOREW: w[0] = op(n.a0) | ((u32)n.buf << 16); w[1] = (u32)n.off; break;
         case K_ISZ: case K_CANON: w[0] = (u32)n.slot | (op(n.a0) << 16); break;
         case K_SEL: w[0] = (u32)n.slot | (op(n.b0) << 16); w[1] = op(n.a0) | (op(n.a1) << 16); break;
-        case K_CMP: case K_FLAG: w[0] = (u32)n.slot; w[1] = op(n.a0) | (op(n.a1) << 16); break;
+        case K_CMP: case K_FLAG: case K_BITAND: w[0] = (u32)n.slot; w[1] = op(n.a0) | (op(n.a1) << 16); break;
+        case K_BIT: w[0] = (u32)n.slot | (op(n.a0) << 16); w[1] = (u32)n.off; break;
         case K_STATUS:
           assert(n.stat.size() <= 7);
           w[0] = (u32)n.stat.size() | ((u32)n.buf << 16);

@@ -187,6 +187,12 @@ static inline SFp constant(const u32* mont_limbs) {
   return SFp(B->const_atom(mont_limbs));
 }
 SFp input(int buf, int off);          // big-endian wire bytes -> Montgomery value
+SFp input_raw(int buf, int off, int nbytes = 48);   // big-endian integer of nbytes (multiple of 4, <= 48), NOT in Montgomery form
+SFp to_mont(const SFp& raw);          // raw integer (< 2^384) -> Montgomery value
+SFp raw_const(const u32* limbs);      // constant raw integer
+static inline SFp bit_flag(const SFp& raw, int bit) { Node n; n.kind = K_BIT; n.a0 = materialize(raw); n.off = bit; return SFp(Builder::cur()->add_node(n)); }
+static inline SFp bit_and(const SFp& a, const SFp& b) { Node n; n.kind = K_BITAND; n.a0 = materialize(a); n.a1 = materialize(b); return SFp(Builder::cur()->add_node(n)); }
+static inline SFp f_not(const SFp& a);
 void output(const SFp& x, int buf, int off);
 static inline SFp inputw(int buf, int off) { Node n; n.kind = K_LOADW; n.buf = buf; n.off = off; return SFp(Builder::cur()->add_node(n)); }
 static inline void outputw(const SFp& x, int buf, int off) { Node n; n.kind = K_STOREW; n.a0 = materialize(x); n.buf = buf; n.off = off; n.live = true; Builder::cur()->add_node(n); }
@@ -203,6 +209,7 @@ static inline SFp f_and(const SFp& a, const SFp& b) { return flag_op(0, a, b); }
 static inline SFp f_or(const SFp& a, const SFp& b) { return flag_op(1, a, b); }
 static inline SFp f_xor(const SFp& a, const SFp& b) { return flag_op(2, a, b); }
 static inline SFp f_andnot(const SFp& a, const SFp& b) { return flag_op(3, a, b); }
+static inline SFp f_not(const SFp& a) { return f_andnot(SFp(Builder::cur()->rawone_atom), a); }
 // int8 status[item] = code of the first flag that is 0 (flags listed most significant first), else 0
 static inline void status_out(const std::vector<std::pair<SFp, int>>& checks, int buf) {
   Node n; n.kind = K_STATUS; n.buf = buf; n.live = true;

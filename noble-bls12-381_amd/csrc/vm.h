@@ -13,7 +13,7 @@
 namespace nbls {
 
 enum StepKind : uint8_t {
-  K_LOAD = 0,    // slot <- 48 big-endian bytes of an input buffer (raw integer, < 2^384)
+  K_LOAD = 0,    // slot <- p0 (0 = 48) big-endian bytes of an input buffer (raw integer, < 2^384)
   K_MUL = 1,     // slot <- mont((a0 [+|-] a1) * (b0 [+|-] b1)), result in [0,2p)
   K_LIN = 2,     // slot <- sum of +-slots, reduced to [0,2p)
   K_STORE = 3,   // 48 big-endian bytes of an output buffer <- canonical(slot)   (slot must hold value/R already)
@@ -25,6 +25,8 @@ enum StepKind : uint8_t {
   K_CANON = 9,   // slot <- canonical representative in [0,p)
   K_CMP = 10,    // flag slot <- predicate on raw integers: p0 = 0: a > b ; 1: a is odd
   K_FLAG = 11,   // flag slot <- boolean op of two flags: p0 = 0 and, 1 or, 2 xor, 3 and-not (a & !b)
+  K_BIT = 13,    // flag slot <- bit (w1) of a raw integer slot            (wire-format flag bits, index.ts:305-314)
+  K_BITAND = 14, // slot <- a & b (raw 384-bit integers)                   (value mod 2^381, index.ts:309)
   K_DOT = 12,    // slot <- m * mont(sum_i A_i * B_i) +- up to 4 slots, ONE Montgomery reduction for the whole sum;
                  //         every A_i, B_i is (+-x) or (+-x +- y).  Subsumes Fp2/Fp6/Fp12 recombination
 };

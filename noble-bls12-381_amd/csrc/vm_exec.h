@@ -336,8 +336,9 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, 
       u32 w0 = d[0], off = d[1];
       const IOBuf& b = bufs[(w0 >> 16) & 7];
       const u32* src = (const u32*)(b.ptr + (u64)cx.item * b.stride + off);
+      const int nw = st.p0 ? (int)st.p0 / 4 : 12;   // number of 32-bit words (big-endian integer of p0 bytes)
 #pragma unroll
-      for (int i = 0; i < 12; i++) res[i] = cx.live ? bswap32(src[11 - i]) : 0u;
+      for (int i = 0; i < 12; i++) res[i] = (cx.live && i < nw) ? bswap32(src[nw - 1 - i]) : 0u;
       return slot_addr(w0 & 0xffff, cx.inst);
     }
     case K_LOADW: {
@@ -413,6 +414,23 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, 
 #pragma unroll
       for (int i = 0; i < 12; i++) res[i] = 0;
       res[0] = f;
+      return slot_addr(w0 & 0xffff, cx.inst);
+    }
+    case K_BIT: {
+      u32 w0 = d[0], bit = d[1];
+      u32 w = lds[slot_addr(w0 >> 16, cx.inst) + (bit >> 5)];
+#pragma unroll
+      for (int i = 0; i < 12; i++) res[i] = 0;
+      res[0] = (w >> (bit & 31)) & 1;
+      return slot_addr(w0 & 0xffff, cx.inst);
+    }
+    case K_BITAND: {
+      u32 w0 = d[0], w1 = d[1];
+      u32 X[12], Y[12];
+      ld12(X, lds, slot_addr(w1 & 0xffff, cx.inst));
+      ld12(Y, lds, slot_addr(w1 >> 16, cx.inst));
+#pragma unroll
+      for (int i = 0; i < 12; i++) res[i] = X[i] & Y[i];
       return slot_addr(w0 & 0xffff, cx.inst);
     }
     case K_FLAG: {

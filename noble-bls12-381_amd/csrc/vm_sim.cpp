@@ -56,5 +56,29 @@ __attribute__((visibility("default"))) void nbls_sim_fp_inv(unsigned n, const u3
   if (table.empty()) { table.resize(382 * 12); make_inv_table(table.data()); }
   for (unsigned k = 0; k < n; k++) fp_mont_inverse(out + 12 * k, in + 12 * k, table.data());
 }
+// out = in^e on raw Montgomery limbs; which: 0 = (p+1)/4 on Fp, 1 = (p^2+7)/16 on Fp2, 2 = (p^2-9)/16 on Fp2 (stand-ins for the pow kernels)
+static void mmh(u32* r, const u32* a, const u32* b) { const u32 P2[12] = NBLS_2P32; u32 t[12]; mont_mul12(t, a, b); csub<12>(t, P2); memcpy(r, t, 48); }
+static void addh(u32* r, const u32* a, const u32* b) { const u32 P2[12] = NBLS_2P32; u32 t[12], c = 0; for (int i = 0; i < 12; i++) t[i] = addc(a[i], b[i], c, &c); csub<12>(t, P2); memcpy(r, t, 48); }
+static void subh(u32* r, const u32* a, const u32* b) { const u32 P2[12] = NBLS_2P32; u32 t[12], br = 0, c = 0; for (int i = 0; i < 12; i++) t[i] = subb(a[i], b[i], br, &br); for (int i = 0; i < 12; i++) t[i] = addc(t[i], P2[i], c, &c); csub<12>(t, P2); memcpy(r, t, 48); }
+static void fp2mulh(u32* r, const u32* a, const u32* b) {
+  u32 t1[12], t2[12], s1[12], s2[12], m[12];
+  mmh(t1, a, b); mmh(t2, a + 12, b + 12); addh(s1, a, a + 12); addh(s2, b, b + 12); mmh(m, s1, s2);
+  u32 r0[12], r1[12]; subh(r0, t1, t2); subh(m, m, t1); subh(r1, m, t2); memcpy(r, r0, 48); memcpy(r + 12, r1, 48);
+}
+__attribute__((visibility("default"))) void nbls_sim_fp_pow(unsigned n, const u32* in, u32* out, int which) {
+  const uint64_t* e = which == 0 ? NBLS_EXP_P_PLUS_1_DIV_4 : which == 1 ? NBLS_EXP_P2_PLUS_7_DIV_16 : NBLS_EXP_P2_MINUS_9_DIV_16;
+  int bits = which == 0 ? NBLS_P_PLUS_1_DIV_4_BITS : which == 1 ? NBLS_P2_PLUS_7_DIV_16_BITS : NBLS_P2_MINUS_9_DIV_16_BITS;
+  for (unsigned k = 0; k < n; k++) {
+    if (which == 0) {
+      u32 acc[12]; memcpy(acc, NBLS_R1, 48);
+      for (int i = bits - 1; i >= 0; i--) { mmh(acc, acc, acc); if ((e[i >> 6] >> (i & 63)) & 1) mmh(acc, acc, in + 12 * k); }
+      memcpy(out + 12 * k, acc, 48);
+    } else {
+      u32 acc[24] = {0}; memcpy(acc, NBLS_R1, 48);
+      for (int i = bits - 1; i >= 0; i--) { fp2mulh(acc, acc, acc); if ((e[i >> 6] >> (i & 63)) & 1) fp2mulh(acc, acc, in + 24 * k); }
+      memcpy(out + 24 * k, acc, 96);
+    }
+  }
+}
 __attribute__((visibility("default"))) void nbls_sim_stats() { for (int i = 0; i < P_COUNT; i++) print_stats(get_program((ProgId)i)); }
 }

@@ -5,7 +5,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-PROGRAMS = ['miller_bytes', 'miller_raw', 'miller_fe', 'norm_raw', 'norm_bytes', 'fe_easy', 'expx', 'fe_mid1', 'fe_mid2', 'fe_final', 'fp12_mul2', 'raw_to_bytes']
+PROGRAMS = ['miller_bytes', 'miller_raw', 'miller_fe', 'norm_raw', 'norm_bytes', 'fe_easy', 'expx', 'fe_mid1', 'fe_mid2', 'fe_final', 'fp12_mul2', 'raw_to_bytes',
+            'g1_validate', 'g2_validate', 'g1_dec_a', 'g1_dec_b', 'g2_dec_a', 'g2_dec_b', 'h2c_a', 'h2c_b',
+            'g1_to_proj', 'g1_add2', 'g1_norm', 'g1_to_affine', 'g2_to_proj', 'g2_add2', 'g2_norm', 'g2_to_affine', 't_swu', 't_iso', 't_clear']
+DST_DEFAULT = b'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_'   # htfDefaults.DST, reference index.ts:64
 
 
 class NblsError(RuntimeError):
@@ -35,6 +38,15 @@ def load_library():
     lib.nbls_final_exp_batch_dev.argtypes = [vp, sz, vp, vp, vp]
     lib.nbls_fp12_product_final_dev.argtypes = [vp, sz, vp, i32, vp, vp]
     lib.nbls_program_stats.argtypes = [vp, i32, C.POINTER(C.c_uint32)]
+    lib.nbls_g1_validate_batch.argtypes = [vp, sz, vp, vp]
+    lib.nbls_g2_validate_batch.argtypes = [vp, sz, vp, vp]
+    lib.nbls_g1_decompress_batch.argtypes = [vp, sz, vp, vp, vp]
+    lib.nbls_g2_decompress_batch.argtypes = [vp, sz, vp, vp, vp]
+    lib.nbls_hash_to_g2_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp]
+    lib.nbls_g1_sum.argtypes = [vp, sz, vp, vp, vp]
+    lib.nbls_g2_sum.argtypes = [vp, sz, vp, vp, vp]
+    lib.nbls_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, sz, C.POINTER(i32)]
+    lib.nbls_verify_batch_dev_inputs.argtypes = [vp, sz, vp, vp, vp, C.POINTER(i32), vp, vp]
     lib.nbls_timing_enable.argtypes = [vp, i32]
     lib.nbls_timing_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     return lib
@@ -88,6 +100,53 @@ class Engine:
         out = C.create_string_buffer(576 * max(n, 1))
         self._chk(self.lib.nbls_final_exp_batch(self.h, n, fp12s, out))
         return out.raw[:576 * n]
+
+    def validate_batch(self, pts, g2=False):
+        sz = 192 if g2 else 96
+        n = len(pts) // sz
+        st = C.create_string_buffer(max(n, 1))
+        self._chk((self.lib.nbls_g2_validate_batch if g2 else self.lib.nbls_g1_validate_batch)(self.h, n, pts, st))
+        return list(st.raw[:n])
+
+    def decompress_batch(self, comp, g2=False):
+        e = 96 if g2 else 48
+        n = len(comp) // e
+        out = C.create_string_buffer(max(2 * e * n, 1))
+        st = C.create_string_buffer(max(n, 1))
+        self._chk((self.lib.nbls_g2_decompress_batch if g2 else self.lib.nbls_g1_decompress_batch)(self.h, n, comp, out, st))
+        return out.raw[:2 * e * n], list(st.raw[:n])
+
+    @staticmethod
+    def _pack(msgs):
+        offs = [0]
+        for m in msgs:
+            offs.append(offs[-1] + len(m))
+        return b''.join(msgs), (C.c_uint32 * len(offs))(*offs)
+
+    def hash_to_g2_batch(self, msgs, dst=DST_DEFAULT):
+        blob, offs = self._pack(msgs)
+        out = C.create_string_buffer(max(192 * len(msgs), 1))
+        self._chk(self.lib.nbls_hash_to_g2_batch(self.h, len(msgs), blob, offs, dst, len(dst), out))
+        return out.raw[:192 * len(msgs)]
+
+    def point_sum(self, pts, g2=False):
+        sz = 192 if g2 else 96
+        out = C.create_string_buffer(sz)
+        st = C.create_string_buffer(1)
+        self._chk((self.lib.nbls_g2_sum if g2 else self.lib.nbls_g1_sum)(self.h, len(pts) // sz, pts, out, st))
+        return out.raw, st.raw[0]
+
+    def verify_batch(self, sig96, msgs, pks48, dst=DST_DEFAULT):
+        """-> True/False; raises NblsError where the reference throws while decoding its arguments"""
+        blob, offs = self._pack(msgs)
+        ok = C.c_int(0)
+        self._chk(self.lib.nbls_verify_batch(self.h, len(msgs), sig96, blob, offs, b''.join(pks48), dst, len(dst), C.byref(ok)))
+        return bool(ok.value)
+
+    def verify_batch_dev(self, n, d_sig, d_uniform, d_pk, stream=None):
+        ok = C.c_int(0)
+        self._chk(self.lib.nbls_verify_batch_dev_inputs(self.h, n, d_sig, d_uniform, d_pk, C.byref(ok), None, stream))
+        return bool(ok.value)
 
     # ---- device-pointer entry points (torch uint8 CUDA tensors); enqueue on `stream` (int handle) or the context stream
     def pairing_batch_dev(self, n, d_g1, d_g2, d_out, with_final_exp=True, stream=None):

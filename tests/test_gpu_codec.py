@@ -1,0 +1,106 @@
+"""GPU parity tests for the rows of SURVEY 8(a) around the pairing: validity checks, decoders, hash-to-G2, sums, verifyBatch."""
+import hashlib
+import importlib
+import pytest
+from goldenio import hx
+
+pytestmark = pytest.mark.gpu
+STATUS = {'ok': 0, 'zero': 1, 'Invalid G1 point: not on curve Fp': 2, 'Invalid G2 point: not on curve Fp2': 2,
+          'Invalid G1 point: must be of prime-order subgroup': 3, 'Invalid G2 point: must be of prime-order subgroup': 3,
+          'Invalid compressed G1 point': 4, 'Failed to find a square root': 4}
+
+
+@pytest.fixture(scope='module')
+def eng():
+    return importlib.import_module('noble-bls12-381_amd').Engine(0)
+
+
+def test_validity(eng, golden):
+    for g2 in (False, True):
+        vs = golden['validity']['g2' if g2 else 'g1']
+        assert eng.validate_batch(b''.join(hx(v['aff']) for v in vs), g2) == [STATUS[v['result']] for v in vs]
+
+
+def test_pairing_with_validation(eng, oracle, golden):
+    v1, v2 = golden['validity']['g1'], golden['validity']['g2']
+    g1 = b''.join(hx(v['aff']) for v in v1)
+    g2 = b''.join(hx(v['aff']) for v in v2)
+    out, st = eng.pairing_batch(g1, g2, True, True)
+    for i in range(len(v1)):
+        rst, ref = oracle.pairing(g1[96 * i:96 * i + 96], g2[192 * i:192 * i + 192], True, True)
+        assert st[i] == rst
+        assert out[576 * i:576 * i + 576] == (ref if rst == 0 else bytes(576))
+
+
+def test_decompress(eng, oracle, golden, testdata):
+    for g2 in (False, True):
+        vs = golden['codec']['g2' if g2 else 'g1']
+        out, st = eng.decompress_batch(b''.join(hx(v['hex']) for v in vs), g2)
+        sz = 192 if g2 else 96
+        for i, v in enumerate(vs):
+            assert st[i] == STATUS[v['result']], (g2, i)
+            assert out[sz * i:sz * (i + 1)] == (hx(v['aff']) if st[i] == 0 else bytes(sz))
+    # zkcrypto compressed vectors (test/deterministic.test.ts:49-113), i*G for i = 1..255
+    comp = b''.join(hx(testdata['zk_g1_compressed'][i]) for i in range(1, 256))
+    out, st = eng.decompress_batch(comp, False)
+    assert st == [0] * 255 and out == b''.join(hx(testdata['zk_g1_uncompressed'][i]) for i in range(1, 256))
+    comp = b''.join(hx(testdata['zk_g2_compressed'][i]) for i in range(1, 200))
+    out, st = eng.decompress_batch(comp, True)
+    exp = b''
+    for i in range(1, 200):
+        z = hx(testdata['zk_g2_uncompressed'][i])
+        exp += z[48:96] + z[0:48] + z[144:192] + z[96:144]
+    assert st == [0] * 199 and out == exp
+    assert eng.decompress_batch(hx(testdata['zk_g1_compressed'][0]), False)[1] == [1]
+
+
+def test_hash_to_g2(eng, oracle, golden, testdata):
+    d = {}
+    for v in golden['h2c']:
+        d.setdefault(v['dst'], []).append(v)
+    for dst, vs in d.items():
+        out = eng.hash_to_g2_batch([hx(v['msg']) for v in vs], dst.encode())
+        for i, v in enumerate(vs):
+            assert out[192 * i:192 * (i + 1)] == hx(v['aff'])
+    suite = testdata['h2c_g2_ro']
+    out = eng.hash_to_g2_batch([hx(v['msg']) for v in suite['vectors']], suite['dst'].encode())
+    for i, v in enumerate(suite['vectors']):
+        e = hx(v['x1x0y1y0'])
+        assert out[192 * i:192 * (i + 1)] == e[48:96] + e[0:48] + e[144:192] + e[96:144]
+    msgs = [hashlib.sha256(b'm%d' % i).digest()[: 1 + i % 32] for i in range(300)]
+    out = eng.hash_to_g2_batch(msgs)
+    for i in (0, 1, 63, 64, 65, 299):
+        assert out[192 * i:192 * (i + 1)] == oracle.hash_to_g2(msgs[i])[1]
+
+
+def test_point_sums(eng, oracle, golden):
+    for g2, key, sz in ((False, 'g1pts', 96), (True, 'g2pts', 192)):
+        pts = b''.join(hx(v['aff']) + hx(v['affQ']) for v in golden[key])
+        for n in (1, 2, 3, 7, 12):
+            out, st = eng.point_sum(pts[:sz * n], g2)
+            rst, ref = (oracle.g2_sum if g2 else oracle.g1_sum)(pts[:sz * n])
+            assert (st, out) == (rst, ref)
+
+
+def test_verify_batch(eng, oracle, golden, testdata):
+    vb = golden['verify_batch']
+    msgs, pks = [hx(m) for m in vb['msgs']], [hx(p) for p in vb['pks']]
+    assert eng.verify_batch(hx(vb['agg_sig']), msgs, pks) is True
+    m2 = list(msgs); m2[2] = m2[2][:5] + bytes([m2[2][5] ^ 0x40]) + m2[2][6:]
+    assert eng.verify_batch(hx(vb['agg_sig']), m2, pks) is False
+    p2 = list(pks); p2[1] = pks[0]
+    assert eng.verify_batch(hx(vb['agg_sig']), msgs, p2) is False
+    # single signatures from the reference's sign KATs (test/index.test.ts:287-293): verify == verifyBatch with n = 1
+    for priv, msg, sig in testdata['sign_vectors'][:6]:
+        pk = oracle.get_public_key(hx(priv.rjust(64, '0')))
+        assert eng.verify_batch(hx(sig), [hx(msg)], [pk]) is True
+        assert eng.verify_batch(hx(sig), [hx(msg) + b'x'], [pk]) is False
+    # larger batch built with the oracle: 64 signers, aggregate signature
+    sks = [hashlib.sha256(b'sk%d' % i).digest() for i in range(64)]
+    sks = [(int.from_bytes(s, 'big') % (2**254) + 1).to_bytes(32, 'big') for s in sks]
+    msgs = [hashlib.sha256(b'msg%d' % i).digest() for i in range(64)]
+    pks = [oracle.get_public_key(s) for s in sks]
+    sigs = [oracle.sign(m, s)[1] for m, s in zip(msgs, sks)]
+    agg = oracle.aggregate_signatures(sigs)[1]
+    assert eng.verify_batch(agg, msgs, pks) is True
+    assert eng.verify_batch(agg, msgs[::-1], pks) is False

@@ -59,3 +59,62 @@ def test_final_exp_and_product(sim, oracle, golden, testdata):
     vmsim_py.run(sim, 'NORM_RAW', 1, {3: (Fp, 576), 4: (N1, 48)})
     vmsim_py.final_exp(sim, 1, Fp, N1, outb)
     assert outb.raw == hx(p['result'])
+
+
+STATUS = {'ok': 0, 'Invalid G1 point: not on curve Fp': 2, 'Invalid G2 point: not on curve Fp2': 2,
+          'Invalid G1 point: must be of prime-order subgroup': 3, 'Invalid G2 point: must be of prime-order subgroup': 3}
+
+
+def test_validity_programs(sim, golden):
+    for grp, prog, buf, sz in (('g1', 'G1_VALIDATE', 0, 96), ('g2', 'G2_VALIDATE', 1, 192)):
+        vs = golden['validity'][grp]
+        pts = b''.join(hx(v['aff']) for v in vs)
+        st = C.create_string_buffer(len(vs))
+        vmsim_py.run(sim, prog, len(vs), {buf: (C.create_string_buffer(pts, len(pts)), sz), 7: (st, 1)})
+        assert list(st.raw) == [STATUS[v['result']] for v in vs], grp
+
+
+CODEC_STATUS = {'ok': 0, 'zero': 1, 'Invalid G1 point: must be of prime-order subgroup': 3, 'Invalid G2 point: must be of prime-order subgroup': 3,
+                'Invalid compressed G1 point': 4, 'Failed to find a square root': 4}
+
+
+def test_decompress_programs(sim, golden):
+    vs = golden['codec']['g1']
+    out, st = vmsim_py.g1_decompress(sim, b''.join(hx(v['hex']) for v in vs))
+    for i, v in enumerate(vs):
+        assert st[i] == CODEC_STATUS[v['result']], (i, v['result'])
+        if st[i] == 0:
+            assert out[96 * i:96 * (i + 1)] == hx(v['aff'])
+        else:
+            assert out[96 * i:96 * (i + 1)] == bytes(96)
+    vs = golden['codec']['g2']
+    out, st = vmsim_py.g2_decompress(sim, b''.join(hx(v['hex']) for v in vs))
+    for i, v in enumerate(vs):
+        assert st[i] == CODEC_STATUS[v['result']], (i, v['result'])
+        if st[i] == 0:
+            assert out[192 * i:192 * (i + 1)] == hx(v['aff'])
+
+
+def test_hash_to_g2_program(sim, oracle, golden, testdata):
+    vs = golden['h2c']
+    uni = b''.join(oracle.expand_message_xmd(hx(v['msg']), v['dst'].encode(), 256) for v in vs)
+    out = vmsim_py.hash_to_g2(sim, uni)
+    for i, v in enumerate(vs):
+        assert out[192 * i:192 * (i + 1)] == hx(v['aff']), i
+    suite = testdata['h2c_g2_ro']          # RFC 9380 vectors held by test/hashToCurve.test.ts
+    uni = b''.join(oracle.expand_message_xmd(hx(v['msg']), suite['dst'].encode(), 256) for v in suite['vectors'])
+    out = vmsim_py.hash_to_g2(sim, uni)
+    for i, v in enumerate(suite['vectors']):
+        e = hx(v['x1x0y1y0'])
+        assert out[192 * i:192 * (i + 1)] == e[48:96] + e[0:48] + e[144:192] + e[96:144], i
+
+
+def test_point_sum_programs(sim, oracle, golden):
+    for g2, key, sz in ((False, 'g1pts', 96), (True, 'g2pts', 192)):
+        pts = b''.join(hx(v['aff']) for v in golden[key])
+        for n in (1, 2, 3, 5, 6):
+            out, st = vmsim_py.point_sum(sim, pts[:sz * n], g2)
+            ref_st, ref = (oracle.g2_sum if g2 else oracle.g1_sum)(pts[:sz * n])
+            assert st == ref_st == 0 and out == ref, (g2, n)
+        v = golden[key][0]
+        assert vmsim_py.point_sum(sim, hx(v['aff']) + hx(v['affQ']), g2)[0] == hx(v['sum_aff'])

@@ -5,7 +5,8 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, 'noble-bls12-381_amd')
-PROGS = ['MILLER_BYTES', 'MILLER_RAW', 'MILLER_FE', 'NORM_RAW', 'NORM_BYTES', 'FE_EASY', 'EXPX', 'FE_MID1', 'FE_MID2', 'FE_FINAL', 'MUL2', 'RAW_TO_BYTES']
+PROGS = ['MILLER_BYTES', 'MILLER_RAW', 'MILLER_FE', 'NORM_RAW', 'NORM_BYTES', 'FE_EASY', 'EXPX', 'FE_MID1', 'FE_MID2', 'FE_FINAL', 'MUL2', 'RAW_TO_BYTES', 'G1_VALIDATE', 'G2_VALIDATE', 'G1_DEC_A', 'G1_DEC_B', 'G2_DEC_A', 'G2_DEC_B', 'H2C_A', 'H2C_B',
+         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR']
 P = {n: i for i, n in enumerate(PROGS)}
 
 
@@ -41,3 +42,66 @@ def final_exp(lib, n, F, N, out):
     bufs = {i: (T[i], 576) for i in range(7)}
     bufs[7] = (out, 576)
     run(lib, 'FE_FINAL', n, bufs)
+
+
+def buf(data_or_size):
+    if isinstance(data_or_size, int):
+        return C.create_string_buffer(max(data_or_size, 1))
+    return C.create_string_buffer(data_or_size, len(data_or_size))
+
+
+def g1_decompress(lib, comp):
+    n = len(comp) // 48
+    X, R, Cd, out, st = buf(48 * n), buf(48 * n), buf(48 * n), buf(96 * n), buf(n)
+    inb = buf(comp)
+    run(lib, 'G1_DEC_A', n, {0: (inb, 48), 3: (X, 48), 4: (R, 48)})
+    lib.nbls_sim_fp_pow(C.c_uint(n), R, Cd, 0)
+    run(lib, 'G1_DEC_B', n, {0: (inb, 48), 3: (X, 48), 4: (R, 48), 5: (Cd, 48), 6: (out, 96), 7: (st, 1)})
+    return out.raw, list(st.raw)
+
+
+def g2_decompress(lib, comp):
+    n = len(comp) // 96
+    X, R, Cd, out, st = buf(96 * n), buf(96 * n), buf(96 * n), buf(192 * n), buf(n)
+    inb = buf(comp)
+    run(lib, 'G2_DEC_A', n, {0: (inb, 96), 3: (X, 96), 4: (R, 96)})
+    lib.nbls_sim_fp_pow(C.c_uint(n), R, Cd, 1)
+    run(lib, 'G2_DEC_B', n, {0: (inb, 96), 3: (X, 96), 4: (R, 96), 5: (Cd, 96), 6: (out, 192), 7: (st, 1)})
+    return out.raw, list(st.raw)
+
+
+def hash_to_g2(lib, uniform):
+    """uniform: n * 256 bytes of expand_message_xmd output"""
+    n = len(uniform) // 256
+    T, E, Pw, Q, N, NI, out, st = buf(192 * n), buf(192 * n), buf(192 * n), buf(288 * n), buf(48 * n), buf(48 * n), buf(192 * n), buf(n)
+    run(lib, 'H2C_A', n, {0: (buf(uniform), 256), 3: (T, 192), 4: (E, 192)})
+    lib.nbls_sim_fp_pow(C.c_uint(2 * n), E, Pw, 2)
+    run(lib, 'H2C_B', n, {3: (T, 192), 5: (Pw, 192), 6: (Q, 288), 7: (N, 48)})
+    lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
+    run(lib, 'G2_TO_AFFINE', n, {3: (Q, 288), 4: (NI, 48), 2: (out, 192), 7: (st, 1)})
+    return out.raw
+
+
+def point_sum(lib, pts, g2=False):
+    sz, psz = (192, 288) if g2 else (96, 144)
+    pre = 'G2' if g2 else 'G1'
+    n = len(pts) // sz
+    A, Bf = buf(psz * (n + 2)), buf(psz * (n + 2))
+    run(lib, pre + '_TO_PROJ', n, {(1 if g2 else 0): (buf(pts), sz), 3: (A, psz)})
+    ident = bytearray(psz)
+    one = bytes.fromhex('fdff02000000097602000cc40b00f4ebba58c7535798485f455752705358ce776dec56a2971a075c93e480fac35ef615')  # R mod p, little-endian words
+    ident[(96 if g2 else 48):(96 if g2 else 48) + 48] = one
+    m = n
+    src, dst = A, Bf
+    while m > 1:
+        if m & 1:
+            C.memmove(C.addressof(src) + m * psz, bytes(ident), psz)
+            m += 1
+        run(lib, pre + '_ADD2', m // 2, {3: (src, 2 * psz), 5: (dst, psz)})
+        src, dst = dst, src
+        m //= 2
+    N, NI, out, st = buf(48), buf(48), buf(sz), buf(1)
+    run(lib, pre + '_NORM', 1, {3: (src, psz), 4: (N, 48)})
+    lib.nbls_sim_fp_inv(C.c_uint(1), N, NI)
+    run(lib, pre + '_TO_AFFINE', 1, {3: (src, psz), 4: (NI, 48), 2: (out, sz), 7: (st, 1)})
+    return out.raw, st.raw[0]

@@ -212,6 +212,9 @@ def emit(path, bits, fp_t, guard, qual):
     fp('NBLS_R1', 1)            # Montgomery one
     fp('NBLS_R2', RMONT)        # R^2 mod p, as mont(R)
     fp('NBLS_RAW_ONE', 1, raw=True)
+    fp('NBLS_R3', RMONT * RMONT)            # R^3 mod p as mont(R^2): montmul(t, R3) = t R^2
+    fp('NBLS_HALF_P_RAW', (P - 1) // 2, raw=True)   # v > (p-1)/2  <=>  floor(2v/p) = 1 (sign flags, index.ts:314)
+    fp('NBLS_MASK381_RAW', (1 << 381) - 1, raw=True)
     a('#define NBLS_N0_64 0x%016xull' % N0_64)
     a('#define NBLS_N0_32 0x%08xu' % N0_32)
     a('#define NBLS_X 0x%016xull' % X)
@@ -221,6 +224,8 @@ def emit(path, bits, fp_t, guard, qual):
     fp2('NBLS_PSI_X', PSI_X)
     fp2('NBLS_PSI_Y', PSI_Y)
     fp('NBLS_G1X', G1X)
+    fp('NBLS_G1X_RAW', G1X, raw=True)
+    fp('NBLS_NEG_G1Y_RAW', P - G1Y, raw=True)
     fp('NBLS_G1Y', G1Y)
     fp2('NBLS_G2X', G2X)
     fp2('NBLS_G2Y', G2Y)
@@ -228,6 +233,7 @@ def emit(path, bits, fp_t, guard, qual):
     fp2arr('NBLS_FROB6_1', FROB6_1)
     fp2arr('NBLS_FROB6_2', FROB6_2)
     fp2arr('NBLS_ROOTS8', ROOTS8)
+    fp2arr('NBLS_ROOTS8_INV', [f2inv(r) for r in ROOTS8[:4]])   # 1/R[k], k = 0..3 (Fp2.sqrt: candidate / root, math.ts:501)
     fp2arr('NBLS_ETAS', ETAS)
     fp2('NBLS_SWU_Z', SWU_Z)
     fp2('NBLS_SWU_A', SWU_A)
