@@ -111,6 +111,27 @@ class Oracle:
         self.lib.oracle_verify_batch.restype = C.c_int
         return self.lib.oracle_verify_batch(C.c_size_t(len(msgs)), sig, b''.join(msgs), arr, b''.join(pks), dst, C.c_size_t(len(dst)))
 
+    @staticmethod
+    def _pack(msgs):
+        offs = [0]
+        for m in msgs:
+            offs.append(offs[-1] + len(m))
+        return b''.join(msgs), (C.c_uint32 * len(offs))(*offs)
+
+    def aggregate_sign(self, msgs, sks, dst=DST_DEFAULT, threads=8):
+        """-> (list of 48-byte public keys, aggregate signature sum_i sk_i H(m_i))"""
+        blob, offs = self._pack(msgs)
+        n = len(msgs)
+        pks = self._out(48 * n)
+        sig = self._out(96)
+        self.lib.oracle_aggregate_sign(C.c_size_t(n), blob, offs, b''.join(sks), dst, C.c_size_t(len(dst)), pks, sig, C.c_int(threads))
+        return [pks.raw[48 * i:48 * (i + 1)] for i in range(n)], sig.raw
+
+    def verify_batch_mt(self, sig, msgs, pks, dst=DST_DEFAULT, threads=8):
+        blob, offs = self._pack(msgs)
+        self.lib.oracle_verify_batch_mt.restype = C.c_int
+        return self.lib.oracle_verify_batch_mt(C.c_size_t(len(msgs)), sig, blob, offs, b''.join(pks), dst, C.c_size_t(len(dst)), C.c_int(threads))
+
     def aggregate_public_keys(self, pks):
         return self.call('aggregate_public_keys', 48, C.c_size_t(len(pks)), b''.join(pks))
 

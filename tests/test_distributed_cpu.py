@@ -1,0 +1,70 @@
+"""world_size-2 gloo test of the sharded multi-pairing product on CPU: the collective logic of
+parallel.miller_product_sharded with the oracle standing in for the GPU engine."""
+import importlib
+import os
+import sys
+import hashlib
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleBackend:
+    def __init__(self, oracle):
+        self.o = oracle
+
+    def local_product(self, g1, g2):
+        return torch.frombuffer(bytearray(self.o.miller_product(bytes(g1.numpy().tobytes()), bytes(g2.numpy().tobytes()), False)), dtype=torch.uint8)
+
+    def finish(self, partials, final_exp=True):
+        import ctypes as C
+        raw = bytes(partials.numpy().tobytes())
+        acc = raw[:576]
+        for k in range(1, len(raw) // 576):
+            acc = self.o.bin('fp12_mul', acc, raw[576 * k:576 * (k + 1)], 576)
+        if final_exp:
+            acc = self.o.un('fp12_final_exp', acc, 576)
+        return torch.frombuffer(bytearray(acc), dtype=torch.uint8)
+
+
+def _worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import oracle_py
+    par = importlib.import_module('noble-bls12-381_amd.parallel')
+    o = oracle_py.load(rebuild=False)
+    g1g, g2g = o.g1_generator(), o.g2_generator()
+    G1 = b''.join(o.g1_mul(g1g, int.from_bytes(hashlib.sha256(b'a%d' % i).digest(), 'big') % 2**200 + 1)[1] for i in range(n))
+    G2 = b''.join(o.g2_mul(g2g, int.from_bytes(hashlib.sha256(b'b%d' % i).digest(), 'big') % 2**200 + 1)[1] for i in range(n))
+    lo, hi = par.shard_bounds(n, world, rank)
+    t1 = torch.frombuffer(bytearray(G1[96 * lo:96 * hi]), dtype=torch.uint8)
+    t2 = torch.frombuffer(bytearray(G2[192 * lo:192 * hi]), dtype=torch.uint8)
+    res = par.miller_product_sharded(OracleBackend(o), t1, t2, final_exp=True)
+    ref = o.miller_product(G1, G2, True)
+    q.put((rank, bytes(res.numpy().tobytes()) == ref))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_sharded_product_gloo_world2(oracle):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 5, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_shard_bounds():
+    par = importlib.import_module('noble-bls12-381_amd.parallel')
+    for n in (0, 1, 7, 4096, 1000000):
+        for w in (1, 2, 4, 8):
+            b = [par.shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
