@@ -1,0 +1,280 @@
+/*
+ * index.js -- drop-in facade with the exported names of paulmillr/noble-bls12-381 v1.4.0 (reference index.ts:715-821)
+ * over the MI355X engine (libnbls.so via the N-API addon).  Argument handling, error messages and result encodings follow
+ * the reference; the arithmetic runs on the GPU.  Additive batched entry points: pairingBatch, millerProduct.
+ *
+ * Not in this build (SURVEY 8(f).1, "next"): getPublicKey and sign (secret-scalar multiplication) -- they throw.
+ * The reference's re-exported field classes (Fp, Fr, Fp2) are host-side bigint helpers outside the hot path and are not
+ * provided; Fp12 is a thin byte-backed wrapper (toBytes / equals / multiply / finalExponentiate).
+ */
+'use strict';
+const path = require('path');
+const native = require(path.join(__dirname, 'nbls_napi.node'));
+
+const CURVE = {
+  P: 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaabn,
+  r: 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001n,
+  x: 0xd201000000010000n,
+};
+const htfDefaults = { DST: 'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_' };      // reference index.ts:60-81
+let inited = false;
+function ensureInit() { if (!inited) { native.init(Number(process.env.NBLS_DEVICE || 0)); inited = true; } }
+
+// ---- byte helpers (reference math.ts:158-212)
+function hexToBytes(hex) {
+  if (typeof hex !== 'string') throw new TypeError('hexToBytes: expected string, got ' + typeof hex);
+  if (hex.length % 2) throw new Error('hexToBytes: received invalid unpadded hex');
+  const a = new Uint8Array(hex.length / 2);
+  for (let i = 0; i < a.length; i++) { const b = Number.parseInt(hex.slice(2 * i, 2 * i + 2), 16); if (Number.isNaN(b)) throw new Error('Invalid byte sequence'); a[i] = b; }
+  return a;
+}
+const hexes = Array.from({ length: 256 }, (v, i) => i.toString(16).padStart(2, '0'));
+function bytesToHex(u8) { let s = ''; for (let i = 0; i < u8.length; i++) s += hexes[u8[i]]; return s; }
+function ensureBytes(hex) { return hex instanceof Uint8Array ? Uint8Array.from(hex) : hexToBytes(hex); }
+function concat(...arrs) { const n = arrs.reduce((a, b) => a + b.length, 0); const r = new Uint8Array(n); let o = 0; for (const a of arrs) { r.set(a, o); o += a.length; } return r; }
+function toBig(u8) { return BigInt('0x' + (bytesToHex(u8) || '0')); }
+function stringToBytes(str) { const b = new Uint8Array(str.length); for (let i = 0; i < str.length; i++) b[i] = str.charCodeAt(i); return b; }
+function isZeroBytes(u8) { for (let i = 0; i < u8.length; i++) if (u8[i]) return false; return true; }
+const G1_STATUS = { 2: 'Invalid G1 point: not on curve Fp', 3: 'Invalid G1 point: must be of prime-order subgroup', 4: 'Invalid compressed G1 point' };
+const G2_STATUS = { 2: 'Invalid G2 point: not on curve Fp2', 3: 'Invalid G2 point: must be of prime-order subgroup', 4: 'Failed to find a square root' };
+
+// ---- Fp12: byte-backed (Fp12.toBytes order, reference math.ts:875-884)
+class Fp12 {
+  constructor(bytes) { this.bytes = bytes; }
+  toBytes() { return Uint8Array.from(this.bytes); }
+  equals(rhs) { return bytesToHex(this.bytes) === bytesToHex(rhs.bytes); }
+  finalExponentiate() { ensureInit(); return new Fp12(native.finalExpBatch(this.bytes)); }
+  static get ONE() { const b = new Uint8Array(576); b[47] = 1; return new Fp12(b); }
+}
+
+// ---- points: affine wire bytes, or the zero point
+class PointG1 {
+  constructor(aff, zero = false) { this.aff = aff; this.zero = zero; }
+  static get ZERO() { return new PointG1(new Uint8Array(96), true); }
+  static get BASE() {
+    return new PointG1(hexToBytes('17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb' +
+      '08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1'));
+  }
+  isZero() { return this.zero; }
+  // reference index.ts:298-327
+  static fromHex(bytes) {
+    bytes = ensureBytes(bytes); ensureInit();
+    if (bytes.length === 48) {
+      const { out, status } = native.g1Decompress(bytes);
+      if (status[0] === 1) return PointG1.ZERO;
+      if (status[0]) throw new Error(G1_STATUS[status[0]]);
+      return new PointG1(out);
+    } else if (bytes.length === 96) {
+      if ((bytes[0] & (1 << 6)) !== 0) return PointG1.ZERO;
+      const p = new PointG1(bytes); p.assertValidity(); return p;
+    }
+    throw new Error('Invalid point G1, expected 48/96 bytes');
+  }
+  assertValidity() {
+    if (this.zero) return this;
+    ensureInit();
+    const st = native.g1Validate(this.aff).status[0];
+    if (st) throw new Error(G1_STATUS[st]);
+    return this;
+  }
+  negate() {
+    if (this.zero) return this;
+    const y = toBig(this.aff.subarray(48));
+    const ny = y === 0n ? 0n : CURVE.P - y;
+    return new PointG1(concat(this.aff.subarray(0, 48), hexToBytes(ny.toString(16).padStart(96, '0'))));
+  }
+  add(rhs) { return PointG1.sum([this, rhs]); }
+  static sum(points) {
+    ensureInit();
+    const nz = points.filter((p) => !p.zero);
+    if (!nz.length) return PointG1.ZERO;
+    const { out, status } = native.g1Sum(concat(...nz.map((p) => p.aff)));
+    return status[0] === 1 ? PointG1.ZERO : new PointG1(out);
+  }
+  equals(rhs) { return this.zero === rhs.zero && (this.zero || bytesToHex(this.aff) === bytesToHex(rhs.aff)); }
+  // reference index.ts:359-381
+  toHex(isCompressed = false) {
+    this.assertValidity();
+    if (isCompressed) {
+      if (this.zero) return 'c' + '0'.repeat(95);
+      const x = toBig(this.aff.subarray(0, 48)), y = toBig(this.aff.subarray(48));
+      const flag = (y * 2n) / CURVE.P;
+      return (x + flag * (1n << 381n) + (1n << 383n)).toString(16).padStart(96, '0');
+    }
+    if (this.zero) return '4'.padEnd(192, '0');
+    return bytesToHex(this.aff);
+  }
+  toRawBytes(isCompressed = false) { return hexToBytes(this.toHex(isCompressed)); }
+  toAffine() { return [toBig(this.aff.subarray(0, 48)), toBig(this.aff.subarray(48))]; }
+}
+
+class PointG2 {
+  constructor(aff, zero = false) { this.aff = aff; this.zero = zero; }   // aff = x.c0 || x.c1 || y.c0 || y.c1
+  static get ZERO() { return new PointG2(new Uint8Array(192), true); }
+  static get BASE() {
+    return new PointG2(hexToBytes('024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8' +
+      '13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e' +
+      '0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801' +
+      '0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be'));
+  }
+  isZero() { return this.zero; }
+  // reference index.ts:481-490
+  static async hashToCurve(msg, options) {
+    msg = ensureBytes(msg); ensureInit();
+    const dst = stringToBytes((options && options.DST) || htfDefaults.DST);
+    return new PointG2(native.hashToG2(msg, Uint32Array.from([0, msg.length]), dst));
+  }
+  // reference index.ts:500-530
+  static fromSignature(hex) {
+    hex = ensureBytes(hex); ensureInit();
+    const half = hex.length / 2;
+    if (half !== 48 && half !== 96) throw new Error('Invalid compressed signature length, must be 96 or 192');
+    if (half === 96) return PointG2.fromHex(hex);
+    const { out, status } = native.g2Decompress(hex);
+    if (status[0] === 1) return PointG2.ZERO;
+    if (status[0]) throw new Error(G2_STATUS[status[0]]);
+    return new PointG2(out);
+  }
+  // uncompressed 192-byte form x.c1 || x.c0 || y.c1 || y.c0 (reference index.ts:563-579)
+  static fromHex(bytes) {
+    bytes = ensureBytes(bytes);
+    if (bytes.length === 192 && !(bytes[0] & 0x80)) {
+      if ((bytes[0] & (1 << 6)) !== 0) return PointG2.ZERO;
+      const p = new PointG2(concat(bytes.subarray(48, 96), bytes.subarray(0, 48), bytes.subarray(144, 192), bytes.subarray(96, 144)));
+      p.assertValidity(); return p;
+    }
+    if (bytes.length === 96) return PointG2.fromSignature(bytes);
+    throw new Error('Invalid point G2, expected 96/192 bytes');
+  }
+  assertValidity() {
+    if (this.zero) return this;
+    ensureInit();
+    const st = native.g2Validate(this.aff).status[0];
+    if (st) throw new Error(G2_STATUS[st]);
+    return this;
+  }
+  add(rhs) { return PointG2.sum([this, rhs]); }
+  static sum(points) {
+    ensureInit();
+    const nz = points.filter((p) => !p.zero);
+    if (!nz.length) return PointG2.ZERO;
+    const { out, status } = native.g2Sum(concat(...nz.map((p) => p.aff)));
+    return status[0] === 1 ? PointG2.ZERO : new PointG2(out);
+  }
+  equals(rhs) { return this.zero === rhs.zero && (this.zero || bytesToHex(this.aff) === bytesToHex(rhs.aff)); }
+  // reference index.ts:586-598
+  toSignature() {
+    if (this.zero) return hexToBytes('c' + '0'.repeat(191));
+    const a = this.aff, x0 = a.subarray(0, 48), x1 = toBig(a.subarray(48, 96)), y0 = toBig(a.subarray(96, 144)), y1 = toBig(a.subarray(144, 192));
+    const tmp = y1 > 0n ? y1 * 2n : y0 * 2n;
+    const z1 = x1 + (tmp / CURVE.P) * (1n << 381n) + (1n << 383n);
+    return concat(hexToBytes(z1.toString(16).padStart(96, '0')), x0);
+  }
+  toHex(isCompressed = false) {
+    this.assertValidity();
+    if (isCompressed) return bytesToHex(this.toSignature());
+    if (this.zero) return '4'.padEnd(384, '0');
+    const a = this.aff;
+    return bytesToHex(concat(a.subarray(48, 96), a.subarray(0, 48), a.subarray(144, 192), a.subarray(96, 144)));
+  }
+  toRawBytes(isCompressed = false) { return hexToBytes(this.toHex(isCompressed)); }
+}
+
+// ---- reference index.ts:715-722
+function pairing(P, Q, withFinalExponent = true) {
+  if (P.isZero() || Q.isZero()) throw new Error('No pairings at point of Infinity');
+  ensureInit();
+  const { out, status } = native.pairingBatch(P.aff, Q.aff, withFinalExponent, true);
+  if (status[0]) throw new Error(status[0] >= 10 ? G2_STATUS[status[0] - 10] : G1_STATUS[status[0]]);
+  return new Fp12(out);
+}
+// additive: n independent pairings in one call; points are PointG1[] / PointG2[] or packed affine byte arrays
+function pairingBatch(Ps, Qs, withFinalExponent = true, validate = true) {
+  ensureInit();
+  const g1 = Ps instanceof Uint8Array ? Ps : concat(...Ps.map((p) => p.aff));
+  const g2 = Qs instanceof Uint8Array ? Qs : concat(...Qs.map((q) => q.aff));
+  return native.pairingBatch(g1, g2, withFinalExponent, validate);
+}
+function millerProduct(Ps, Qs, finalExp = true, validate = true) {
+  ensureInit();
+  const g1 = Ps instanceof Uint8Array ? Ps : concat(...Ps.map((p) => p.aff));
+  const g2 = Qs instanceof Uint8Array ? Qs : concat(...Qs.map((q) => q.aff));
+  return native.millerProduct(g1, g2, finalExp, validate);
+}
+
+function normP1(point) { return point instanceof PointG1 ? point : PointG1.fromHex(point); }
+function normP2(point) { return point instanceof PointG2 ? point : PointG2.fromSignature(point); }
+async function normP2Hash(point) { return point instanceof PointG2 ? point : PointG2.hashToCurve(point); }
+
+function getPublicKey() { throw new Error('getPublicKey: not implemented in this build (secret-scalar multiplication is a follow-on row, SURVEY 8(f).1)'); }
+async function sign() { throw new Error('sign: not implemented in this build (secret-scalar multiplication is a follow-on row, SURVEY 8(f).1)'); }
+
+// reference index.ts:756-767: e(-P, H(m)) * e(G, S) == 1 with one final exponentiation
+async function verify(signature, message, publicKey) {
+  const P = normP1(publicKey);
+  const Hm = await normP2Hash(message);
+  const S = normP2(signature);
+  if (P.isZero() || Hm.isZero() || S.isZero()) throw new Error('No pairings at point of Infinity');
+  const r = native.millerProduct(concat(P.negate().aff, PointG1.BASE.aff), concat(Hm.aff, S.aff), true, true);
+  if (r.code) { const st = r.status[0] || r.status[1]; throw new Error(st >= 10 ? G2_STATUS[st - 10] : G1_STATUS[st]); }
+  return new Fp12(r.out).equals(Fp12.ONE);
+}
+// reference index.ts:771-788
+function aggregatePublicKeys(publicKeys) {
+  if (!publicKeys.length) throw new Error('Expected non-empty array');
+  const agg = PointG1.sum(publicKeys.map(normP1));
+  if (publicKeys[0] instanceof PointG1) return agg.assertValidity();
+  return agg.toRawBytes(true);
+}
+function aggregateSignatures(signatures) {
+  if (!signatures.length) throw new Error('Expected non-empty array');
+  const agg = PointG2.sum(signatures.map(normP2));
+  if (signatures[0] instanceof PointG2) return agg.assertValidity();
+  return agg.toSignature();
+}
+// reference index.ts:792-821
+async function verifyBatch(signature, messages, publicKeys) {
+  if (!messages.length) throw new Error('Expected non-empty messages array');
+  if (publicKeys.length !== messages.length) throw new Error('Pubkey count should equal msg count');
+  ensureInit();
+  const allWire = !(signature instanceof PointG2) && messages.every((m) => !(m instanceof PointG2)) && publicKeys.every((k) => !(k instanceof PointG1)) &&
+    publicKeys.every((k) => ensureBytes(k).length === 48) && ensureBytes(signature).length === 96;
+  if (allWire) {
+    // fast path: one engine call (hex inputs hash to distinct message objects in the reference, so no grouping applies)
+    const msgs = messages.map(ensureBytes);
+    const offs = new Uint32Array(msgs.length + 1); msgs.forEach((m, i) => { offs[i + 1] = offs[i] + m.length; });
+    const r = native.verifyBatch(ensureBytes(signature), concat(...msgs), offs, concat(...publicKeys.map(ensureBytes)), stringToBytes(htfDefaults.DST));
+    if (r.code) { normP2(signature); publicKeys.forEach(normP1); throw new Error('invalid point'); }   // re-derive the reference's exception
+    return r.ok;
+  }
+  const sig = normP2(signature);
+  const nMessages = await Promise.all(messages.map(normP2Hash));
+  const nPublicKeys = publicKeys.map(normP1);
+  try {
+    const g1 = [], g2 = [];
+    for (const message of new Set(nMessages)) {            // group keys per identical message OBJECT (reference index.ts:804-809)
+      const group = PointG1.sum(nMessages.map((m, i) => (m === message ? nPublicKeys[i] : null)).filter((p) => p));
+      if (group.isZero() || message.isZero()) throw new Error('No pairings at point of Infinity');
+      g1.push(group); g2.push(message);
+    }
+    if (sig.isZero()) throw new Error('No pairings at point of Infinity');
+    g1.push(PointG1.BASE.negate()); g2.push(sig);
+    const r = native.millerProduct(concat(...g1.map((p) => p.aff)), concat(...g2.map((p) => p.aff)), true, true);
+    if (r.code) throw new Error('invalid point');
+    return new Fp12(r.out).equals(Fp12.ONE);
+  } catch (e) {
+    return false;
+  }
+}
+
+const utils = {
+  bytesToHex, hexToBytes, stringToBytes,
+  getDSTLabel() { return htfDefaults.DST; },
+  setDSTLabel(newLabel) {
+    if (typeof newLabel !== 'string' || newLabel.length > 2048 || newLabel.length === 0) throw new TypeError('Invalid DST');
+    htfDefaults.DST = newLabel;
+  },
+};
+
+module.exports = { CURVE, Fp12, PointG1, PointG2, pairing, pairingBatch, millerProduct, getPublicKey, sign, verify, verifyBatch,
+  aggregatePublicKeys, aggregateSignatures, utils, init: (dev) => { native.init(dev || 0); inited = true; } };

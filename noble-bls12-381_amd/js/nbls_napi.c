@@ -1,0 +1,116 @@
+/*
+ * nbls_napi.c -- thin N-API addon: exposes the C ABI of libnbls.so (include/nbls.h) to Node.  No arithmetic here.
+ * libnbls.so is loaded with dlopen at module init so the addon builds with plain gcc (no HIP needed):
+ *     gcc -shared -fPIC -I/usr/include/node -I../../include nbls_napi.c -o nbls_napi.node -ldl
+ * All calls are synchronous (they block for the duration of the GPU work); index.js wraps the reference's async functions
+ * (verify, verifyBatch) in Promises.  Typed arrays are passed by reference (napi_get_typedarray_info), no copies.
+ */
+#include <node_api.h>
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "nbls.h"
+
+static void* lib;
+#define SYM(name) static __typeof__(&name) p_##name;
+SYM(nbls_init) SYM(nbls_destroy) SYM(nbls_strerror) SYM(nbls_pairing_batch) SYM(nbls_miller_product) SYM(nbls_final_exp_batch)
+SYM(nbls_g1_validate_batch) SYM(nbls_g2_validate_batch) SYM(nbls_g1_decompress_batch) SYM(nbls_g2_decompress_batch)
+SYM(nbls_hash_to_g2_batch) SYM(nbls_g1_sum) SYM(nbls_g2_sum) SYM(nbls_verify_batch)
+static nbls_ctx* ctx;
+
+#define CHECK(env, call) do { if ((call) != napi_ok) { napi_throw_error(env, NULL, "N-API call failed: " #call); return NULL; } } while (0)
+static napi_value throw_code(napi_env env, int code) { char m[128]; snprintf(m, sizeof m, "nbls: %s (code %d)", p_nbls_strerror ? p_nbls_strerror(code) : "error", code); napi_throw_error(env, NULL, m); return NULL; }
+
+static int get_bytes(napi_env env, napi_value v, uint8_t** data, size_t* len) {
+  bool is_ta = false; napi_is_typedarray(env, v, &is_ta);
+  if (is_ta) { napi_typedarray_type t; napi_value ab; size_t off; void* d; if (napi_get_typedarray_info(env, v, &t, len, &d, &ab, &off) != napi_ok) return 0; if (t == napi_uint32_array) *len *= 4; *data = (uint8_t*)d; return 1; }
+  bool is_buf = false; napi_is_buffer(env, v, &is_buf);
+  if (is_buf) { void* d; if (napi_get_buffer_info(env, v, &d, len) != napi_ok) return 0; *data = (uint8_t*)d; return 1; }
+  return 0;
+}
+static napi_value new_u8(napi_env env, size_t n, uint8_t** data) {
+  napi_value ab, ta; void* d; if (napi_create_arraybuffer(env, n, &d, &ab) != napi_ok) return NULL; *data = (uint8_t*)d;
+  if (napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &ta) != napi_ok) return NULL; return ta;
+}
+static napi_value result2(napi_env env, napi_value out, napi_value status) {
+  napi_value o; napi_create_object(env, &o); napi_set_named_property(env, o, "out", out); napi_set_named_property(env, o, "status", status); return o;
+}
+#define ARGS(n) size_t argc = n; napi_value argv[n]; CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL)); if (argc < n) { napi_throw_type_error(env, NULL, "missing arguments"); return NULL; }
+#define NEED_CTX() if (!ctx) { napi_throw_error(env, NULL, "nbls: call init(deviceId) first"); return NULL; }
+#define BYTES(i, d, l) uint8_t* d; size_t l; if (!get_bytes(env, argv[i], &d, &l)) { napi_throw_type_error(env, NULL, "expected Uint8Array"); return NULL; }
+
+static napi_value Init(napi_env env, napi_callback_info info) {
+  ARGS(1); int32_t dev = 0; napi_get_value_int32(env, argv[0], &dev);
+  if (ctx) { p_nbls_destroy(ctx); ctx = NULL; }
+  int r = p_nbls_init(dev, &ctx); if (r) return throw_code(env, r);
+  napi_value t; napi_get_boolean(env, true, &t); return t;
+}
+/* pairingBatch(g1, g2, withFinalExp, validate) -> {out, status} */
+static napi_value PairingBatch(napi_env env, napi_callback_info info) {
+  ARGS(4); NEED_CTX(); BYTES(0, g1, l1); BYTES(1, g2, l2); bool fe, val; napi_get_value_bool(env, argv[2], &fe); napi_get_value_bool(env, argv[3], &val);
+  size_t n = l1 / 96; if (l1 != n * 96 || l2 != n * 192) { napi_throw_range_error(env, NULL, "bad point array lengths"); return NULL; }
+  uint8_t *out, *st; napi_value vo = new_u8(env, n * 576, &out), vs = new_u8(env, n, &st);
+  int r = p_nbls_pairing_batch(ctx, n, g1, g2, fe, val, out, (int8_t*)st); if (r) return throw_code(env, r);
+  return result2(env, vo, vs);
+}
+/* millerProduct(g1, g2, finalExp, validate) -> {out, status, code} */
+static napi_value MillerProduct(napi_env env, napi_callback_info info) {
+  ARGS(4); NEED_CTX(); BYTES(0, g1, l1); BYTES(1, g2, l2); bool fe, val; napi_get_value_bool(env, argv[2], &fe); napi_get_value_bool(env, argv[3], &val);
+  size_t n = l1 / 96; if (l1 != n * 96 || l2 != n * 192) { napi_throw_range_error(env, NULL, "bad point array lengths"); return NULL; }
+  uint8_t *out, *st; napi_value vo = new_u8(env, 576, &out), vs = new_u8(env, n, &st);
+  int r = p_nbls_miller_product(ctx, n, g1, g2, fe, val, out, (int8_t*)st); if (r && r != NBLS_EDECODE) return throw_code(env, r);
+  napi_value o = result2(env, vo, vs), c; napi_create_int32(env, r, &c); napi_set_named_property(env, o, "code", c); return o;
+}
+static napi_value FinalExpBatch(napi_env env, napi_callback_info info) {
+  ARGS(1); NEED_CTX(); BYTES(0, in, l); size_t n = l / 576; uint8_t* out; napi_value vo = new_u8(env, n * 576, &out);
+  int r = p_nbls_final_exp_batch(ctx, n, in, out); if (r) return throw_code(env, r); return vo;
+}
+#define POINT_FN(NAME, CALL, IN_SZ, OUT_SZ) \
+  static napi_value NAME(napi_env env, napi_callback_info info) { ARGS(1); NEED_CTX(); BYTES(0, in, l); size_t n = l / (IN_SZ); \
+    uint8_t *out, *st; napi_value vo = new_u8(env, n * (OUT_SZ), &out), vs = new_u8(env, n, &st); \
+    int r = CALL; if (r) return throw_code(env, r); return result2(env, vo, vs); }
+POINT_FN(G1Decompress, p_nbls_g1_decompress_batch(ctx, n, in, out, (int8_t*)st), 48, 96)
+POINT_FN(G2Decompress, p_nbls_g2_decompress_batch(ctx, n, in, out, (int8_t*)st), 96, 192)
+POINT_FN(G1Validate, p_nbls_g1_validate_batch(ctx, n, in, (int8_t*)st), 96, 0)
+POINT_FN(G2Validate, p_nbls_g2_validate_batch(ctx, n, in, (int8_t*)st), 192, 0)
+static napi_value G1Sum(napi_env env, napi_callback_info info) { ARGS(1); NEED_CTX(); BYTES(0, in, l); uint8_t *out, *st; napi_value vo = new_u8(env, 96, &out), vs = new_u8(env, 1, &st);
+  int r = p_nbls_g1_sum(ctx, l / 96, in, out, (int8_t*)st); if (r) return throw_code(env, r); return result2(env, vo, vs); }
+static napi_value G2Sum(napi_env env, napi_callback_info info) { ARGS(1); NEED_CTX(); BYTES(0, in, l); uint8_t *out, *st; napi_value vo = new_u8(env, 192, &out), vs = new_u8(env, 1, &st);
+  int r = p_nbls_g2_sum(ctx, l / 192, in, out, (int8_t*)st); if (r) return throw_code(env, r); return result2(env, vo, vs); }
+/* hashToG2(msgs, offsets(Uint32Array n+1), dst) -> Uint8Array n*192 */
+static napi_value HashToG2(napi_env env, napi_callback_info info) {
+  ARGS(3); NEED_CTX(); BYTES(0, msgs, lm); BYTES(1, offs, lo); BYTES(2, dst, ld); size_t n = lo / 4 - 1; (void)lm;
+  uint8_t* out; napi_value vo = new_u8(env, n * 192, &out);
+  int r = p_nbls_hash_to_g2_batch(ctx, n, msgs, (const uint32_t*)offs, dst, ld, out); if (r) return throw_code(env, r); return vo;
+}
+/* verifyBatch(sig96, msgs, offsets, pks48, dst) -> {code, ok} */
+static napi_value VerifyBatch(napi_env env, napi_callback_info info) {
+  ARGS(5); NEED_CTX(); BYTES(0, sig, ls); BYTES(1, msgs, lm); BYTES(2, offs, lo); BYTES(3, pks, lp); BYTES(4, dst, ld); (void)lm; (void)ls;
+  size_t n = lo / 4 - 1; if (lp != n * 48) { napi_throw_range_error(env, NULL, "bad public key array length"); return NULL; }
+  int ok = 0; int r = p_nbls_verify_batch(ctx, n, sig, msgs, (const uint32_t*)offs, pks, dst, ld, &ok);
+  if (r && r != NBLS_EDECODE) return throw_code(env, r);
+  napi_value o, c, k; napi_create_object(env, &o); napi_create_int32(env, r, &c); napi_get_boolean(env, ok != 0, &k);
+  napi_set_named_property(env, o, "code", c); napi_set_named_property(env, o, "ok", k); return o;
+}
+
+static napi_value ModuleInit(napi_env env, napi_value exports) {
+  const char* path = getenv("NBLS_LIB");
+  char buf[4096];
+  if (!path) { Dl_info di; if (dladdr((void*)ModuleInit, &di) && di.dli_fname) { snprintf(buf, sizeof buf, "%s", di.dli_fname); char* s = strrchr(buf, '/'); if (s) { *s = 0; s = strrchr(buf, '/'); if (s) { snprintf(s, sizeof buf - (s - buf), "/libnbls.so"); path = buf; } } } }
+  lib = dlopen(path ? path : "libnbls.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) { napi_throw_error(env, NULL, dlerror()); return exports; }
+#define LOAD(name) p_##name = (__typeof__(p_##name))dlsym(lib, #name); if (!p_##name) { napi_throw_error(env, NULL, "libnbls.so lacks " #name); return exports; }
+  LOAD(nbls_init) LOAD(nbls_destroy) LOAD(nbls_strerror) LOAD(nbls_pairing_batch) LOAD(nbls_miller_product) LOAD(nbls_final_exp_batch)
+  LOAD(nbls_g1_validate_batch) LOAD(nbls_g2_validate_batch) LOAD(nbls_g1_decompress_batch) LOAD(nbls_g2_decompress_batch)
+  LOAD(nbls_hash_to_g2_batch) LOAD(nbls_g1_sum) LOAD(nbls_g2_sum) LOAD(nbls_verify_batch)
+  napi_property_descriptor d[] = {
+    {"init", 0, Init, 0, 0, 0, napi_enumerable, 0}, {"pairingBatch", 0, PairingBatch, 0, 0, 0, napi_enumerable, 0}, {"millerProduct", 0, MillerProduct, 0, 0, 0, napi_enumerable, 0},
+    {"finalExpBatch", 0, FinalExpBatch, 0, 0, 0, napi_enumerable, 0}, {"g1Decompress", 0, G1Decompress, 0, 0, 0, napi_enumerable, 0}, {"g2Decompress", 0, G2Decompress, 0, 0, 0, napi_enumerable, 0},
+    {"g1Validate", 0, G1Validate, 0, 0, 0, napi_enumerable, 0}, {"g2Validate", 0, G2Validate, 0, 0, 0, napi_enumerable, 0}, {"g1Sum", 0, G1Sum, 0, 0, 0, napi_enumerable, 0},
+    {"g2Sum", 0, G2Sum, 0, 0, 0, napi_enumerable, 0}, {"hashToG2", 0, HashToG2, 0, 0, 0, napi_enumerable, 0}, {"verifyBatch", 0, VerifyBatch, 0, 0, 0, napi_enumerable, 0}};
+  napi_define_properties(env, exports, sizeof d / sizeof d[0], d);
+  return exports;
+}
+NAPI_MODULE(NODE_GYP_MODULE_NAME, ModuleInit)

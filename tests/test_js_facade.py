@@ -1,0 +1,31 @@
+"""The noble-compatible JS facade: the addon builds and loads on CPU; on a GPU box the facade is checked against the golden vectors."""
+import os
+import shutil
+import subprocess
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JS = os.path.join(ROOT, 'noble-bls12-381_amd', 'js')
+needs_node = pytest.mark.skipif(shutil.which('node') is None or not os.path.exists('/usr/include/node/node_api.h'), reason='node / N-API headers not available')
+
+
+def _build():
+    subprocess.check_call(['gcc', '-O2', '-shared', '-fPIC', '-D_GNU_SOURCE', '-I/usr/include/node', '-I' + os.path.join(ROOT, 'include'),
+                           os.path.join(JS, 'nbls_napi.c'), '-o', os.path.join(JS, 'nbls_napi.node'), '-ldl'])
+
+
+@needs_node
+def test_addon_builds_and_exports():
+    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'noble-bls12-381_amd', 'csrc'), '../libnbls.so'])
+    _build()
+    out = subprocess.check_output(['node', '-e', "const b=require('%s'); console.log(Object.keys(b).sort().join(','))" % os.path.join(JS, 'index.js')]).decode()
+    for name in ('pairing', 'verify', 'verifyBatch', 'aggregatePublicKeys', 'aggregateSignatures', 'sign', 'getPublicKey', 'PointG1', 'PointG2', 'utils', 'Fp12', 'CURVE'):
+        assert name in out.split(',') or name in out
+
+
+@needs_node
+@pytest.mark.gpu
+def test_facade_on_gpu():
+    _build()
+    out = subprocess.run(['node', os.path.join(ROOT, 'tests', 'js', 'test_facade.js')], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'JS facade ok' in out.stdout, out.stdout + out.stderr
