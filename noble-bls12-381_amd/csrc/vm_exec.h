@@ -137,6 +137,48 @@ NBLS_HD void wide_mac(u32* acc, const u32* a, const u32* b) {
   acc[24] += c;
 }
 
+// ---- lazy-carry accumulation --------------------------------------------------------------------------------
+// The sum of products of a DOT lane-op is accumulated WITHOUT carry propagation: word positions (2k, 2k+1) share the 64-bit
+// accumulator e[k], positions (2k+1, 2k+2) share o[k]; a limb product a_j*b_i (64 bits, at position i+j) is added to the
+// accumulator aligned with it by ONE v_mad_u64_u32, whose hardware carry-out is counted in a third word (ec[k] at position
+// 2k+2, oc[k] at 2k+3) by ONE v_addc.  No per-row carry chain, no register shuffling; carries are resolved once per lane-op
+// (lazy_normalize) before the Montgomery reduction.
+struct LazyAcc { u64 e[12]; u64 o[12]; u32 ec[12]; u32 oc[12]; };
+
+NBLS_HD void mac3(u64& acc, u32& cw, u32 a, u32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u64 cy;
+  asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2" : "+v"(acc), "+v"(cw), "=&s"(cy) : "v"(a), "v"(b));
+#else
+  u64 s = acc + (u64)a * b; cw += (s < acc) ? 1u : 0u; acc = s;
+#endif
+}
+NBLS_HD void lazy_zero(LazyAcc& L) {
+#pragma unroll
+  for (int i = 0; i < 12; i++) { L.e[i] = 0; L.o[i] = 0; L.ec[i] = 0; L.oc[i] = 0; }
+}
+NBLS_HD void lazy_mac(LazyAcc& L, const u32* a, const u32* b) {
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+      const int w = i + j;
+      if ((w & 1) == 0) mac3(L.e[w / 2], L.ec[w / 2], a[j], b[i]); else mac3(L.o[(w - 1) / 2], L.oc[(w - 1) / 2], a[j], b[i]);
+    }
+  }
+}
+// resolve the carries: t[0..24] = the accumulated integer
+NBLS_HD void lazy_normalize(u32* t, const LazyAcc& L) {
+  u64 c = 0;
+#pragma unroll
+  for (int w = 0; w < 25; w++) {
+    u64 s = c;
+    if ((w & 1) == 0) { if (w / 2 < 12) s += (u32)L.e[w / 2]; if (w >= 2) { s += (u32)(L.o[(w - 2) / 2] >> 32); s += L.ec[(w - 2) / 2]; } }
+    else { s += (u32)(L.e[(w - 1) / 2] >> 32); s += (u32)L.o[(w - 1) / 2]; if (w >= 3) s += L.oc[(w - 3) / 2]; }
+    t[w] = (u32)s; c = s >> 32;
+  }
+}
+
 // Montgomery reduction of a 25-word accumulator V: r (13 words) = V / R mod-ish, r < V/R + p
 NBLS_HD void wide_redc(u32* r, u32* acc) {
   const u32 P[12] = NBLS_P32;
