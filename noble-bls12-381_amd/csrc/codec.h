@@ -81,10 +81,10 @@ static inline void g2_decompress_B(int in_buf, int x_buf, int rhs_buf, int cand_
 }
 
 // ---------------------------------------------------------------- hash_to_field tail + SWU + isogeny + cofactor (index.ts:256-263, 481-490)
-// os2ip(64 bytes) mod p: v = top16 * 2^384 + low48  ->  Montgomery form  top16 * R^2 + low48 * R  =  REDC(top16 * R^3 + low48 * R^2)
+// os2ip(64 bytes) mod p: v = top16 * 2^384 + low48  ->  Montgomery form  v R = REDC(top16 * (2^384 R^2) + low48 * R^2)
 static inline SFp field_elem_from_64(int buf, int off) {
   Builder* B = Builder::cur();
-  Operand t; t.s0 = materialize(input_raw(buf, off, 16)); Operand r3; r3.s0 = B->const_atom(NBLS_R3);
+  Operand t; t.s0 = materialize(input_raw(buf, off, 16)); Operand r3; r3.s0 = B->const_atom(NBLS_TOP384);
   Operand l; l.s0 = materialize(input_raw(buf, off + 16, 48)); Operand r2; r2.s0 = B->r2_atom;
   SFp f; f.f = form_add({{PROD_BASE + B->product(t, r3), 1}}, {{PROD_BASE + B->product(l, r2), 1}}, 1);
   return SFp(materialize(f));
@@ -138,7 +138,7 @@ static inline Pt<SFp2> swu_finish(const SwuState& s, const SFp2& gp) {
 // isogenyMapG2 (math.ts:1315-1325) on a projective point (X : Y : Z): homogenised Horner evaluation, no inversion
 static inline Pt<SFp2> isogeny_g2_proj(const Pt<SFp2>& p) {
   SFp2 Z2 = mat(sqr(p.z)), Z3 = mat(mul(Z2, p.z));
-  auto horner = [&](const u32 c[4][2][12]) {
+  auto horner = [&](const u32 c[4][2][NLIMBS]) {
     // sum_i c[i] X^(3-i) Z^i  (coefficient lists are highest degree first)
     SFp2 X2 = mat(sqr(p.x)), X3 = mat(mul(X2, p.x));
     return mat(mul(fp2_const(c[0]), X3) + mul(fp2_const(c[1]), mat(mul(X2, p.z))) + mul(fp2_const(c[2]), mat(mul(p.x, Z2))) + mul(fp2_const(c[3]), Z3));

@@ -18,6 +18,8 @@ extern "C" int nbls_fp_inv_launch(unsigned n, const void* in, void* out, const v
 extern "C" int nbls_fp_pow_launch(unsigned n, const void* in, void* out, const void* nibbles, int nnib, void* scratch, int is_fp2, void* stream);
 
 using namespace nbls;
+static const size_t RAW = RAW_FP_BYTES;     // one raw field element in HBM scratch (14 limbs + padding)
+static const size_t F12 = 12 * RAW;        // raw Fp12
 
 #define EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -91,11 +93,11 @@ static int ensure_scratch(nbls_ctx* ctx, size_t n) {
   size_t cap = n + n / 8 + 64;
   if (ctx->F) { hipFree(ctx->F); hipFree(ctx->F2); hipFree(ctx->N); hipFree(ctx->NI); for (auto& t : ctx->T) hipFree(t); }
   ctx->cap_F = 0;
-  HIPCHK(hipMalloc(&ctx->F, (cap + 2) * 576));
-  HIPCHK(hipMalloc(&ctx->F2, (cap / 2 + 2) * 576));
-  HIPCHK(hipMalloc(&ctx->N, cap * 48));
-  HIPCHK(hipMalloc(&ctx->NI, cap * 48));
-  for (auto& t : ctx->T) HIPCHK(hipMalloc(&t, cap * 576));
+  HIPCHK(hipMalloc(&ctx->F, (cap + 2) * F12));
+  HIPCHK(hipMalloc(&ctx->F2, (cap / 2 + 2) * F12));
+  HIPCHK(hipMalloc(&ctx->N, cap * RAW));
+  HIPCHK(hipMalloc(&ctx->NI, cap * RAW));
+  for (auto& t : ctx->T) HIPCHK(hipMalloc(&t, cap * F12));
   ctx->cap_F = cap;
   return NBLS_OK;
 }
@@ -124,7 +126,7 @@ static int need(nbls_ctx* ctx, int i, size_t bytes, uint8_t** out) {
 }
 static int run_pow(nbls_ctx* ctx, int which, size_t n, const void* in, void* out, hipStream_t s) {
   int is_fp2 = which != 0;
-  uint8_t* scratch; int r = need(ctx, 11, n * 16 * (is_fp2 ? 96 : 48), &scratch); if (r) return r;
+  uint8_t* scratch; int r = need(ctx, 11, n * 16 * (is_fp2 ? 2 : 1) * RAW, &scratch); if (r) return r;
   int e = nbls_fp_pow_launch((unsigned)n, in, out, ctx->nib[which], ctx->nnib[which], scratch, is_fp2, s);
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
   return NBLS_OK;
@@ -143,8 +145,8 @@ static int reduce_product(nbls_ctx* ctx, size_t n, uint8_t** result, hipStream_t
   uint8_t *src = ctx->F, *dst = ctx->F2;
   size_t m = n;
   while (m > 1) {
-    if (m & 1) { HIPCHK(hipMemcpyAsync(src + m * 576, ctx->one12, 576, hipMemcpyDeviceToDevice, s)); m++; }
-    int r = run(ctx, P_MUL2, m / 2, {B(3, src, 1152), B(5, dst, 576)}, s); if (r) return r;
+    if (m & 1) { HIPCHK(hipMemcpyAsync(src + m * F12, ctx->one12, F12, hipMemcpyDeviceToDevice, s)); m++; }
+    int r = run(ctx, P_MUL2, m / 2, {B(3, src, 2 * F12), B(5, dst, F12)}, s); if (r) return r;
     std::swap(src, dst); m /= 2;
   }
   *result = src;
@@ -155,21 +157,21 @@ static int final_exp_pipeline(nbls_ctx* ctx, size_t n, uint8_t* f_raw, void* d_o
   int r;
   uint8_t** T = ctx->T;
   if ((r = run_inv(ctx, n, s))) return r;
-  if ((r = run(ctx, P_FE_EASY, n, {B(3, f_raw, 576), B(4, ctx->NI, 48), B(5, T[0], 576)}, s))) return r;
-  if ((r = run(ctx, P_EXPX, n, {B(3, T[0], 576), B(5, T[1], 576)}, s))) return r;                       // t2
-  if ((r = run(ctx, P_FE_MID1, n, {B(3, T[0], 576), B(5, T[1], 576), B(6, T[2], 576)}, s))) return r;   // t3
-  if ((r = run(ctx, P_EXPX, n, {B(3, T[2], 576), B(5, T[3], 576)}, s))) return r;                       // t4
-  if ((r = run(ctx, P_EXPX, n, {B(3, T[3], 576), B(5, T[4], 576)}, s))) return r;                       // t5
-  if ((r = run(ctx, P_EXPX, n, {B(3, T[4], 576), B(5, T[6], 576)}, s))) return r;                       // t6' (parked in T7's buffer)
-  if ((r = run(ctx, P_FE_MID2, n, {B(3, T[6], 576), B(5, T[1], 576), B(6, T[5], 576)}, s))) return r;   // t6
-  if ((r = run(ctx, P_EXPX, n, {B(3, T[5], 576), B(5, T[6], 576)}, s))) return r;                       // t7
-  return run(ctx, P_FE_FINAL, n, {B(0, T[0], 576), B(1, T[1], 576), B(2, T[2], 576), B(3, T[3], 576), B(4, T[4], 576), B(5, T[5], 576), B(6, T[6], 576), B(7, d_out, 576)}, s);
+  if ((r = run(ctx, P_FE_EASY, n, {B(3, f_raw, F12), B(4, ctx->NI, RAW), B(5, T[0], F12)}, s))) return r;
+  if ((r = run(ctx, P_EXPX, n, {B(3, T[0], F12), B(5, T[1], F12)}, s))) return r;                       // t2
+  if ((r = run(ctx, P_FE_MID1, n, {B(3, T[0], F12), B(5, T[1], F12), B(6, T[2], F12)}, s))) return r;   // t3
+  if ((r = run(ctx, P_EXPX, n, {B(3, T[2], F12), B(5, T[3], F12)}, s))) return r;                       // t4
+  if ((r = run(ctx, P_EXPX, n, {B(3, T[3], F12), B(5, T[4], F12)}, s))) return r;                       // t5
+  if ((r = run(ctx, P_EXPX, n, {B(3, T[4], F12), B(5, T[6], F12)}, s))) return r;                       // t6' (parked in T7's buffer)
+  if ((r = run(ctx, P_FE_MID2, n, {B(3, T[6], F12), B(5, T[1], F12), B(6, T[5], F12)}, s))) return r;   // t6
+  if ((r = run(ctx, P_EXPX, n, {B(3, T[5], F12), B(5, T[6], F12)}, s))) return r;                       // t7
+  return run(ctx, P_FE_FINAL, n, {B(0, T[0], F12), B(1, T[1], F12), B(2, T[2], F12), B(3, T[3], F12), B(4, T[4], F12), B(5, T[5], F12), B(6, T[6], F12), B(7, d_out, 576)}, s);
 }
 // one raw Fp12 -> final exponentiation (or plain encoding) -> wire bytes on device
 static int finish_single(nbls_ctx* ctx, uint8_t* f_raw, int final_exp, void* d_out, hipStream_t s) {
   int r;
-  if (!final_exp) return run(ctx, P_RAW_TO_BYTES, 1, {B(3, f_raw, 576), B(2, d_out, 576)}, s);
-  if ((r = run(ctx, P_NORM_RAW, 1, {B(3, f_raw, 576), B(4, ctx->N, 48)}, s))) return r;
+  if (!final_exp) return run(ctx, P_RAW_TO_BYTES, 1, {B(3, f_raw, F12), B(2, d_out, 576)}, s);
+  if ((r = run(ctx, P_NORM_RAW, 1, {B(3, f_raw, F12), B(4, ctx->N, RAW)}, s))) return r;
   return final_exp_pipeline(ctx, 1, f_raw, d_out, s);
 }
 
@@ -183,10 +185,10 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
   if (hipSetDevice(device_id) != hipSuccess) { delete ctx; return NBLS_ENOGPU; }
   if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   // Montgomery one as a raw Fp12 (pads odd-sized product reductions)
-  u32 one[144]; memset(one, 0, sizeof one); memcpy(one, NBLS_R1, 48);
-  if (hipMalloc(&ctx->one12, 576) != hipSuccess || hipMemcpy(ctx->one12, one, 576, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
+  u32 one[12 * SLOT_WORDS]; memset(one, 0, sizeof one); memcpy(one, NBLS_R1, NLIMBS * 4);
+  if (hipMalloc(&ctx->one12, F12) != hipSuccess || hipMemcpy(ctx->one12, one, F12, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   {
-    std::vector<u32> tab(382 * 12); make_inv_table(tab.data());
+    std::vector<u32> tab(382 * NLIMBS); make_inv_table(tab.data());
     if (hipMalloc(&ctx->inv_table, tab.size() * 4) != hipSuccess || hipMemcpy(ctx->inv_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   }
   {
@@ -200,12 +202,12 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
     }
     // -G1 in wire form: x || (p - y)   (standard integers, big-endian)
     uint8_t ng[96];
-    auto be = [](uint8_t* o, const u32* w) { for (int i = 0; i < 12; i++) { u32 v = w[11 - i]; o[4 * i] = v >> 24; o[4 * i + 1] = v >> 16; o[4 * i + 2] = v >> 8; o[4 * i + 3] = v; } };
+    auto be = [](uint8_t* o, const u32* limbs) { u32 w[12]; limbs_to_words(w, limbs); for (int i = 0; i < 12; i++) { u32 v = w[11 - i]; o[4 * i] = v >> 24; o[4 * i + 1] = v >> 16; o[4 * i + 2] = v >> 8; o[4 * i + 3] = v; } };
     be(ng, NBLS_G1X_RAW); be(ng + 48, NBLS_NEG_G1Y_RAW);
-    u32 id1[36] = {0}, id2[72] = {0}; memcpy(id1 + 12, NBLS_R1, 48); memcpy(id2 + 24, NBLS_R1, 48);
+    u32 id1[3 * SLOT_WORDS] = {0}, id2[6 * SLOT_WORDS] = {0}; memcpy(id1 + SLOT_WORDS, NBLS_R1, NLIMBS * 4); memcpy(id2 + 2 * SLOT_WORDS, NBLS_R1, NLIMBS * 4);   // (0 : 1 : 0)
     if (hipMalloc(&ctx->neg_g1, 96) != hipSuccess || hipMemcpy(ctx->neg_g1, ng, 96, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMalloc(&ctx->ident_g1, 144) != hipSuccess || hipMemcpy(ctx->ident_g1, id1, 144, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMalloc(&ctx->ident_g2, 288) != hipSuccess || hipMemcpy(ctx->ident_g2, id2, 288, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
+        hipMalloc(&ctx->ident_g1, 3 * RAW) != hipSuccess || hipMemcpy(ctx->ident_g1, id1, 3 * RAW, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc(&ctx->ident_g2, 6 * RAW) != hipSuccess || hipMemcpy(ctx->ident_g2, id2, 6 * RAW, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   }
   for (int i = 0; i < P_COUNT; i++) { int r = upload(ctx, (ProgId)i); if (r) { int e = ctx->last_hip; (void)e; nbls_destroy(ctx); return r; } }
   *out = ctx;
@@ -248,7 +250,7 @@ EXPORT int nbls_pairing_batch_dev(nbls_ctx* ctx, size_t n, const void* d_g1, con
   int r;
   if (!with_final_exp) return run(ctx, P_MILLER_BYTES, n, {B(0, d_g1, 96), B(1, d_g2, 192), B(2, d_out, 576)}, s);
   if ((r = ensure_scratch(ctx, n))) return r;
-  if ((r = run(ctx, P_MILLER_FE, n, {B(0, d_g1, 96), B(1, d_g2, 192), B(3, ctx->F, 576), B(4, ctx->N, 48)}, s))) return r;
+  if ((r = run(ctx, P_MILLER_FE, n, {B(0, d_g1, 96), B(1, d_g2, 192), B(3, ctx->F, F12), B(4, ctx->N, RAW)}, s))) return r;
   return final_exp_pipeline(ctx, n, ctx->F, d_out, s);
 }
 
@@ -288,9 +290,9 @@ EXPORT int nbls_miller_product_dev(nbls_ctx* ctx, size_t n, const void* d_g1, co
   int r;
   if ((r = ensure_scratch(ctx, n ? n : 1))) return r;
   uint8_t* res = ctx->F;
-  if (n == 0) { HIPCHK(hipMemcpyAsync(ctx->F, ctx->one12, 576, hipMemcpyDeviceToDevice, s)); }
+  if (n == 0) { HIPCHK(hipMemcpyAsync(ctx->F, ctx->one12, F12, hipMemcpyDeviceToDevice, s)); }
   else {
-    if ((r = run(ctx, P_MILLER_RAW, n, {B(0, d_g1, 96), B(1, d_g2, 192), B(3, ctx->F, 576)}, s))) return r;
+    if ((r = run(ctx, P_MILLER_RAW, n, {B(0, d_g1, 96), B(1, d_g2, 192), B(3, ctx->F, F12)}, s))) return r;
     if ((r = reduce_product(ctx, n, &res, s))) return r;
   }
   return finish_single(ctx, res, final_exp, d_out, s);
@@ -330,7 +332,7 @@ EXPORT int nbls_final_exp_batch_dev(nbls_ctx* ctx, size_t n, const void* d_in, v
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   int r;
   if ((r = ensure_scratch(ctx, n))) return r;
-  if ((r = run(ctx, P_NORM_BYTES, n, {B(2, d_in, 576), B(3, ctx->F, 576), B(4, ctx->N, 48)}, s))) return r;
+  if ((r = run(ctx, P_NORM_BYTES, n, {B(2, d_in, 576), B(3, ctx->F, F12), B(4, ctx->N, RAW)}, s))) return r;
   return final_exp_pipeline(ctx, n, ctx->F, d_out, s);
 }
 
@@ -361,10 +363,10 @@ EXPORT int nbls_fp12_product_final_dev(nbls_ctx* ctx, size_t n, const void* d_in
   int r;
   if ((r = ensure_scratch(ctx, n ? n : 1))) return r;
   uint8_t* res = ctx->F;
-  if (n == 0) { HIPCHK(hipMemcpyAsync(ctx->F, ctx->one12, 576, hipMemcpyDeviceToDevice, s)); }
+  if (n == 0) { HIPCHK(hipMemcpyAsync(ctx->F, ctx->one12, F12, hipMemcpyDeviceToDevice, s)); }
   else {
     // wire bytes -> raw Montgomery (P_NORM_BYTES also writes N, which is ignored here)
-    if ((r = run(ctx, P_NORM_BYTES, n, {B(2, d_in, 576), B(3, ctx->F, 576), B(4, ctx->N, 48)}, s))) return r;
+    if ((r = run(ctx, P_NORM_BYTES, n, {B(2, d_in, 576), B(3, ctx->F, F12), B(4, ctx->N, RAW)}, s))) return r;
     if ((r = reduce_product(ctx, n, &res, s))) return r;
   }
   return finish_single(ctx, res, final_exp, d_out, s);
@@ -410,29 +412,29 @@ static int dev_validate(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, voi
 }
 // PointG1.fromHex (48 B) / PointG2.fromSignature (96 B): compressed -> affine wire bytes + status
 static int dev_decompress(nbls_ctx* ctx, bool g2, size_t n, const void* d_in, void* d_out, void* d_status, hipStream_t s) {
-  const size_t e = g2 ? 96 : 48;
+  const size_t e = g2 ? 96 : 48, q = g2 ? 2 * RAW : RAW;
   uint8_t *X, *R, *Cd; int r;
-  if ((r = need(ctx, 0, n * e, &X)) || (r = need(ctx, 1, n * e, &R)) || (r = need(ctx, 2, n * e, &Cd))) return r;
-  if ((r = run(ctx, g2 ? P_G2_DEC_A : P_G1_DEC_A, n, {B(0, d_in, e), B(3, X, e), B(4, R, e)}, s))) return r;
+  if ((r = need(ctx, 0, n * q, &X)) || (r = need(ctx, 1, n * q, &R)) || (r = need(ctx, 2, n * q, &Cd))) return r;
+  if ((r = run(ctx, g2 ? P_G2_DEC_A : P_G1_DEC_A, n, {B(0, d_in, e), B(3, X, q), B(4, R, q)}, s))) return r;
   if ((r = run_pow(ctx, g2 ? 1 : 0, n, R, Cd, s))) return r;
-  return run(ctx, g2 ? P_G2_DEC_B : P_G1_DEC_B, n, {B(0, d_in, e), B(3, X, e), B(4, R, e), B(5, Cd, e), B(6, d_out, 2 * e), B(7, d_status, 1)}, s);
+  return run(ctx, g2 ? P_G2_DEC_B : P_G1_DEC_B, n, {B(0, d_in, e), B(3, X, q), B(4, R, q), B(5, Cd, q), B(6, d_out, 2 * e), B(7, d_status, 1)}, s);
 }
 // 256 uniform bytes per message (expand_message_xmd output) -> hash point, affine wire bytes (PointG2.hashToCurve, index.ts:481-490)
 static int dev_hash_to_g2(nbls_ctx* ctx, size_t n, const void* d_uniform, void* d_out, hipStream_t s) {
   uint8_t *T, *E, *Pw, *Q, *N, *NI, *st; int r;
-  if ((r = need(ctx, 0, n * 192, &T)) || (r = need(ctx, 1, n * 192, &E)) || (r = need(ctx, 2, n * 192, &Pw)) || (r = need(ctx, 3, n * 288, &Q)) ||
-      (r = need(ctx, 4, n * 48, &N)) || (r = need(ctx, 5, n * 48, &NI)) || (r = need(ctx, 6, n, &st))) return r;
-  if ((r = run(ctx, P_H2C_A, n, {B(0, d_uniform, 256), B(3, T, 192), B(4, E, 192)}, s))) return r;
+  if ((r = need(ctx, 0, n * 4 * RAW, &T)) || (r = need(ctx, 1, n * 4 * RAW, &E)) || (r = need(ctx, 2, n * 4 * RAW, &Pw)) || (r = need(ctx, 3, n * 6 * RAW, &Q)) ||
+      (r = need(ctx, 4, n * RAW, &N)) || (r = need(ctx, 5, n * RAW, &NI)) || (r = need(ctx, 6, n, &st))) return r;
+  if ((r = run(ctx, P_H2C_A, n, {B(0, d_uniform, 256), B(3, T, 4 * RAW), B(4, E, 4 * RAW)}, s))) return r;
   if ((r = run_pow(ctx, 2, 2 * n, E, Pw, s))) return r;
-  if ((r = run(ctx, P_H2C_B, n, {B(3, T, 192), B(5, Pw, 192), B(6, Q, 288), B(7, N, 48)}, s))) return r;
+  if ((r = run(ctx, P_H2C_B, n, {B(3, T, 4 * RAW), B(5, Pw, 4 * RAW), B(6, Q, 6 * RAW), B(7, N, RAW)}, s))) return r;
   if ((r = run_inv_buf(ctx, n, N, NI, s))) return r;
-  return run(ctx, P_G2_TO_AFFINE, n, {B(3, Q, 288), B(4, NI, 48), B(2, d_out, 192), B(7, st, 1)}, s);
+  return run(ctx, P_G2_TO_AFFINE, n, {B(3, Q, 6 * RAW), B(4, NI, RAW), B(2, d_out, 192), B(7, st, 1)}, s);
 }
 // sum of n affine points (left fold of add == tree of complete additions): affine wire bytes + status (1 = sum is the zero point)
 static int dev_point_sum(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, void* d_out, void* d_status, hipStream_t s) {
-  const size_t a = g2 ? 192 : 96, p = g2 ? 288 : 144;
+  const size_t a = g2 ? 192 : 96, p = g2 ? 6 * RAW : 3 * RAW;
   uint8_t *A, *Bf, *N, *NI; int r;
-  if ((r = need(ctx, 0, (n + 2) * p, &A)) || (r = need(ctx, 1, (n / 2 + 2) * p, &Bf)) || (r = need(ctx, 4, 48, &N)) || (r = need(ctx, 5, 48, &NI))) return r;
+  if ((r = need(ctx, 0, (n + 2) * p, &A)) || (r = need(ctx, 1, (n / 2 + 2) * p, &Bf)) || (r = need(ctx, 4, RAW, &N)) || (r = need(ctx, 5, RAW, &NI))) return r;
   uint8_t* ident = g2 ? ctx->ident_g2 : ctx->ident_g1;
   if (n == 0) { HIPCHK(hipMemcpyAsync(A, ident, p, hipMemcpyDeviceToDevice, s)); }
   else if ((r = run(ctx, g2 ? P_G2_TO_PROJ : P_G1_TO_PROJ, n, {B(g2 ? 1 : 0, d_pts, a), B(3, A, p)}, s))) return r;
@@ -442,9 +444,9 @@ static int dev_point_sum(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, vo
     if ((r = run(ctx, g2 ? P_G2_ADD2 : P_G1_ADD2, m / 2, {B(3, src, 2 * p), B(5, dst, p)}, s))) return r;
     std::swap(src, dst); m /= 2;
   }
-  if ((r = run(ctx, g2 ? P_G2_NORM : P_G1_NORM, 1, {B(3, src, p), B(4, N, 48)}, s))) return r;
+  if ((r = run(ctx, g2 ? P_G2_NORM : P_G1_NORM, 1, {B(3, src, p), B(4, N, RAW)}, s))) return r;
   if ((r = run_inv_buf(ctx, 1, N, NI, s))) return r;
-  return run(ctx, g2 ? P_G2_TO_AFFINE : P_G1_TO_AFFINE, 1, {B(3, src, p), B(4, NI, 48), B(2, d_out, a), B(7, d_status, 1)}, s);
+  return run(ctx, g2 ? P_G2_TO_AFFINE : P_G1_TO_AFFINE, 1, {B(3, src, p), B(4, NI, RAW), B(2, d_out, a), B(7, d_status, 1)}, s);
 }
 
 // ---- host-buffer wrappers ------------------------------------------------------------------------------------

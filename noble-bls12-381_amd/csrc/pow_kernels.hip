@@ -7,106 +7,104 @@
 
 namespace nbls {
 
-// out[i] = in[i]^-1 on raw Montgomery limbs (12 words per element), values in [0,2p) in and out.
+// Fixed-exponent powers, one element per lane, 4-bit fixed windows (exponent given as nibbles, most significant first).
+// Fp:  Fp.pow / Fp.sqrt's a^((p+1)/4) (math.ts:251-264).   Fp2: Fp2.pow for Fp2.sqrt and sqrt_div_fp2 (math.ts:463-465, 493, 1200).
+// Elements are raw scratch elements (16 words: 14 limbs + padding), Montgomery form; every product contracts the value
+// to below ~1.1 p, sums stay far below the 16p subtraction bias.
+struct Fp2r { u32 c0[NL], c1[NL]; };
+__device__ __forceinline__ void mm(u32* r, const u32* a, const u32* b) { mont_mul28(r, a, b); }
+__device__ __forceinline__ void add28(u32* r, const u32* a, const u32* b) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) r[i] = a[i] + b[i];
+  carry_norm(r);
+}
+__device__ __forceinline__ void sub28(u32* r, const u32* a, const u32* b) {   // a - b + 16p
+  const u32 BIAS[NL] = NBLS_BIAS16_28;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r[i] = a[i] + BIAS[i] - b[i];
+  carry_norm(r);
+}
+__device__ __forceinline__ void fp2_mul_r(Fp2r& r, const Fp2r& a, const Fp2r& b) {   // schoolbook with one reduction per component
+  const u32 BIAS[NL] = NBLS_BIAS16_28;
+  u32 nb[NL];
+#pragma unroll
+  for (int i = 0; i < NL; i++) nb[i] = BIAS[i] - a.c1[i];
+  carry_norm(nb);
+  u64 acc[2 * NL];
+#pragma unroll
+  for (int i = 0; i < 2 * NL; i++) acc[i] = 0;
+  mac28(acc, a.c0, b.c0); mac28(acc, nb, b.c1);          // a0 b0 - a1 b1
+  u32 r0[NL]; redc28(r0, acc);
+#pragma unroll
+  for (int i = 0; i < 2 * NL; i++) acc[i] = 0;
+  mac28(acc, a.c0, b.c1); mac28(acc, a.c1, b.c0);        // a0 b1 + a1 b0
+  redc28(r.c1, acc);
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.c0[i] = r0[i];
+}
+__device__ __forceinline__ void fp2_sqr_r(Fp2r& r, const Fp2r& a) {                  // math.ts:477-484
+  u32 s[NL], d[NL], e[NL], r0[NL];
+  add28(s, a.c0, a.c1); sub28(d, a.c0, a.c1); add28(e, a.c0, a.c0);
+  mm(r0, s, d); mm(r.c1, e, a.c1);
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.c0[i] = r0[i];
+}
+
 extern "C" __global__ void __launch_bounds__(64) nbls_fp_inv_kernel(unsigned n, const u32* __restrict__ in, u32* __restrict__ out, const u32* __restrict__ table) {
   unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  u32 x[12], y[12];
+  u32 x[NL], y[NL];
 #pragma unroll
-  for (int k = 0; k < 12; k++) x[k] = in[12 * i + k];
+  for (int k = 0; k < NL; k++) x[k] = in[SLOT_WORDS * i + k];
   fp_mont_inverse(y, x, table);
 #pragma unroll
-  for (int k = 0; k < 12; k++) out[12 * i + k] = y[k];
-}
-
-}  // namespace nbls
-
-namespace nbls {
-
-// Fixed-exponent powers, one element per lane, 4-bit fixed windows (exponent given as nibbles, most significant first).
-// Fp:  Fp.pow / Fp.sqrt's a^((p+1)/4) (math.ts:251-264).   Fp2: Fp2.pow for Fp2.sqrt and sqrt_div_fp2 (math.ts:463-465, 493, 1200).
-// Values are raw Montgomery limbs in [0,2p) in and out.
-struct Fp2r { u32 c0[12], c1[12]; };
-__device__ __forceinline__ void mm(u32* r, const u32* a, const u32* b) { const u32 P2[12] = NBLS_2P32; mont_mul12(r, a, b); csub<12>(r, P2); }
-__device__ __forceinline__ void add2p(u32* r, const u32* a, const u32* b) {   // a + b reduced to [0,2p)
-  const u32 P2[12] = NBLS_2P32; u32 c = 0;
-#pragma unroll
-  for (int i = 0; i < 12; i++) r[i] = addc(a[i], b[i], c, &c);
-  csub<12>(r, P2);
-}
-__device__ __forceinline__ void sub2p(u32* r, const u32* a, const u32* b) {   // a - b + 2p reduced to [0,2p)
-  const u32 P2[12] = NBLS_2P32; u32 br = 0, t[12];
-#pragma unroll
-  for (int i = 0; i < 12; i++) t[i] = subb(a[i], b[i], br, &br);
-  u32 c = 0;
-#pragma unroll
-  for (int i = 0; i < 12; i++) r[i] = addc(t[i], P2[i], c, &c);
-  csub<12>(r, P2);
-}
-__device__ __forceinline__ void fp2_mul_r(Fp2r& r, const Fp2r& a, const Fp2r& b) {   // Karatsuba, math.ts:451-462
-  u32 t1[12], t2[12], s1[12], s2[12], m[12];
-  mm(t1, a.c0, b.c0); mm(t2, a.c1, b.c1);
-  add2p(s1, a.c0, a.c1); add2p(s2, b.c0, b.c1); mm(m, s1, s2);
-  sub2p(r.c0, t1, t2);
-  sub2p(m, m, t1); sub2p(r.c1, m, t2);
-}
-__device__ __forceinline__ void fp2_sqr_r(Fp2r& r, const Fp2r& a) {                  // math.ts:477-484
-  u32 s[12], d[12], e[12];
-  add2p(s, a.c0, a.c1); sub2p(d, a.c0, a.c1); add2p(e, a.c0, a.c0);
-  u32 r0[12]; mm(r0, s, d); mm(r.c1, e, a.c1);
-#pragma unroll
-  for (int i = 0; i < 12; i++) r.c0[i] = r0[i];
+  for (int k = 0; k < NL; k++) out[SLOT_WORDS * i + k] = y[k];
+  out[SLOT_WORDS * i + 14] = 0; out[SLOT_WORDS * i + 15] = 0;
 }
 
 extern "C" __global__ void __launch_bounds__(64) nbls_fp_pow_kernel(unsigned n, const u32* __restrict__ in, u32* __restrict__ out, const unsigned char* __restrict__ nib, int nnib, u32* __restrict__ scratch) {
   unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  // table[j] = x^j, j = 0..15, kept in global scratch (16 * 12 words per element, lane-interleaved by element)
-  u32* tab = scratch + (size_t)i * 16 * 12;
-  u32 x[12], acc[12];
+  u32* tab = scratch + (size_t)i * 16 * 16;   // table[j] = x^j, j = 0..15, in global scratch
+  u32 x[NL], acc[NL], t[NL];
 #pragma unroll
-  for (int k = 0; k < 12; k++) { x[k] = in[12 * i + k]; acc[k] = NBLS_R1[k]; tab[k] = NBLS_R1[k]; tab[12 + k] = x[k]; }
-  {
-    u32 t[12];
+  for (int k = 0; k < NL; k++) { x[k] = in[16 * i + k]; acc[k] = NBLS_R1[k]; tab[k] = NBLS_R1[k]; tab[16 + k] = x[k]; t[k] = x[k]; }
+  for (int j = 2; j < 16; j++) {
+    u32 u[NL]; mm(u, t, x);
 #pragma unroll
-    for (int k = 0; k < 12; k++) t[k] = x[k];
-    for (int j = 2; j < 16; j++) {
-      u32 u[12]; mm(u, t, x);
-#pragma unroll
-      for (int k = 0; k < 12; k++) { t[k] = u[k]; tab[12 * j + k] = u[k]; }
-    }
+    for (int k = 0; k < NL; k++) { t[k] = u[k]; tab[16 * j + k] = u[k]; }
   }
   for (int w = 0; w < nnib; w++) {
-    u32 t[12];
     if (w) { mm(t, acc, acc); mm(acc, t, t); mm(t, acc, acc); mm(acc, t, t); }
     unsigned d = nib[w];   // uniform
     if (d) {
-      u32 e[12];
+      u32 e[NL];
 #pragma unroll
-      for (int k = 0; k < 12; k++) e[k] = tab[12 * d + k];
+      for (int k = 0; k < NL; k++) e[k] = tab[16 * d + k];
       mm(t, acc, e);
 #pragma unroll
-      for (int k = 0; k < 12; k++) acc[k] = t[k];
+      for (int k = 0; k < NL; k++) acc[k] = t[k];
     }
   }
 #pragma unroll
-  for (int k = 0; k < 12; k++) out[12 * i + k] = acc[k];
+  for (int k = 0; k < NL; k++) out[16 * i + k] = acc[k];
+  out[16 * i + 14] = 0; out[16 * i + 15] = 0;
 }
 
 extern "C" __global__ void __launch_bounds__(64) nbls_fp2_pow_kernel(unsigned n, const u32* __restrict__ in, u32* __restrict__ out, const unsigned char* __restrict__ nib, int nnib, u32* __restrict__ scratch) {
   unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  u32* tab = scratch + (size_t)i * 16 * 24;
+  u32* tab = scratch + (size_t)i * 16 * 32;
   Fp2r x, acc, t;
 #pragma unroll
-  for (int k = 0; k < 12; k++) { x.c0[k] = in[24 * i + k]; x.c1[k] = in[24 * i + 12 + k]; acc.c0[k] = NBLS_R1[k]; acc.c1[k] = 0; }
+  for (int k = 0; k < NL; k++) { x.c0[k] = in[32 * i + k]; x.c1[k] = in[32 * i + 16 + k]; acc.c0[k] = NBLS_R1[k]; acc.c1[k] = 0; }
 #pragma unroll
-  for (int k = 0; k < 12; k++) { tab[k] = acc.c0[k]; tab[12 + k] = 0; tab[24 + k] = x.c0[k]; tab[36 + k] = x.c1[k]; }
+  for (int k = 0; k < NL; k++) { tab[k] = acc.c0[k]; tab[16 + k] = 0; tab[32 + k] = x.c0[k]; tab[48 + k] = x.c1[k]; }
   t = x;
   for (int j = 2; j < 16; j++) {
     Fp2r u; fp2_mul_r(u, t, x); t = u;
 #pragma unroll
-    for (int k = 0; k < 12; k++) { tab[24 * j + k] = u.c0[k]; tab[24 * j + 12 + k] = u.c1[k]; }
+    for (int k = 0; k < NL; k++) { tab[32 * j + k] = u.c0[k]; tab[32 * j + 16 + k] = u.c1[k]; }
   }
   for (int w = 0; w < nnib; w++) {
     if (w) { fp2_sqr_r(t, acc); fp2_sqr_r(acc, t); fp2_sqr_r(t, acc); fp2_sqr_r(acc, t); }
@@ -114,12 +112,13 @@ extern "C" __global__ void __launch_bounds__(64) nbls_fp2_pow_kernel(unsigned n,
     if (d) {
       Fp2r e;
 #pragma unroll
-      for (int k = 0; k < 12; k++) { e.c0[k] = tab[24 * d + k]; e.c1[k] = tab[24 * d + 12 + k]; }
+      for (int k = 0; k < NL; k++) { e.c0[k] = tab[32 * d + k]; e.c1[k] = tab[32 * d + 16 + k]; }
       fp2_mul_r(t, acc, e); acc = t;
     }
   }
 #pragma unroll
-  for (int k = 0; k < 12; k++) { out[24 * i + k] = acc.c0[k]; out[24 * i + 12 + k] = acc.c1[k]; }
+  for (int k = 0; k < NL; k++) { out[32 * i + k] = acc.c0[k]; out[32 * i + 16 + k] = acc.c1[k]; }
+  out[32 * i + 14] = out[32 * i + 15] = out[32 * i + 30] = out[32 * i + 31] = 0;
 }
 
 }  // namespace nbls

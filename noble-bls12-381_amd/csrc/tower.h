@@ -14,7 +14,7 @@ struct SFp6 { SFp2 c0, c1, c2; };
 struct SFp12 { SFp6 c0, c1; };
 
 static inline SFp fp_const(const u32* m) { return constant(m); }
-static inline SFp2 fp2_const(const u32 m[2][12]) { return {constant(m[0]), constant(m[1])}; }
+static inline SFp2 fp2_const(const u32 m[2][NLIMBS]) { return {constant(m[0]), constant(m[1])}; }
 static inline SFp fp_one() { return constant(NBLS_R1); }
 static inline SFp2 fp2_one() { return {fp_one(), SFp()}; }
 static inline SFp2 fp2_zero() { return {SFp(), SFp()}; }

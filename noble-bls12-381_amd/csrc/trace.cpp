@@ -4,23 +4,24 @@
 #include <cmath>
 #include <queue>
 #include "consts_gen.h"
+#include "vm_exec.h"
 
 namespace nbls {
 
-static const double P_OVER_R = 0.10158;   // p / 2^384, rounded up
+static const double P_OVER_R = 1.0 / 1234.0;   // p / 2^392 = 0.00079..., rounded up
+static const double NEG_CAP = 16.0;             // negated atoms must stay below the 16p bias
+static const double OUT_CAP = 10.0;             // results above this bound get their post-added terms folded into the dot product
+static const double OP_CAP = 24.0;              // product operands above this bound are contracted first (keeps bounds from compounding)
 
-static void add_mod_p(u32* x, const u32* y) {
-  uint64_t c = 0;
-  for (int i = 0; i < 12; i++) { uint64_t s = (uint64_t)x[i] + y[i] + c; x[i] = (u32)s; c = s >> 32; }
-  // conditional subtract p (values stay < 2p < 2^384, so no carry-out)
-  u32 d[12]; uint64_t br = 0;
-  for (int i = 0; i < 12; i++) { uint64_t t = (uint64_t)x[i] - NBLS_P[i] - br; d[i] = (u32)t; br = (t >> 63) & 1; }
-  if (!br) memcpy(x, d, 48);
+static void add_mod_p(u32* x, const u32* y) {   // canonical 14-limb values
+  for (int i = 0; i < NLIMBS; i++) x[i] += y[i];
+  carry_norm(x);
+  csub_p(x);
 }
 
 Builder::Builder() {
   cur() = this;
-  static const u32 zero[12] = {0};
+  static const u32 zero[NLIMBS] = {0};
   zero_atom = const_atom(zero);
   one_atom = const_atom(NBLS_R1);
   r2_atom = const_atom(NBLS_R2);
@@ -31,17 +32,31 @@ int Builder::small_const(int c) {
   assert(c > 0 && c < 4096);
   auto it = small_consts.find(c);
   if (it != small_consts.end()) return it->second;
-  u32 acc[12] = {0}, dbl[12];
-  memcpy(dbl, NBLS_R1, 48);
-  for (int k = c; k; k >>= 1) { if (k & 1) add_mod_p(acc, dbl); u32 t[12]; memcpy(t, dbl, 48); add_mod_p(dbl, t); }
+  u32 acc[NLIMBS] = {0}, dbl[NLIMBS];
+  memcpy(dbl, NBLS_R1, NLIMBS * 4);
+  for (int k = c; k; k >>= 1) { if (k & 1) add_mod_p(acc, dbl); u32 t[NLIMBS]; memcpy(t, dbl, NLIMBS * 4); add_mod_p(dbl, t); }
   int id = const_atom(acc);
   small_consts[c] = id;
   return id;
 }
 
+int Builder::frac_const(int c, int m) {
+  auto it = frac_consts.find({c, m}); if (it != frac_consts.end()) return it->second;
+  u32 unit[NLIMBS];   // 1/m in Montgomery form
+  if (m == 1) memcpy(unit, NBLS_R1, NLIMBS * 4);
+  else if (m == 2) memcpy(unit, NBLS_HALF, NLIMBS * 4);
+  else if (m == 3) memcpy(unit, NBLS_INV3, NLIMBS * 4);
+  else { assert(m == 4); memcpy(unit, NBLS_HALF, NLIMBS * 4); u32 acc[NLIMBS] = {0};   // 1/4 = (1/2) * (1/2): halve 1/2 = (x + (x odd ? p : 0)) / 2
+         memcpy(acc, NBLS_HALF, NLIMBS * 4); halve28(acc); csub_p(acc); memcpy(unit, acc, NLIMBS * 4); }
+  u32 acc[NLIMBS] = {0};
+  for (int k = 0; k < std::abs(c); k++) add_mod_p(acc, unit);
+  if (c < 0) { u32 P[NLIMBS] = NBLS_P_INIT, z = 0; for (int i = 0; i < NLIMBS; i++) z |= acc[i]; if (z) { for (int i = 0; i < NLIMBS; i++) acc[i] = P[i] + (i < NLIMBS - 1 ? (1u << 28) : 0) - acc[i] - (i > 0 ? 1 : 0); carry_norm(acc); csub_p(acc); } }
+  int id = const_atom(acc); frac_consts[{c, m}] = id; return id;
+}
+
 SFp input(int buf, int off) {
   Builder* B = Builder::cur();
-  Node n; n.kind = K_LOAD; n.buf = buf; n.off = off; n.raw = true;
+  Node n; n.kind = K_LOAD; n.buf = buf; n.off = off; n.raw = true; n.bound = 9.85;
   int raw = B->add_node(n);
   // x * R^2 / R = x R : to Montgomery form (valid for any x < 2^384)
   Operand a; a.s0 = raw; Operand b; b.s0 = B->r2_atom;
@@ -49,7 +64,7 @@ SFp input(int buf, int off) {
   return SFp(materialize(r));
 }
 SFp input_raw(int buf, int off, int nbytes) {
-  Node n; n.kind = K_LOAD; n.buf = buf; n.off = off; n.raw = true; n.p0 = (uint8_t)(nbytes == 48 ? 0 : nbytes);
+  Node n; n.kind = K_LOAD; n.buf = buf; n.off = off; n.raw = true; n.bound = 9.85; n.p0 = (uint8_t)(nbytes == 48 ? 0 : nbytes);
   return SFp(Builder::cur()->add_node(n));
 }
 SFp to_mont(const SFp& raw) {
@@ -67,29 +82,48 @@ void output(const SFp& x, int buf, int off) {
   B->add_node(n);
 }
 
-static int stages_for(double total_bound_p) {   // reduce [0, total) to [0, 2p) by conditional subtractions of 2p << s
-  int s = 0; while (2.0 * (1 << s) < total_bound_p) s++;
-  return s;
+int Builder::contract(int atom) {
+  if (atom_bound(atom) <= 1.5 || nodes[atom].kind == 0xff) return atom;
+  auto it = contract_cache.find(atom); if (it != contract_cache.end()) return it->second;
+  Node n; n.kind = K_DOT; Operand a; a.s0 = atom; Operand b; b.s0 = one_atom;
+  n.prods.push_back({a, b, false}); n.mult = 1;
+  n.bound = atom_bound(atom) * P_OVER_R + 1.0;
+  int id = add_node(n); contract_cache[atom] = id; return id;
 }
 
 // Emit one DOT node for (prods, lin) -- caller guarantees the limits.
-static int emit_dot(Builder* B, const std::vector<DotProduct>& prods, int mult, const std::vector<std::pair<int, int>>& lin, bool halve_it) {
+static int emit_dot(Builder* B, std::vector<DotProduct> prods, int mult, std::vector<std::pair<int, int>> lin, bool halve_it) {
+  // negated atoms must be below the 16p bias: contract the (rare) large ones first
+  for (auto& p : prods) {
+    auto fix = [&](int& a) { if (a >= 0 && B->atom_bound(a) > NEG_CAP) a = B->contract(a); };
+    auto cap = [&](int& a) { if (a >= 0 && B->atom_bound(a) > OP_CAP && !B->nodes[a].raw) a = B->contract(a); };
+    cap(p.a.s0); cap(p.a.s1); cap(p.b.s0); cap(p.b.s1);
+    if (p.neg) { fix(p.a.s0); if (!p.a.n1) fix(p.a.s1); } else if (p.a.n1) fix(p.a.s1);
+    if (p.b.n1) fix(p.b.s1);
+  }
+  for (auto& t : lin) if (B->atom_bound(t.first) > (t.second < 0 ? NEG_CAP : OP_CAP)) t.first = B->contract(t.first);
   Node n; n.kind = K_DOT; n.prods = prods; n.mult = mult; n.lin = lin; n.halve = halve_it;
-  double V = 0; for (auto& p : prods) V += B->operand_bound(p.a) * B->operand_bound(p.b);
+  double V = 0; for (auto& p : prods) V += B->operand_bound(p.a, p.neg) * B->operand_bound(p.b, false);
   double D = prods.empty() ? 0.0 : V * P_OVER_R + 1.0;
-  double T = mult * D + 2.0 * lin.size();
-  n.stages = stages_for(T);
-  assert(n.stages <= 4);
+  double T = mult * D; for (auto& t : lin) T += t.second < 0 ? NEG_CAP : B->atom_bound(t.first);
+  if (halve_it) T = T / 2 + 0.5;
+  if (T >= 1000.0) { fprintf(stderr, "DOT bound %.1f: mult=%d D=%.2f V=%.1f k=%zu L=%zu\n", T, mult, D, V, prods.size(), lin.size()); for (auto& p : prods) fprintf(stderr, "  A(%d:%.1f,%d:%.1f n1=%d neg=%d) B(%d:%.1f,%d:%.1f n1=%d)\n", p.a.s0, B->atom_bound(p.a.s0), p.a.s1, p.a.s1>=0?B->atom_bound(p.a.s1):0, p.a.n1, p.neg, p.b.s0, B->atom_bound(p.b.s0), p.b.s1, p.b.s1>=0?B->atom_bound(p.b.s1):0, p.b.n1); for (auto& t : lin) fprintf(stderr, "  lin %d:%.1f sign %d\n", t.first, B->atom_bound(t.first), t.second); }
+  assert(T < 1000.0);
+  n.bound = T;
   return B->add_node(n);
 }
 static int emit_lin(Builder* B, std::vector<std::pair<int, int>> terms, bool halve_it) {
+  for (auto& t : terms) if (B->atom_bound(t.first) > (t.second < 0 ? NEG_CAP : OP_CAP)) t.first = B->contract(t.first);
+  auto bound_of = [&](const std::vector<std::pair<int, int>>& ts) { double T = 0; for (auto& t : ts) T += t.second < 0 ? NEG_CAP : B->atom_bound(t.first); return T; };
   while ((int)terms.size() > MAX_LIN_TERMS) {
-    Node n; n.kind = K_LIN; n.lin.assign(terms.begin(), terms.begin() + MAX_LIN_TERMS);
+    Node n; n.kind = K_LIN; n.lin.assign(terms.begin(), terms.begin() + MAX_LIN_TERMS); n.bound = bound_of(n.lin);
     int id = B->add_node(n);
     terms.erase(terms.begin(), terms.begin() + MAX_LIN_TERMS);
     terms.insert(terms.begin(), {id, 1});
   }
-  Node n; n.kind = K_LIN; n.lin = terms; n.halve = halve_it;
+  Node n; n.kind = K_LIN; n.lin = terms; n.halve = halve_it; n.bound = bound_of(terms);
+  if (halve_it) n.bound = n.bound / 2 + 0.5;
+  assert(n.bound < 1000.0);
   return B->add_node(n);
 }
 
@@ -139,29 +173,29 @@ int materialize(const SFp& x, bool halve_it) {
       else atoms.push_back({a, c});
     }
   }
-  if (mult > 1) for (auto& d : dps) (void)d;
   std::vector<std::pair<int, int>> lin;
   for (auto& a : atoms) for (int k = 0; k < std::abs(a.second); k++) lin.push_back({a.first, a.second > 0 ? 1 : -1});
 
   int id;
+  if (!dps.empty() && !lin.empty()) {
+    // If the post-added terms would make the result large, fold them into the accumulator as products with small
+    // constants (x * (c/m)): the Montgomery reduction then contracts everything to about m p.
+    double T = mult * 2.0; for (auto& t : lin) T += t.second < 0 ? NEG_CAP : B->atom_bound(t.first);
+    if (T > OUT_CAP) {
+      std::map<int, int> net; for (auto& t : lin) net[t.first] += t.second;
+      for (auto& kv : net) if (kv.second) { Operand a; a.s0 = kv.first; Operand c; c.s0 = B->frac_const(kv.second, mult); dps.push_back({a, c, false}); }
+      lin.clear();
+    }
+  }
   if (dps.empty()) {
     id = emit_lin(B, lin, halve_it);
   } else {
     if ((int)lin.size() > MAX_DOT_LINEAR) { int a = emit_lin(B, lin, false); lin.clear(); lin.push_back({a, 1}); }
-    // chunk the products so that every lane-op respects k <= 8, REDC bound <= 9p and total bound <= 32p
-    for (;;) {
-      double V = 0; size_t take = 0;
-      while (take < dps.size() && take < (size_t)MAX_DOT_PRODUCTS) {
-        double v = B->operand_bound(dps[take].a) * B->operand_bound(dps[take].b);
-        double D = (V + v) * P_OVER_R + 1.0;
-        if (mult * D + 2.0 * (lin.size() + 1) > 32.0) break;
-        V += v; take++;
-      }
-      assert(take > 0);
-      if (take == dps.size()) break;
-      std::vector<DotProduct> chunk(dps.begin(), dps.begin() + take);
+    // chunk the products: at most 8 per lane-op (column accumulators hold 112 limb products)
+    while (dps.size() > (size_t)MAX_DOT_PRODUCTS) {
+      std::vector<DotProduct> chunk(dps.begin(), dps.begin() + MAX_DOT_PRODUCTS);
       int a = emit_dot(B, chunk, mult, {}, false);
-      dps.erase(dps.begin(), dps.begin() + take);
+      dps.erase(dps.begin(), dps.begin() + MAX_DOT_PRODUCTS);
       if ((int)lin.size() >= MAX_DOT_LINEAR) { int l = emit_lin(B, lin, false); lin.clear(); lin.push_back({l, 1}); }
       lin.push_back({a, 1});
     }
@@ -187,16 +221,6 @@ static void node_deps(const Node& n, std::vector<int>& d) {
     default: break;
   }
   d.erase(std::remove(d.begin(), d.end(), -1), d.end());
-}
-
-static void make_pm2(std::vector<u32>& out) {
-  // k * 2p for k = 0..16, 13 significant words, padded to 16
-  u32 acc[16] = {0};
-  for (int k = 0; k <= 16; k++) {
-    for (int i = 0; i < 16; i++) out.push_back(acc[i]);
-    uint64_t c = 0;
-    for (int i = 0; i < 16; i++) { uint64_t s = (uint64_t)acc[i] + (i < 12 ? NBLS_2P[i] : 0) + c; acc[i] = (u32)s; c = s >> 32; }
-  }
 }
 
 Program Builder::compile(const std::string& name, int W) {
@@ -313,13 +337,11 @@ Program Builder::compile(const std::string& name, int W) {
     if (n0.kind == K_LIN) {
       size_t mx = 0; for (int c : L) mx = std::max(mx, nodes[c].lin.size());
       st.p0 = (uint8_t)mx; st.stride = mx > 6 ? 8 : 4;
-      int stages = 0; while ((1u << stages) < mx) stages++;
-      st.p1 = (uint8_t)stages;
       P.n_lin_steps++; P.n_lin_ops += (u32)L.size();
     } else if (n0.kind == K_DOT) {
-      size_t mk = 0, ml = 0; int stg = 0;
-      for (int c : L) { mk = std::max(mk, nodes[c].prods.size()); ml = std::max(ml, nodes[c].lin.size()); stg = std::max(stg, nodes[c].stages); P.n_products += (u32)nodes[c].prods.size(); }
-      st.p0 = (uint8_t)mk; st.p1 = (uint8_t)stg; st.pad = (u32)ml;
+      size_t mk = 0, ml = 0;
+      for (int c : L) { mk = std::max(mk, nodes[c].prods.size()); ml = std::max(ml, nodes[c].lin.size()); P.n_products += (u32)nodes[c].prods.size(); }
+      st.p0 = (uint8_t)mk; st.pad = (u32)ml;
       st.stride = (u32)((4 + 2 * mk + 3) / 4 * 4);
       P.n_dot_steps++; P.n_dot_ops += (u32)L.size(); P.n_prod_slots += (u32)(mk * W);
     } else {
@@ -364,9 +386,8 @@ Program Builder::compile(const std::string& name, int W) {
     }
     P.steps.push_back(st);
   }
-  P.nconst = (u32)const_words.size() / 12;
+  P.nconst = (u32)const_words.size() / SLOT_WORDS;
   P.consts = const_words;
-  make_pm2(P.consts);
   return P;
 }
 

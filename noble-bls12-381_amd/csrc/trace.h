@@ -29,7 +29,7 @@ struct Program {
   std::string name;
   std::vector<Step> steps;
   std::vector<u32> descs;
-  std::vector<u32> consts;   // nconst*12 words + PM2 table (17*16 words)
+  std::vector<u32> consts;   // nconst * SLOT_WORDS words
   u32 nconst = 0, W = 64, G = 1, slots = 0;
   // statistics
   u32 n_dot_steps = 0, n_lin_steps = 0, n_other_steps = 0, n_dot_ops = 0, n_products = 0, n_prod_slots = 0, n_lin_ops = 0, n_lin_terms = 0;
@@ -61,7 +61,7 @@ struct Node {
   std::vector<std::pair<int, int>> stat;                   // STATUS (flag atom, code)
   int buf = 0, off = 0;
   int const_idx = -1;
-  int stages = 0;
+  double bound = 2.0;      // magnitude bound of the stored value in units of p (values are normalised 28-bit limbs)
   // scheduling state
   bool live = false;
   int step = -1, lane = 0, slot = -1, last_use = -1, height = 0, ndeps = 0;
@@ -71,12 +71,13 @@ struct Node {
 struct SFp;
 struct Builder {
   std::vector<Node> nodes;
-  std::vector<u32> const_words;                      // 12 words per constant
+  std::vector<u32> const_words;                      // SLOT_WORDS words per constant (14 limbs + padding)
   std::map<std::vector<u32>, int> const_map;         // limbs -> node id
   std::vector<ProdKey> prods;
   std::map<ProdKey, int> prod_map;
   std::map<Form, int> mat_cse, halve_cse;
   std::map<int, int> small_consts;                   // integer -> constant atom (Montgomery form)
+  std::map<int, int> contract_cache;                 // atom -> contracted atom
   int zero_atom = -1, one_atom = -1, r2_atom = -1, rawone_atom = -1;
   int TMAX = 12;         // soft cap on the size of a lazy form
   static Builder*& cur() { static thread_local Builder* b = nullptr; return b; }
@@ -85,14 +86,17 @@ struct Builder {
 
   int add_node(const Node& n) { nodes.push_back(n); return (int)nodes.size() - 1; }
   int const_atom(const u32* limbs) {
-    std::vector<u32> key(limbs, limbs + 12);
+    std::vector<u32> key(limbs, limbs + NLIMBS);
     auto it = const_map.find(key);
     if (it != const_map.end()) return it->second;
-    Node n; n.kind = 0xff; n.const_idx = (int)const_words.size() / 12;
+    Node n; n.kind = 0xff; n.const_idx = (int)const_words.size() / SLOT_WORDS; n.bound = 1.0;
     const_words.insert(const_words.end(), key.begin(), key.end());
+    const_words.push_back(0); const_words.push_back(0);
     int id = add_node(n); const_map[key] = id; return id;
   }
   int small_const(int c);                            // Montgomery form of a small positive integer
+  int frac_const(int c, int m);                      // Montgomery form of c / m mod p  (c small, possibly negative; m in 1..4)
+  std::map<std::pair<int, int>, int> frac_consts;
   int product(const Operand& a, const Operand& b) {
     ProdKey k{a, b}; if (k.b < k.a) std::swap(k.a, k.b);
     auto it = prod_map.find(k); if (it != prod_map.end()) return it->second;
@@ -100,8 +104,14 @@ struct Builder {
   }
   bool is_const(int atom) const { return nodes[atom].kind == 0xff; }
   // magnitude bound of an atom in units of p
-  double atom_bound(int atom) const { const Node& n = nodes[atom]; return n.kind == 0xff ? 1.0 : n.raw ? 9.85 : 2.0; }
-  double operand_bound(const Operand& o) const { return atom_bound(o.s0) + (o.s1 >= 0 ? atom_bound(o.s1) : 0.0); }
+  double atom_bound(int atom) const { return nodes[atom].bound; }
+  // worst-case bound of a product operand; every negated term enters as 16p - x
+  double operand_bound(const Operand& o, bool negated) const {
+    double b = negated ? 16.0 : atom_bound(o.s0);
+    if (o.s1 >= 0) b += (o.n1 != negated) ? 16.0 : atom_bound(o.s1);
+    return b;
+  }
+  int contract(int atom);                            // x -> x * R / R : same value mod p, bound ~1: keeps negated atoms below the 16p bias
   Program compile(const std::string& name, int W);
 };
 
@@ -182,7 +192,7 @@ static inline SFp sqr(const SFp& a) { return mul(a, a); }
 // ---- constants, inputs, outputs
 static inline SFp constant(const u32* mont_limbs) {
   Builder* B = Builder::cur();
-  bool z = true; for (int i = 0; i < 12; i++) z = z && mont_limbs[i] == 0;
+  bool z = true; for (int i = 0; i < NLIMBS; i++) z = z && mont_limbs[i] == 0;
   if (z) return SFp();
   return SFp(B->const_atom(mont_limbs));
 }
@@ -190,21 +200,28 @@ SFp input(int buf, int off);          // big-endian wire bytes -> Montgomery val
 SFp input_raw(int buf, int off, int nbytes = 48);   // big-endian integer of nbytes (multiple of 4, <= 48), NOT in Montgomery form
 SFp to_mont(const SFp& raw);          // raw integer (< 2^384) -> Montgomery value
 SFp raw_const(const u32* limbs);      // constant raw integer
-static inline SFp bit_flag(const SFp& raw, int bit) { Node n; n.kind = K_BIT; n.a0 = materialize(raw); n.off = bit; return SFp(Builder::cur()->add_node(n)); }
-static inline SFp bit_and(const SFp& a, const SFp& b) { Node n; n.kind = K_BITAND; n.a0 = materialize(a); n.a1 = materialize(b); return SFp(Builder::cur()->add_node(n)); }
+static inline SFp bit_flag(const SFp& raw, int bit) { Node n; n.kind = K_BIT; n.bound = 0.001; n.a0 = materialize(raw); n.off = bit; return SFp(Builder::cur()->add_node(n)); }
+static inline SFp bit_and(const SFp& a, const SFp& b) { Node n; n.kind = K_BITAND; n.bound = 1.3; n.a0 = materialize(a); n.a1 = materialize(b); return SFp(Builder::cur()->add_node(n)); }
 static inline SFp f_not(const SFp& a);
 void output(const SFp& x, int buf, int off);
-static inline SFp inputw(int buf, int off) { Node n; n.kind = K_LOADW; n.buf = buf; n.off = off; return SFp(Builder::cur()->add_node(n)); }
-static inline void outputw(const SFp& x, int buf, int off) { Node n; n.kind = K_STOREW; n.a0 = materialize(x); n.buf = buf; n.off = off; n.live = true; Builder::cur()->add_node(n); }
-// flags (raw 0/1 integers in a slot)
-static inline SFp is_zero(const SFp& x) { Node n; n.kind = K_ISZ; n.a0 = materialize(x); return SFp(Builder::cur()->add_node(n)); }
-static inline SFp select(const SFp& flag, const SFp& a, const SFp& b) {
-  Node n; n.kind = K_SEL; n.b0 = materialize(flag); n.a0 = materialize(a); n.a1 = materialize(b); return SFp(Builder::cur()->add_node(n));
+// raw scratch element k of an item sits at byte k * RAW_FP_BYTES; `off` is given as k * 48 (one wire-sized element per raw element)
+static inline int raw_off(int off) { return off / 48 * RAW_FP_BYTES; }
+static inline SFp inputw(int buf, int off) { Node n; n.kind = K_LOADW; n.buf = buf; n.off = raw_off(off); n.bound = 8.0; return SFp(Builder::cur()->add_node(n)); }
+static inline void outputw(const SFp& x, int buf, int off) {
+  Builder* B = Builder::cur(); Node n; n.kind = K_STOREW; n.a0 = materialize(x);
+  if (B->atom_bound(n.a0) > 8.0) n.a0 = B->contract(n.a0);     // scratch elements are reloaded with bound 8
+  n.buf = buf; n.off = raw_off(off); n.live = true; B->add_node(n);
 }
-static inline SFp canon(const SFp& x) { Node n; n.kind = K_CANON; n.a0 = materialize(x); return SFp(Builder::cur()->add_node(n)); }
-static inline SFp cmp_gt(const SFp& a, const SFp& b) { Node n; n.kind = K_CMP; n.p0 = 0; n.a0 = materialize(a); n.a1 = materialize(b); return SFp(Builder::cur()->add_node(n)); }
-static inline SFp is_odd(const SFp& a) { Node n; n.kind = K_CMP; n.p0 = 1; n.a0 = materialize(a); n.a1 = n.a0; return SFp(Builder::cur()->add_node(n)); }
-static inline SFp flag_op(int op, const SFp& a, const SFp& b) { Node n; n.kind = K_FLAG; n.p0 = (uint8_t)op; n.a0 = materialize(a); n.a1 = materialize(b); return SFp(Builder::cur()->add_node(n)); }
+// flags (raw 0/1 integers in a slot)
+static inline SFp is_zero(const SFp& x) { Builder* B = Builder::cur(); Node n; n.kind = K_ISZ; n.a0 = B->contract(materialize(x)); n.bound = 0.001; return SFp(B->add_node(n)); }   // zero test needs a value below 2p
+static inline SFp select(const SFp& flag, const SFp& a, const SFp& b) {
+  Builder* B = Builder::cur(); Node n; n.kind = K_SEL; n.b0 = materialize(flag); n.a0 = materialize(a); n.a1 = materialize(b);
+  n.bound = std::max(B->atom_bound(n.a0), B->atom_bound(n.a1)); return SFp(B->add_node(n));
+}
+static inline SFp canon(const SFp& x) { Node n; n.kind = K_CANON; n.a0 = materialize(x); n.bound = 1.0; return SFp(Builder::cur()->add_node(n)); }   // input must be below 2p (callers contract first)
+static inline SFp cmp_gt(const SFp& a, const SFp& b) { Node n; n.kind = K_CMP; n.bound = 0.001; n.p0 = 0; n.a0 = materialize(a); n.a1 = materialize(b); return SFp(Builder::cur()->add_node(n)); }
+static inline SFp is_odd(const SFp& a) { Node n; n.kind = K_CMP; n.bound = 0.001; n.p0 = 1; n.a0 = materialize(a); n.a1 = n.a0; return SFp(Builder::cur()->add_node(n)); }
+static inline SFp flag_op(int op, const SFp& a, const SFp& b) { Node n; n.kind = K_FLAG; n.bound = 0.001; n.p0 = (uint8_t)op; n.a0 = materialize(a); n.a1 = materialize(b); return SFp(Builder::cur()->add_node(n)); }
 static inline SFp f_and(const SFp& a, const SFp& b) { return flag_op(0, a, b); }
 static inline SFp f_or(const SFp& a, const SFp& b) { return flag_op(1, a, b); }
 static inline SFp f_xor(const SFp& a, const SFp& b) { return flag_op(2, a, b); }

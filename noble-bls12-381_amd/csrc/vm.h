@@ -5,7 +5,9 @@
 // resulting DAG of Fp operations into wave-wide STEPS (<= W lane-operations each, one kind per step) and
 // allocates LDS slots.  One wavefront executes the step list for G = 64/W work items ("instances") at once:
 // every lane performs one complete 12x32-bit Montgomery multiplication (or one linear combination) per step,
-// operands and results live in LDS slots (48 B each), values are kept in the redundant range [0, 2p).
+// operands and results live in LDS slots (64 B each: 14 limbs of 28 bits + padding), Montgomery radix R = 2^392; values
+// are kept normalised (limbs < 2^28) and small multiples of p -- the 11 bits of headroom make conditional subtractions
+// unnecessary except when a canonical representative is required.
 // Within one wavefront LDS operations execute in order, so no barriers are needed anywhere.
 #pragma once
 #include <stdint.h>
@@ -17,8 +19,8 @@ enum StepKind : uint8_t {
   K_MUL = 1,     // slot <- mont((a0 [+|-] a1) * (b0 [+|-] b1)), result in [0,2p)
   K_LIN = 2,     // slot <- sum of +-slots, reduced to [0,2p)
   K_STORE = 3,   // 48 big-endian bytes of an output buffer <- canonical(slot)   (slot must hold value/R already)
-  K_LOADW = 4,   // slot <- 12 raw little-endian words of a scratch buffer
-  K_STOREW = 5,  // scratch buffer <- 12 raw words of slot
+  K_LOADW = 4,   // slot <- one raw element (14 limbs) of a scratch buffer
+  K_STOREW = 5,  // scratch buffer <- the 14 limbs of slot
   K_ISZ = 6,     // slot <- (value == 0 mod p) ? 1 : 0   (raw integer flag)
   K_SEL = 7,     // slot <- flag ? a : b
   K_STATUS = 8,  // int8 status[item] <- first code whose flag is 0, else 0
@@ -45,7 +47,10 @@ struct Step {
 static const uint32_t OP_SLOT_MASK = 0x1fff;
 static const uint32_t OP_CONST = 0x2000;
 static const uint32_t OP_MODE_SHIFT = 14;   // second operand of MUL: 0 none, 1 add, 2 sub ; LIN term: 1 = negative
-static const int MAX_LIN_TERMS = 14;   // header word + 7 words of 2 terms (stride 8)
+static const int MAX_LIN_TERMS = 7;    // limb-wise sums must stay below 2^32: 7 x 2^29
+static const int SLOT_WORDS = 16;      // 14 limbs + 2 padding words (16-byte aligned LDS / HBM scratch elements)
+static const int NLIMBS = 14;
+static const int RAW_FP_BYTES = 64;    // one raw field element in HBM scratch
 static const int MAX_BUFS = 8;
 // K_DOT lane descriptor: w0 = dst | k<<16 | L<<20 | m<<24 | halve<<27 ; w1 reserved ; w2,w3 = 4 linear terms (u16: slot|const|neg<<14)
 //   then per product 2 words: (a0 | a1<<16), (b0 | b1<<16); operand u16 = slot | const<<13 | neg<<14 | present<<15 (a1/b1 only)
@@ -59,7 +64,7 @@ struct IOBuf { uint8_t* ptr; uint64_t stride; };
 struct KernelArgs {
   const Step* steps;
   const uint32_t* descs;
-  const uint32_t* consts;   // nconst * 12 words followed by the PM2 table (17 * 16 words)
+  const uint32_t* consts;   // nconst * SLOT_WORDS words
   uint32_t nsteps, nconst;
   uint32_t W, G;            // lanes per instance, instances per wave (G * W <= 64)
   uint32_t slots;           // LDS slots per instance
@@ -67,6 +72,6 @@ struct KernelArgs {
   IOBuf bufs[MAX_BUFS];
 };
 
-static inline uint32_t lds_words(uint32_t nconst, uint32_t G, uint32_t slots) { return nconst * 12 + 17 * 16 + G * slots * 12; }
+static inline uint32_t lds_words(uint32_t nconst, uint32_t G, uint32_t slots) { return nconst * SLOT_WORDS + G * slots * SLOT_WORDS; }
 
 }  // namespace nbls

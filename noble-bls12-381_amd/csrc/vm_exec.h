@@ -2,9 +2,18 @@
 //   * vm_kernel.hip : the gfx950 kernel (LDS = __shared__ memory, one wavefront per workgroup)
 //   * vm_sim.cpp    : a host-side simulator used ONLY by the CPU test-suite to check compiled programs
 //                     without a GPU (tests/); it is not part of libnbls.so.
-// Field representation: 12 x 32-bit little-endian limbs, Montgomery form (R = 2^384), redundant range [0,2p).
+//
+// Field representation: 14 limbs of 28 bits (in 32-bit words, little-endian limb order), Montgomery form with
+// R = 2^392.  Why 28 bits: on gfx950 v_mad_u64_u32 AND every carry-consuming add (v_addc_co) issue at half rate, and a
+// lone wavefront issues one VALU instruction per ~5.5 clocks whatever it is (tools/ubench/carry_rates.hip), so the cost of
+// a big-integer product is its instruction COUNT.  With 28-bit limbs a 64-bit column accumulator absorbs 112 limb
+// products without overflow, so a limb product is ONE in-place v_mad_u64_u32 (196 per product, no carry handling at all);
+// additions and subtractions are carry-free limb-wise operations followed by one normalisation pass; and because
+// p < 2^381 there are 11 bits of headroom (values up to 2047 p fit), so results never need conditional subtractions
+// except where a canonical representative is required (store to wire format, zero tests, comparisons).
 #pragma once
 #include "vm.h"
+#include "consts_gen.h"
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -17,370 +26,241 @@ namespace nbls {
 typedef uint32_t u32;
 typedef uint64_t u64;
 
-#define NBLS_P32 {0xffffaaabu,0xb9feffffu,0xb153ffffu,0x1eabfffeu,0xf6b0f624u,0x6730d2a0u,0xf38512bfu,0x64774b84u,0x434bacd7u,0x4b1ba7b6u,0x397fe69au,0x1a0111eau}
-#define NBLS_2P32 {0xffff5556u,0x73fdffffu,0x62a7ffffu,0x3d57fffdu,0xed61ec48u,0xce61a541u,0xe70a257eu,0xc8ee9709u,0x869759aeu,0x96374f6cu,0x72ffcd34u,0x340223d4u}
-#define NBLS_N0INV 0xfffcfffdu
+#define NL 14
+#define LMASK 0x0fffffffu
+// p, 16p (biased: every limb >= 2^28 - 1 so that BIAS16 - x is limb-wise non-negative for any normalised x <= 16p), -p^-1 mod 2^28
+#define NBLS_P28 NBLS_P_INIT
+#define NBLS_BIAS16_28 NBLS_BIAS16_INIT
+#define NBLS_N0_28 NBLS_N0_LIMB
 
-NBLS_HD u32 addc(u32 a, u32 b, u32 cin, u32* cout) {
-#if defined(__has_builtin) && __has_builtin(__builtin_addc)
-  unsigned co; u32 r = __builtin_addc(a, b, cin, &co); *cout = co; return r;
-#else
-  u64 s = (u64)a + b + cin; *cout = (u32)(s >> 32); return (u32)s;
-#endif
-}
-NBLS_HD u32 subb(u32 a, u32 b, u32 bin, u32* bout) {
-#if defined(__has_builtin) && __has_builtin(__builtin_subc)
-  unsigned bo; u32 r = __builtin_subc(a, b, bin, &bo); *bout = bo; return r;
-#else
-  u64 d = (u64)a - b - bin; *bout = (u32)(d >> 63); return (u32)d;
-#endif
-}
-
-// r = a*b/R (mod p), r < a*b/R + p.  Row-wise CIOS: 12 MADs (v_mad_u64_u32) + one 32-bit carry chain per row.
-NBLS_HD void mont_mul12(u32* __restrict__ r, const u32* a, const u32* b) {
-  const u32 P[12] = NBLS_P32;
-  u32 t[13];
-#pragma unroll
-  for (int i = 0; i < 13; i++) t[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 12; i++) {
-    u32 lo[12], hi[12], s[13];
-#pragma unroll
-    for (int j = 0; j < 12; j++) { u64 x = (u64)a[j] * b[i] + t[j]; lo[j] = (u32)x; hi[j] = (u32)(x >> 32); }
-    u32 c = 0;
-    s[0] = lo[0];
-#pragma unroll
-    for (int j = 1; j < 12; j++) s[j] = addc(lo[j], hi[j - 1], c, &c);
-    s[12] = addc(t[12], hi[11], c, &c);
-    u32 top = c;
-    u32 m = s[0] * NBLS_N0INV;
-#pragma unroll
-    for (int j = 0; j < 12; j++) { u64 x = (u64)m * P[j] + s[j]; lo[j] = (u32)x; hi[j] = (u32)(x >> 32); }
-    c = 0;
-#pragma unroll
-    for (int j = 1; j < 12; j++) t[j - 1] = addc(lo[j], hi[j - 1], c, &c);
-    t[11] = addc(s[12], hi[11], c, &c);
-    t[12] = top + c;
-  }
-#pragma unroll
-  for (int i = 0; i < 12; i++) r[i] = t[i];
-  // t[12] == 0 whenever a*b < 2^384 * p * 8 (all callers: operands < 4p)
-}
-
-// if (x >= m) x -= m, N words
-template <int N>
-NBLS_HD void csub(u32* x, const u32* m) {
-  u32 d[N], br = 0;
-#pragma unroll
-  for (int i = 0; i < N; i++) d[i] = subb(x[i], m[i], br, &br);
-#pragma unroll
-  for (int i = 0; i < N; i++) x[i] = br ? x[i] : d[i];
-}
-
-// A = a0 (+|-) a1 for a MUL operand; mode 1 add, 2 sub (adds 2p so the value stays non-negative).  Result < 4p.
-NBLS_HD void pre_add(u32* A, const u32* a1, u32 mode) {
-  const u32 P2[12] = NBLS_2P32;
-  u32 mask = (mode == 2) ? 0xffffffffu : 0u, c = (mode == 2) ? 1u : 0u;
-#pragma unroll
-  for (int i = 0; i < 12; i++) A[i] = addc(A[i], a1[i] ^ mask, c, &c);
-  c = 0;
-#pragma unroll
-  for (int i = 0; i < 12; i++) A[i] = addc(A[i], P2[i] & mask, c, &c);
-}
-
-// operand of a DOT product: (+-x) or (+-x +- y), plus 2p per negated term; result in (0, 4p)
-template <typename LDSP>
-NBLS_HD void dot_operand(u32* A, u32 enc, LDSP lds, u32 inst) {
-  const u32 P2[12] = NBLS_2P32;
-  const u32 e0 = enc & 0xffff, e1 = enc >> 16;
-  const u32 o0 = ((e0 & OP_CONST) ? 0u : inst) + (e0 & OP_SLOT_MASK) * 12u;
-#pragma unroll
-  for (int i = 0; i < 12; i++) A[i] = lds[o0 + i];
-  if ((enc & (OP_NEG | (OP_PRESENT << 16))) == 0) return;   // plain slot: the common case
-  if (e0 & OP_NEG) {   // 2p - x
-    u32 br = 0;
-#pragma unroll
-    for (int i = 0; i < 12; i++) A[i] = subb(P2[i], A[i], br, &br);
-  }
-  if (e1 & OP_PRESENT) {
-    const u32 o1 = ((e1 & OP_CONST) ? 0u : inst) + (e1 & OP_SLOT_MASK) * 12u;
-    u32 m1 = (e1 & OP_NEG) ? 0xffffffffu : 0u, c = m1 & 1u;
-#pragma unroll
-    for (int i = 0; i < 12; i++) A[i] = addc(A[i], lds[o1 + i] ^ m1, c, &c);
-    if (m1) {
-      c = 0;
-#pragma unroll
-      for (int i = 0; i < 12; i++) A[i] = addc(A[i], P2[i], c, &c);
-    }
-  }
-}
-
-// acc (25 words) += a * b  (full 24-word product, then one 25-word addition)
-NBLS_HD void wide_mac(u32* acc, const u32* a, const u32* b) {
-  u32 t[24];
-#pragma unroll
-  for (int i = 0; i < 24; i++) t[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 12; i++) {
-    u32 lo[12], hi[12];
-#pragma unroll
-    for (int j = 0; j < 12; j++) { u64 x = (u64)a[j] * b[i] + t[i + j]; lo[j] = (u32)x; hi[j] = (u32)(x >> 32); }
-    u32 c = 0;
-    t[i] = lo[0];
-#pragma unroll
-    for (int j = 1; j < 12; j++) t[i + j] = addc(lo[j], hi[j - 1], c, &c);
-    t[i + 12] = hi[11] + c;   // fresh word: the partial product of rows 0..i is < 2^(32(i+13))
-  }
+// x (limbs < 2^32 - 16, value < 2^392) -> normalised limbs (< 2^28; the top limb keeps the rest)
+NBLS_HD void carry_norm(u32* x) {
   u32 c = 0;
 #pragma unroll
-  for (int i = 0; i < 24; i++) acc[i] = addc(acc[i], t[i], c, &c);
-  acc[24] += c;
+  for (int i = 0; i < NL - 1; i++) { u32 v = x[i] + c; x[i] = v & LMASK; c = v >> 28; }
+  x[NL - 1] += c;
 }
 
-// ---- lazy-carry accumulation --------------------------------------------------------------------------------
-// The sum of products of a DOT lane-op is accumulated WITHOUT carry propagation: word positions (2k, 2k+1) share the 64-bit
-// accumulator e[k], positions (2k+1, 2k+2) share o[k]; a limb product a_j*b_i (64 bits, at position i+j) is added to the
-// accumulator aligned with it by ONE v_mad_u64_u32, whose hardware carry-out is counted in a third word (ec[k] at position
-// 2k+2, oc[k] at 2k+3) by ONE v_addc.  No per-row carry chain, no register shuffling; carries are resolved once per lane-op
-// (lazy_normalize) before the Montgomery reduction.
-struct LazyAcc { u64 e[12]; u64 o[12]; u32 ec[12]; u32 oc[12]; };
+template <typename LDSP>
+NBLS_HD void ld14(u32* x, LDSP lds, u32 off) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) x[i] = lds[off + i];
+}
+NBLS_HD u32 slot_addr(u32 op, u32 inst) { return ((op & OP_CONST) ? 0u : inst) + (op & OP_SLOT_MASK) * (u32)SLOT_WORDS; }
 
-NBLS_HD void mac3(u64& acc, u32& cw, u32 a, u32 b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  u64 cy;
-  asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2" : "+v"(acc), "+v"(cw), "=&s"(cy) : "v"(a), "v"(b));
-#else
-  u64 s = acc + (u64)a * b; cw += (s < acc) ? 1u : 0u; acc = s;
-#endif
-}
-NBLS_HD void lazy_zero(LazyAcc& L) {
+// operand of a DOT product: (+-x) or (+-x +- y); a negated term enters as BIAS16 - x (= 16p - x, limb-wise non-negative)
+template <typename LDSP>
+NBLS_HD void dot_operand(u32* A, u32 enc, LDSP lds, u32 inst) {
+  const u32 BIAS[NL] = NBLS_BIAS16_28;
+  const u32 e0 = enc & 0xffff, e1 = enc >> 16;
+  ld14(A, lds, slot_addr(e0, inst));
+  if ((enc & (OP_NEG | (OP_PRESENT << 16))) == 0) return;   // plain slot: the common case
+  if (e0 & OP_NEG) {
 #pragma unroll
-  for (int i = 0; i < 12; i++) { L.e[i] = 0; L.o[i] = 0; L.ec[i] = 0; L.oc[i] = 0; }
-}
-NBLS_HD void lazy_mac(LazyAcc& L, const u32* a, const u32* b) {
+    for (int i = 0; i < NL; i++) A[i] = BIAS[i] - A[i];
+  }
+  if (e1 & OP_PRESENT) {
+    u32 X[NL];
+    ld14(X, lds, slot_addr(e1, inst));
+    if (e1 & OP_NEG) {
 #pragma unroll
-  for (int i = 0; i < 12; i++) {
+      for (int i = 0; i < NL; i++) A[i] += BIAS[i] - X[i];
+    } else {
 #pragma unroll
-    for (int j = 0; j < 12; j++) {
-      const int w = i + j;
-      if ((w & 1) == 0) mac3(L.e[w / 2], L.ec[w / 2], a[j], b[i]); else mac3(L.o[(w - 1) / 2], L.oc[(w - 1) / 2], a[j], b[i]);
+      for (int i = 0; i < NL; i++) A[i] += X[i];
     }
   }
+  carry_norm(A);
 }
-// resolve the carries: t[0..24] = the accumulated integer
-NBLS_HD void lazy_normalize(u32* t, const LazyAcc& L) {
+
+// acc[i+j] += a[j] * b[i]: 196 in-place v_mad_u64_u32, no carries (column sums stay below 2^63 for <= 8 products)
+NBLS_HD void mac28(u64* acc, const u32* a, const u32* b) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+#pragma unroll
+    for (int j = 0; j < NL; j++) acc[i + j] += (u64)a[j] * b[i];
+  }
+}
+// Montgomery reduction of the lazy column accumulators: r (normalised) = V / 2^392 mod-ish, r < V / 2^392 + p
+NBLS_HD void redc28(u32* r, u64* acc) {
+  const u32 P[NL] = NBLS_P28;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    const u32 m = ((u32)acc[i] * NBLS_N0_28) & LMASK;
+#pragma unroll
+    for (int j = 0; j < NL; j++) acc[i + j] += (u64)m * P[j];
+    acc[i + 1] += acc[i] >> 28;
+  }
   u64 c = 0;
 #pragma unroll
-  for (int w = 0; w < 25; w++) {
-    u64 s = c;
-    if ((w & 1) == 0) { if (w / 2 < 12) s += (u32)L.e[w / 2]; if (w >= 2) { s += (u32)(L.o[(w - 2) / 2] >> 32); s += L.ec[(w - 2) / 2]; } }
-    else { s += (u32)(L.e[(w - 1) / 2] >> 32); s += (u32)L.o[(w - 1) / 2]; if (w >= 3) s += L.oc[(w - 3) / 2]; }
-    t[w] = (u32)s; c = s >> 32;
+  for (int k = 0; k < NL - 1; k++) { u64 v = acc[NL + k] + c; r[k] = (u32)v & LMASK; c = v >> 28; }
+  r[NL - 1] = (u32)(acc[2 * NL - 1] + c);
+}
+// r = a * b / R, normalised, < a*b/R + p   (used by the per-lane kernels in pow_kernels.hip / fp_inv.h)
+NBLS_HD void mont_mul28(u32* r, const u32* a, const u32* b) {
+  u64 acc[2 * NL];
+#pragma unroll
+  for (int i = 0; i < 2 * NL; i++) acc[i] = 0;
+  mac28(acc, a, b);
+  redc28(r, acc);
+}
+// x (normalised, < 2p) -> canonical [0, p)
+NBLS_HD void csub_p(u32* x) {
+  const u32 P[NL] = NBLS_P28;
+  u32 d[NL], br = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) { u32 t = x[i] - P[i] - br; br = t >> 31; d[i] = (i < NL - 1) ? (t & LMASK) : t; }
+#pragma unroll
+  for (int i = 0; i < NL; i++) x[i] = br ? x[i] : d[i];
+}
+// 28-bit limbs <-> twelve 32-bit words of the same integer (< 2^384)
+NBLS_HD void limbs_to_words(u32* w, const u32* x) {
+#pragma unroll
+  for (int k = 0; k < 12; k++) {
+    const int bit = 32 * k, l = bit / 28, off = bit % 28;
+    u64 v = x[l];
+    if (l + 1 < NL) v |= (u64)x[l + 1] << 28;
+    if (l + 2 < NL) v |= (u64)x[l + 2] << 56;
+    w[k] = (u32)(v >> off);
   }
 }
-
-// Montgomery reduction of a 25-word accumulator V: r (13 words) = V / R mod-ish, r < V/R + p
-NBLS_HD void wide_redc(u32* r, u32* acc) {
-  const u32 P[12] = NBLS_P32;
-  u32 carry = 0;
+NBLS_HD void words_to_limbs(u32* x, const u32* w) {
 #pragma unroll
-  for (int i = 0; i < 12; i++) {
-    u32 m = acc[i] * NBLS_N0INV;
-    u32 lo[12], hi[12];
-#pragma unroll
-    for (int j = 0; j < 12; j++) { u64 x = (u64)m * P[j] + acc[i + j]; lo[j] = (u32)x; hi[j] = (u32)(x >> 32); }
-    u32 c = 0;
-#pragma unroll
-    for (int j = 1; j < 12; j++) acc[i + j] = addc(lo[j], hi[j - 1], c, &c);
-    u32 c1, c2;
-    u32 w = addc(acc[i + 12], hi[11], c, &c1);
-    acc[i + 12] = addc(w, carry, 0, &c2);
-    carry = c1 + c2;
+  for (int i = 0; i < NL; i++) {
+    const int bit = 28 * i, k = bit / 32, off = bit % 32;
+    u64 v = w[k];
+    if (k + 1 < 12) v |= (u64)w[k + 1] << 32;
+    x[i] = (u32)(v >> off) & LMASK;
   }
-#pragma unroll
-  for (int i = 0; i < 12; i++) r[i] = acc[12 + i];
-  r[12] = acc[24] + carry;
 }
-
 NBLS_HD u32 bswap32(u32 x) { return (x >> 24) | ((x >> 8) & 0xff00u) | ((x << 8) & 0xff0000u) | (x << 24); }
-
-NBLS_HD bool is_zero_mod_p(const u32* x) {   // x in [0,2p)
-  const u32 P[12] = NBLS_P32;
+NBLS_HD bool is_zero_mod_p(const u32* x) {   // x normalised, < 2p
+  const u32 P[NL] = NBLS_P28;
   u32 z = 0, e = 0;
 #pragma unroll
-  for (int i = 0; i < 12; i++) { z |= x[i]; e |= x[i] ^ P[i]; }
+  for (int i = 0; i < NL; i++) { z |= x[i]; e |= x[i] ^ P[i]; }
   return z == 0 || e == 0;
 }
-
-}  // namespace nbls
+// (x + (x odd ? p : 0)) / 2 on normalised limbs
+NBLS_HD void halve28(u32* r) {
+  const u32 P[NL] = NBLS_P28;
+  const u32 mask = (r[0] & 1) ? 0xffffffffu : 0u;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r[i] += P[i] & mask;
+  carry_norm(r);
+#pragma unroll
+  for (int i = 0; i < NL - 1; i++) r[i] = (r[i] >> 1) | ((r[i + 1] & 1) << 27);
+  r[NL - 1] >>= 1;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Per-lane step execution.  `lds` is the workgroup's LDS image (device) or a plain array (simulator):
-//   words [0, nconst*12)            program constants (shared by all instances)
-//   words [pm2, pm2 + 17*16)        k * 2p for k = 0..16, 13 significant words each (LIN offsets / reduction moduli)
-//   words [inst, inst + slots*12)   this instance's slots
-// The function reads operands, computes, and returns the result in `res` together with the destination word
-// offset (or 0xffffffff when the step has no LDS destination); the caller commits the 12 words afterwards, so
-// that every read of a step precedes every write of that step (in-order LDS within a wavefront; explicit
-// two-phase loop in the simulator).
-namespace nbls {
-
+//   words [0, nconst*16)            program constants (shared by all instances)
+//   words [inst, inst + slots*16)   this instance's slots
+// The function reads operands, computes, and returns the result in `res` (14 limbs) together with the destination
+// word offset (or 0xffffffff when the step has no LDS destination); the caller commits the limbs afterwards, so that
+// every read of a step precedes every write of that step (in-order LDS within a wavefront; explicit two-phase loop in
+// the simulator).
 struct LaneCtx {
   u32 inst;       // word offset of the instance region
-  u32 pm2;        // word offset of the PM2 table
   u32 item;       // global work-item index
   bool live;      // item < n_items (dead instances compute on zeros but never touch global memory)
 };
 
-NBLS_HD u32 slot_addr(u32 op, u32 inst) { return ((op & OP_CONST) ? 0u : inst) + (op & OP_SLOT_MASK) * 12u; }
-
-template <typename LDSP>
-NBLS_HD void ld12(u32* x, LDSP lds, u32 off) {
-#pragma unroll
-  for (int i = 0; i < 12; i++) x[i] = lds[off + i];
-}
-
 template <typename LDSP>
 NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, already loaded */, const u32* __restrict__ gd /* this lane's descriptor in global memory */,
                       LDSP lds, const LaneCtx& cx, const IOBuf* bufs, u32* res) {
-  const u32 P[12] = NBLS_P32;
-  const u32 P2[12] = NBLS_2P32;
+  const u32 BIAS[NL] = NBLS_BIAS16_28;
   switch (st.kind) {
-    case K_MUL: {
-      u32 w0 = d[0], w1 = d[1], w2 = d[2];
-      u32 A[12], B[12], X[12];
-      ld12(A, lds, slot_addr(w0 & 0xffff, cx.inst));
-      ld12(B, lds, slot_addr(w1 & 0xffff, cx.inst));
-      if (st.p0 & 1) { u32 m = w0 >> (16 + OP_MODE_SHIFT); if (m) { ld12(X, lds, slot_addr(w0 >> 16, cx.inst)); pre_add(A, X, m); } }
-      if (st.p0 & 2) { u32 m = w1 >> (16 + OP_MODE_SHIFT); if (m) { ld12(X, lds, slot_addr(w1 >> 16, cx.inst)); pre_add(B, X, m); } }
-      mont_mul12(res, A, B);
-      csub<12>(res, P2);
-      return slot_addr(w2 & 0xffff, cx.inst);
-    }
     case K_DOT: {
       const u32 w0 = d[0];
       const u32 k = (w0 >> 16) & 0xf, L = (w0 >> 20) & 0xf, mult = (w0 >> 24) & 0x7;
-      u32 r[13];
+      u32 r[NL];
       if (st.p0 > 0) {   // uniform
-        u32 acc[25];
+        u64 acc[2 * NL];
 #pragma unroll
-        for (int i = 0; i < 25; i++) acc[i] = 0;
+        for (int i = 0; i < 2 * NL; i++) acc[i] = 0;
         u32 na = d[4], nb = d[5];
         for (u32 i = 0; i < st.p0; i++) {   // uniform trip count; next product's operand words are fetched ahead
           const u32 ea = na, eb = nb;
           if (i + 1 < st.p0) { na = gd[6 + 2 * i]; nb = gd[7 + 2 * i]; }
           if (i < k) {
-            u32 A[12], B[12];
+            u32 A[NL], B[NL];
             dot_operand(A, ea, lds, cx.inst);
             dot_operand(B, eb, lds, cx.inst);
-            wide_mac(acc, A, B);
+            mac28(acc, A, B);
           }
         }
-        wide_redc(r, acc);
+        redc28(r, acc);
       } else {
 #pragma unroll
-        for (int i = 0; i < 13; i++) r[i] = 0;
+        for (int i = 0; i < NL; i++) r[i] = 0;
       }
-      if (mult > 1) {   // m * dot, m <= 4
-        u32 t[13];
+      if (mult > 1) {
 #pragma unroll
-        for (int i = 0; i < 13; i++) t[i] = r[i];
-        for (u32 j = 1; j < mult; j++) {
-          u32 c = 0;
-#pragma unroll
-          for (int i = 0; i < 13; i++) r[i] = addc(r[i], t[i], c, &c);
-        }
+        for (int i = 0; i < NL; i++) r[i] *= mult;     // m <= 4: limbs < 2^30
       }
-      u32 nneg = 0;
 #pragma unroll
       for (int t = 0; t < MAX_DOT_LINEAR; t++) {
         if (t < (int)st.pad) {   // uniform
           u32 term = (d[2 + t / 2] >> (16 * (t & 1))) & 0xffff;
           if ((u32)t < L) {
-            u32 neg = (term >> OP_MODE_SHIFT) & 1, mask = neg ? 0xffffffffu : 0u, c = neg;
-            u32 X[12];
-            ld12(X, lds, slot_addr(term, cx.inst));
+            u32 X[NL];
+            ld14(X, lds, slot_addr(term, cx.inst));
+            if (term & OP_NEG) {
 #pragma unroll
-            for (int i = 0; i < 12; i++) r[i] = addc(r[i], X[i] ^ mask, c, &c);
-            r[12] = r[12] + mask + c;
-            nneg += neg;
+              for (int i = 0; i < NL; i++) r[i] += BIAS[i] - X[i];
+            } else {
+#pragma unroll
+              for (int i = 0; i < NL; i++) r[i] += X[i];
+            }
           }
         }
       }
-      if (st.pad > 0) {
-        u32 c = 0, off = cx.pm2 + nneg * 16;
+      if (mult > 1 || st.pad > 0) carry_norm(r);
+      if (w0 & (1u << 27)) halve28(r);
 #pragma unroll
-        for (int i = 0; i < 13; i++) r[i] = addc(r[i], lds[off + i], c, &c);
-      }
-      for (int s = (int)st.p1 - 1; s >= 0; s--) {
-        u32 M[13], off = cx.pm2 + (16u << s);
-#pragma unroll
-        for (int i = 0; i < 13; i++) M[i] = lds[off + i];
-        csub<13>(r, M);
-      }
-      if (w0 & (1u << 27)) {   // halve
-        u32 mask = (r[0] & 1) ? 0xffffffffu : 0u, c = 0;
-#pragma unroll
-        for (int i = 0; i < 12; i++) r[i] = addc(r[i], P[i] & mask, c, &c);
-#pragma unroll
-        for (int i = 0; i < 11; i++) r[i] = (r[i] >> 1) | (r[i + 1] << 31);
-        r[11] >>= 1;
-      }
-#pragma unroll
-      for (int i = 0; i < 12; i++) res[i] = r[i];
+      for (int i = 0; i < NL; i++) res[i] = r[i];
       return slot_addr(w0 & 0xffff, cx.inst);
     }
     case K_LIN: {
-      const u32* w = d;
-      u32 nt = (w[0] >> 16) & 0xff, nneg = 0;
-      u32 acc[13];
+      const u32 w0 = d[0];
+      const u32 nt = (w0 >> 16) & 0xff;
+      u32 r[NL];
 #pragma unroll
-      for (int i = 0; i < 13; i++) acc[i] = 0;
+      for (int i = 0; i < NL; i++) r[i] = 0;
 #pragma unroll
-      for (int t = 0; t < 14; t++) {
+      for (int t = 0; t < MAX_LIN_TERMS; t++) {
         if (t < (int)st.p0) {   // uniform
-          u32 term = (w[1 + t / 2] >> (16 * (t & 1))) & 0xffff;
+          u32 term = (d[1 + t / 2] >> (16 * (t & 1))) & 0xffff;
           if ((u32)t < nt) {
-            u32 neg = (term >> OP_MODE_SHIFT) & 1, mask = neg ? 0xffffffffu : 0u, c = neg;
-            u32 X[12];
-            ld12(X, lds, slot_addr(term, cx.inst));
+            u32 X[NL];
+            ld14(X, lds, slot_addr(term, cx.inst));
+            if (term & OP_NEG) {
 #pragma unroll
-            for (int i = 0; i < 12; i++) acc[i] = addc(acc[i], X[i] ^ mask, c, &c);
-            acc[12] = acc[12] + mask + c;
-            nneg += neg;
+              for (int i = 0; i < NL; i++) r[i] += BIAS[i] - X[i];
+            } else {
+#pragma unroll
+              for (int i = 0; i < NL; i++) r[i] += X[i];
+            }
           }
         }
       }
-      {
-        u32 c = 0, off = cx.pm2 + nneg * 16;
+      carry_norm(r);
+      if (w0 & (1u << 24)) halve28(r);
 #pragma unroll
-        for (int i = 0; i < 13; i++) acc[i] = addc(acc[i], lds[off + i], c, &c);
-      }
-      for (int s = (int)st.p1 - 1; s >= 0; s--) {
-        u32 M[13], off = cx.pm2 + (16u << s);
-#pragma unroll
-        for (int i = 0; i < 13; i++) M[i] = lds[off + i];
-        csub<13>(acc, M);
-      }
-      if (w[0] & (1u << 24)) {   // halve: (x + (x odd ? p : 0)) >> 1, result < 1.5p
-        u32 mask = (acc[0] & 1) ? 0xffffffffu : 0u, c = 0;
-#pragma unroll
-        for (int i = 0; i < 12; i++) acc[i] = addc(acc[i], P[i] & mask, c, &c);
-#pragma unroll
-        for (int i = 0; i < 11; i++) acc[i] = (acc[i] >> 1) | (acc[i + 1] << 31);
-        acc[11] >>= 1;
-      }
-#pragma unroll
-      for (int i = 0; i < 12; i++) res[i] = acc[i];
-      return slot_addr(w[0] & 0xffff, cx.inst);
+      for (int i = 0; i < NL; i++) res[i] = r[i];
+      return slot_addr(w0 & 0xffff, cx.inst);
     }
     case K_LOAD: {
       u32 w0 = d[0], off = d[1];
       const IOBuf& b = bufs[(w0 >> 16) & 7];
       const u32* src = (const u32*)(b.ptr + (u64)cx.item * b.stride + off);
       const int nw = st.p0 ? (int)st.p0 / 4 : 12;   // number of 32-bit words (big-endian integer of p0 bytes)
+      u32 w[12];
 #pragma unroll
-      for (int i = 0; i < 12; i++) res[i] = (cx.live && i < nw) ? bswap32(src[nw - 1 - i]) : 0u;
+      for (int i = 0; i < 12; i++) w[i] = (cx.live && i < nw) ? bswap32(src[nw - 1 - i]) : 0u;
+      words_to_limbs(res, w);
       return slot_addr(w0 & 0xffff, cx.inst);
     }
     case K_LOADW: {
@@ -388,41 +268,43 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, 
       const IOBuf& b = bufs[(w0 >> 16) & 7];
       const u32* src = (const u32*)(b.ptr + (u64)cx.item * b.stride + off);
 #pragma unroll
-      for (int i = 0; i < 12; i++) res[i] = cx.live ? src[i] : 0u;
+      for (int i = 0; i < NL; i++) res[i] = cx.live ? src[i] : 0u;
       return slot_addr(w0 & 0xffff, cx.inst);
     }
     case K_STORE: {
       u32 w0 = d[0], off = d[1];
-      u32 X[12];
-      ld12(X, lds, slot_addr(w0 & 0xffff, cx.inst));
-      csub<12>(X, P);
+      u32 X[NL], w[12];
+      ld14(X, lds, slot_addr(w0 & 0xffff, cx.inst));
+      csub_p(X);
+      limbs_to_words(w, X);
       if (cx.live) {
         const IOBuf& b = bufs[(w0 >> 16) & 7];
         u32* dst = (u32*)(b.ptr + (u64)cx.item * b.stride + off);
 #pragma unroll
-        for (int i = 0; i < 12; i++) dst[11 - i] = bswap32(X[i]);
+        for (int i = 0; i < 12; i++) dst[11 - i] = bswap32(w[i]);
       }
       return 0xffffffffu;
     }
     case K_STOREW: {
       u32 w0 = d[0], off = d[1];
-      u32 X[12];
-      ld12(X, lds, slot_addr(w0 & 0xffff, cx.inst));
+      u32 X[NL];
+      ld14(X, lds, slot_addr(w0 & 0xffff, cx.inst));
       if (cx.live) {
         const IOBuf& b = bufs[(w0 >> 16) & 7];
         u32* dst = (u32*)(b.ptr + (u64)cx.item * b.stride + off);
 #pragma unroll
-        for (int i = 0; i < 12; i++) dst[i] = X[i];
+        for (int i = 0; i < NL; i++) dst[i] = X[i];
+        dst[14] = 0; dst[15] = 0;
       }
       return 0xffffffffu;
     }
     case K_ISZ: {
       u32 w0 = d[0];
-      u32 X[12];
-      ld12(X, lds, slot_addr(w0 >> 16, cx.inst));
+      u32 X[NL];
+      ld14(X, lds, slot_addr(w0 >> 16, cx.inst));
       bool z = is_zero_mod_p(X);
 #pragma unroll
-      for (int i = 0; i < 12; i++) res[i] = 0;
+      for (int i = 0; i < NL; i++) res[i] = 0;
       res[0] = z ? 1u : 0u;
       return slot_addr(w0 & 0xffff, cx.inst);
     }
@@ -430,49 +312,49 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, 
       u32 w0 = d[0], w1 = d[1];
       u32 f = lds[slot_addr(w0 >> 16, cx.inst)];
       u32 src = f ? (w1 & 0xffff) : (w1 >> 16);
-      ld12(res, lds, slot_addr(src, cx.inst));
+      ld14(res, lds, slot_addr(src, cx.inst));
       return slot_addr(w0 & 0xffff, cx.inst);
     }
     case K_CANON: {
       u32 w0 = d[0];
-      ld12(res, lds, slot_addr(w0 >> 16, cx.inst));
-      csub<12>(res, P);
+      ld14(res, lds, slot_addr(w0 >> 16, cx.inst));
+      csub_p(res);
       return slot_addr(w0 & 0xffff, cx.inst);
     }
     case K_CMP: {
       u32 w0 = d[0], w1 = d[1];
-      u32 X[12], Y[12];
-      ld12(X, lds, slot_addr(w1 & 0xffff, cx.inst));
+      u32 X[NL], Y[NL];
+      ld14(X, lds, slot_addr(w1 & 0xffff, cx.inst));
       u32 f;
-      if (st.p0 == 0) {   // X > Y  <=>  Y - X borrows
-        ld12(Y, lds, slot_addr(w1 >> 16, cx.inst));
+      if (st.p0 == 0) {   // X > Y  <=>  Y - X borrows (normalised limbs)
+        ld14(Y, lds, slot_addr(w1 >> 16, cx.inst));
         u32 br = 0;
 #pragma unroll
-        for (int i = 0; i < 12; i++) (void)subb(Y[i], X[i], br, &br);
+        for (int i = 0; i < NL; i++) { u32 t = Y[i] - X[i] - br; br = t >> 31; }
         f = br;
       } else {
         f = X[0] & 1;
       }
 #pragma unroll
-      for (int i = 0; i < 12; i++) res[i] = 0;
+      for (int i = 0; i < NL; i++) res[i] = 0;
       res[0] = f;
       return slot_addr(w0 & 0xffff, cx.inst);
     }
     case K_BIT: {
       u32 w0 = d[0], bit = d[1];
-      u32 w = lds[slot_addr(w0 >> 16, cx.inst) + (bit >> 5)];
+      u32 w = lds[slot_addr(w0 >> 16, cx.inst) + bit / 28];
 #pragma unroll
-      for (int i = 0; i < 12; i++) res[i] = 0;
-      res[0] = (w >> (bit & 31)) & 1;
+      for (int i = 0; i < NL; i++) res[i] = 0;
+      res[0] = (w >> (bit % 28)) & 1;
       return slot_addr(w0 & 0xffff, cx.inst);
     }
     case K_BITAND: {
       u32 w0 = d[0], w1 = d[1];
-      u32 X[12], Y[12];
-      ld12(X, lds, slot_addr(w1 & 0xffff, cx.inst));
-      ld12(Y, lds, slot_addr(w1 >> 16, cx.inst));
+      u32 X[NL], Y[NL];
+      ld14(X, lds, slot_addr(w1 & 0xffff, cx.inst));
+      ld14(Y, lds, slot_addr(w1 >> 16, cx.inst));
 #pragma unroll
-      for (int i = 0; i < 12; i++) res[i] = X[i] & Y[i];
+      for (int i = 0; i < NL; i++) res[i] = X[i] & Y[i];
       return slot_addr(w0 & 0xffff, cx.inst);
     }
     case K_FLAG: {
@@ -480,7 +362,7 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, 
       u32 a = lds[slot_addr(w1 & 0xffff, cx.inst)] & 1, b = lds[slot_addr(w1 >> 16, cx.inst)] & 1;
       u32 f = st.p0 == 0 ? (a & b) : st.p0 == 1 ? (a | b) : st.p0 == 2 ? (a ^ b) : (a & (b ^ 1));
 #pragma unroll
-      for (int i = 0; i < 12; i++) res[i] = 0;
+      for (int i = 0; i < NL; i++) res[i] = 0;
       res[0] = f;
       return slot_addr(w0 & 0xffff, cx.inst);
     }

@@ -9,14 +9,13 @@ namespace nbls {
 extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel(KernelArgs ka) {
   extern __shared__ __attribute__((aligned(16))) u32 smem[];
   const u32 lane = threadIdx.x;
-  const u32 shared_words = ka.nconst * 12 + 17 * 16;
+  const u32 shared_words = ka.nconst * SLOT_WORDS;
   for (u32 i = lane; i < shared_words; i += 64) smem[i] = ka.consts[i];
   const u32 W = ka.W;
   const u32 inst_id = lane / W;
   const u32 lane_in = (inst_id < ka.G) ? (lane - inst_id * W) : 0xffffu;
   LaneCtx cx;
-  cx.pm2 = ka.nconst * 12;
-  cx.inst = shared_words + inst_id * ka.slots * 12;
+  cx.inst = shared_words + inst_id * ka.slots * SLOT_WORDS;
   cx.item = blockIdx.x * ka.G + inst_id;
   cx.live = inst_id < ka.G && cx.item < ka.n_items;
   __syncthreads();   // single wave: orders the constant fill before first use
@@ -41,11 +40,11 @@ extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel(KernelArgs ka) {
     }
     if (lane_in < st.nlanes) {
       u32 d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-      u32 res[12];
+      u32 res[NL];
       u32 dst = exec_lane(st, d, ka.descs + st.desc_off + lane_in * st.stride, smem, cx, ka.bufs, res);
       if (dst != 0xffffffffu) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) smem[dst + i] = res[i];
+        for (int i = 0; i < NL; i++) smem[dst + i] = res[i];
       }
     }
     st = nst; d0 = n0; d1 = n1;

@@ -13,7 +13,7 @@
 using namespace nbls;
 
 static void sim_run(const Program& p, unsigned n_items, const IOBuf* bufs) {
-  const unsigned shared = p.nconst * 12 + 17 * 16;
+  const unsigned shared = p.nconst * SLOT_WORDS;
   std::vector<u32> lds(lds_words(p.nconst, p.G, p.slots));
   unsigned blocks = (n_items + p.G - 1) / p.G;
   for (unsigned blk = 0; blk < blocks; blk++) {
@@ -21,14 +21,14 @@ static void sim_run(const Program& p, unsigned n_items, const IOBuf* bufs) {
     memcpy(lds.data(), p.consts.data(), shared * 4);
     for (size_t s = 0; s < p.steps.size(); s++) {
       const Step& st = p.steps[s];
-      struct Pending { u32 dst; u32 v[12]; };
+      struct Pending { u32 dst; u32 v[NL]; };
       std::vector<Pending> pend;
       for (unsigned lane = 0; lane < 64; lane++) {
         unsigned inst = lane / p.W;
         if (inst >= p.G) continue;
         unsigned lane_in = lane - inst * p.W;
         if (lane_in >= st.nlanes) continue;
-        LaneCtx cx; cx.pm2 = p.nconst * 12; cx.inst = shared + inst * p.slots * 12; cx.item = blk * p.G + inst; cx.live = cx.item < n_items;
+        LaneCtx cx; cx.inst = shared + inst * p.slots * SLOT_WORDS; cx.item = blk * p.G + inst; cx.live = cx.item < n_items;
         Pending pd;
         u32 dw[8] = {0};
         const u32* gd = p.descs.data() + st.desc_off + lane_in * st.stride;
@@ -36,7 +36,7 @@ static void sim_run(const Program& p, unsigned n_items, const IOBuf* bufs) {
         pd.dst = exec_lane(st, dw, gd, lds.data(), cx, bufs, pd.v);
         if (pd.dst != 0xffffffffu) pend.push_back(pd);
       }
-      for (auto& pd : pend) memcpy(&lds[pd.dst], pd.v, 48);
+      for (auto& pd : pend) memcpy(&lds[pd.dst], pd.v, NL * 4);
     }
   }
 }
@@ -50,33 +50,35 @@ __attribute__((visibility("default"))) int nbls_sim_run(int prog, unsigned n_ite
   sim_run(get_program((ProgId)prog), n_items, b);
   return 0;
 }
-// out = in^-1 on raw Montgomery limbs: the same fp_mont_inverse routine the inversion kernel runs per lane
+// out = in^-1 on raw elements (16 words each): the same fp_mont_inverse routine the inversion kernel runs per lane
 __attribute__((visibility("default"))) void nbls_sim_fp_inv(unsigned n, const u32* in, u32* out) {
   static std::vector<u32> table;
-  if (table.empty()) { table.resize(382 * 12); make_inv_table(table.data()); }
-  for (unsigned k = 0; k < n; k++) fp_mont_inverse(out + 12 * k, in + 12 * k, table.data());
+  if (table.empty()) { table.resize(382 * NL); make_inv_table(table.data()); }
+  for (unsigned k = 0; k < n; k++) { u32 r[NL]; fp_mont_inverse(r, in + SLOT_WORDS * k, table.data()); memcpy(out + SLOT_WORDS * k, r, NL * 4); out[SLOT_WORDS * k + 14] = out[SLOT_WORDS * k + 15] = 0; }
 }
-// out = in^e on raw Montgomery limbs; which: 0 = (p+1)/4 on Fp, 1 = (p^2+7)/16 on Fp2, 2 = (p^2-9)/16 on Fp2 (stand-ins for the pow kernels)
-static void mmh(u32* r, const u32* a, const u32* b) { const u32 P2[12] = NBLS_2P32; u32 t[12]; mont_mul12(t, a, b); csub<12>(t, P2); memcpy(r, t, 48); }
-static void addh(u32* r, const u32* a, const u32* b) { const u32 P2[12] = NBLS_2P32; u32 t[12], c = 0; for (int i = 0; i < 12; i++) t[i] = addc(a[i], b[i], c, &c); csub<12>(t, P2); memcpy(r, t, 48); }
-static void subh(u32* r, const u32* a, const u32* b) { const u32 P2[12] = NBLS_2P32; u32 t[12], br = 0, c = 0; for (int i = 0; i < 12; i++) t[i] = subb(a[i], b[i], br, &br); for (int i = 0; i < 12; i++) t[i] = addc(t[i], P2[i], c, &c); csub<12>(t, P2); memcpy(r, t, 48); }
-static void fp2mulh(u32* r, const u32* a, const u32* b) {
-  u32 t1[12], t2[12], s1[12], s2[12], m[12];
-  mmh(t1, a, b); mmh(t2, a + 12, b + 12); addh(s1, a, a + 12); addh(s2, b, b + 12); mmh(m, s1, s2);
-  u32 r0[12], r1[12]; subh(r0, t1, t2); subh(m, m, t1); subh(r1, m, t2); memcpy(r, r0, 48); memcpy(r + 12, r1, 48);
+// out = in^e; which: 0 = (p+1)/4 on Fp, 1 = (p^2+7)/16 on Fp2, 2 = (p^2-9)/16 on Fp2 (stand-ins for the pow kernels; raw elements of 16 words)
+static void mmh(u32* r, const u32* a, const u32* b) { u32 t[NL]; mont_mul28(t, a, b); memcpy(r, t, NL * 4); }
+static void addh(u32* r, const u32* a, const u32* b) { u32 t[NL]; for (int i = 0; i < NL; i++) t[i] = a[i] + b[i]; carry_norm(t); memcpy(r, t, NL * 4); }
+static void subh(u32* r, const u32* a, const u32* b) { const u32 BIAS[NL] = NBLS_BIAS16_28; u32 t[NL]; for (int i = 0; i < NL; i++) t[i] = a[i] + BIAS[i] - b[i]; carry_norm(t); memcpy(r, t, NL * 4); }
+static void fp2mulh(u32* r, const u32* a, const u32* b) {   // elements: c0 at [0..13], c1 at [16..29]
+  u32 t1[NL], t2[NL], s1[NL], s2[NL], m[NL];
+  mmh(t1, a, b); mmh(t2, a + 16, b + 16); addh(s1, a, a + 16); addh(s2, b, b + 16); mmh(m, s1, s2);
+  u32 r0[NL], r1[NL], u[NL]; subh(r0, t1, t2); addh(u, t1, t2); subh(r1, m, u);
+  u32 one[NL]; memcpy(one, NBLS_R1, NL * 4); mmh(r0, r0, one); mmh(r1, r1, one);   // contract (keeps values far below the 16p subtraction bias)
+  memset(r, 0, 32 * 4); memcpy(r, r0, NL * 4); memcpy(r + 16, r1, NL * 4);
 }
 __attribute__((visibility("default"))) void nbls_sim_fp_pow(unsigned n, const u32* in, u32* out, int which) {
   const uint64_t* e = which == 0 ? NBLS_EXP_P_PLUS_1_DIV_4 : which == 1 ? NBLS_EXP_P2_PLUS_7_DIV_16 : NBLS_EXP_P2_MINUS_9_DIV_16;
   int bits = which == 0 ? NBLS_P_PLUS_1_DIV_4_BITS : which == 1 ? NBLS_P2_PLUS_7_DIV_16_BITS : NBLS_P2_MINUS_9_DIV_16_BITS;
   for (unsigned k = 0; k < n; k++) {
     if (which == 0) {
-      u32 acc[12]; memcpy(acc, NBLS_R1, 48);
-      for (int i = bits - 1; i >= 0; i--) { mmh(acc, acc, acc); if ((e[i >> 6] >> (i & 63)) & 1) mmh(acc, acc, in + 12 * k); }
-      memcpy(out + 12 * k, acc, 48);
+      u32 acc[16] = {0}; memcpy(acc, NBLS_R1, NL * 4);
+      for (int i = bits - 1; i >= 0; i--) { mmh(acc, acc, acc); if ((e[i >> 6] >> (i & 63)) & 1) mmh(acc, acc, in + 16 * k); }
+      memcpy(out + 16 * k, acc, 64);
     } else {
-      u32 acc[24] = {0}; memcpy(acc, NBLS_R1, 48);
-      for (int i = bits - 1; i >= 0; i--) { fp2mulh(acc, acc, acc); if ((e[i >> 6] >> (i & 63)) & 1) fp2mulh(acc, acc, in + 24 * k); }
-      memcpy(out + 24 * k, acc, 96);
+      u32 acc[32] = {0}; memcpy(acc, NBLS_R1, NL * 4);
+      for (int i = bits - 1; i >= 0; i--) { fp2mulh(acc, acc, acc); if ((e[i >> 6] >> (i & 63)) & 1) fp2mulh(acc, acc, in + 32 * k); }
+      memcpy(out + 32 * k, acc, 128);
     }
   }
 }

@@ -5,6 +5,17 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, 'noble-bls12-381_amd')
+RAW = 64          # bytes of one raw field element in scratch (14 limbs of 28 bits + padding)
+F12 = 12 * RAW     # raw Fp12
+P_MOD = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+
+
+def raw_elem(v):
+    """standard integer -> raw Montgomery element (R = 2^392, 14 x 28-bit limbs in u32 words, 64 bytes)"""
+    m = (v << 392) % P_MOD
+    return b''.join(((m >> (28 * i)) & 0xfffffff).to_bytes(4, 'little') for i in range(14)) + bytes(8)
+
+
 PROGS = ['MILLER_BYTES', 'MILLER_RAW', 'MILLER_FE', 'NORM_RAW', 'NORM_BYTES', 'FE_EASY', 'EXPX', 'FE_MID1', 'FE_MID2', 'FE_FINAL', 'MUL2', 'RAW_TO_BYTES', 'G1_VALIDATE', 'G2_VALIDATE', 'G1_DEC_A', 'G1_DEC_B', 'G2_DEC_A', 'G2_DEC_B', 'H2C_A', 'H2C_B',
          'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR']
 P = {n: i for i, n in enumerate(PROGS)}
@@ -28,18 +39,18 @@ def run(lib, prog, n, bufs):
 
 def final_exp(lib, n, F, N, out):
     """The launch sequence of final_exp_pipeline() in csrc/nbls_api.cpp, on the simulator."""
-    NI = C.create_string_buffer(48 * n)
-    T = [C.create_string_buffer(576 * n) for _ in range(7)]
+    NI = C.create_string_buffer(RAW * n)
+    T = [C.create_string_buffer(F12 * n) for _ in range(7)]
     lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
-    run(lib, 'FE_EASY', n, {3: (F, 576), 4: (NI, 48), 5: (T[0], 576)})
-    run(lib, 'EXPX', n, {3: (T[0], 576), 5: (T[1], 576)})
-    run(lib, 'FE_MID1', n, {3: (T[0], 576), 5: (T[1], 576), 6: (T[2], 576)})
-    run(lib, 'EXPX', n, {3: (T[2], 576), 5: (T[3], 576)})
-    run(lib, 'EXPX', n, {3: (T[3], 576), 5: (T[4], 576)})
-    run(lib, 'EXPX', n, {3: (T[4], 576), 5: (T[6], 576)})
-    run(lib, 'FE_MID2', n, {3: (T[6], 576), 5: (T[1], 576), 6: (T[5], 576)})
-    run(lib, 'EXPX', n, {3: (T[5], 576), 5: (T[6], 576)})
-    bufs = {i: (T[i], 576) for i in range(7)}
+    run(lib, 'FE_EASY', n, {3: (F, F12), 4: (NI, RAW), 5: (T[0], F12)})
+    run(lib, 'EXPX', n, {3: (T[0], F12), 5: (T[1], F12)})
+    run(lib, 'FE_MID1', n, {3: (T[0], F12), 5: (T[1], F12), 6: (T[2], F12)})
+    run(lib, 'EXPX', n, {3: (T[2], F12), 5: (T[3], F12)})
+    run(lib, 'EXPX', n, {3: (T[3], F12), 5: (T[4], F12)})
+    run(lib, 'EXPX', n, {3: (T[4], F12), 5: (T[6], F12)})
+    run(lib, 'FE_MID2', n, {3: (T[6], F12), 5: (T[1], F12), 6: (T[5], F12)})
+    run(lib, 'EXPX', n, {3: (T[5], F12), 5: (T[6], F12)})
+    bufs = {i: (T[i], F12) for i in range(7)}
     bufs[7] = (out, 576)
     run(lib, 'FE_FINAL', n, bufs)
 
@@ -52,45 +63,45 @@ def buf(data_or_size):
 
 def g1_decompress(lib, comp):
     n = len(comp) // 48
-    X, R, Cd, out, st = buf(48 * n), buf(48 * n), buf(48 * n), buf(96 * n), buf(n)
+    X, R, Cd, out, st = buf(RAW * n), buf(RAW * n), buf(RAW * n), buf(96 * n), buf(n)
     inb = buf(comp)
-    run(lib, 'G1_DEC_A', n, {0: (inb, 48), 3: (X, 48), 4: (R, 48)})
+    run(lib, 'G1_DEC_A', n, {0: (inb, 48), 3: (X, RAW), 4: (R, RAW)})
     lib.nbls_sim_fp_pow(C.c_uint(n), R, Cd, 0)
-    run(lib, 'G1_DEC_B', n, {0: (inb, 48), 3: (X, 48), 4: (R, 48), 5: (Cd, 48), 6: (out, 96), 7: (st, 1)})
+    run(lib, 'G1_DEC_B', n, {0: (inb, 48), 3: (X, RAW), 4: (R, RAW), 5: (Cd, RAW), 6: (out, 96), 7: (st, 1)})
     return out.raw, list(st.raw)
 
 
 def g2_decompress(lib, comp):
     n = len(comp) // 96
-    X, R, Cd, out, st = buf(96 * n), buf(96 * n), buf(96 * n), buf(192 * n), buf(n)
+    X, R, Cd, out, st = buf(2 * RAW * n), buf(2 * RAW * n), buf(2 * RAW * n), buf(192 * n), buf(n)
     inb = buf(comp)
-    run(lib, 'G2_DEC_A', n, {0: (inb, 96), 3: (X, 96), 4: (R, 96)})
+    run(lib, 'G2_DEC_A', n, {0: (inb, 96), 3: (X, 2 * RAW), 4: (R, 2 * RAW)})
     lib.nbls_sim_fp_pow(C.c_uint(n), R, Cd, 1)
-    run(lib, 'G2_DEC_B', n, {0: (inb, 96), 3: (X, 96), 4: (R, 96), 5: (Cd, 96), 6: (out, 192), 7: (st, 1)})
+    run(lib, 'G2_DEC_B', n, {0: (inb, 96), 3: (X, 2 * RAW), 4: (R, 2 * RAW), 5: (Cd, 2 * RAW), 6: (out, 192), 7: (st, 1)})
     return out.raw, list(st.raw)
 
 
 def hash_to_g2(lib, uniform):
     """uniform: n * 256 bytes of expand_message_xmd output"""
     n = len(uniform) // 256
-    T, E, Pw, Q, N, NI, out, st = buf(192 * n), buf(192 * n), buf(192 * n), buf(288 * n), buf(48 * n), buf(48 * n), buf(192 * n), buf(n)
-    run(lib, 'H2C_A', n, {0: (buf(uniform), 256), 3: (T, 192), 4: (E, 192)})
+    T, E, Pw, Q, N, NI, out, st = buf(4 * RAW * n), buf(4 * RAW * n), buf(4 * RAW * n), buf(6 * RAW * n), buf(RAW * n), buf(RAW * n), buf(192 * n), buf(n)
+    run(lib, 'H2C_A', n, {0: (buf(uniform), 256), 3: (T, 4 * RAW), 4: (E, 4 * RAW)})
     lib.nbls_sim_fp_pow(C.c_uint(2 * n), E, Pw, 2)
-    run(lib, 'H2C_B', n, {3: (T, 192), 5: (Pw, 192), 6: (Q, 288), 7: (N, 48)})
+    run(lib, 'H2C_B', n, {3: (T, 4 * RAW), 5: (Pw, 4 * RAW), 6: (Q, 6 * RAW), 7: (N, RAW)})
     lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
-    run(lib, 'G2_TO_AFFINE', n, {3: (Q, 288), 4: (NI, 48), 2: (out, 192), 7: (st, 1)})
+    run(lib, 'G2_TO_AFFINE', n, {3: (Q, 6 * RAW), 4: (NI, RAW), 2: (out, 192), 7: (st, 1)})
     return out.raw
 
 
 def point_sum(lib, pts, g2=False):
-    sz, psz = (192, 288) if g2 else (96, 144)
+    sz, psz = (192, 6 * RAW) if g2 else (96, 3 * RAW)
     pre = 'G2' if g2 else 'G1'
     n = len(pts) // sz
     A, Bf = buf(psz * (n + 2)), buf(psz * (n + 2))
     run(lib, pre + '_TO_PROJ', n, {(1 if g2 else 0): (buf(pts), sz), 3: (A, psz)})
     ident = bytearray(psz)
-    one = bytes.fromhex('fdff02000000097602000cc40b00f4ebba58c7535798485f455752705358ce776dec56a2971a075c93e480fac35ef615')  # R mod p, little-endian words
-    ident[(96 if g2 else 48):(96 if g2 else 48) + 48] = one
+    yo = (2 * RAW) if g2 else RAW          # (0 : 1 : 0): y = Montgomery one
+    ident[yo:yo + RAW] = raw_elem(1)
     m = n
     src, dst = A, Bf
     while m > 1:
@@ -100,8 +111,8 @@ def point_sum(lib, pts, g2=False):
         run(lib, pre + '_ADD2', m // 2, {3: (src, 2 * psz), 5: (dst, psz)})
         src, dst = dst, src
         m //= 2
-    N, NI, out, st = buf(48), buf(48), buf(sz), buf(1)
-    run(lib, pre + '_NORM', 1, {3: (src, psz), 4: (N, 48)})
+    N, NI, out, st = buf(RAW), buf(RAW), buf(sz), buf(1)
+    run(lib, pre + '_NORM', 1, {3: (src, psz), 4: (N, RAW)})
     lib.nbls_sim_fp_inv(C.c_uint(1), N, NI)
-    run(lib, pre + '_TO_AFFINE', 1, {3: (src, psz), 4: (NI, 48), 2: (out, sz), 7: (st, 1)})
+    run(lib, pre + '_TO_AFFINE', 1, {3: (src, psz), 4: (NI, RAW), 2: (out, sz), 7: (st, 1)})
     return out.raw, st.raw[0]

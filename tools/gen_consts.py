@@ -167,39 +167,49 @@ N0_32 = (-pow(P, -1, 1 << 32)) % (1 << 32)
 assert N0_64 == 0x89f3fffcfffcfffd and N0_32 == 0xfffcfffd
 
 
-def mont(v):
-    return (v % P) * RMONT % P
+def mont(v, rbits=RBITS):
+    return (v % P) * (1 << rbits) % P
 
 
-def limbs(v, bits):
-    n = RBITS // bits
+def limbs(v, bits, rbits=RBITS):
+    n = rbits // bits
     return [(v >> (bits * i)) & ((1 << bits) - 1) for i in range(n)]
 
 
-def c_fp(v, bits, raw=False):
-    w = limbs(v if raw else mont(v), bits)
+def c_fp(v, bits, raw=False, rbits=RBITS):
+    w = limbs(v if raw else mont(v, rbits), bits, rbits)
     fmt = '0x%016xull' if bits == 64 else '0x%08xu'
     return '{' + ','.join(fmt % x for x in w) + '}'
 
 
-def emit(path, bits, fp_t, guard, qual):
+def emit(path, bits, fp_t, guard, qual, rbits=RBITS):
     L = []
     a = L.append
-    a('/* GENERATED by tools/gen_consts.py -- do not edit.  Montgomery form, R = 2^384, %d-bit limbs, little-endian limb order. */' % bits)
+    a('/* GENERATED by tools/gen_consts.py -- do not edit.  Montgomery form, R = 2^%d, %d-bit limbs, little-endian limb order. */' % (rbits, bits))
     a('#ifndef %s\n#define %s' % (guard, guard))
     word = 'uint64_t' if bits == 64 else 'uint32_t'
-    n = RBITS // bits
+    n = rbits // bits
+    RM = 1 << rbits
+    if bits == 28:
+        # bias for limb-wise subtraction: 16p with every limb >= 2^28 - 1 (limb i borrows 2^28 from limb i+1), see vm_exec.h
+        c = limbs(16 * P, 28, rbits)
+        b16 = [c[0] + (1 << 28)] + [c[i] + (1 << 28) - 1 for i in range(1, n - 1)] + [c[n - 1] - 1]
+        assert sum(x << (28 * i) for i, x in enumerate(b16)) == 16 * P and all(x >= (1 << 28) - 1 for x in b16[:-1])
+        a('%s uint32_t NBLS_BIAS16[%d] = {%s};' % (qual, n, ','.join('0x%08xu' % x for x in b16)))
+        a('#define NBLS_BIAS16_INIT {%s}' % ','.join('0x%08xu' % x for x in b16))
+        a('#define NBLS_P_INIT {%s}' % ','.join('0x%08xu' % x for x in limbs(P, 28, rbits)))
+        a('#define NBLS_P_WORDS_INIT {%s}' % ','.join('0x%08xu' % ((P >> (32 * i)) & 0xffffffff) for i in range(12)))
 
     def fp(name, v, raw=False):
-        a('%s %s %s[%d] = %s;' % (qual, word, name, n, c_fp(v, bits, raw)))
+        a('%s %s %s[%d] = %s;' % (qual, word, name, n, c_fp(v, bits, raw, rbits)))
 
     def fp2(name, v):
-        a('%s %s %s[2][%d] = {%s,%s};' % (qual, word, name, n, c_fp(v[0], bits), c_fp(v[1], bits)))
+        a('%s %s %s[2][%d] = {%s,%s};' % (qual, word, name, n, c_fp(v[0], bits, False, rbits), c_fp(v[1], bits, False, rbits)))
 
     def fp2arr(name, vs):
         a('%s %s %s[%d][2][%d] = {' % (qual, word, name, len(vs), n))
         for v in vs:
-            a('  {%s,%s},' % (c_fp(v[0], bits), c_fp(v[1], bits)))
+            a('  {%s,%s},' % (c_fp(v[0], bits, False, rbits), c_fp(v[1], bits, False, rbits)))
         a('};')
 
     def exp(name, e):
@@ -210,14 +220,18 @@ def emit(path, bits, fp_t, guard, qual):
     fp('NBLS_P', P, raw=True)
     fp('NBLS_2P', 2 * P, raw=True)
     fp('NBLS_R1', 1)            # Montgomery one
-    fp('NBLS_R2', RMONT)        # R^2 mod p, as mont(R)
+    fp('NBLS_R2', RM)           # R^2 mod p, as mont(R)
     fp('NBLS_RAW_ONE', 1, raw=True)
-    fp('NBLS_R3', RMONT * RMONT)            # R^3 mod p as mont(R^2): montmul(t, R3) = t R^2
+    fp('NBLS_R3', RM * RM)                  # R^3 mod p as mont(R^2): montmul(t, R3) = t R^2
+    fp('NBLS_TOP384', (1 << 384) * RM)     # montmul(t, TOP384) = t * 2^384 * R : high part of a 64-byte integer (hash_to_field)
     fp('NBLS_HALF_P_RAW', (P - 1) // 2, raw=True)   # v > (p-1)/2  <=>  floor(2v/p) = 1 (sign flags, index.ts:314)
     fp('NBLS_MASK381_RAW', (1 << 381) - 1, raw=True)
+    a('#define NBLS_LIMB_BITS %d\n#define NBLS_NLIMBS %d\n#define NBLS_RBITS %d' % (bits, n, rbits))
+    a('#define NBLS_N0_LIMB 0x%xu' % ((-pow(P, -1, 1 << bits)) % (1 << bits)))
     a('#define NBLS_N0_64 0x%016xull' % N0_64)
     a('#define NBLS_N0_32 0x%08xu' % N0_32)
     a('#define NBLS_X 0x%016xull' % X)
+    fp('NBLS_INV3', pow(3, -1, P))   # 1/3 (folding a post-added term into a dot product that carries a multiplier 3)
     fp('NBLS_HALF', (P + 1) // 2)   # 1/2, used where the reference writes .div(2n) (math.ts:1349-1350)
     fp('NBLS_BETA', BETA)
     fp('NBLS_PSI2_C1', PSI2_C1[0])
@@ -255,7 +269,8 @@ def emit(path, bits, fp_t, guard, qual):
 
 def main():
     emit(os.path.join(ROOT, 'oracle', 'consts_gen.h'), 64, 'fp', 'NBLS_ORACLE_CONSTS_GEN_H', 'static const')
-    emit(os.path.join(ROOT, 'noble-bls12-381_amd', 'csrc', 'consts_gen.h'), 32, 'fp', 'NBLS_CONSTS_GEN_H', 'static const')
+    # HIP engine: 14 limbs of 28 bits (stored in u32), Montgomery radix R = 2^392 -- see DESIGN.md 3.1
+    emit(os.path.join(ROOT, 'noble-bls12-381_amd', 'csrc', 'consts_gen.h'), 28, 'fp', 'NBLS_CONSTS_GEN_H', 'static const', rbits=392)
 
 
 if __name__ == '__main__':
