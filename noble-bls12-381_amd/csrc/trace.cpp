@@ -9,7 +9,8 @@
 namespace nbls {
 
 static const double P_OVER_R = 1.0 / 1234.0;   // p / 2^392 = 0.00079..., rounded up
-static const double NEG_CAP = 16.0;             // negated atoms must stay below the 16p bias
+static const double NEG_CAP = 6.0;              // negated linear terms above this bound are contracted first (their bound is paid as a +k p offset)
+static const int MAX_OFFS = 15;                 // DOT: 4-bit multiple of p baked into the accumulator
 static const double OUT_CAP = 10.0;             // results above this bound get their post-added terms folded into the dot product
 static const double OP_CAP = 24.0;              // product operands above this bound are contracted first (keeps bounds from compounding)
 
@@ -82,6 +83,13 @@ void output(const SFp& x, int buf, int off) {
   B->add_node(n);
 }
 
+int Builder::kp_atom(int k) {
+  assert(k >= 1 && k <= 64);
+  u32 P[NLIMBS] = NBLS_P_INIT, acc[NLIMBS] = {0};
+  for (int i = 0; i < k; i++) { for (int j = 0; j < NLIMBS; j++) acc[j] += P[j]; carry_norm(acc); }
+  int id = const_atom(acc); nodes[id].bound = k; return id;
+}
+
 int Builder::contract(int atom) {
   if (atom_bound(atom) <= 1.5 || nodes[atom].kind == 0xff) return atom;
   auto it = contract_cache.find(atom); if (it != contract_cache.end()) return it->second;
@@ -93,37 +101,65 @@ int Builder::contract(int atom) {
 
 // Emit one DOT node for (prods, lin) -- caller guarantees the limits.
 static int emit_dot(Builder* B, std::vector<DotProduct> prods, int mult, std::vector<std::pair<int, int>> lin, bool halve_it) {
-  // negated atoms must be below the 16p bias: contract the (rare) large ones first
   for (auto& p : prods) {
-    auto fix = [&](int& a) { if (a >= 0 && B->atom_bound(a) > NEG_CAP) a = B->contract(a); };
     auto cap = [&](int& a) { if (a >= 0 && B->atom_bound(a) > OP_CAP && !B->nodes[a].raw) a = B->contract(a); };
     cap(p.a.s0); cap(p.a.s1); cap(p.b.s0); cap(p.b.s1);
-    if (p.neg) { fix(p.a.s0); if (!p.a.n1) fix(p.a.s1); } else if (p.a.n1) fix(p.a.s1);
-    if (p.b.n1) fix(p.b.s1);
   }
   for (auto& t : lin) if (B->atom_bound(t.first) > (t.second < 0 ? NEG_CAP : OP_CAP)) t.first = B->contract(t.first);
-  Node n; n.kind = K_DOT; n.prods = prods; n.mult = mult; n.lin = lin; n.halve = halve_it;
-  double V = 0; for (auto& p : prods) V += B->operand_bound(p.a, p.neg) * B->operand_bound(p.b, false);
-  double D = prods.empty() ? 0.0 : V * P_OVER_R + 1.0;
-  double T = mult * D; for (auto& t : lin) T += t.second < 0 ? NEG_CAP : B->atom_bound(t.first);
+  Node n; n.kind = K_DOT; n.mult = mult; n.halve = halve_it;
+  // value bounds: REDC(T) lies in (T/R, T/R + p); products that may be negative are compensated by offs * p
+  double Vpos = 0, Vneg = 0, Lpos = 0, Lneg = 0;
+  for (auto& p : prods) {
+    double v = B->operand_bound(p.a) * B->operand_bound(p.b);
+    bool maybe_neg = p.neg || (p.a.s1 >= 0 && p.a.n1) || (p.b.s1 >= 0 && p.b.n1);
+    bool surely_neg = p.neg && !(p.a.s1 >= 0 && p.a.n1) && !(p.b.s1 >= 0 && p.b.n1);
+    if (maybe_neg) Vneg += v;
+    if (!surely_neg) Vpos += v;
+  }
+  for (auto& t : lin) (t.second < 0 ? Lneg : Lpos) += B->atom_bound(t.first);
+  int offs = (int)std::ceil(Vneg * P_OVER_R + Lneg / mult - 1e-9);
+  if (offs > MAX_OFFS) { fprintf(stderr, "DOT offset %d: Vneg=%.1f Lneg=%.1f mult=%d\n", offs, Vneg, Lneg, mult); }
+  assert(offs <= MAX_OFFS);
+  n.offs = offs;
+  double T = mult * (Vpos * P_OVER_R + 1.0 + offs) + Lpos;
   if (halve_it) T = T / 2 + 0.5;
-  if (T >= 1000.0) { fprintf(stderr, "DOT bound %.1f: mult=%d D=%.2f V=%.1f k=%zu L=%zu\n", T, mult, D, V, prods.size(), lin.size()); for (auto& p : prods) fprintf(stderr, "  A(%d:%.1f,%d:%.1f n1=%d neg=%d) B(%d:%.1f,%d:%.1f n1=%d)\n", p.a.s0, B->atom_bound(p.a.s0), p.a.s1, p.a.s1>=0?B->atom_bound(p.a.s1):0, p.a.n1, p.neg, p.b.s0, B->atom_bound(p.b.s0), p.b.s1, p.b.s1>=0?B->atom_bound(p.b.s1):0, p.b.n1); for (auto& t : lin) fprintf(stderr, "  lin %d:%.1f sign %d\n", t.first, B->atom_bound(t.first), t.second); }
   assert(T < 1000.0);
+  // limb budget of the signed column accumulators: sum of c_a * c_b <= 8, c = 2 for an un-normalised sum operand
+  auto is_sum = [](const Operand& o) { return o.s1 >= 0 && !o.n1; };
+  for (;;) {
+    int total = 0, worst = -1, worst_cc = 0;
+    for (size_t i = 0; i < prods.size(); i++) {
+      auto& p = prods[i];
+      int ca = is_sum(p.a) && !p.norm_a ? 2 : 1, cb = is_sum(p.b) && !p.norm_b ? 2 : 1;
+      total += ca * cb;
+      if (ca * cb > worst_cc) { worst_cc = ca * cb; worst = (int)i; }
+    }
+    if (total <= 8) break;
+    assert(worst >= 0 && worst_cc > 1);
+    auto& p = prods[worst];
+    if (is_sum(p.a) && !p.norm_a) p.norm_a = true; else p.norm_b = true;
+  }
+  n.prods = prods; n.lin = lin;
   n.bound = T;
   return B->add_node(n);
 }
 static int emit_lin(Builder* B, std::vector<std::pair<int, int>> terms, bool halve_it) {
   for (auto& t : terms) if (B->atom_bound(t.first) > (t.second < 0 ? NEG_CAP : OP_CAP)) t.first = B->contract(t.first);
-  auto bound_of = [&](const std::vector<std::pair<int, int>>& ts) { double T = 0; for (auto& t : ts) T += t.second < 0 ? NEG_CAP : B->atom_bound(t.first); return T; };
-  while ((int)terms.size() > MAX_LIN_TERMS) {
-    Node n; n.kind = K_LIN; n.lin.assign(terms.begin(), terms.begin() + MAX_LIN_TERMS); n.bound = bound_of(n.lin);
+  // negative terms are limb-wise subtractions; a constant k p keeps the value non-negative
+  auto finish = [&](std::vector<std::pair<int, int>>& ts) {
+    double neg = 0; for (auto& t : ts) if (t.second < 0) neg += B->atom_bound(t.first);
+    if (neg > 0) ts.push_back({B->kp_atom((int)std::ceil(neg - 1e-9)), 1});
+  };
+  auto bound_of = [&](const std::vector<std::pair<int, int>>& ts) { double T = 0; for (auto& t : ts) if (t.second > 0) T += B->atom_bound(t.first); return T; };
+  while ((int)terms.size() > MAX_LIN_TERMS - 1) {
+    Node n; n.kind = K_LIN; n.lin.assign(terms.begin(), terms.begin() + MAX_LIN_TERMS - 1); finish(n.lin); n.bound = bound_of(n.lin);
     int id = B->add_node(n);
-    terms.erase(terms.begin(), terms.begin() + MAX_LIN_TERMS);
+    terms.erase(terms.begin(), terms.begin() + MAX_LIN_TERMS - 1);
     terms.insert(terms.begin(), {id, 1});
   }
-  Node n; n.kind = K_LIN; n.lin = terms; n.halve = halve_it; n.bound = bound_of(terms);
+  Node n; n.kind = K_LIN; n.lin = terms; finish(n.lin); n.halve = halve_it; n.bound = bound_of(n.lin);
   if (halve_it) n.bound = n.bound / 2 + 0.5;
-  assert(n.bound < 1000.0);
+  assert(n.bound < 1000.0 && (int)n.lin.size() <= MAX_LIN_TERMS);
   return B->add_node(n);
 }
 
@@ -180,7 +216,7 @@ int materialize(const SFp& x, bool halve_it) {
   if (!dps.empty() && !lin.empty()) {
     // If the post-added terms would make the result large, fold them into the accumulator as products with small
     // constants (x * (c/m)): the Montgomery reduction then contracts everything to about m p.
-    double T = mult * 2.0; for (auto& t : lin) T += t.second < 0 ? NEG_CAP : B->atom_bound(t.first);
+    double T = mult * 3.0; for (auto& t : lin) T += std::min(B->atom_bound(t.first), t.second < 0 ? NEG_CAP : OP_CAP);
     if (T > OUT_CAP) {
       std::map<int, int> net; for (auto& t : lin) net[t.first] += t.second;
       for (auto& kv : net) if (kv.second) { Operand a; a.s0 = kv.first; Operand c; c.s0 = B->frac_const(kv.second, mult); dps.push_back({a, c, false}); }
@@ -323,10 +359,23 @@ Program Builder::compile(const std::string& name, int W) {
     assert(n.slot >= 0);
     return (u32)n.slot;
   };
-  auto enc_operand = [&](const Operand& o, bool negate) -> u32 {
-    u32 e0 = op(o.s0) | (negate ? OP_NEG : 0u);
-    u32 e1 = o.s1 >= 0 ? (op(o.s1) | ((o.n1 != negate) ? OP_NEG : 0u) | OP_PRESENT) : 0u;
+  auto enc_operand = [&](const Operand& o, bool negate, bool norm) -> u32 {
+    u32 e0 = op(o.s0) | (negate ? OP_NEG : 0u) | (norm ? OP_NORM : 0u);
+    u32 e1 = o.s1 >= 0 ? (op(o.s1) | (o.n1 ? OP_NEG : 0u) | OP_PRESENT) : 0u;
     return e0 | (e1 << 16);
+  };
+  // a product's minus sign goes where it is free (reverse a difference), else onto a single-slot operand
+  auto enc_product = [&](DotProduct p, u32& wa, u32& wb) {
+    bool nega = false, negb = false;
+    if (p.neg) {
+      if (p.a.s1 >= 0 && p.a.n1) std::swap(p.a.s0, p.a.s1);
+      else if (p.b.s1 >= 0 && p.b.n1) std::swap(p.b.s0, p.b.s1);
+      else if (p.a.s1 < 0) nega = true;
+      else if (p.b.s1 < 0) negb = true;
+      else nega = true;
+    }
+    wa = enc_operand(p.a, nega, p.norm_a); wb = enc_operand(p.b, negb, p.norm_b);
+    P.n_norm_operands += p.norm_a + p.norm_b; P.n_neg_operands += nega + negb; P.n_comb_operands += (p.a.s1 >= 0) + (p.b.s1 >= 0);
   };
   for (size_t s = 0; s < step_nodes.size(); s++) {
     const std::vector<int>& L = step_nodes[s];
@@ -354,12 +403,12 @@ Program Builder::compile(const std::string& name, int W) {
       switch (n.kind) {
         case K_DOT:
           assert(n.prods.size() <= (size_t)MAX_DOT_PRODUCTS && n.lin.size() <= (size_t)MAX_DOT_LINEAR && n.mult >= 1 && n.mult <= 4);
-          w[0] = (u32)n.slot | ((u32)n.prods.size() << 16) | ((u32)n.lin.size() << 20) | ((u32)n.mult << 24) | (n.halve ? (1u << 27) : 0u);
+          w[0] = (u32)n.slot | ((u32)n.prods.size() << 16) | ((u32)n.lin.size() << 20) | ((u32)n.mult << 24) | (n.halve ? (1u << 27) : 0u) | ((u32)n.offs << 28);
           for (size_t t = 0; t < n.lin.size(); t++) {
             u32 term = op(n.lin[t].first) | (n.lin[t].second < 0 ? (1u << OP_MODE_SHIFT) : 0u);
             w[2 + t / 2] |= term << (16 * (t & 1));
           }
-          for (size_t i = 0; i < n.prods.size(); i++) { w[4 + 2 * i] = enc_operand(n.prods[i].a, n.prods[i].neg); w[5 + 2 * i] = enc_operand(n.prods[i].b, false); }
+          for (size_t i = 0; i < n.prods.size(); i++) enc_product(n.prods[i], w[4 + 2 * i], w[5 + 2 * i]);
           break;
         case K_LIN:
           w[0] = (u32)n.slot | ((u32)n.lin.size() << 16) | (n.halve ? (1u << 24) : 0u);

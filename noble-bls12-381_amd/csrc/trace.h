@@ -32,7 +32,7 @@ struct Program {
   std::vector<u32> consts;   // nconst * SLOT_WORDS words
   u32 nconst = 0, W = 64, G = 1, slots = 0;
   // statistics
-  u32 n_dot_steps = 0, n_lin_steps = 0, n_other_steps = 0, n_dot_ops = 0, n_products = 0, n_prod_slots = 0, n_lin_ops = 0, n_lin_terms = 0;
+  u32 n_dot_steps = 0, n_lin_steps = 0, n_other_steps = 0, n_dot_ops = 0, n_products = 0, n_prod_slots = 0, n_lin_ops = 0, n_lin_terms = 0, n_norm_operands = 0, n_neg_operands = 0, n_comb_operands = 0;
   u32 lds_bytes() const { return lds_words(nconst, G, slots) * 4; }
 };
 
@@ -48,7 +48,7 @@ typedef long long TermKey;                         // atom id, or PROD_BASE + pr
 static const TermKey PROD_BASE = 1LL << 40;
 typedef std::vector<std::pair<TermKey, int>> Form;   // sorted by key, no zero coefficients
 
-struct DotProduct { Operand a, b; bool neg; };       // neg: the product enters with a minus sign
+struct DotProduct { Operand a, b; bool neg; bool norm_a = false, norm_b = false; };   // neg: the product enters with a minus sign; norm_*: normalise that (sum) operand first
 
 struct Node {
   uint8_t kind = 0;        // StepKind, or 0xff for constants
@@ -56,7 +56,7 @@ struct Node {
   bool halve = false;      // DOT/LIN: divide the reduced result by two (mod p)
   bool raw = false;        // K_LOAD result: any 384-bit integer (not < 2p)
   int a0 = -1, a1 = -1, b0 = -1;                           // generic sources (a0 = src, a1 = second src, b0 = flag)
-  std::vector<DotProduct> prods; int mult = 1;             // DOT
+  std::vector<DotProduct> prods; int mult = 1; int offs = 0;   // DOT: m * (REDC(sum of products) + offs * p) +- lin
   std::vector<std::pair<int, int>> lin;                    // DOT / LIN linear terms (atom, sign)
   std::vector<std::pair<int, int>> stat;                   // STATUS (flag atom, code)
   int buf = 0, off = 0;
@@ -105,13 +105,10 @@ struct Builder {
   bool is_const(int atom) const { return nodes[atom].kind == 0xff; }
   // magnitude bound of an atom in units of p
   double atom_bound(int atom) const { return nodes[atom].bound; }
-  // worst-case bound of a product operand; every negated term enters as 16p - x
-  double operand_bound(const Operand& o, bool negated) const {
-    double b = negated ? 16.0 : atom_bound(o.s0);
-    if (o.s1 >= 0) b += (o.n1 != negated) ? 16.0 : atom_bound(o.s1);
-    return b;
-  }
-  int contract(int atom);                            // x -> x * R / R : same value mod p, bound ~1: keeps negated atoms below the 16p bias
+  // magnitude bound of a (signed) product operand
+  double operand_bound(const Operand& o) const { return atom_bound(o.s0) + (o.s1 >= 0 ? atom_bound(o.s1) : 0.0); }
+  int kp_atom(int k);                                // the constant k * p (normalised limbs), used to keep sums with negative terms non-negative
+  int contract(int atom);                            // x -> x * R / R : same value mod p, bound ~1
   Program compile(const std::string& name, int W);
 };
 

@@ -57,7 +57,8 @@ static const int MAX_BUFS = 8;
 static const int MAX_DOT_PRODUCTS = 8;
 static const int MAX_DOT_LINEAR = 4;
 static const uint32_t OP_NEG = 0x4000;
-static const uint32_t OP_PRESENT = 0x8000;
+static const uint32_t OP_PRESENT = 0x8000;   // on the second term of a product operand: term present
+static const uint32_t OP_NORM = 0x8000;      // on the first term: normalise the (sum) operand's limbs before multiplying
 
 struct IOBuf { uint8_t* ptr; uint64_t stride; };
 

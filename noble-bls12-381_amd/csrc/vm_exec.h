@@ -7,10 +7,15 @@
 // R = 2^392.  Why 28 bits: on gfx950 v_mad_u64_u32 AND every carry-consuming add (v_addc_co) issue at half rate, and a
 // lone wavefront issues one VALU instruction per ~5.5 clocks whatever it is (tools/ubench/carry_rates.hip), so the cost of
 // a big-integer product is its instruction COUNT.  With 28-bit limbs a 64-bit column accumulator absorbs 112 limb
-// products without overflow, so a limb product is ONE in-place v_mad_u64_u32 (196 per product, no carry handling at all);
-// additions and subtractions are carry-free limb-wise operations followed by one normalisation pass; and because
-// p < 2^381 there are 11 bits of headroom (values up to 2047 p fit), so results never need conditional subtractions
-// except where a canonical representative is required (store to wire format, zero tests, comparisons).
+// products without overflow, so a limb product is ONE in-place multiply-add (196 per product, no carry handling at all).
+// Product operands are SIGNED limb vectors: x - y and -x are plain limb-wise subtractions (limbs in (-2^28, 2^28)), x + y
+// has limbs below 2^29, nothing is normalised before the multiplication, and the products go through v_mad_i64_i32 into
+// signed column accumulators (budget: sum over the products of c_a * c_b <= 8, c = 2 for an un-normalised sum, else 1;
+// the tracer asks for a normalisation pass where a lane-op would exceed it).  The Montgomery reduction works on the
+// signed columns with arithmetic shifts; a multiple of p baked into the upper columns (offs * p * R) keeps the reduced
+// value non-negative.  Because p < 2^381 there are 11 bits of headroom (values up to 2047 p fit), so results never need
+// conditional subtractions except where a canonical representative is required (store to wire format, zero tests,
+// comparisons).  Slots always hold non-negative values with normalised limbs.
 #pragma once
 #include "vm.h"
 #include "consts_gen.h"
@@ -28,17 +33,19 @@ typedef uint64_t u64;
 
 #define NL 14
 #define LMASK 0x0fffffffu
-// p, 16p (biased: every limb >= 2^28 - 1 so that BIAS16 - x is limb-wise non-negative for any normalised x <= 16p), -p^-1 mod 2^28
+// p, -p^-1 mod 2^28
 #define NBLS_P28 NBLS_P_INIT
-#define NBLS_BIAS16_28 NBLS_BIAS16_INIT
 #define NBLS_N0_28 NBLS_N0_LIMB
+#define NBLS_BIAS16_28 NBLS_BIAS16_INIT   // 16p with every limb >= 2^28 - 1 (per-lane pow kernels only)
+typedef int32_t i32;
+typedef int64_t i64;
 
-// x (limbs < 2^32 - 16, value < 2^392) -> normalised limbs (< 2^28; the top limb keeps the rest)
+// x (signed limbs in (-2^31, 2^31), value in [0, 2^392)) -> normalised limbs (< 2^28; the top limb keeps the rest)
 NBLS_HD void carry_norm(u32* x) {
-  u32 c = 0;
+  i32 c = 0;
 #pragma unroll
-  for (int i = 0; i < NL - 1; i++) { u32 v = x[i] + c; x[i] = v & LMASK; c = v >> 28; }
-  x[NL - 1] += c;
+  for (int i = 0; i < NL - 1; i++) { i32 v = (i32)x[i] + c; x[i] = (u32)v & LMASK; c = v >> 28; }
+  x[NL - 1] = (u32)((i32)x[NL - 1] + c);
 }
 
 template <typename LDSP>
@@ -48,40 +55,45 @@ NBLS_HD void ld14(u32* x, LDSP lds, u32 off) {
 }
 NBLS_HD u32 slot_addr(u32 op, u32 inst) { return ((op & OP_CONST) ? 0u : inst) + (op & OP_SLOT_MASK) * (u32)SLOT_WORDS; }
 
-// operand of a DOT product: (+-x) or (+-x +- y); a negated term enters as BIAS16 - x (= 16p - x, limb-wise non-negative)
+// operand of a DOT product, as signed limbs: x, x + y or x - y, optionally normalised (sums only), optionally negated
 template <typename LDSP>
 NBLS_HD void dot_operand(u32* A, u32 enc, LDSP lds, u32 inst) {
-  const u32 BIAS[NL] = NBLS_BIAS16_28;
   const u32 e0 = enc & 0xffff, e1 = enc >> 16;
   ld14(A, lds, slot_addr(e0, inst));
-  if ((enc & (OP_NEG | (OP_PRESENT << 16))) == 0) return;   // plain slot: the common case
-  if (e0 & OP_NEG) {
-#pragma unroll
-    for (int i = 0; i < NL; i++) A[i] = BIAS[i] - A[i];
-  }
+  if ((enc & (OP_NEG | OP_NORM | (OP_PRESENT << 16))) == 0) return;   // plain slot: the common case
   if (e1 & OP_PRESENT) {
     u32 X[NL];
     ld14(X, lds, slot_addr(e1, inst));
     if (e1 & OP_NEG) {
 #pragma unroll
-      for (int i = 0; i < NL; i++) A[i] += BIAS[i] - X[i];
+      for (int i = 0; i < NL; i++) A[i] -= X[i];
     } else {
 #pragma unroll
       for (int i = 0; i < NL; i++) A[i] += X[i];
     }
   }
-  carry_norm(A);
+  if (e0 & OP_NORM) carry_norm(A);
+  if (e0 & OP_NEG) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) A[i] = 0u - A[i];
+  }
 }
 
-// acc[i+j] += a[j] * b[i]: 196 in-place v_mad_u64_u32, no carries (column sums stay below 2^63 for <= 8 products)
+// acc[i+j] += a[j] * b[i] on signed limbs: 196 in-place v_mad_i64_i32, no carries
 NBLS_HD void mac28(u64* acc, const u32* a, const u32* b) {
 #pragma unroll
   for (int i = 0; i < NL; i++) {
 #pragma unroll
-    for (int j = 0; j < NL; j++) acc[i + j] += (u64)a[j] * b[i];
+    for (int j = 0; j < NL; j++) acc[i + j] = (u64)((i64)acc[i + j] + (i64)(i32)a[j] * (i64)(i32)b[i]);
   }
 }
-// Montgomery reduction of the lazy column accumulators: r (normalised) = V / 2^392 mod-ish, r < V / 2^392 + p
+// acc = offs * p * R (the bias that keeps a reduction with negative products non-negative)
+NBLS_HD void acc_init(u64* acc, u32 offs) {
+  const u32 P[NL] = NBLS_P28;
+#pragma unroll
+  for (int i = 0; i < NL; i++) { acc[i] = 0; acc[NL + i] = (u64)offs * P[i]; }
+}
+// Montgomery reduction of the signed lazy column accumulators (value V >= 0): r (normalised) in [V / 2^392, V / 2^392 + p)
 NBLS_HD void redc28(u32* r, u64* acc) {
   const u32 P[NL] = NBLS_P28;
 #pragma unroll
@@ -89,12 +101,12 @@ NBLS_HD void redc28(u32* r, u64* acc) {
     const u32 m = ((u32)acc[i] * NBLS_N0_28) & LMASK;
 #pragma unroll
     for (int j = 0; j < NL; j++) acc[i + j] += (u64)m * P[j];
-    acc[i + 1] += acc[i] >> 28;
+    acc[i + 1] = (u64)((i64)acc[i + 1] + ((i64)acc[i] >> 28));
   }
-  u64 c = 0;
+  i64 c = 0;
 #pragma unroll
-  for (int k = 0; k < NL - 1; k++) { u64 v = acc[NL + k] + c; r[k] = (u32)v & LMASK; c = v >> 28; }
-  r[NL - 1] = (u32)(acc[2 * NL - 1] + c);
+  for (int k = 0; k < NL - 1; k++) { i64 v = (i64)acc[NL + k] + c; r[k] = (u32)v & LMASK; c = v >> 28; }
+  r[NL - 1] = (u32)((i64)acc[2 * NL - 1] + c);
 }
 // r = a * b / R, normalised, < a*b/R + p   (used by the per-lane kernels in pow_kernels.hip / fp_inv.h)
 NBLS_HD void mont_mul28(u32* r, const u32* a, const u32* b) {
@@ -170,7 +182,6 @@ struct LaneCtx {
 template <typename LDSP>
 NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, already loaded */, const u32* __restrict__ gd /* this lane's descriptor in global memory */,
                       LDSP lds, const LaneCtx& cx, const IOBuf* bufs, u32* res) {
-  const u32 BIAS[NL] = NBLS_BIAS16_28;
   switch (st.kind) {
     case K_DOT: {
       const u32 w0 = d[0];
@@ -178,8 +189,7 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, 
       u32 r[NL];
       if (st.p0 > 0) {   // uniform
         u64 acc[2 * NL];
-#pragma unroll
-        for (int i = 0; i < 2 * NL; i++) acc[i] = 0;
+        acc_init(acc, w0 >> 28);
         u32 na = d[4], nb = d[5];
         for (u32 i = 0; i < st.p0; i++) {   // uniform trip count; next product's operand words are fetched ahead
           const u32 ea = na, eb = nb;
@@ -198,7 +208,7 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, 
       }
       if (mult > 1) {
 #pragma unroll
-        for (int i = 0; i < NL; i++) r[i] *= mult;     // m <= 4: limbs < 2^30
+        for (int i = 0; i < NL; i++) r[i] *= mult;     // m <= 4; with <= 4 linear terms the limb sums stay inside (-2^31, 2^31)
       }
 #pragma unroll
       for (int t = 0; t < MAX_DOT_LINEAR; t++) {
@@ -209,7 +219,7 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, 
             ld14(X, lds, slot_addr(term, cx.inst));
             if (term & OP_NEG) {
 #pragma unroll
-              for (int i = 0; i < NL; i++) r[i] += BIAS[i] - X[i];
+              for (int i = 0; i < NL; i++) r[i] -= X[i];
             } else {
 #pragma unroll
               for (int i = 0; i < NL; i++) r[i] += X[i];
@@ -238,7 +248,7 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, 
             ld14(X, lds, slot_addr(term, cx.inst));
             if (term & OP_NEG) {
 #pragma unroll
-              for (int i = 0; i < NL; i++) r[i] += BIAS[i] - X[i];
+              for (int i = 0; i < NL; i++) r[i] -= X[i];
             } else {
 #pragma unroll
               for (int i = 0; i < NL; i++) r[i] += X[i];
