@@ -335,6 +335,74 @@ Program Builder::compile(const std::string& name, int W) {
     remaining -= (int)chosen.size();
     for (int c : chosen) for (int u : nodes[c].users) if (--nodes[u].ndeps == 0) ready.emplace(qkey(nodes[u]), PQ(cmp)).first->second.push(u);
   }
+  // 4b. operand forms.  A product's minus sign goes where it is free (reverse a difference), else onto a single-slot
+  // operand.  Then, because every lane of a wavefront walks the same product loop, the products of each lane-op are
+  // permuted (and their operands swapped) so that product index i has the same operand shape in as many lanes of the
+  // step as possible: the kernel's per-shape branches (second term, subtract, normalise, negate) are taken only where
+  // some lane needs them.
+  auto form_mask = [](const Operand& o, bool norm, bool neg) { return (o.s1 >= 0 ? (o.n1 ? 2 : 1) : 0) | (norm ? 4 : 0) | (neg ? 8 : 0); };
+  auto form_cost = [](int m) { return (m ? 6 : 0) + ((m & 3) ? 11 : 0) + ((m & 1) ? 14 : 0) + ((m & 2) ? 14 : 0) + ((m & 4) ? 41 : 0) + ((m & 8) ? 14 : 0); };
+  for (auto& L : step_nodes) {
+    if (nodes[L[0]].kind != K_DOT) continue;
+    for (int c : L) for (auto& p : nodes[c].prods) {
+      if (!p.neg) continue;
+      if (p.a.s1 >= 0 && p.a.n1) std::swap(p.a.s0, p.a.s1);
+      else if (p.b.s1 >= 0 && p.b.n1) std::swap(p.b.s0, p.b.s1);
+      else if (p.a.s1 < 0) p.neg_a = true;
+      else if (p.b.s1 < 0) p.neg_b = true;
+      else p.neg_a = true;
+      p.neg = false;
+    }
+    size_t mk = 0; for (int c : L) mk = std::max(mk, nodes[c].prods.size());
+    std::vector<int> ua(mk, 0), ub(mk, 0);
+    std::vector<int> order(L.begin(), L.end());
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return nodes[x].prods.size() > nodes[y].prods.size(); });
+    for (int c : order) {
+      auto& pr = nodes[c].prods;
+      std::vector<DotProduct> placed(mk); std::vector<char> used(mk, 0);
+      std::vector<size_t> idx(pr.size()); for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
+      auto weight = [&](const DotProduct& p) { return form_cost(form_mask(p.a, p.norm_a, p.neg_a)) + form_cost(form_mask(p.b, p.norm_b, p.neg_b)); };
+      std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return weight(pr[x]) > weight(pr[y]); });
+      size_t hi = 0;
+      for (size_t i : idx) {
+        const DotProduct& p = pr[i];
+        int ma = form_mask(p.a, p.norm_a, p.neg_a), mb = form_mask(p.b, p.norm_b, p.neg_b);
+        int best = -1, best_cost = 1 << 30; bool best_swap = false;
+        for (size_t j = 0; j < mk; j++) {
+          if (used[j]) continue;
+          if (j >= pr.size() && j > hi) break;   // keep the lane's products packed at the low indices (k = number of products)
+          for (int sw = 0; sw < 2; sw++) {
+            int xa = sw ? mb : ma, xb = sw ? ma : mb;
+            int inc = form_cost(ua[j] | xa) - form_cost(ua[j]) + form_cost(ub[j] | xb) - form_cost(ub[j]);
+            if (inc < best_cost) { best_cost = inc; best = (int)j; best_swap = sw; }
+          }
+        }
+        if (best >= (int)pr.size()) best = -1;
+        if (getenv("NBLS_NO_ALIGN")) { best = (int)i; best_swap = false; }
+        if (best < 0) { for (size_t j = 0; j < pr.size(); j++) if (!used[j]) { best = (int)j; break; } best_swap = false; }
+        DotProduct q = p;
+        if (best_swap) { std::swap(q.a, q.b); std::swap(q.norm_a, q.norm_b); std::swap(q.neg_a, q.neg_b); }
+        placed[best] = q; used[best] = 1; hi = std::max(hi, (size_t)best + 1);
+        ua[best] |= form_mask(q.a, q.norm_a, q.neg_a); ub[best] |= form_mask(q.b, q.norm_b, q.neg_b);
+      }
+      placed.resize(pr.size());
+      pr = placed;
+    }
+    if (getenv("NBLS_DUMP_STEPS")) { fprintf(stderr, "%s dot step lanes=%zu k:", name.c_str(), L.size()); for (int c : L) fprintf(stderr, " %zu", nodes[c].prods.size()); fprintf(stderr, "\n"); }
+    // cost model of the step (VALU instructions per wavefront)
+    double est = 310 + 80;
+    for (size_t j = 0; j < mk; j++) est += 196 + 22 + form_cost(ua[j]) + form_cost(ub[j]);
+    size_t ml = 0; bool any_mult = false, any_halve = false;
+    for (int c : L) { ml = std::max(ml, nodes[c].lin.size()); any_mult |= nodes[c].mult > 1; any_halve |= nodes[c].halve; }
+    est += ml * 30 + (any_mult ? 14 : 0) + ((any_mult || ml) ? 41 : 0) + (any_halve ? 60 : 0);
+    P.est_valu += est;
+  }
+  for (auto& L : step_nodes) {
+    const Node& n0 = nodes[L[0]];
+    if (n0.kind == K_DOT) continue;
+    if (n0.kind == K_LIN) { size_t mx = 0; bool h = false; for (int c : L) { mx = std::max(mx, nodes[c].lin.size()); h |= nodes[c].halve; } P.est_valu += 80 + mx * 30 + 41 + (h ? 60 : 0); }
+    else P.est_valu += 150;
+  }
   // 5. slot allocation (linear scan; a destination may reuse a slot whose last read is in the same step)
   for (int i = 0; i < N; i++) { Node& n = nodes[i]; if (!n.live || n.kind == 0xff) continue; for (int u : n.users) n.last_use = std::max(n.last_use, nodes[u].step); }
   std::vector<int> free_slots; int nslots = 0;
@@ -364,18 +432,9 @@ Program Builder::compile(const std::string& name, int W) {
     u32 e1 = o.s1 >= 0 ? (op(o.s1) | (o.n1 ? OP_NEG : 0u) | OP_PRESENT) : 0u;
     return e0 | (e1 << 16);
   };
-  // a product's minus sign goes where it is free (reverse a difference), else onto a single-slot operand
-  auto enc_product = [&](DotProduct p, u32& wa, u32& wb) {
-    bool nega = false, negb = false;
-    if (p.neg) {
-      if (p.a.s1 >= 0 && p.a.n1) std::swap(p.a.s0, p.a.s1);
-      else if (p.b.s1 >= 0 && p.b.n1) std::swap(p.b.s0, p.b.s1);
-      else if (p.a.s1 < 0) nega = true;
-      else if (p.b.s1 < 0) negb = true;
-      else nega = true;
-    }
-    wa = enc_operand(p.a, nega, p.norm_a); wb = enc_operand(p.b, negb, p.norm_b);
-    P.n_norm_operands += p.norm_a + p.norm_b; P.n_neg_operands += nega + negb; P.n_comb_operands += (p.a.s1 >= 0) + (p.b.s1 >= 0);
+  auto enc_product = [&](const DotProduct& p, u32& wa, u32& wb) {
+    wa = enc_operand(p.a, p.neg_a, p.norm_a); wb = enc_operand(p.b, p.neg_b, p.norm_b);
+    P.n_norm_operands += p.norm_a + p.norm_b; P.n_neg_operands += p.neg_a + p.neg_b; P.n_comb_operands += (p.a.s1 >= 0) + (p.b.s1 >= 0);
   };
   for (size_t s = 0; s < step_nodes.size(); s++) {
     const std::vector<int>& L = step_nodes[s];

@@ -33,6 +33,7 @@ struct Program {
   u32 nconst = 0, W = 64, G = 1, slots = 0;
   // statistics
   u32 n_dot_steps = 0, n_lin_steps = 0, n_other_steps = 0, n_dot_ops = 0, n_products = 0, n_prod_slots = 0, n_lin_ops = 0, n_lin_terms = 0, n_norm_operands = 0, n_neg_operands = 0, n_comb_operands = 0;
+  double est_valu = 0;       // cost-model estimate of VALU instructions per wave (see Builder::compile)
   u32 lds_bytes() const { return lds_words(nconst, G, slots) * 4; }
 };
 
@@ -48,7 +49,7 @@ typedef long long TermKey;                         // atom id, or PROD_BASE + pr
 static const TermKey PROD_BASE = 1LL << 40;
 typedef std::vector<std::pair<TermKey, int>> Form;   // sorted by key, no zero coefficients
 
-struct DotProduct { Operand a, b; bool neg; bool norm_a = false, norm_b = false; };   // neg: the product enters with a minus sign; norm_*: normalise that (sum) operand first
+struct DotProduct { Operand a, b; bool neg; bool norm_a = false, norm_b = false; bool neg_a = false, neg_b = false; };   // neg: the product enters with a minus sign; norm_*: normalise that (sum) operand first
 
 struct Node {
   uint8_t kind = 0;        // StepKind, or 0xff for constants
