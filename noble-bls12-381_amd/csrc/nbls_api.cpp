@@ -14,7 +14,7 @@
 #include <thread>
 
 extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream);
-extern "C" int nbls_fp_inv_launch(unsigned n, const void* in, void* out, const void* table, void* stream);
+extern "C" int nbls_fp_inv_launch(unsigned n, const void* in, void* out, void* stream);
 extern "C" int nbls_fp_pow_launch(unsigned n, const void* in, void* out, const void* nibbles, int nnib, void* scratch, int is_fp2, void* stream);
 
 using namespace nbls;
@@ -34,7 +34,7 @@ struct nbls_ctx {
   std::mutex mu;
   DevProgram prog[P_COUNT];
   // scratch (device)
-  uint8_t *F = nullptr, *F2 = nullptr, *N = nullptr, *NI = nullptr, *io_g1 = nullptr, *io_g2 = nullptr, *io_f12 = nullptr, *one12 = nullptr, *inv_table = nullptr;
+  uint8_t *F = nullptr, *F2 = nullptr, *N = nullptr, *NI = nullptr, *io_g1 = nullptr, *io_g2 = nullptr, *io_f12 = nullptr, *one12 = nullptr;
   uint8_t* T[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // t1..t7 of the final exponentiation, raw Fp12
   // general scratch pool for the codec / hash / sum pipelines (grown on demand)
   static const int NSB = 12;
@@ -82,7 +82,7 @@ static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pa
 static int run_inv(nbls_ctx* ctx, size_t n, hipStream_t s) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s); }
-  int e = nbls_fp_inv_launch((unsigned)n, ctx->N, ctx->NI, ctx->inv_table, s);
+  int e = nbls_fp_inv_launch((unsigned)n, ctx->N, ctx->NI, s);
   if (ctx->timing) { hipEventRecord(e1, s); ctx->tev.push_back({(int)P_COUNT, {e0, e1}}); }
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
   return NBLS_OK;
@@ -132,7 +132,7 @@ static int run_pow(nbls_ctx* ctx, int which, size_t n, const void* in, void* out
   return NBLS_OK;
 }
 static int run_inv_buf(nbls_ctx* ctx, size_t n, const void* in, void* out, hipStream_t s) {
-  int e = nbls_fp_inv_launch((unsigned)n, in, out, ctx->inv_table, s);
+  int e = nbls_fp_inv_launch((unsigned)n, in, out, s);
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
   return NBLS_OK;
 }
@@ -188,10 +188,6 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
   u32 one[12 * SLOT_WORDS]; memset(one, 0, sizeof one); memcpy(one, NBLS_R1, NLIMBS * 4);
   if (hipMalloc(&ctx->one12, F12) != hipSuccess || hipMemcpy(ctx->one12, one, F12, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   {
-    std::vector<u32> tab(382 * NLIMBS); make_inv_table(tab.data());
-    if (hipMalloc(&ctx->inv_table, tab.size() * 4) != hipSuccess || hipMemcpy(ctx->inv_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
-  }
-  {
     const uint64_t* exps[3] = {NBLS_EXP_P_PLUS_1_DIV_4, NBLS_EXP_P2_PLUS_7_DIV_16, NBLS_EXP_P2_MINUS_9_DIV_16};
     const int bits[3] = {NBLS_P_PLUS_1_DIV_4_BITS, NBLS_P2_PLUS_7_DIV_16_BITS, NBLS_P2_MINUS_9_DIV_16_BITS};
     for (int k = 0; k < 3; k++) {
@@ -218,7 +214,7 @@ EXPORT void nbls_destroy(nbls_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   for (auto& d : ctx->prog) { if (d.steps) hipFree(d.steps); if (d.descs) hipFree(d.descs); if (d.consts) hipFree(d.consts); }
-  for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->inv_table}) if (p) hipFree(p);
+  for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12}) if (p) hipFree(p);
   for (uint8_t* p : ctx->T) if (p) hipFree(p);
   for (uint8_t* p : ctx->sb) if (p) hipFree(p);
   for (uint8_t* p : ctx->nib) if (p) hipFree(p);

@@ -50,13 +50,13 @@ __device__ __forceinline__ void fp2_sqr_r(Fp2r& r, const Fp2r& a) {             
   for (int i = 0; i < NL; i++) r.c0[i] = r0[i];
 }
 
-extern "C" __global__ void __launch_bounds__(64) nbls_fp_inv_kernel(unsigned n, const u32* __restrict__ in, u32* __restrict__ out, const u32* __restrict__ table) {
+extern "C" __global__ void __launch_bounds__(64) nbls_fp_inv_kernel(unsigned n, const u32* __restrict__ in, u32* __restrict__ out) {
   unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 x[NL], y[NL];
 #pragma unroll
   for (int k = 0; k < NL; k++) x[k] = in[SLOT_WORDS * i + k];
-  fp_mont_inverse(y, x, table);
+  fp_mont_inverse(y, x);
 #pragma unroll
   for (int k = 0; k < NL; k++) out[SLOT_WORDS * i + k] = y[k];
   out[SLOT_WORDS * i + 14] = 0; out[SLOT_WORDS * i + 15] = 0;
@@ -130,8 +130,8 @@ extern "C" int nbls_fp_pow_launch(unsigned n, const void* in, void* out, const v
   return (int)hipGetLastError();
 }
 
-extern "C" int nbls_fp_inv_launch(unsigned n, const void* in, void* out, const void* table, void* stream) {
+extern "C" int nbls_fp_inv_launch(unsigned n, const void* in, void* out, void* stream) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(nbls::nbls_fp_inv_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, (const nbls::u32*)in, (nbls::u32*)out, (const nbls::u32*)table);
+  hipLaunchKernelGGL(nbls::nbls_fp_inv_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, (const nbls::u32*)in, (nbls::u32*)out);
   return (int)hipGetLastError();
 }

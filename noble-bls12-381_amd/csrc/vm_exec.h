@@ -53,7 +53,11 @@ NBLS_HD void ld14(u32* x, LDSP lds, u32 off) {
 #pragma unroll
   for (int i = 0; i < NL; i++) x[i] = lds[off + i];
 }
-NBLS_HD u32 slot_addr(u32 op, u32 inst) { return ((op & OP_CONST) ? 0u : inst) + (op & OP_SLOT_MASK) * (u32)SLOT_WORDS; }
+// word offset of an operand's slot: constants live at the start of the LDS image, everything else in the instance region
+NBLS_HD u32 slot_addr(u32 op, u32 inst) {
+  const u32 is_const = (u32)((i32)(op << 18) >> 31);   // OP_CONST (bit 13) -> all ones
+  return (inst & ~is_const) + ((op & OP_SLOT_MASK) << 4);
+}
 
 // operand of a DOT product, as signed limbs: x, x + y or x - y, optionally normalised (sums only), optionally negated
 template <typename LDSP>

@@ -52,9 +52,7 @@ __attribute__((visibility("default"))) int nbls_sim_run(int prog, unsigned n_ite
 }
 // out = in^-1 on raw elements (16 words each): the same fp_mont_inverse routine the inversion kernel runs per lane
 __attribute__((visibility("default"))) void nbls_sim_fp_inv(unsigned n, const u32* in, u32* out) {
-  static std::vector<u32> table;
-  if (table.empty()) { table.resize(382 * NL); make_inv_table(table.data()); }
-  for (unsigned k = 0; k < n; k++) { u32 r[NL]; fp_mont_inverse(r, in + SLOT_WORDS * k, table.data()); memcpy(out + SLOT_WORDS * k, r, NL * 4); out[SLOT_WORDS * k + 14] = out[SLOT_WORDS * k + 15] = 0; }
+  for (unsigned k = 0; k < n; k++) { u32 r[NL]; fp_mont_inverse(r, in + SLOT_WORDS * k); memcpy(out + SLOT_WORDS * k, r, NL * 4); out[SLOT_WORDS * k + 14] = out[SLOT_WORDS * k + 15] = 0; }
 }
 // out = in^e; which: 0 = (p+1)/4 on Fp, 1 = (p^2+7)/16 on Fp2, 2 = (p^2-9)/16 on Fp2 (stand-ins for the pow kernels; raw elements of 16 words)
 static void mmh(u32* r, const u32* a, const u32* b) { u32 t[NL]; mont_mul28(t, a, b); memcpy(r, t, NL * 4); }

@@ -118,3 +118,23 @@ def test_point_sum_programs(sim, oracle, golden):
             assert st == ref_st == 0 and out == ref, (g2, n)
         v = golden[key][0]
         assert vmsim_py.point_sum(sim, hx(v['aff']) + hx(v['affQ']), g2)[0] == hx(v['sum_aff'])
+
+
+def test_fp_inverse_edge_cases(sim):
+    """the per-lane inversion routine (fp_inv.h) on structured inputs: any representative below 2^392, powers of two,
+    all-ones, values next to p, tiny and zero; expected a^-1 in the same Montgomery form (Fp.invert, math.ts:134-156)"""
+    import random
+    p = vmsim_py.P_MOD
+    rnd = random.Random(381)
+    xs = [rnd.randrange(1, p) for _ in range(500)] + [rnd.randrange(1, 1 << rnd.randrange(1, 392)) for _ in range(1500)]
+    xs += [1 << i for i in range(392)] + [(1 << i) - 1 for i in range(1, 392)] + [p - (1 << i) for i in range(380)]
+    xs += [1, 2, p - 1, 0, 5 * p + 3, (1 << 391) + 12345, p + 1, 2 * p - 1]
+    inp = b''.join(b''.join(((x >> (28 * i)) & 0xfffffff).to_bytes(4, 'little') for i in range(14)) + bytes(8) for x in xs)
+    src = C.create_string_buffer(inp, len(inp)); dst = C.create_string_buffer(len(inp))
+    sim.nbls_sim_fp_inv(C.c_uint(len(xs)), src, dst)
+    R = 1 << 392
+    for k, x in enumerate(xs):
+        o = dst.raw[64 * k:64 * k + 64]
+        got = sum(int.from_bytes(o[4 * i:4 * i + 4], 'little') << (28 * i) for i in range(14))
+        assert got < 2 * p
+        assert got % p == ((pow(x % p, -1, p) * R * R) % p if x % p else 0), hex(x)

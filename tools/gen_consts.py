@@ -198,6 +198,7 @@ def emit(path, bits, fp_t, guard, qual, rbits=RBITS):
         a('%s uint32_t NBLS_BIAS16[%d] = {%s};' % (qual, n, ','.join('0x%08xu' % x for x in b16)))
         a('#define NBLS_BIAS16_INIT {%s}' % ','.join('0x%08xu' % x for x in b16))
         a('#define NBLS_P_INIT {%s}' % ','.join('0x%08xu' % x for x in limbs(P, 28, rbits)))
+        a('#define NBLS_R3_INIT {%s}' % ','.join('0x%08xu' % x for x in limbs(pow(RM, 3, P), 28, rbits)))
         a('#define NBLS_P_WORDS_INIT {%s}' % ','.join('0x%08xu' % ((P >> (32 * i)) & 0xffffffff) for i in range(12)))
 
     def fp(name, v, raw=False):
