@@ -11,7 +11,8 @@ Prints ONE JSON line (see DESIGN.md section 6 for the field definitions):
   roofline     dominant kernel (nbls_vm_kernel) against the gfx950 integer-multiplier issue rate:
                achieved = algorithmic 32x32 multiply-adds per second (Fp multiplications of the
                reference algorithm x 300 MAD32) from HIP-event kernel durations measured in this run;
-               peak = 256 CU x 64 lanes/clk (v_mad_u64_u32 issues at half the FP32 rate, tools/ubench) x 2.4 GHz
+               peak = 256 CU x 64 lanes/clk (one 32x32->64 multiply-add per lane per 4 clocks per SIMD, measured with
+               tools/ubench/int_rates.hip) x 2.4 GHz
   cpu_baseline oracle/ (C restatement of the reference algorithm) on the host cores, bounded sample, rank 0, N=1 only
 """
 import argparse
@@ -171,11 +172,20 @@ def main():
         mads = n * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL
         vm_ms = ms_miller + ms_hard
         achieved = mads / (vm_ms * 1e-3) / 1e12
-        hbm_bytes = n * (96 + 192 + 576 + 2 * (576 + 48) + 2 * 48)     # wire in/out + scratch F/N round trip
+        # algorithmic HBM bytes per pairing: wire points in (288) and Fp12 out (576) + the raw scratch
+        # elements (768 B per Fp12, 64 B per Fp) every phase program reads and writes:
+        # miller_fe W 832 | fp_inv R 64 W 64 | fe_easy R 832 W 768 | 4 x expx R 768 W 768 | fe_mid1/2 R 1536 W 768 | fe_final R 5376
+        hbm_bytes = n * (288 + 832 + 128 + 832 + 768 + 4 * 1536 + 2 * 2304 + 5376 + 576)
+        traffic = None
+        try:   # HBM bytes measured with rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, see profiles/README.md), same batch size only
+            with open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')) as fh:
+                traffic = json.load(fh).get(str(n), {}).get('bytes_per_step')
+        except OSError:
+            pass
         roof = {
             'bound': 'valu-int32-mad', 'kernel': 'nbls_vm_kernel (all step programs of one pairing batch)',
             'achieved': round(achieved, 4), 'peak': round(PEAK_TMAD, 3), 'unit': 'TMAD32/s', 'frac': round(achieved / PEAK_TMAD, 4),
-            'traffic': None,
+            'traffic': traffic,
             'kernel_ms': {k: round(v, 4) for k, v in per_step.items()},
             'miller_frac': round(n * FPMUL_MILLER * MAD_PER_FPMUL / (ms_miller * 1e-3) / 1e12 / PEAK_TMAD, 4),
             'final_exp_frac': round(n * FPMUL_FINALEXP * MAD_PER_FPMUL / (ms_hard * 1e-3) / 1e12 / PEAK_TMAD, 4),
@@ -237,7 +247,7 @@ def main():
         line = {
             'metric': 'pairings/sec', 'value': round(value, 2), 'unit': 'pairings/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'u32 (12-limb Montgomery, 381-bit Fp)', 'data': 'synthetic',
+            'dtype': 'i64 column accumulators over 14 x 28-bit limbs (v_mad_i64_i32), 381-bit Fp in Montgomery form R=2^392', 'data': 'synthetic',
             'config': {'workload': 'batch of %d independent BLS12-381 pairings per GPU (Miller loop + final exponentiation, inputs pre-validated, bit-exact vs reference), inputs/outputs resident in HBM' % n,
                        'batch_per_gpu': n, 'sharding': 'independent batches per rank, no collective'},
             'roofline': roof, 'cpu_baseline': cpu, 'product': product, 'verify_batch': vbatch,

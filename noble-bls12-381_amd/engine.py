@@ -16,7 +16,7 @@ class NblsError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, 'libnbls.so')
+    return os.environ.get('NBLS_LIBRARY') or os.path.join(_HERE, 'libnbls.so')   # NBLS_LIBRARY: explicit path of the engine library
 
 
 def load_library():

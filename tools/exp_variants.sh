@@ -1,0 +1,8 @@
+#!/bin/bash
+# Build an experimental variant of libnbls.so with extra compiler flags into noble-bls12-381_amd/variants/ (git-ignored);
+# run it with NBLS_LIBRARY=<path> tools/exp_time.py.   Usage: tools/exp_variants.sh <name> "<extra hipcc flags>"
+set -e
+cd "$(dirname "$0")/../noble-bls12-381_amd/csrc"
+mkdir -p ../variants
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-value -Wno-unused-result -shared $2 -I../../include -o ../variants/libnbls_$1.so nbls_api.cpp vm_kernel.hip pow_kernels.hip trace.cpp programs.cpp
+ls -la ../variants
