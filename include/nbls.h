@@ -80,6 +80,19 @@ int nbls_hash_to_g2_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const ui
 int nbls_g1_sum(nbls_ctx* ctx, size_t n, const uint8_t* pts96, uint8_t* out96, int8_t* status);
 int nbls_g2_sum(nbls_ctx* ctx, size_t n, const uint8_t* pts192, uint8_t* out192, int8_t* status);
 
+/* [k_i]P_i for per-item scalars (32 bytes big-endian each; any value, the reference reduces mod r first: normalizePrivKey
+ * index.ts:269-279).  g1_aff == NULL multiplies the G1 generator: the core of getPublicKey / PointG1.fromPrivateKey
+ * (index.ts:350-353, 738-740).  Double-and-add-always ladder: instruction stream and memory access pattern do not depend on
+ * the scalar.  status: 0 ok, 1 result is the zero point, 5 scalar is 0 mod r (the reference throws). */
+int nbls_g1_mul_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff /* n*96 or NULL */, const uint8_t* scalars32, uint8_t* out96, int8_t* status);
+int nbls_g2_mul_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff /* n*192 */, const uint8_t* scalars32, uint8_t* out192, int8_t* status);
+
+/* sign(message_i, privateKey_i) -- reference index.ts:744-752: PointG2.hashToCurve(message) multiplied by the key; output is
+ * the affine signature point (192 B), which PointG2.toSignature (index.ts:586-602) compresses on the caller's side.
+ * Messages as in nbls_hash_to_g2_batch. */
+int nbls_sign_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len,
+                    const uint8_t* keys32, uint8_t* out192, int8_t* status);
+
 /* verifyBatch(signature, messages, publicKeys) on wire inputs -- reference index.ts:792-821 with every message distinct.
  * *ok = 1/0; returns NBLS_EDECODE where the reference throws while decoding its arguments. */
 int nbls_verify_batch(nbls_ctx* ctx, size_t n, const uint8_t* sig96, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
@@ -92,7 +105,7 @@ int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_sig96, c
 int nbls_program_stats(nbls_ctx* ctx, int prog, uint32_t* out8);   /* steps, mul_steps, lin_steps, mul_ops, lin_ops, lin_terms, slots, lds_bytes */
 int nbls_device_synchronize(nbls_ctx* ctx);
 /* Per-kernel HIP-event timing (benchmark roofline leg): ms[i]/counts[i] for program i, last entry = inversion kernel. */
-#define NBLS_N_PROGRAMS 33
+#define NBLS_N_PROGRAMS 40
 int nbls_timing_enable(nbls_ctx* ctx, int on);
 int nbls_timing_read(nbls_ctx* ctx, float* ms /*[NBLS_N_PROGRAMS+1]*/, uint32_t* counts /*[NBLS_N_PROGRAMS+1]*/);
 

@@ -59,6 +59,23 @@ template <class F> static inline Pt<F> pt_mul_u64(const Pt<F>& p, uint64_t k) {
   for (int i = top - 1; i >= 0; i--) { r = pt_dbl(r); if ((k >> i) & 1) r = pt_add(r, p); }
   return r;
 }
+// [k]P for a per-item scalar held in a raw integer slot (nbits processed MSB first): double-and-add-always with a
+// masked select per bit, so the instruction stream and the LDS access pattern are independent of k (the reference's
+// constant-time path is wNAF with precomputes, math.ts:1116-1157; the group element is the same).  The complete formulas
+// make the identity start value and every intermediate case valid.
+template <class F> static inline F sel(const SFp& f, const F& a, const F& b);
+template <> inline SFp sel<SFp>(const SFp& f, const SFp& a, const SFp& b) { return select(f, a, b); }
+template <> inline SFp2 sel<SFp2>(const SFp& f, const SFp2& a, const SFp2& b) { return {select(f, a.c0, b.c0), select(f, a.c1, b.c1)}; }
+template <class F> static inline Pt<F> pt_mul_ladder(const Pt<F>& p, const SFp& k_raw, int nbits) {
+  Pt<F> r = pt_mat(pt_identity<F>());
+  for (int i = nbits - 1; i >= 0; i--) {
+    r = pt_dbl(r);
+    Pt<F> t = pt_add(r, p);
+    SFp b = bit_flag(k_raw, i);
+    r = {sel<F>(b, t.x, r.x), sel<F>(b, t.y, r.y), sel<F>(b, t.z, r.z)};
+  }
+  return r;
+}
 // projective equality flags (math.ts:915-927): X1 Z2 == X2 Z1 and Y1 Z2 == Y2 Z1
 static inline SFp eq_zero(const SFp& d) { return is_zero(d); }
 static inline SFp eq_zero(const SFp2& d) { return f_and(is_zero(d.c0), is_zero(d.c1)); }

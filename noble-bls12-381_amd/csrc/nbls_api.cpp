@@ -41,6 +41,7 @@ struct nbls_ctx {
   uint8_t* sb[NSB] = {nullptr}; size_t sb_cap[NSB] = {0};
   uint8_t* nib[3] = {nullptr, nullptr, nullptr}; int nnib[3] = {0, 0, 0};   // exponent nibbles: (p+1)/4, (p^2+7)/16, (p^2-9)/16
   uint8_t* neg_g1 = nullptr;    // -G1 generator, affine wire bytes (verify: e(-G, S))
+  uint8_t* gen_g1 = nullptr;    // G1 generator, affine wire bytes (getPublicKey)
   uint8_t* ident_g1 = nullptr; uint8_t* ident_g2 = nullptr;   // projective identity (0 : 1 : 0), raw
   size_t cap_F = 0, cap_io = 0;
   int last_hip = 0;
@@ -200,12 +201,15 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
     uint8_t ng[96];
     auto be = [](uint8_t* o, const u32* limbs) { u32 w[12]; limbs_to_words(w, limbs); for (int i = 0; i < 12; i++) { u32 v = w[11 - i]; o[4 * i] = v >> 24; o[4 * i + 1] = v >> 16; o[4 * i + 2] = v >> 8; o[4 * i + 3] = v; } };
     be(ng, NBLS_G1X_RAW); be(ng + 48, NBLS_NEG_G1Y_RAW);
+    uint8_t gg[96]; be(gg, NBLS_G1X_RAW); be(gg + 48, NBLS_G1Y_RAW);
+    if (hipMalloc(&ctx->gen_g1, 96) != hipSuccess || hipMemcpy(ctx->gen_g1, gg, 96, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
     u32 id1[3 * SLOT_WORDS] = {0}, id2[6 * SLOT_WORDS] = {0}; memcpy(id1 + SLOT_WORDS, NBLS_R1, NLIMBS * 4); memcpy(id2 + 2 * SLOT_WORDS, NBLS_R1, NLIMBS * 4);   // (0 : 1 : 0)
     if (hipMalloc(&ctx->neg_g1, 96) != hipSuccess || hipMemcpy(ctx->neg_g1, ng, 96, hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc(&ctx->ident_g1, 3 * RAW) != hipSuccess || hipMemcpy(ctx->ident_g1, id1, 3 * RAW, hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc(&ctx->ident_g2, 6 * RAW) != hipSuccess || hipMemcpy(ctx->ident_g2, id2, 6 * RAW, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   }
-  for (int i = 0; i < P_COUNT; i++) { int r = upload(ctx, (ProgId)i); if (r) { int e = ctx->last_hip; (void)e; nbls_destroy(ctx); return r; } }
+  for (int i = 0; i < P_COUNT; i++) { if (i == P_G1_MUL || i == P_G2_MUL) continue;   // the scalar-multiplication ladders are uploaded on first use
+    int r = upload(ctx, (ProgId)i); if (r) { int e = ctx->last_hip; (void)e; nbls_destroy(ctx); return r; } }
   *out = ctx;
   return NBLS_OK;
 }
@@ -214,7 +218,7 @@ EXPORT void nbls_destroy(nbls_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   for (auto& d : ctx->prog) { if (d.steps) hipFree(d.steps); if (d.descs) hipFree(d.descs); if (d.consts) hipFree(d.consts); }
-  for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12}) if (p) hipFree(p);
+  for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->gen_g1}) if (p) hipFree(p);
   for (uint8_t* p : ctx->T) if (p) hipFree(p);
   for (uint8_t* p : ctx->sb) if (p) hipFree(p);
   for (uint8_t* p : ctx->nib) if (p) hipFree(p);
@@ -513,6 +517,63 @@ static int sum_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* pts, uint8_
 }
 EXPORT int nbls_g1_sum(nbls_ctx* ctx, size_t n, const uint8_t* pts96, uint8_t* out96, int8_t* status) { return sum_host(ctx, false, n, pts96, out96, status); }
 EXPORT int nbls_g2_sum(nbls_ctx* ctx, size_t n, const uint8_t* pts192, uint8_t* out192, int8_t* status) { return sum_host(ctx, true, n, pts192, out192, status); }
+
+// [k_i]P_i for per-item 256-bit big-endian scalars (pt_stride 0 = one point for all items): ladder -> inversion -> affine
+static int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, size_t pt_stride, const void* d_scalars, void* d_out, void* d_status, hipStream_t s) {
+  const size_t a = g2 ? 192 : 96, p = g2 ? 6 * RAW : 3 * RAW;
+  uint8_t *Pj, *N, *NI; int r;
+  if ((r = need(ctx, 0, n * p, &Pj)) || (r = need(ctx, 4, n * RAW, &N)) || (r = need(ctx, 5, n * RAW, &NI))) return r;
+  if ((r = run(ctx, g2 ? P_G2_MUL : P_G1_MUL, n, {B(g2 ? 1 : 0, d_pts, pt_stride), B(2, d_scalars, 32), B(3, Pj, p), B(4, N, RAW)}, s))) return r;
+  if ((r = run_inv_buf(ctx, n, N, NI, s))) return r;
+  return run(ctx, g2 ? P_G2_TO_AFFINE : P_G1_TO_AFFINE, n, {B(3, Pj, p), B(4, NI, RAW), B(2, d_out, a), B(7, d_status, 1)}, s);
+}
+// scalar k is acceptable iff k mod r != 0 (normalizePrivKey, index.ts:269-279, reduces mod r and rejects zero); the ladder
+// itself takes any 256-bit value since the points are in the order-r subgroup
+static bool scalar_is_zero_mod_r(const uint8_t* k32) {
+  static const uint8_t R_BE[32] = {0x73, 0xed, 0xa7, 0x53, 0x29, 0x9d, 0x7d, 0x48, 0x33, 0x39, 0xd8, 0x08, 0x09, 0xa1, 0xd8, 0x05,
+                                   0x53, 0xbd, 0xa4, 0x02, 0xff, 0xfe, 0x5b, 0xfe, 0xff, 0xff, 0xff, 0xff, 0x00, 0x00, 0x00, 0x01};
+  uint8_t m[32] = {0};   // m = 0, r, 2r, 3r  (4r > 2^256 - 1? 4r = 0x1cfb6..., 33 bytes: stop at 3r)
+  for (int mult = 0; mult < 4; mult++) {
+    if (memcmp(m, k32, 32) == 0) return true;
+    unsigned c = 0; for (int i = 31; i >= 0; i--) { unsigned v = (unsigned)m[i] + R_BE[i] + c; m[i] = (uint8_t)v; c = v >> 8; }
+    if (c) break;
+  }
+  return false;
+}
+static int mul_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* pts, const uint8_t* scalars32, uint8_t* out, int8_t* status) {
+  if (!ctx || (n && (!scalars32 || !out)) || (g2 && n && !pts)) return NBLS_EINVAL; if (!n) return NBLS_OK;
+  const size_t a = g2 ? 192 : 96;
+  LOCKED(ctx); HostIO io{ctx}; void *dp = pts ? io.alloc(n * a) : nullptr, *dk = io.alloc(n * 32), *o = io.alloc(n * a), *st = io.alloc(n);
+  if ((pts && !dp) || !dk || !o || !st) return NBLS_EHIP;
+  if (pts) HIPCHK(hipMemcpyAsync(dp, pts, n * a, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(dk, scalars32, n * 32, hipMemcpyHostToDevice, s));
+  int r = dev_point_mul(ctx, g2, n, pts ? dp : ctx->gen_g1, pts ? a : 0, dk, o, st, s); if (r) return r;
+  std::vector<int8_t> tmp(n);
+  HIPCHK(hipMemcpyAsync(out, o, n * a, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(tmp.data(), st, n, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+  for (size_t i = 0; i < n; i++) if (scalar_is_zero_mod_r(scalars32 + 32 * i)) tmp[i] = 5;
+  if (status) memcpy(status, tmp.data(), n);
+  return NBLS_OK;
+}
+// PointG1.fromPrivateKey / getPublicKey core (index.ts:350-353, 738-740): [k_i]P_i, P = generator when g1_aff is NULL
+EXPORT int nbls_g1_mul_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, const uint8_t* scalars32, uint8_t* out96, int8_t* status) { return mul_host(ctx, false, n, g1_aff, scalars32, out96, status); }
+EXPORT int nbls_g2_mul_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, const uint8_t* scalars32, uint8_t* out192, int8_t* status) { return mul_host(ctx, true, n, g2_aff, scalars32, out192, status); }
+// sign(message_i, key_i) (index.ts:744-752): hashToCurve -> multiply by the key -> affine signature point (the caller
+// compresses, PointG2.toSignature index.ts:586-602).  status: 0 ok, 5 key is 0 mod r.
+EXPORT int nbls_sign_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len, const uint8_t* keys32, uint8_t* out192, int8_t* status) {
+  if (!ctx || (n && (!offsets || !out192 || !dst || !keys32))) return NBLS_EINVAL; if (!n) return NBLS_OK;
+  std::vector<uint8_t> uni; if (!expand_all(n, msgs, offsets, dst, dst_len, uni)) return NBLS_EINVAL;
+  LOCKED(ctx); HostIO io{ctx}; void *d = io.alloc(n * 256), *h = io.alloc(n * 192), *dk = io.alloc(n * 32), *o = io.alloc(n * 192), *st = io.alloc(n);
+  if (!d || !h || !dk || !o || !st) return NBLS_EHIP;
+  HIPCHK(hipMemcpyAsync(d, uni.data(), n * 256, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(dk, keys32, n * 32, hipMemcpyHostToDevice, s));
+  int r = dev_hash_to_g2(ctx, n, d, h, s); if (r) return r;
+  if ((r = dev_point_mul(ctx, true, n, h, 192, dk, o, st, s))) return r;
+  std::vector<int8_t> tmp(n);
+  HIPCHK(hipMemcpyAsync(out192, o, n * 192, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(tmp.data(), st, n, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+  for (size_t i = 0; i < n; i++) if (scalar_is_zero_mod_r(keys32 + 32 * i)) tmp[i] = 5;
+  if (status) memcpy(status, tmp.data(), n);
+  return NBLS_OK;
+}
 
 // verifyBatch(signature, messages, publicKeys) on wire inputs (index.ts:792-821): every message hashes to its own point
 // (hex inputs are distinct objects in the reference), n pairings e(pk_i, H(m_i)) times e(-G, sig), one final exponentiation.

@@ -257,6 +257,22 @@ static Program build(ProgId id) {
       outputw(q.x.c0, 6, 0); outputw(q.x.c1, 6, 48); outputw(q.y.c0, 6, 96); outputw(q.y.c1, 6, 144); outputw(q.z.c0, 6, 192); outputw(q.z.c1, 6, 240);
       return B.compile(id == P_T_ISO ? "t_iso" : "t_clear", 8);
     }
+    case P_G1_MUL: {
+      SFp x = input(0, 0), y = input(0, 48);
+      SFp k = input_raw(2, 0, 32);
+      Pt<SFp> r = pt_mul_ladder(pt_affine(x, y), k, 256);
+      outputw(r.x, 3, 0); outputw(r.y, 3, 48); outputw(r.z, 3, 96);
+      outputw(r.z, 4, 0);
+      return B.compile("g1_mul", 8);
+    }
+    case P_G2_MUL: {
+      SFp2 x = input_fp2(1, 0), y = input_fp2(1, 96);
+      SFp k = input_raw(2, 0, 32);
+      Pt<SFp2> r = pt_mul_ladder(pt_affine(x, y), k, 256);
+      outputw(r.x.c0, 3, 0); outputw(r.x.c1, 3, 48); outputw(r.y.c0, 3, 96); outputw(r.y.c1, 3, 144); outputw(r.z.c0, 3, 192); outputw(r.z.c1, 3, 240);
+      outputw(sqr(r.z.c0) + sqr(r.z.c1), 4, 0);      // Fp2 norm, inverted by the inversion kernel (Fp2.invert, math.ts:522-526)
+      return B.compile("g2_mul", 16);
+    }
     default: break;
   }
   return Program();

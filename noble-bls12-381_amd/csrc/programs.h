@@ -26,6 +26,7 @@ enum ProgId {
   P_G1_TO_PROJ, P_G1_ADD2, P_G1_NORM, P_G1_TO_AFFINE,     // point sums: aggregatePublicKeys (index.ts:771-778)
   P_G2_TO_PROJ, P_G2_ADD2, P_G2_NORM, P_G2_TO_AFFINE,     // aggregateSignatures (index.ts:781-788), hash-to-G2 output
   P_T_SWU, P_T_ISO, P_T_CLEAR,   // test-only pieces of hash-to-G2 (unit parity against golden vectors): SWU map, 3-isogeny, cofactor clearing
+  P_G1_MUL, P_G2_MUL,            // [k]P for per-item 256-bit scalars: point (buf 0 / 1), scalar 32 B (buf 2) -> projective (3), norm of Z (4)   (getPublicKey / sign, index.ts:738-752)
   P_COUNT
 };
 const Program& get_program(ProgId id);

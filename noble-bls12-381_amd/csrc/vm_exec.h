@@ -324,9 +324,14 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, 
     }
     case K_SEL: {
       u32 w0 = d[0], w1 = d[1];
-      u32 f = lds[slot_addr(w0 >> 16, cx.inst)];
-      u32 src = f ? (w1 & 0xffff) : (w1 >> 16);
-      ld14(res, lds, slot_addr(src, cx.inst));
+      // both sources are read and merged with a mask: the LDS access pattern does not depend on the flag (the flag
+      // can be a secret scalar bit in the sign / getPublicKey ladders)
+      const u32 m = 0u - (lds[slot_addr(w0 >> 16, cx.inst)] != 0 ? 1u : 0u);
+      u32 Xa[NL], Xb[NL];
+      ld14(Xa, lds, slot_addr(w1 & 0xffff, cx.inst));
+      ld14(Xb, lds, slot_addr(w1 >> 16, cx.inst));
+#pragma unroll
+      for (int i = 0; i < NL; i++) res[i] = (Xa[i] & m) | (Xb[i] & ~m);
       return slot_addr(w0 & 0xffff, cx.inst);
     }
     case K_CANON: {

@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PROGRAMS = ['miller_bytes', 'miller_raw', 'miller_fe', 'norm_raw', 'norm_bytes', 'fe_easy', 'expx', 'fe_mid1', 'fe_mid2', 'fe_final', 'fp12_mul2', 'raw_to_bytes',
             'g1_validate', 'g2_validate', 'g1_dec_a', 'g1_dec_b', 'g2_dec_a', 'g2_dec_b', 'h2c_a', 'h2c_b',
-            'g1_to_proj', 'g1_add2', 'g1_norm', 'g1_to_affine', 'g2_to_proj', 'g2_add2', 'g2_norm', 'g2_to_affine', 't_swu', 't_iso', 't_clear']
+            'g1_to_proj', 'g1_add2', 'g1_norm', 'g1_to_affine', 'g2_to_proj', 'g2_add2', 'g2_norm', 'g2_to_affine', 't_swu', 't_iso', 't_clear', 'g1_mul', 'g2_mul']
 DST_DEFAULT = b'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_'   # htfDefaults.DST, reference index.ts:64
 
 
@@ -45,6 +45,9 @@ def load_library():
     lib.nbls_hash_to_g2_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp]
     lib.nbls_g1_sum.argtypes = [vp, sz, vp, vp, vp]
     lib.nbls_g2_sum.argtypes = [vp, sz, vp, vp, vp]
+    lib.nbls_g1_mul_batch.argtypes = [vp, sz, vp, vp, vp, vp]
+    lib.nbls_g2_mul_batch.argtypes = [vp, sz, vp, vp, vp, vp]
+    lib.nbls_sign_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, vp]
     lib.nbls_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, sz, C.POINTER(i32)]
     lib.nbls_verify_batch_dev_inputs.argtypes = [vp, sz, vp, vp, vp, C.POINTER(i32), vp, vp]
     lib.nbls_timing_enable.argtypes = [vp, i32]
@@ -135,6 +138,49 @@ class Engine:
         st = C.create_string_buffer(1)
         self._chk((self.lib.nbls_g2_sum if g2 else self.lib.nbls_g1_sum)(self.h, len(pts) // sz, pts, out, st))
         return out.raw, st.raw[0]
+
+    # ---- secret-scalar side (reference index.ts:738-752); scalars / keys are 32-byte big-endian strings
+    P_MOD = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+
+    def point_mul_batch(self, scalars, pts=None, g2=False):
+        """[k_i]P_i -> (affine wire bytes, status bytes); pts=None multiplies the G1 generator (PointG1.fromPrivateKey)"""
+        n = len(scalars)
+        sz = 192 if g2 else 96
+        out = C.create_string_buffer(max(sz * n, 1)); st = C.create_string_buffer(max(n, 1))
+        f = self.lib.nbls_g2_mul_batch if g2 else self.lib.nbls_g1_mul_batch
+        self._chk(f(self.h, n, pts, b''.join(scalars), out, st))
+        return out.raw[:sz * n], st.raw[:n]
+
+    @classmethod
+    def compress_g1(cls, aff96):
+        """PointG1.toHex(true) of a non-zero affine point (index.ts:359-371)"""
+        x = int.from_bytes(aff96[:48], 'big'); y = int.from_bytes(aff96[48:], 'big')
+        return (x + ((y * 2) // cls.P_MOD << 381) + (1 << 383)).to_bytes(48, 'big')
+
+    @classmethod
+    def compress_g2(cls, aff192):
+        """PointG2.toSignature of a non-zero affine point (index.ts:586-602)"""
+        x0, x1, y0, y1 = (int.from_bytes(aff192[48 * i:48 * i + 48], 'big') for i in range(4))
+        tmp = y1 * 2 if y1 > 0 else y0 * 2
+        z1 = x1 + ((tmp // cls.P_MOD) << 381) + (1 << 383)
+        return z1.to_bytes(48, 'big') + x0.to_bytes(48, 'big')
+
+    def get_public_keys(self, keys):
+        """getPublicKey for a batch of private keys -> list of 48-byte compressed keys; raises like the reference on a zero key"""
+        aff, st = self.point_mul_batch(keys)
+        if any(st):
+            raise NblsError('Private key must be 0 < key < CURVE.r')
+        return [self.compress_g1(aff[96 * i:96 * i + 96]) for i in range(len(keys))]
+
+    def sign_batch(self, msgs, keys, dst=DST_DEFAULT):
+        """sign(msg_i, key_i) -> list of 96-byte compressed signatures"""
+        blob, offs = self._pack(msgs)
+        n = len(msgs)
+        out = C.create_string_buffer(max(192 * n, 1)); st = C.create_string_buffer(max(n, 1))
+        self._chk(self.lib.nbls_sign_batch(self.h, n, blob, offs, dst, len(dst), b''.join(keys), out, st))
+        if any(st.raw[:n]):
+            raise NblsError('Private key must be 0 < key < CURVE.r')
+        return [self.compress_g2(out.raw[192 * i:192 * i + 192]) for i in range(n)]
 
     def verify_batch(self, sig96, msgs, pks48, dst=DST_DEFAULT):
         """-> True/False; raises NblsError where the reference throws while decoding its arguments"""

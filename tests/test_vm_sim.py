@@ -138,3 +138,29 @@ def test_fp_inverse_edge_cases(sim):
         got = sum(int.from_bytes(o[4 * i:4 * i + 4], 'little') << (28 * i) for i in range(14))
         assert got < 2 * p
         assert got % p == ((pow(x % p, -1, p) * R * R) % p if x % p else 0), hex(x)
+
+
+def test_scalar_mul_programs(sim, oracle, golden):
+    """the double-and-add-always ladders behind getPublicKey / sign (index.ts:738-752) against the oracle's scalar
+    multiplication: random and structured scalars (1, 2, r-1, r+1, 2^256-1, a value with a long zero run)"""
+    import random
+    r = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    rnd = random.Random(12381)
+    ks = [1, 2, r - 1, r + 1, (1 << 256) - 1, 1 << 200, rnd.randrange(1, r), rnd.randrange(1, r)]
+    g1 = oracle.g1_generator()
+    p1 = hx(golden['g1pts'][0]) if isinstance(golden['g1pts'][0], str) else g1
+    pts1 = b''.join([g1, p1] * 4)
+    out, st = vmsim_py.point_mul(sim, pts1, b''.join(k.to_bytes(32, 'big') for k in ks))
+    for i, k in enumerate(ks):
+        assert st[i] == 0
+        assert out[96 * i:96 * i + 96] == oracle.g1_mul(pts1[96 * i:96 * i + 96], k % r)[1], i
+    g2 = oracle.g2_generator()
+    q = oracle.g2_mul(g2, 0xabcdef123456789)[1]
+    pts2 = b''.join([g2, q] * 4)
+    out, st = vmsim_py.point_mul(sim, pts2, b''.join(k.to_bytes(32, 'big') for k in ks), g2=True)
+    for i, k in enumerate(ks):
+        assert st[i] == 0
+        assert out[192 * i:192 * i + 192] == oracle.g2_mul(pts2[192 * i:192 * i + 192], k % r)[1], i
+    # k = r: the result is the zero point (status 1), which the host wrapper reports as an invalid key (status 5)
+    out, st = vmsim_py.point_mul(sim, g1, r.to_bytes(32, 'big'))
+    assert st[0] == 1

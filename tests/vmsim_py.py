@@ -17,7 +17,7 @@ def raw_elem(v):
 
 
 PROGS = ['MILLER_BYTES', 'MILLER_RAW', 'MILLER_FE', 'NORM_RAW', 'NORM_BYTES', 'FE_EASY', 'EXPX', 'FE_MID1', 'FE_MID2', 'FE_FINAL', 'MUL2', 'RAW_TO_BYTES', 'G1_VALIDATE', 'G2_VALIDATE', 'G1_DEC_A', 'G1_DEC_B', 'G2_DEC_A', 'G2_DEC_B', 'H2C_A', 'H2C_B',
-         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR']
+         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'G1_MUL', 'G2_MUL']
 P = {n: i for i, n in enumerate(PROGS)}
 
 
@@ -116,3 +116,15 @@ def point_sum(lib, pts, g2=False):
     lib.nbls_sim_fp_inv(C.c_uint(1), N, NI)
     run(lib, pre + '_TO_AFFINE', 1, {3: (src, psz), 4: (NI, RAW), 2: (out, sz), 7: (st, 1)})
     return out.raw, st.raw[0]
+
+
+def point_mul(lib, pts, scalars32, g2=False):
+    """dev_point_mul() of csrc/nbls_api.cpp on the simulator: ladder -> inversion -> affine"""
+    sz, psz = (192, 6 * RAW) if g2 else (96, 3 * RAW)
+    pre = 'G2' if g2 else 'G1'
+    n = len(scalars32) // 32
+    Pj, N, NI, out, st = buf(psz * n), buf(RAW * n), buf(RAW * n), buf(sz * n), buf(n)
+    run(lib, pre + '_MUL', n, {(1 if g2 else 0): (buf(pts), sz), 2: (buf(scalars32), 32), 3: (Pj, psz), 4: (N, RAW)})
+    lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
+    run(lib, pre + '_TO_AFFINE', n, {3: (Pj, psz), 4: (NI, RAW), 2: (out, sz), 7: (st, 1)})
+    return out.raw, st.raw

@@ -241,6 +241,7 @@ def emit(path, bits, fp_t, guard, qual, rbits=RBITS):
     fp('NBLS_G1X', G1X)
     fp('NBLS_G1X_RAW', G1X, raw=True)
     fp('NBLS_NEG_G1Y_RAW', P - G1Y, raw=True)
+    fp('NBLS_G1Y_RAW', G1Y, raw=True)
     fp('NBLS_G1Y', G1Y)
     fp2('NBLS_G2X', G2X)
     fp2('NBLS_G2Y', G2Y)
