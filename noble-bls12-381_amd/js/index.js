@@ -3,7 +3,7 @@
  * over the MI355X engine (libnbls.so via the N-API addon).  Argument handling, error messages and result encodings follow
  * the reference; the arithmetic runs on the GPU.  Additive batched entry points: pairingBatch, millerProduct.
  *
- * Not in this build (SURVEY 8(f).1, "next"): getPublicKey and sign (secret-scalar multiplication) -- they throw.
+ * getPublicKey / sign run the double-and-add-always ladders of the engine (SURVEY 8(f).1); additive: getPublicKeys, signBatch.
  * The reference's re-exported field classes (Fp, Fr, Fp2) are host-side bigint helpers outside the hot path and are not
  * provided; Fp12 is a thin byte-backed wrapper (toBytes / equals / multiply / finalExponentiate).
  */
@@ -206,8 +206,45 @@ function normP1(point) { return point instanceof PointG1 ? point : PointG1.fromH
 function normP2(point) { return point instanceof PointG2 ? point : PointG2.fromSignature(point); }
 async function normP2Hash(point) { return point instanceof PointG2 ? point : PointG2.hashToCurve(point); }
 
-function getPublicKey() { throw new Error('getPublicKey: not implemented in this build (secret-scalar multiplication is a follow-on row, SURVEY 8(f).1)'); }
-async function sign() { throw new Error('sign: not implemented in this build (secret-scalar multiplication is a follow-on row, SURVEY 8(f).1)'); }
+// reference index.ts:269-279
+function normalizePrivKey(key) {
+  let int;
+  if (key instanceof Uint8Array && key.length === 32) int = toBig(key);
+  else if (typeof key === 'string' && key.length === 64) int = BigInt('0x' + key);
+  else if (typeof key === 'number' && key > 0 && Number.isSafeInteger(key)) int = BigInt(key);
+  else if (typeof key === 'bigint' && key > 0n) int = key;
+  else throw new TypeError('Expected valid private key');
+  int = ((int % CURVE.r) + CURVE.r) % CURVE.r;
+  if (!(0n < int && int < CURVE.r)) throw new Error('Private key must be 0 < key < CURVE.r');
+  return int;
+}
+const keyBytes = (k) => hexToBytes(normalizePrivKey(k).toString(16).padStart(64, '0'));
+// reference index.ts:738-740: PointG1.fromPrivateKey(privateKey).toRawBytes(true)
+function getPublicKeys(privateKeys) {
+  ensureInit();
+  const { out } = native.g1Mul(null, concat(...privateKeys.map(keyBytes)));
+  return privateKeys.map((_, i) => new PointG1(out.slice(96 * i, 96 * i + 96)).toRawBytes(true));
+}
+function getPublicKey(privateKey) { return getPublicKeys([privateKey])[0]; }
+// reference index.ts:744-752
+async function sign(message, privateKey) {
+  ensureInit();
+  if (message instanceof PointG2) {
+    message.assertValidity();
+    const { out } = native.g2Mul(message.aff, keyBytes(privateKey));
+    return new PointG2(out);
+  }
+  return (await signBatch([message], [privateKey]))[0];
+}
+async function signBatch(messages, privateKeys) {
+  ensureInit();
+  if (messages.length !== privateKeys.length) throw new Error('Expected equal number of messages and private keys');
+  const msgs = messages.map(ensureBytes);
+  const offs = new Uint32Array(msgs.length + 1);
+  msgs.forEach((m, i) => { offs[i + 1] = offs[i] + m.length; });
+  const { out } = native.signBatch(concat(...msgs), offs, stringToBytes(htfDefaults.DST), concat(...privateKeys.map(keyBytes)));
+  return msgs.map((_, i) => new PointG2(out.slice(192 * i, 192 * i + 192)).toSignature());
+}
 
 // reference index.ts:756-767: e(-P, H(m)) * e(G, S) == 1 with one final exponentiation
 async function verify(signature, message, publicKey) {
@@ -276,5 +313,5 @@ const utils = {
   },
 };
 
-module.exports = { CURVE, Fp12, PointG1, PointG2, pairing, pairingBatch, millerProduct, getPublicKey, sign, verify, verifyBatch,
+module.exports = { CURVE, Fp12, PointG1, PointG2, pairing, pairingBatch, millerProduct, getPublicKey, getPublicKeys, sign, signBatch, verify, verifyBatch,
   aggregatePublicKeys, aggregateSignatures, utils, init: (dev) => { native.init(dev || 0); inited = true; } };

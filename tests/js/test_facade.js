@@ -33,7 +33,20 @@ const hex = bls.utils.bytesToHex, un = bls.utils.hexToBytes;
     const bad = un(s.msg); bad[0] ^= 1;
     assert.strictEqual(await bls.verify(s.sig, bad, s.pk), false);
   }
-  for (const [priv, msg, sig] of td.sign_vectors.slice(0, 4)) { void priv; void msg; void sig; }
+  // getPublicKey / sign: the reference's sign vectors (test/index.test.ts:20-29) and the reference-run triples
+  for (const [priv, msg, sig] of td.sign_vectors.slice(0, 24)) assert.strictEqual(hex(await bls.sign(msg, priv)), sig);
+  const batch = td.sign_vectors.slice(24, 152);
+  assert.deepStrictEqual((await bls.signBatch(batch.map((v) => v[1]), batch.map((v) => v[0]))).map(hex), batch.map((v) => v[2]));
+  for (const s of gold.sigs) {
+    assert.strictEqual(hex(bls.getPublicKey(s.sk)), s.pk);
+    assert.strictEqual(hex(await bls.sign(s.msg, s.sk)), s.sig);
+    assert.strictEqual(hex(bls.getPublicKey(BigInt('0x' + s.sk))), s.pk);
+    const sp = await bls.sign(await bls.PointG2.hashToCurve(un(s.msg)), s.sk);        // point in, point out (index.ts:745, 751)
+    assert.strictEqual(hex(sp.toSignature()), s.sig);
+  }
+  assert.throws(() => bls.getPublicKey(0n), /Expected valid private key/);
+  assert.throws(() => bls.getPublicKey(bls.CURVE.r), /Private key must be 0 < key < CURVE.r/);
+  assert.throws(() => bls.getPublicKey('zz'), /Expected valid private key/);
   // aggregate + verifyBatch
   const vb = gold.verify_batch;
   assert.strictEqual(hex(bls.aggregatePublicKeys(vb.pks)), vb.agg_pk);
