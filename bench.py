@@ -58,6 +58,7 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--verify-batch', type=int, default=65536, help='signatures in the verifyBatch leg (BASELINE configs[2]); 0 disables')
+    ap.add_argument('--sign-batch', type=int, default=8192, help='signatures produced in the sign leg (SURVEY 8(f).1); 0 disables')
     ap.add_argument('--product-terms', type=int, default=262144, help='terms of the sharded multi-pairing product leg (BASELINE configs[4]); 0 disables')
     args = ap.parse_args()
 
@@ -65,13 +66,14 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the engine has no CPU path)')
     torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
     pkg = importlib.import_module('noble-bls12-381_amd')
     import oracle_py
     oracle = oracle_py.load(rebuild=not os.path.exists(os.path.join(ROOT, 'oracle', 'libnbls_oracle.so')))
@@ -244,13 +246,36 @@ def main():
                       'ms': round(vdt_dev * 1e3, 3), 'host_call_sigs_per_s': round(nv / vdt, 2), 'host_call_ms': round(vdt * 1e3, 3),
                       'host_call_note': 'full nbls_verify_batch from host buffers: host SHA-256 expand_message_xmd + PCIe copies included',
                       'cpu_baseline': {'value': round(ns / cdt, 2), 'unit': 'sigs/s', 'cores': min(th, 64), 'kind': 'port', 'sample': '%d signatures (sign-side setup included in neither)' % ns, 'ok': int(okc)}}
+        sleg = None
+        if world == 1 and args.sign_batch > 0:
+            ns_ = args.sign_batch
+            sks_ = [(int.from_bytes(hashlib.sha256(b'nbls-bench-sk2' + i.to_bytes(4, 'big')).digest(), 'big') % (2 ** 254) + 1).to_bytes(32, 'big') for i in range(ns_)]
+            msgs_ = [hashlib.sha256(b'msg2' + i.to_bytes(4, 'big')).digest() for i in range(ns_)]
+            sg = eng.sign_batch(msgs_, sks_)
+            for i in (0, 1, ns_ // 2, ns_ - 1):       # parity spot check against the oracle
+                assert sg[i] == oracle.sign(msgs_[i], sks_[i])[1], 'sign parity check failed'
+            eng.timing_enable(True)
+            s0 = time.perf_counter()
+            eng.sign_batch_affine(msgs_, sks_)
+            sdt = time.perf_counter() - s0
+            stm = eng.timing_read(); eng.timing_enable(False)
+            k0 = time.perf_counter()
+            eng.point_mul_batch(sks_)
+            kdt = time.perf_counter() - k0
+            c0 = time.perf_counter()
+            for i in range(16):
+                oracle.sign(msgs_[i], sks_[i])
+            csdt = (time.perf_counter() - c0) / 16
+            sleg = {'metric': 'sign sigs/sec: nbls_sign_batch from host buffers (host SHA-256 expand_message_xmd + hash-to-G2 + constant-time G2 ladder + affine), compression not included', 'n': ns_, 'value': round(ns_ / sdt, 2), 'ms': round(sdt * 1e3, 3),
+                    'g2_ladder_kernel_ms': round(stm.get('g2_mul', (0, 0))[0], 3), 'get_public_key_keys_per_s': round(ns_ / kdt, 2),
+                    'cpu_baseline': {'value': round(1 / csdt, 2), 'unit': 'sigs/s', 'cores': 1, 'kind': 'port', 'sample': '16 signatures on one host thread (oracle/)'}}
         line = {
             'metric': 'pairings/sec', 'value': round(value, 2), 'unit': 'pairings/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'i64 column accumulators over 14 x 28-bit limbs (v_mad_i64_i32), 381-bit Fp in Montgomery form R=2^392', 'data': 'synthetic',
             'config': {'workload': 'batch of %d independent BLS12-381 pairings per GPU (Miller loop + final exponentiation, inputs pre-validated, bit-exact vs reference), inputs/outputs resident in HBM' % n,
                        'batch_per_gpu': n, 'sharding': 'independent batches per rank, no collective'},
-            'roofline': roof, 'cpu_baseline': cpu, 'product': product, 'verify_batch': vbatch,
+            'roofline': roof, 'cpu_baseline': cpu, 'product': product, 'verify_batch': vbatch, 'sign': sleg,
         }
         print(json.dumps(line))
     if world > 1:

@@ -172,15 +172,20 @@ class Engine:
             raise NblsError('Private key must be 0 < key < CURVE.r')
         return [self.compress_g1(aff[96 * i:96 * i + 96]) for i in range(len(keys))]
 
-    def sign_batch(self, msgs, keys, dst=DST_DEFAULT):
-        """sign(msg_i, key_i) -> list of 96-byte compressed signatures"""
+    def sign_batch_affine(self, msgs, keys, dst=DST_DEFAULT):
+        """nbls_sign_batch as is: (n * 192 affine signature bytes, status bytes)"""
         blob, offs = self._pack(msgs)
         n = len(msgs)
         out = C.create_string_buffer(max(192 * n, 1)); st = C.create_string_buffer(max(n, 1))
         self._chk(self.lib.nbls_sign_batch(self.h, n, blob, offs, dst, len(dst), b''.join(keys), out, st))
-        if any(st.raw[:n]):
+        return out.raw[:192 * n], st.raw[:n]
+
+    def sign_batch(self, msgs, keys, dst=DST_DEFAULT):
+        """sign(msg_i, key_i) -> list of 96-byte compressed signatures"""
+        aff, st = self.sign_batch_affine(msgs, keys, dst)
+        if any(st):
             raise NblsError('Private key must be 0 < key < CURVE.r')
-        return [self.compress_g2(out.raw[192 * i:192 * i + 192]) for i in range(n)]
+        return [self.compress_g2(aff[192 * i:192 * i + 192]) for i in range(len(msgs))]
 
     def verify_batch(self, sig96, msgs, pks48, dst=DST_DEFAULT):
         """-> True/False; raises NblsError where the reference throws while decoding its arguments"""
