@@ -15,6 +15,7 @@
 
 extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream);
 extern "C" int nbls_fp_inv_launch(unsigned n, const void* in, void* out, void* stream);
+extern "C" int nbls_xmd256_launch(unsigned n, const void* msgs, const void* offsets, const void* dst, unsigned dst_len, void* out, void* stream);
 extern "C" int nbls_fp_pow_launch(unsigned n, const void* in, void* out, const void* nibbles, int nnib, void* scratch, int is_fp2, void* stream);
 
 using namespace nbls;
@@ -37,7 +38,7 @@ struct nbls_ctx {
   uint8_t *F = nullptr, *F2 = nullptr, *N = nullptr, *NI = nullptr, *io_g1 = nullptr, *io_g2 = nullptr, *io_f12 = nullptr, *one12 = nullptr;
   uint8_t* T[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // t1..t7 of the final exponentiation, raw Fp12
   // general scratch pool for the codec / hash / sum pipelines (grown on demand)
-  static const int NSB = 12;
+  static const int NSB = 14;
   uint8_t* sb[NSB] = {nullptr}; size_t sb_cap[NSB] = {0};
   uint8_t* nib[3] = {nullptr, nullptr, nullptr}; int nnib[3] = {0, 0, 0};   // exponent nibbles: (p+1)/4, (p^2+7)/16, (p^2-9)/16
   uint8_t* neg_g1 = nullptr;    // -G1 generator, affine wire bytes (verify: e(-G, S))
@@ -485,24 +486,32 @@ static int decompress_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* in, 
 EXPORT int nbls_g1_decompress_batch(nbls_ctx* ctx, size_t n, const uint8_t* in48, uint8_t* out96, int8_t* status) { return decompress_host(ctx, false, n, in48, out96, status); }
 EXPORT int nbls_g2_decompress_batch(nbls_ctx* ctx, size_t n, const uint8_t* in96, uint8_t* out192, int8_t* status) { return decompress_host(ctx, true, n, in96, out192, status); }
 
-// expand_message_xmd for all messages on the host cores (SHA-256 is not the data-parallel part of this path)
-static bool expand_all(size_t n, const uint8_t* msgs, const uint32_t* offs, const uint8_t* dst, size_t dst_len, std::vector<uint8_t>& uni) {
-  uni.resize(n * 256);
-  unsigned nt = std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::max<size_t>(1, n / 256)); if (nt > 32) nt = 32;
-  std::vector<std::thread> th; std::vector<char> ok(nt, 1);
-  for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t] {
-    for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) if (!expand_message_xmd(msgs + offs[i], offs[i + 1] - offs[i], dst, dst_len, &uni[256 * i], 256)) ok[t] = 0;
-  });
-  for (auto& x : th) x.join();
-  for (char c : ok) if (!c) return false;
-  return true;
+// expand_message_xmd for all messages on the device (xmd_kernel.hip): uploads the message blob, the n+1 offsets and the DST
+// into the scratch pool and leaves 256 uniform bytes per message in *d_uniform.  Only a DST longer than 255 bytes is touched
+// on the host (RFC 9380 5.3.3: replaced by its SHA-256 digest), which is per call, not per message.
+static int dev_expand(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offs, const uint8_t* dst, size_t dst_len, uint8_t** d_uniform, hipStream_t s) {
+  for (size_t i = 0; i < n; i++) if (offs[i + 1] < offs[i]) return NBLS_EINVAL;
+  const size_t total = offs[n] - offs[0];
+  uint8_t dst_hash[32];
+  if (dst_len > 255) { Sha256 c; c.update((const uint8_t*)"H2C-OVERSIZE-DST-", 17); c.update(dst, dst_len); c.final(dst_hash); dst = dst_hash; dst_len = 32; }
+  uint8_t *dm, *dofs, *dd, *du; int r;
+  if ((r = need(ctx, 7, total + 4, &dm)) || (r = need(ctx, 12, (n + 1) * 4 + 256, &dofs)) || (r = need(ctx, 8, n * 256, &du))) return r;
+  dd = dofs + (n + 1) * 4;
+  std::vector<uint32_t> rel(n + 1); for (size_t i = 0; i <= n; i++) rel[i] = offs[i] - offs[0];
+  if (total) HIPCHK(hipMemcpyAsync(dm, msgs + offs[0], total, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(dofs, rel.data(), (n + 1) * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(dd, dst, dst_len, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));     // `rel` and a hashed DST live on this stack frame
+  int e = nbls_xmd256_launch((unsigned)n, dm, dofs, dd, (unsigned)dst_len, du, s);
+  if (e) { ctx->last_hip = e; return NBLS_EHIP; }
+  *d_uniform = du;
+  return NBLS_OK;
 }
 EXPORT int nbls_hash_to_g2_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len, uint8_t* out192) {
   if (!ctx || (n && (!offsets || !out192 || !dst))) return NBLS_EINVAL; if (!n) return NBLS_OK;
-  std::vector<uint8_t> uni; if (!expand_all(n, msgs, offsets, dst, dst_len, uni)) return NBLS_EINVAL;
-  LOCKED(ctx); HostIO io{ctx}; void *d = io.alloc(n * 256), *o = io.alloc(n * 192); if (!d || !o) return NBLS_EHIP;
-  HIPCHK(hipMemcpyAsync(d, uni.data(), n * 256, hipMemcpyHostToDevice, s));
-  int r = dev_hash_to_g2(ctx, n, d, o, s); if (r) return r;
+  LOCKED(ctx); HostIO io{ctx}; void* o = io.alloc(n * 192); if (!o) return NBLS_EHIP;
+  uint8_t* d; int r = dev_expand(ctx, n, msgs, offsets, dst, dst_len, &d, s); if (r) return r;
+  if ((r = dev_hash_to_g2(ctx, n, d, o, s))) return r;
   HIPCHK(hipMemcpyAsync(out192, o, n * 192, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); return NBLS_OK;
 }
 static int sum_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* pts, uint8_t* out, int8_t* status) {
@@ -561,12 +570,11 @@ EXPORT int nbls_g2_mul_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, con
 // compresses, PointG2.toSignature index.ts:586-602).  status: 0 ok, 5 key is 0 mod r.
 EXPORT int nbls_sign_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len, const uint8_t* keys32, uint8_t* out192, int8_t* status) {
   if (!ctx || (n && (!offsets || !out192 || !dst || !keys32))) return NBLS_EINVAL; if (!n) return NBLS_OK;
-  std::vector<uint8_t> uni; if (!expand_all(n, msgs, offsets, dst, dst_len, uni)) return NBLS_EINVAL;
-  LOCKED(ctx); HostIO io{ctx}; void *d = io.alloc(n * 256), *h = io.alloc(n * 192), *dk = io.alloc(n * 32), *o = io.alloc(n * 192), *st = io.alloc(n);
-  if (!d || !h || !dk || !o || !st) return NBLS_EHIP;
-  HIPCHK(hipMemcpyAsync(d, uni.data(), n * 256, hipMemcpyHostToDevice, s));
+  LOCKED(ctx); HostIO io{ctx}; void *h = io.alloc(n * 192), *dk = io.alloc(n * 32), *o = io.alloc(n * 192), *st = io.alloc(n);
+  if (!h || !dk || !o || !st) return NBLS_EHIP;
+  uint8_t* d; int r = dev_expand(ctx, n, msgs, offsets, dst, dst_len, &d, s); if (r) return r;
   HIPCHK(hipMemcpyAsync(dk, keys32, n * 32, hipMemcpyHostToDevice, s));
-  int r = dev_hash_to_g2(ctx, n, d, h, s); if (r) return r;
+  if ((r = dev_hash_to_g2(ctx, n, d, h, s))) return r;
   if ((r = dev_point_mul(ctx, true, n, h, 192, dk, o, st, s))) return r;
   std::vector<int8_t> tmp(n);
   HIPCHK(hipMemcpyAsync(out192, o, n * 192, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(tmp.data(), st, n, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
@@ -583,17 +591,16 @@ EXPORT int nbls_sign_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const u
 EXPORT int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_sig96, const void* d_uniform, const void* d_pk48, int* ok, int8_t* pk_status, void* stream);
 EXPORT int nbls_verify_batch(nbls_ctx* ctx, size_t n, const uint8_t* sig96, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48, const uint8_t* dst, size_t dst_len, int* ok) {
   if (!ctx || !ok || !n || !sig96 || !offsets || !pk48 || !dst) return NBLS_EINVAL;
-  std::vector<uint8_t> uni; if (!expand_all(n, msgs, offsets, dst, dst_len, uni)) return NBLS_EINVAL;
   void *d_sig, *d_uni, *d_pk;
   {
     LOCKED(ctx);
-    uint8_t *a, *b, *c; int r;
-    if ((r = need(ctx, 7, 96, &a)) || (r = need(ctx, 8, n * 256, &b)) || (r = need(ctx, 9, n * 48, &c))) return r;
-    HIPCHK(hipMemcpyAsync(a, sig96, 96, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(b, uni.data(), n * 256, hipMemcpyHostToDevice, s));
+    uint8_t *b, *c; int r;
+    if ((r = dev_expand(ctx, n, msgs, offsets, dst, dst_len, &b, s))) return r;
+    if ((r = need(ctx, 9, n * 48 + 96, &c))) return r;
     HIPCHK(hipMemcpyAsync(c, pk48, n * 48, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c + n * 48, sig96, 96, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
-    d_sig = a; d_uni = b; d_pk = c;
+    d_sig = c + n * 48; d_uni = b; d_pk = c;
   }
   return nbls_verify_batch_dev_inputs(ctx, n, d_sig, d_uni, d_pk, ok, nullptr, nullptr);
 }

@@ -1,0 +1,102 @@
+// xmd_kernel.hip -- expand_message_xmd (RFC 9380 section 5.3.1) with SHA-256 on the GPU, one message per lane: the
+// hash_to_field front end of PointG2.hashToCurve (reference index.ts:207-231 expand_message_xmd, 39-48 sha256).
+// Produces the 256 uniform bytes per message that H2C_A consumes (count = 2, m = 2, L = 64; index.ts:239-267), so a
+// verifyBatch / sign call needs no host pre-pass over the messages.  Byte-serial feeding of the hash state: the messages
+// are short and this stage is < 1 % of a verifyBatch, so clarity wins over throughput here.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nbls {
+typedef uint32_t u32;
+
+__constant__ u32 SHA_K[64] = {
+  0x428a2f98,0x71374491,0xb5c0fbcf,0xe9b5dba5,0x3956c25b,0x59f111f1,0x923f82a4,0xab1c5ed5,0xd807aa98,0x12835b01,0x243185be,0x550c7dc3,0x72be5d74,0x80deb1fe,0x9bdc06a7,0xc19bf174,
+  0xe49b69c1,0xefbe4786,0x0fc19dc6,0x240ca1cc,0x2de92c6f,0x4a7484aa,0x5cb0a9dc,0x76f988da,0x983e5152,0xa831c66d,0xb00327c8,0xbf597fc7,0xc6e00bf3,0xd5a79147,0x06ca6351,0x14292967,
+  0x27b70a85,0x2e1b2138,0x4d2c6dfc,0x53380d13,0x650a7354,0x766a0abb,0x81c2c92e,0x92722c85,0xa2bfe8a1,0xa81a664b,0xc24b8b70,0xc76c51a3,0xd192e819,0xd6990624,0xf40e3585,0x106aa070,
+  0x19a4c116,0x1e376c08,0x2748774c,0x34b0bcb5,0x391c0cb3,0x4ed8aa4a,0x5b9cca4f,0x682e6ff3,0x748f82ee,0x78a5636f,0x84c87814,0x8cc70208,0x90befffa,0xa4506ceb,0xbef9a3f7,0xc67178f2};
+
+struct DevSha {
+  u32 h[8], w[16], n;
+  __device__ static u32 rotr(u32 x, int k) { return (x >> k) | (x << (32 - k)); }
+  __device__ void init() {
+    h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a; h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
+    n = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = 0;
+  }
+  __device__ void compress() {
+    u32 a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    u32 s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = w[i];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+      if (i >= 16) {
+        const u32 w15 = s[(i + 1) & 15], w2 = s[(i + 14) & 15];
+        s[i & 15] += (rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3)) + s[(i + 9) & 15] + (rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10));
+      }
+      const u32 t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + SHA_K[i] + s[i & 15];
+      const u32 t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = 0;
+  }
+  __device__ void byte(u32 v) {
+    const u32 pos = n & 63;
+    // select the word without dynamic register indexing
+#pragma unroll
+    for (int i = 0; i < 16; i++) if ((pos >> 2) == (u32)i) w[i] |= v << (24 - 8 * (pos & 3));
+    n++;
+    if ((n & 63) == 0) compress();
+  }
+  __device__ void word(u32 v) { byte(v >> 24); byte((v >> 16) & 0xff); byte((v >> 8) & 0xff); byte(v & 0xff); }
+  __device__ void finish(u32* out8) {
+    const u32 bits = n * 8;     // messages are far below 512 MB
+    byte(0x80);
+    while ((n & 63) != 56) byte(0);
+    word(0); word(bits);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out8[i] = h[i];
+  }
+};
+
+// out[256 * i ..] = expand_message_xmd(msg_i, DST, 256); dst_len <= 255 (longer DSTs are pre-hashed by the caller, RFC 9380 5.3.3)
+extern "C" __global__ void __launch_bounds__(64) nbls_xmd256_kernel(unsigned n, const uint8_t* __restrict__ msgs, const u32* __restrict__ offsets,
+                                                                    const uint8_t* __restrict__ dst, unsigned dst_len, uint8_t* __restrict__ out) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* m = msgs + offsets[i];
+  const u32 mlen = offsets[i + 1] - offsets[i];
+  DevSha c;
+  u32 b0[8], bi[8];
+  // b_0 = H(Z_pad || msg || l_i_b_str || 0 || DST_prime)
+  c.init();
+  for (int k = 0; k < 16; k++) c.word(0);
+  for (u32 k = 0; k < mlen; k++) c.byte(m[k]);
+  c.byte(0x01); c.byte(0x00); c.byte(0x00);                     // len_in_bytes = 256, then I2OSP(0, 1)
+  for (u32 k = 0; k < dst_len; k++) c.byte(dst[k]);
+  c.byte(dst_len);
+  c.finish(b0);
+  // b_1 = H(b_0 || 1 || DST_prime) ; b_j = H((b_0 xor b_(j-1)) || j || DST_prime)
+  for (u32 j = 1; j <= 8; j++) {
+    c.init();
+#pragma unroll
+    for (int k = 0; k < 8; k++) c.word(j == 1 ? b0[k] : (b0[k] ^ bi[k]));
+    c.byte(j);
+    for (u32 k = 0; k < dst_len; k++) c.byte(dst[k]);
+    c.byte(dst_len);
+    c.finish(bi);
+    u32* o = (u32*)(out + 256 * (size_t)i + 32 * (j - 1));
+#pragma unroll
+    for (int k = 0; k < 8; k++) o[k] = __builtin_bswap32(bi[k]);
+  }
+}
+}  // namespace nbls
+
+extern "C" int nbls_xmd256_launch(unsigned n, const void* msgs, const void* offsets, const void* dst, unsigned dst_len, void* out, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(nbls::nbls_xmd256_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, (const uint8_t*)msgs, (const nbls::u32*)offsets, (const uint8_t*)dst, dst_len, (uint8_t*)out);
+  return (int)hipGetLastError();
+}

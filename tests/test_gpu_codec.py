@@ -104,3 +104,14 @@ def test_verify_batch(eng, oracle, golden, testdata):
     agg = oracle.aggregate_signatures(sigs)[1]
     assert eng.verify_batch(agg, msgs, pks) is True
     assert eng.verify_batch(agg, msgs[::-1], pks) is False
+
+
+def test_hash_to_g2_message_and_dst_lengths(eng, oracle):
+    """device expand_message_xmd (xmd_kernel.hip): every message length across the SHA-256 block boundaries of b_0 and a
+    few DST lengths incl. an oversize DST (> 255 bytes is replaced by its digest, RFC 9380 5.3.3) against the oracle"""
+    msgs = [bytes((7 * i + j) & 0xff for j in range(i)) for i in range(0, 200)] + [b'\xff' * 1000, b'\x00' * 4096]
+    for dst in (b'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_', b'QUUX-V01-CS02-with-BLS12381G2_XMD:SHA-256_SSWU_RO_', b'd', b'x' * 255, b'y' * 300):
+        sub = msgs if len(dst) == 43 else msgs[::17]
+        out = eng.hash_to_g2_batch(sub, dst)
+        for i, m in enumerate(sub):
+            assert out[192 * i:192 * i + 192] == oracle.hash_to_g2(m, dst)[1], (len(m), len(dst))
