@@ -72,7 +72,7 @@ int nbls_g1_decompress_batch(nbls_ctx* ctx, size_t n, const uint8_t* in48, uint8
 int nbls_g2_decompress_batch(nbls_ctx* ctx, size_t n, const uint8_t* in96, uint8_t* out192, int8_t* status);
 
 /* PointG2.hashToCurve(msg, {DST}) for n messages (index.ts:481-490): msgs are concatenated, message i = msgs[offsets[i] ..
- * offsets[i+1]); SHA-256 expand_message_xmd runs on the host cores, everything after it on the GPU. */
+ * offsets[i+1]); SHA-256 expand_message_xmd (index.ts:207-231) and everything after it run on the GPU. */
 int nbls_hash_to_g2_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len, uint8_t* out192);
 
 /* Sum of n affine points: the reduce step of aggregatePublicKeys / aggregateSignatures (index.ts:771-788). *status = 1 when

@@ -1,4 +1,5 @@
-// sha256.h -- host-side SHA-256 and expand_message_xmd (RFC 9380 section 5.3.1) for the hash-to-G2 pre-pass.
+// sha256.h -- host-side SHA-256 (used per CALL for an oversize DST only, RFC 9380 5.3.3; the per-message hashing is
+// xmd_kernel.hip) and a host expand_message_xmd kept as the readable statement of what the kernel computes.
 // Stands for the reference's expand_message_xmd over node's crypto SHA-256 (index.ts:39-48, 207-231).
 #pragma once
 #include <cstdint>
