@@ -1,5 +1,5 @@
 // vm_kernel.hip -- the gfx950 wave-VM kernel: one wavefront (= one workgroup of 64 lanes) interprets a compiled
-// step list for G work items at once; see vm.h / vm_exec.h.  Integer VALU work (v_mad_u64_u32 + carry chains):
+// step list for G work items at once; see vm.h / vm_exec.h.  Integer VALU work (v_mad_i64_i32 into lazy 64-bit columns):
 // no MFMA by construction (independent 381-bit products are not a dense contraction).
 #include <hip/hip_runtime.h>
 #include "vm_exec.h"
