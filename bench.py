@@ -194,6 +194,11 @@ def main():
             'hbm': {'algorithmic_bytes_per_launch': hbm_bytes, 'achieved_GBps': round(hbm_bytes / ((vm_ms + ms_inv) * 1e-3) / 1e9, 3),
                     'peak_GBps': HBM_PEAK_GBPS, 'frac': round(hbm_bytes / ((vm_ms + ms_inv) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6)},
         }
+        # the same batch through the host-buffer entry point (PCIe in and out included) -- reported, never `value`
+        h0 = time.perf_counter()
+        for _ in range(3):
+            eng.pairing_batch(G1, G2, True, False)
+        roof['host_call_pairings_per_s'] = round(3 * n / (time.perf_counter() - h0), 2)
         if world == 1 and not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
             threads = min(cores, 64)

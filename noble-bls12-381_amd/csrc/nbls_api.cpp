@@ -423,11 +423,12 @@ static int dev_decompress(nbls_ctx* ctx, bool g2, size_t n, const void* d_in, vo
 // 256 uniform bytes per message (expand_message_xmd output) -> hash point, affine wire bytes (PointG2.hashToCurve, index.ts:481-490)
 static int dev_hash_to_g2(nbls_ctx* ctx, size_t n, const void* d_uniform, void* d_out, hipStream_t s) {
   uint8_t *T, *E, *Pw, *Q, *N, *NI, *st; int r;
-  if ((r = need(ctx, 0, n * 4 * RAW, &T)) || (r = need(ctx, 1, n * 4 * RAW, &E)) || (r = need(ctx, 2, n * 4 * RAW, &Pw)) || (r = need(ctx, 3, n * 6 * RAW, &Q)) ||
+  if ((r = need(ctx, 0, n * 4 * RAW, &T)) || (r = need(ctx, 1, n * 6 * RAW, &E)) || (r = need(ctx, 2, n * 4 * RAW, &Pw)) || (r = need(ctx, 3, n * 6 * RAW, &Q)) ||
       (r = need(ctx, 4, n * RAW, &N)) || (r = need(ctx, 5, n * RAW, &NI)) || (r = need(ctx, 6, n, &st))) return r;
   if ((r = run(ctx, P_H2C_A, n, {B(0, d_uniform, 256), B(3, T, 4 * RAW), B(4, E, 4 * RAW)}, s))) return r;
   if ((r = run_pow(ctx, 2, 2 * n, E, Pw, s))) return r;
-  if ((r = run(ctx, P_H2C_B, n, {B(3, T, 4 * RAW), B(5, Pw, 4 * RAW), B(6, Q, 6 * RAW), B(7, N, RAW)}, s))) return r;
+  if ((r = run(ctx, P_H2C_B, n, {B(3, T, 4 * RAW), B(5, Pw, 4 * RAW), B(6, E, 6 * RAW)}, s))) return r;        // E is free again: reuse it for the E2 point
+  if ((r = run(ctx, P_H2C_C, n, {B(3, E, 6 * RAW), B(6, Q, 6 * RAW), B(7, N, RAW)}, s))) return r;
   if ((r = run_inv_buf(ctx, n, N, NI, s))) return r;
   return run(ctx, P_G2_TO_AFFINE, n, {B(3, Q, 6 * RAW), B(4, NI, RAW), B(2, d_out, 192), B(7, st, 1)}, s);
 }

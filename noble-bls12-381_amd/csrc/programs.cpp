@@ -203,10 +203,16 @@ static Program build(ProgId id) {
         SFp2 gp = {inputw(5, 96 * k), inputw(5, 96 * k + 48)};
         pts[k] = swu_finish(swu_prepare(t), gp);
       }
-      Pt<SFp2> q = clear_cofactor_g2(isogeny_g2_proj(pt_add_generic(pts[0], pts[1])));   // index.ts:487-489
+      Pt<SFp2> q = isogeny_g2_proj(pt_add_generic(pts[0], pts[1]));   // index.ts:487-488
+      outputw(q.x.c0, 6, 0); outputw(q.x.c1, 6, 48); outputw(q.y.c0, 6, 96); outputw(q.y.c1, 6, 144); outputw(q.z.c0, 6, 192); outputw(q.z.c1, 6, 240);
+      return B.compile("h2c_b", 8);
+    }
+    case P_H2C_C: {   // its own program: chained to H2C_B through HBM so that neither keeps more than ~40 slots live (LDS-limited occupancy)
+      Pt<SFp2> p = {{inputw(3, 0), inputw(3, 48)}, {inputw(3, 96), inputw(3, 144)}, {inputw(3, 192), inputw(3, 240)}};
+      Pt<SFp2> q = clear_cofactor_g2(p);                               // index.ts:489, 659-672
       outputw(q.x.c0, 6, 0); outputw(q.x.c1, 6, 48); outputw(q.y.c0, 6, 96); outputw(q.y.c1, 6, 144); outputw(q.z.c0, 6, 192); outputw(q.z.c1, 6, 240);
       outputw(sqr(q.z.c0) + sqr(q.z.c1), 7, 0);
-      return B.compile("h2c_b", 8);
+      return B.compile("h2c_c", 8);
     }
     case P_G1_TO_PROJ: {
       outputw(input(0, 0), 3, 0); outputw(input(0, 48), 3, 48); outputw(fp_one(), 3, 96);

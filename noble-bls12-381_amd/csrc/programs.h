@@ -22,10 +22,11 @@ enum ProgId {
   P_G2_DEC_A,          // 96 B compressed G2 signature (buf 0) -> x (3), x^3+b (4)                             (index.ts:500-515)
   P_G2_DEC_B,          // compressed (0), x (3), rhs (4), rhs^((p^2+7)/16) (5) -> affine bytes (6), status (7)  (index.ts:516-529)
   P_H2C_A,             // 256 uniform bytes (buf 0) -> u0,u1 (3), SWU exponentiation inputs (4)                 (index.ts:256-263, math.ts:1220-1241)
-  P_H2C_B,             // u0,u1 (3), powers (5) -> projective hash point (6), norm of Z (7)                     (math.ts:1243-1266, index.ts:487-489, 659-672)
+  P_H2C_B,             // u0,u1 (3), powers (5) -> SWU maps, sum on E', 3-isogeny: projective point on E2 (6)    (math.ts:1243-1266, index.ts:487-488)
   P_G1_TO_PROJ, P_G1_ADD2, P_G1_NORM, P_G1_TO_AFFINE,     // point sums: aggregatePublicKeys (index.ts:771-778)
   P_G2_TO_PROJ, P_G2_ADD2, P_G2_NORM, P_G2_TO_AFFINE,     // aggregateSignatures (index.ts:781-788), hash-to-G2 output
   P_T_SWU, P_T_ISO, P_T_CLEAR,   // test-only pieces of hash-to-G2 (unit parity against golden vectors): SWU map, 3-isogeny, cofactor clearing
+  P_H2C_C,             // projective point (3) -> clearCofactor -> projective hash point (6), norm of Z (7)      (index.ts:489, 659-672)
   P_G1_MUL, P_G2_MUL,            // [k]P for per-item 256-bit scalars: point (buf 0 / 1), scalar 32 B (buf 2) -> projective (3), norm of Z (4)   (getPublicKey / sign, index.ts:738-752)
   P_COUNT
 };

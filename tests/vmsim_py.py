@@ -17,7 +17,7 @@ def raw_elem(v):
 
 
 PROGS = ['MILLER_BYTES', 'MILLER_RAW', 'MILLER_FE', 'NORM_RAW', 'NORM_BYTES', 'FE_EASY', 'EXPX', 'FE_MID1', 'FE_MID2', 'FE_FINAL', 'MUL2', 'RAW_TO_BYTES', 'G1_VALIDATE', 'G2_VALIDATE', 'G1_DEC_A', 'G1_DEC_B', 'G2_DEC_A', 'G2_DEC_B', 'H2C_A', 'H2C_B',
-         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'G1_MUL', 'G2_MUL']
+         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'G1_MUL', 'G2_MUL']
 P = {n: i for i, n in enumerate(PROGS)}
 
 
@@ -87,7 +87,9 @@ def hash_to_g2(lib, uniform):
     T, E, Pw, Q, N, NI, out, st = buf(4 * RAW * n), buf(4 * RAW * n), buf(4 * RAW * n), buf(6 * RAW * n), buf(RAW * n), buf(RAW * n), buf(192 * n), buf(n)
     run(lib, 'H2C_A', n, {0: (buf(uniform), 256), 3: (T, 4 * RAW), 4: (E, 4 * RAW)})
     lib.nbls_sim_fp_pow(C.c_uint(2 * n), E, Pw, 2)
-    run(lib, 'H2C_B', n, {3: (T, 4 * RAW), 5: (Pw, 4 * RAW), 6: (Q, 6 * RAW), 7: (N, RAW)})
+    E2 = buf(6 * RAW * n)
+    run(lib, 'H2C_B', n, {3: (T, 4 * RAW), 5: (Pw, 4 * RAW), 6: (E2, 6 * RAW)})
+    run(lib, 'H2C_C', n, {3: (E2, 6 * RAW), 6: (Q, 6 * RAW), 7: (N, RAW)})
     lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
     run(lib, 'G2_TO_AFFINE', n, {3: (Q, 6 * RAW), 4: (NI, RAW), 2: (out, 192), 7: (st, 1)})
     return out.raw
