@@ -43,6 +43,9 @@ struct nbls_ctx {
   uint8_t* nib[3] = {nullptr, nullptr, nullptr}; int nnib[3] = {0, 0, 0};   // exponent nibbles: (p+1)/4, (p^2+7)/16, (p^2-9)/16
   uint8_t* neg_g1 = nullptr;    // -G1 generator, affine wire bytes (verify: e(-G, S))
   uint8_t* gen_g1 = nullptr;    // G1 generator, affine wire bytes (getPublicKey)
+  // side stream for the one-element chains of verifyBatch (signature decompression: a 758-bit Fp2 exponentiation on a single
+  // lane is ~4 ms of pure latency) so that they overlap the batch-wide kernels instead of serialising with them
+  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; uint8_t* side_scratch = nullptr;
   uint8_t* ident_g1 = nullptr; uint8_t* ident_g2 = nullptr;   // projective identity (0 : 1 : 0), raw
   size_t cap_F = 0, cap_io = 0;
   int last_hip = 0;
@@ -126,9 +129,9 @@ static int need(nbls_ctx* ctx, int i, size_t bytes, uint8_t** out) {
   *out = ctx->sb[i];
   return NBLS_OK;
 }
-static int run_pow(nbls_ctx* ctx, int which, size_t n, const void* in, void* out, hipStream_t s) {
+static int run_pow(nbls_ctx* ctx, int which, size_t n, const void* in, void* out, hipStream_t s, uint8_t* scratch = nullptr) {
   int is_fp2 = which != 0;
-  uint8_t* scratch; int r = need(ctx, 11, n * 16 * (is_fp2 ? 2 : 1) * RAW, &scratch); if (r) return r;
+  if (!scratch) { int r = need(ctx, 11, n * 16 * (is_fp2 ? 2 : 1) * RAW, &scratch); if (r) return r; }
   int e = nbls_fp_pow_launch((unsigned)n, in, out, ctx->nib[which], ctx->nnib[which], scratch, is_fp2, s);
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
   return NBLS_OK;
@@ -187,6 +190,8 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
   if (hipSetDevice(device_id) != hipSuccess) { delete ctx; return NBLS_ENOGPU; }
   if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   // Montgomery one as a raw Fp12 (pads odd-sized product reductions)
+  if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess || hipMalloc(&ctx->side_scratch, (6 + 32) * RAW) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   u32 one[12 * SLOT_WORDS]; memset(one, 0, sizeof one); memcpy(one, NBLS_R1, NLIMBS * 4);
   if (hipMalloc(&ctx->one12, F12) != hipSuccess || hipMemcpy(ctx->one12, one, F12, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   {
@@ -219,7 +224,7 @@ EXPORT void nbls_destroy(nbls_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   for (auto& d : ctx->prog) { if (d.steps) hipFree(d.steps); if (d.descs) hipFree(d.descs); if (d.consts) hipFree(d.consts); }
-  for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->gen_g1}) if (p) hipFree(p);
+  for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->gen_g1, ctx->side_scratch}) if (p) hipFree(p);
   for (uint8_t* p : ctx->T) if (p) hipFree(p);
   for (uint8_t* p : ctx->sb) if (p) hipFree(p);
   for (uint8_t* p : ctx->nib) if (p) hipFree(p);
@@ -616,10 +621,19 @@ EXPORT int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_s
     uint8_t *G1, *G2, *ST, *O; int r;
     if ((r = need(ctx, 10, (n + 1) * (96 + 192) + (n + 1) + 576 + 64, &G1))) return r;
     G2 = G1 + (n + 1) * 96; O = G2 + (n + 1) * 192; ST = O + 576;
+    // normP2: PointG2.fromSignature for the ONE signature, on the side stream with its own scratch (overlaps everything below)
+    {
+      uint8_t *X = ctx->side_scratch, *Rr = X + 2 * RAW, *Cd = Rr + 2 * RAW, *pw = Cd + 2 * RAW;
+      HIPCHK(hipEventRecord(ctx->ev_fork, s)); HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+      if ((r = run(ctx, P_G2_DEC_A, 1, {B(0, d_sig96, 96), B(3, X, 2 * RAW), B(4, Rr, 2 * RAW)}, ctx->side))) return r;
+      if ((r = run_pow(ctx, 1, 1, Rr, Cd, ctx->side, pw))) return r;
+      if ((r = run(ctx, P_G2_DEC_B, 1, {B(0, d_sig96, 96), B(3, X, 2 * RAW), B(4, Rr, 2 * RAW), B(5, Cd, 2 * RAW), B(6, G2 + n * 192, 192), B(7, ST + n, 1)}, ctx->side))) return r;
+      HIPCHK(hipEventRecord(ctx->ev_join, ctx->side));
+    }
     if ((r = dev_decompress(ctx, false, n, d_pk48, G1, ST, s))) return r;                       // normP1: PointG1.fromHex
     if ((r = dev_hash_to_g2(ctx, n, d_uniform, G2, s))) return r;                               // normP2Hash: PointG2.hashToCurve
-    if ((r = dev_decompress(ctx, true, 1, d_sig96, G2 + n * 192, ST + n, s))) return r;         // normP2: PointG2.fromSignature
     HIPCHK(hipMemcpyAsync(G1 + n * 96, ctx->neg_g1, 96, hipMemcpyDeviceToDevice, s));           // PointG1.BASE.negate()
+    HIPCHK(hipStreamWaitEvent(s, ctx->ev_join, 0));
     HIPCHK(hipMemcpyAsync(st.data(), ST, n + 1, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
   }
