@@ -298,8 +298,11 @@ EXPORT int nbls_miller_product_dev(nbls_ctx* ctx, size_t n, const void* d_g1, co
   uint8_t* res = ctx->F;
   if (n == 0) { HIPCHK(hipMemcpyAsync(ctx->F, ctx->one12, F12, hipMemcpyDeviceToDevice, s)); }
   else {
-    if ((r = run(ctx, P_MILLER_RAW, n, {B(0, d_g1, 96), B(1, d_g2, 192), B(3, ctx->F, F12)}, s))) return r;
-    if ((r = reduce_product(ctx, n, &res, s))) return r;
+    // pairs are taken two at a time with a shared accumulator (one Fp12 squaring per bit for both); an odd last pair runs alone
+    const size_t n2 = n / 2, m = n2 + (n & 1);
+    if (n2 && (r = run(ctx, P_MILLER_RAW2, n2, {B(0, d_g1, 192), B(1, d_g2, 384), B(3, ctx->F, F12)}, s))) return r;
+    if ((n & 1) && (r = run(ctx, P_MILLER_RAW, 1, {B(0, (const uint8_t*)d_g1 + (n - 1) * 96, 96), B(1, (const uint8_t*)d_g2 + (n - 1) * 192, 192), B(3, ctx->F + n2 * F12, F12)}, s))) return r;
+    if ((r = reduce_product(ctx, m, &res, s))) return r;
   }
   return finish_single(ctx, res, final_exp, d_out, s);
 }

@@ -51,6 +51,44 @@ static SFp12 trace_miller(const SFp& Px, const SFp& Py, const SFp2& Qx, const SF
   return conj(f);
 }
 
+// Product of m Miller loops with ONE shared accumulator: f <- (f * prod_j line_j)^2 per bit instead of m separate
+// accumulators, which saves m-1 of the m Fp12 squarings per bit.  prod_j millerLoop(P_j, Q_j) is the same field element
+// either way ((prod a_j)^2 = prod a_j^2), so Miller products (verify / verifyBatch, index.ts:756-821) stay bit-exact.
+static SFp12 trace_miller_shared(const std::vector<SFp>& Px, const std::vector<SFp>& Py, const std::vector<SFp2>& Qx, const std::vector<SFp2>& Qy) {
+  const size_t m = Px.size();
+  std::vector<SFp2> Rx = Qx, Ry = Qy, Rz(m, fp2_one());
+  SFp12 f = fp12_one();
+  for (int i = 62; i >= 0; i--) {
+    for (size_t j = 0; j < m; j++) {
+      // doubling step, math.ts:1339-1351
+      SFp2 t0 = sqr(Ry[j]), t1 = sqr(Rz[j]);
+      SFp2 t2 = mat(mul_by_b(scale(t1, 3)));
+      SFp2 t3 = scale(t2, 3);
+      SFp2 t4 = mat(sqr(Ry[j] + Rz[j]) - t1 - t0);
+      SFp2 e0 = t2 - t0, e1 = scale(sqr(Rx[j]), 3), e2 = -t4;
+      SFp2 nRx = mul(halve(t0 - t3), mul(Rx[j], Ry[j]));
+      SFp2 nRy = sqr(halve(t0 + t3)) - scale(sqr(t2), 3);
+      SFp2 nRz = mul(t0, t4);
+      Rx[j] = mat(nRx); Ry[j] = mat(nRy); Rz[j] = mat(nRz);
+      f = mat(mul_by_014(f, e0, mul_fp(e1, Px[j]), mul_fp(e2, Py[j])));
+    }
+    if ((NBLS_X >> i) & 1) {
+      for (size_t j = 0; j < m; j++) {
+        // addition step, math.ts:1353-1367
+        SFp2 a0 = mat(Ry[j] - mul(Qy[j], Rz[j])), a1 = mat(Rx[j] - mul(Qx[j], Rz[j]));
+        SFp2 g0 = mul(a0, Qx[j]) - mul(a1, Qy[j]), g1 = -a0, g2 = a1;
+        SFp2 a2 = mat(sqr(a1)), a3 = mat(mul(a2, a1)), a4 = mat(mul(a2, Rx[j]));
+        SFp2 a5 = mat(a3 - scale(a4, 2) + mul(sqr(a0), Rz[j]));
+        SFp2 nRx = mul(a1, a5), nRy = mul(a4 - a5, a0) - mul(a3, Ry[j]), nRz = mul(Rz[j], a3);
+        Rx[j] = mat(nRx); Ry[j] = mat(nRy); Rz[j] = mat(nRz);
+        f = mat(mul_by_014(f, g0, mul_fp(g1, Px[j]), mul_fp(g2, Py[j])));
+      }
+    }
+    if (i != 0) f = mat(sqr(f));
+  }
+  return conj(f);
+}
+
 // ---------------------------------------------------------------- Fp12 inversion split around the one Fp inversion
 // Fp12.invert (math.ts:793-797) -> Fp6.invert (672-680) -> Fp2.invert (522-526) -> Fp.invert.  Everything except
 // the Fp inversion is recomputed on both sides of the inversion kernel (cheap: ~90 Fp products).
@@ -116,6 +154,13 @@ static Program build(ProgId id) {
       SFp Px, Py; SFp2 Qx, Qy; load_points(Px, Py, Qx, Qy);
       outputw_fp12(trace_miller(Px, Py, Qx, Qy), 3, 0);
       return B.compile("miller_raw", MILLER_W);
+    }
+    case P_MILLER_RAW2: {   // two pairs per item: g1 (buf 0, 2 x 96 B), g2 (buf 1, 2 x 192 B) -> raw Fp12 of the product (buf 3)
+      std::vector<SFp> Px, Py; std::vector<SFp2> Qx, Qy;
+      for (int j = 0; j < 2; j++) { Px.push_back(input(0, 96 * j)); Py.push_back(input(0, 96 * j + 48)); Qx.push_back(input_fp2(1, 192 * j)); Qy.push_back(input_fp2(1, 192 * j + 96)); }
+      outputw_fp12(trace_miller_shared(Px, Py, Qx, Qy), 3, 0);
+      B.sched_window = env_int("NBLS_MILLER2_WINDOW", 450);   // keeps the two point-update chains within ~1.5 iterations of the accumulator chain
+      return B.compile("miller_raw2", MILLER_W);
     }
     case P_MILLER_FE: {
       SFp Px, Py; SFp2 Qx, Qy; load_points(Px, Py, Qx, Qy);

@@ -301,34 +301,46 @@ Program Builder::compile(const std::string& name, int W) {
   }
   std::vector<std::vector<int>> step_nodes;
   const int DOTKEY = K_DOT * 256;
+  // sched_window (0 = unlimited): a ready lane-op may issue only if its critical-path height is within the window of the
+  // most critical ready lane-op.  Without it a short side chain (the point updates of a Miller loop with a shared
+  // accumulator) runs many iterations ahead of the main chain and its results pile up in LDS.
+  const int window = sched_window > 0 ? sched_window : (1 << 30);
   while (remaining > 0) {
+    int front = -1;
+    for (auto& kv : ready) if (!kv.second.empty()) front = std::max(front, nodes[kv.second.top()].height);
+    const int minh = front - window;
+    auto eligible = [&](PQ& q) { return !q.empty() && nodes[q.top()].height >= minh; };
+    auto take = [&](PQ& q, std::vector<int>& out) { while (eligible(q) && (int)out.size() < W) { out.push_back(q.top()); q.pop(); } };
     int key = -1;
     // a full DOT step of one class is always worth issuing; otherwise drain the cheap kinds first, then issue the DOT
     // class that holds the most urgent (highest critical path) ready lane-op
-    int best_dot = -1, best_h = -1;
-    for (int c = 1; c >= 0; c--) {
-      auto itq = ready.find(DOTKEY + c);
-      if (itq == ready.end() || itq->second.empty()) continue;
-      if (itq->second.size() >= (size_t)W) { key = DOTKEY + c; break; }
-      int h = nodes[itq->second.top()].height;
-      if (h > best_h) { best_h = h; best_dot = DOTKEY + c; }
-    }
+    std::vector<int> cand[2];
+    for (int c = 1; c >= 0; c--) { auto itq = ready.find(DOTKEY + c); if (itq != ready.end()) take(itq->second, cand[c]); }
+    if ((int)cand[1].size() >= W) key = DOTKEY + 1;
+    else if ((int)cand[0].size() >= W) key = DOTKEY;
     if (key < 0) {
       static const int order[] = {K_LOAD, K_LOADW, K_BIT, K_BITAND, K_LIN, K_ISZ, K_FLAG, K_CMP, K_CANON, K_SEL, K_STOREW, K_STORE, K_STATUS};
       for (int k : order) {
-        for (auto& kv : ready) if (kv.first / 256 == k && !kv.second.empty()) { key = kv.first; break; }
+        for (auto& kv : ready) if (kv.first / 256 == k && eligible(kv.second)) { key = kv.first; break; }
         if (key >= 0) break;
       }
-      if (key < 0) key = best_dot;
+      if (key < 0) {
+        int h1 = cand[1].empty() ? -1 : nodes[cand[1][0]].height, h0 = cand[0].empty() ? -1 : nodes[cand[0][0]].height;
+        key = h1 >= h0 ? DOTKEY + 1 : DOTKEY;
+        assert(h1 >= 0 || h0 >= 0);
+      }
     }
-    PQ& q = ready.find(key)->second;
-    assert(!q.empty());
     std::vector<int> chosen;
-    while (!q.empty() && (int)chosen.size() < W) { chosen.push_back(q.top()); q.pop(); }
-    if (key == DOTKEY + 1) {   // heavy DOT step: light lane-ops ride along in the free lanes at no cost
-      auto itl = ready.find(DOTKEY);
-      if (itl != ready.end()) while (!itl->second.empty() && (int)chosen.size() < W) { chosen.push_back(itl->second.top()); itl->second.pop(); }
+    if (key / 256 == K_DOT) {
+      const int c = key - DOTKEY;
+      chosen = cand[c];
+      if (c == 1) { for (int x : cand[0]) { if ((int)chosen.size() < W) chosen.push_back(x); else ready.find(DOTKEY)->second.push(x); } }   // heavy DOT step: light lane-ops ride along in the free lanes at no cost
+      else for (int x : cand[1]) ready.find(DOTKEY + 1)->second.push(x);
+    } else {
+      for (int c = 0; c < 2; c++) for (int x : cand[c]) ready.find(DOTKEY + c)->second.push(x);
+      take(ready.find(key)->second, chosen);
     }
+    assert(!chosen.empty());
     int sidx = (int)step_nodes.size();
     for (size_t l = 0; l < chosen.size(); l++) { nodes[chosen[l]].step = sidx; nodes[chosen[l]].lane = (int)l; }
     step_nodes.push_back(chosen);

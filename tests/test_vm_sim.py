@@ -164,3 +164,17 @@ def test_scalar_mul_programs(sim, oracle, golden):
     # k = r: the result is the zero point (status 1), which the host wrapper reports as an invalid key (status 5)
     out, st = vmsim_py.point_mul(sim, g1, r.to_bytes(32, 'big'))
     assert st[0] == 1
+
+
+def test_miller_shared_accumulator(sim, oracle, golden):
+    """MILLER_RAW2: two pairs per item with one shared accumulator == product of the two separate Miller loops
+    (the reference multiplies separate millerLoop values, index.ts:756-767, 810-817; same field element)"""
+    n = 5   # 5 items = 10 pairs
+    g1, g2 = _points(golden, 2 * n)
+    F = C.create_string_buffer(vmsim_py.F12 * n)
+    out = C.create_string_buffer(576 * n)
+    vmsim_py.run(sim, 'MILLER_RAW2', n, {0: (C.create_string_buffer(g1, len(g1)), 192), 1: (C.create_string_buffer(g2, len(g2)), 384), 3: (F, vmsim_py.F12)})
+    vmsim_py.run(sim, 'RAW_TO_BYTES', n, {3: (F, vmsim_py.F12), 2: (out, 576)})
+    for i in range(n):
+        ref = oracle.miller_product(g1[192 * i:192 * i + 192], g2[384 * i:384 * i + 384], final_exp=False)
+        assert out.raw[576 * i:576 * i + 576] == ref, i
