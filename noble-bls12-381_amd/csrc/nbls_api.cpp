@@ -381,6 +381,27 @@ EXPORT int nbls_fp12_product_final_dev(nbls_ctx* ctx, size_t n, const void* d_in
   return finish_single(ctx, res, final_exp, d_out, s);
 }
 
+// Placement study: runs the EXPX program on n scratch items and returns, per workgroup, three words: HW_ID | XCC_ID << 32 of its wavefront, start and end tick (s_memtime).
+EXPORT int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks) {
+  if (!ctx || !n || !out_blocks) return NBLS_EINVAL;
+  std::lock_guard<std::mutex> g(ctx->mu); HIPCHK(hipSetDevice(ctx->device));
+  int r = ensure_scratch(ctx, n); if (r) return r;
+  r = upload(ctx, P_EXPX); if (r) return r;
+  const DevProgram& d = ctx->prog[P_EXPX];
+  const size_t blocks = (n + d.p->G - 1) / d.p->G;
+  uint64_t* dbg = nullptr; HIPCHK(hipMalloc(&dbg, blocks * 24));
+  KernelArgs ka; memset(&ka, 0, sizeof ka);
+  ka.steps = d.steps; ka.descs = d.descs; ka.consts = d.consts;
+  ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slots = d.p->slots; ka.n_items = (u32)n;
+  ka.bufs[3].ptr = ctx->T[0]; ka.bufs[3].stride = F12; ka.bufs[5].ptr = ctx->T[1]; ka.bufs[5].stride = F12;
+  ka.hwid_out = dbg;
+  HIPCHK(hipMemsetAsync(ctx->T[0], 0, n * F12, ctx->stream));
+  int e = nbls_vm_launch(&ka, d.p->lds_bytes(), ctx->stream);
+  if (e) { hipFree(dbg); ctx->last_hip = e; return NBLS_EHIP; }
+  HIPCHK(hipMemcpyAsync(out_blocks, dbg, blocks * 24, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
+  hipFree(dbg);
+  return NBLS_OK;
+}
 EXPORT int nbls_program_stats(nbls_ctx* ctx, int prog, uint32_t* o) {
   (void)ctx;
   if (prog < 0 || prog >= P_COUNT || !o) return NBLS_EINVAL;

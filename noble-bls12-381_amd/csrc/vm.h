@@ -71,6 +71,7 @@ struct KernelArgs {
   uint32_t slots;           // LDS slots per instance
   uint32_t n_items;
   IOBuf bufs[MAX_BUFS];
+  uint64_t* hwid_out;       // optional (NULL): per workgroup, HW_ID | XCC_ID << 32 of its wavefront -- placement studies (tools/placement.py)
 };
 
 static inline uint32_t lds_words(uint32_t nconst, uint32_t G, uint32_t slots) { return nconst * SLOT_WORDS + G * slots * SLOT_WORDS; }

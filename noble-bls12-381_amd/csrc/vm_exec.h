@@ -183,59 +183,74 @@ struct LaneCtx {
   bool live;      // item < n_items (dead instances compute on zeros but never touch global memory)
 };
 
+// K_DOT in two pieces so that the two-wave kernel (vm_kernel.hip, small batches) can split the products of a lane-op
+// between two wavefronts: dot_products accumulates products [lo, hi) of this lane's descriptor into the 28 signed
+// columns; dot_result reduces the columns and applies multiplier, post-added slots, normalisation and halving.
+template <typename LDSP>
+NBLS_HD void dot_products(u64* acc, const Step& st, const u32* d, const u32* __restrict__ gd, LDSP lds, const LaneCtx& cx, u32 lo, u32 hi) {
+  const u32 k = (d[0] >> 16) & 0xf;
+  u32 na, nb;
+  if (lo == 0) { na = d[4]; nb = d[5]; } else if (lo < hi) { na = gd[4 + 2 * lo]; nb = gd[5 + 2 * lo]; } else { na = 0; nb = 0; }
+  for (u32 i = lo; i < hi; i++) {   // uniform trip count; next product's operand words are fetched ahead
+    const u32 ea = na, eb = nb;
+    if (i + 1 < hi) { na = gd[6 + 2 * i]; nb = gd[7 + 2 * i]; }
+    if (i < k) {
+      u32 A[NL], B[NL];
+      dot_operand(A, ea, lds, cx.inst);
+      dot_operand(B, eb, lds, cx.inst);
+      mac28(acc, A, B);
+    }
+  }
+}
+template <typename LDSP>
+NBLS_HD u32 dot_result(u32* res, u64* acc, bool have_products, const Step& st, const u32* d, LDSP lds, const LaneCtx& cx) {
+  const u32 w0 = d[0];
+  const u32 L = (w0 >> 20) & 0xf, mult = (w0 >> 24) & 0x7;
+  u32 r[NL];
+  if (have_products) redc28(r, acc);
+  else {
+#pragma unroll
+    for (int i = 0; i < NL; i++) r[i] = 0;
+  }
+  if (mult > 1) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) r[i] *= mult;     // m <= 4; with <= 4 linear terms the limb sums stay inside (-2^31, 2^31)
+  }
+#pragma unroll
+  for (int t = 0; t < MAX_DOT_LINEAR; t++) {
+    if (t < (int)st.pad) {   // uniform
+      u32 term = (d[2 + t / 2] >> (16 * (t & 1))) & 0xffff;
+      if ((u32)t < L) {
+        u32 X[NL];
+        ld14(X, lds, slot_addr(term, cx.inst));
+        if (term & OP_NEG) {
+#pragma unroll
+          for (int i = 0; i < NL; i++) r[i] -= X[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < NL; i++) r[i] += X[i];
+        }
+      }
+    }
+  }
+  if (mult > 1 || st.pad > 0) carry_norm(r);
+  if (w0 & (1u << 27)) halve28(r);
+#pragma unroll
+  for (int i = 0; i < NL; i++) res[i] = r[i];
+  return slot_addr(w0 & 0xffff, cx.inst);
+}
+
 template <typename LDSP>
 NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, already loaded */, const u32* __restrict__ gd /* this lane's descriptor in global memory */,
                       LDSP lds, const LaneCtx& cx, const IOBuf* bufs, u32* res) {
   switch (st.kind) {
     case K_DOT: {
-      const u32 w0 = d[0];
-      const u32 k = (w0 >> 16) & 0xf, L = (w0 >> 20) & 0xf, mult = (w0 >> 24) & 0x7;
-      u32 r[NL];
+      u64 acc[2 * NL];
       if (st.p0 > 0) {   // uniform
-        u64 acc[2 * NL];
-        acc_init(acc, w0 >> 28);
-        u32 na = d[4], nb = d[5];
-        for (u32 i = 0; i < st.p0; i++) {   // uniform trip count; next product's operand words are fetched ahead
-          const u32 ea = na, eb = nb;
-          if (i + 1 < st.p0) { na = gd[6 + 2 * i]; nb = gd[7 + 2 * i]; }
-          if (i < k) {
-            u32 A[NL], B[NL];
-            dot_operand(A, ea, lds, cx.inst);
-            dot_operand(B, eb, lds, cx.inst);
-            mac28(acc, A, B);
-          }
-        }
-        redc28(r, acc);
-      } else {
-#pragma unroll
-        for (int i = 0; i < NL; i++) r[i] = 0;
+        acc_init(acc, d[0] >> 28);
+        dot_products(acc, st, d, gd, lds, cx, 0, st.p0);
       }
-      if (mult > 1) {
-#pragma unroll
-        for (int i = 0; i < NL; i++) r[i] *= mult;     // m <= 4; with <= 4 linear terms the limb sums stay inside (-2^31, 2^31)
-      }
-#pragma unroll
-      for (int t = 0; t < MAX_DOT_LINEAR; t++) {
-        if (t < (int)st.pad) {   // uniform
-          u32 term = (d[2 + t / 2] >> (16 * (t & 1))) & 0xffff;
-          if ((u32)t < L) {
-            u32 X[NL];
-            ld14(X, lds, slot_addr(term, cx.inst));
-            if (term & OP_NEG) {
-#pragma unroll
-              for (int i = 0; i < NL; i++) r[i] -= X[i];
-            } else {
-#pragma unroll
-              for (int i = 0; i < NL; i++) r[i] += X[i];
-            }
-          }
-        }
-      }
-      if (mult > 1 || st.pad > 0) carry_norm(r);
-      if (w0 & (1u << 27)) halve28(r);
-#pragma unroll
-      for (int i = 0; i < NL; i++) res[i] = r[i];
-      return slot_addr(w0 & 0xffff, cx.inst);
+      return dot_result(res, acc, st.p0 > 0, st, d, lds, cx);
     }
     case K_LIN: {
       const u32 w0 = d[0];

@@ -3,6 +3,8 @@ import hashlib
 import importlib
 import os
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from goldenio import hx
 
 pytestmark = pytest.mark.gpu
@@ -103,3 +105,32 @@ def test_batch_4096_properties(eng, oracle):
     ref, _ = oracle.pairing_batch(G1, G2, True, False, threads=min(64, os.cpu_count() or 8))
     assert hashlib.sha256(out).hexdigest() == hashlib.sha256(ref).hexdigest()
     assert out == ref
+
+
+@pytest.mark.parametrize('split', ['0', '1'])
+def test_both_vm_kernels(split):
+    """nbls_vm_kernel (one wavefront per workgroup) and nbls_vm_kernel_split (two wavefronts sharing every K_DOT lane-op, chosen
+    automatically for launches of <= 256 workgroups) forced in turn over the whole pipeline: pairings at several batch sizes
+    against the oracle, a Miller product and a verifyBatch.  NBLS_SPLIT is read once per process, hence the subprocess."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import importlib, os, sys
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+        import oracle_py, goldenio
+        from goldenio import hx
+        pkg = importlib.import_module('noble-bls12-381_amd')
+        eng, oracle, golden = pkg.Engine(0), oracle_py.load(), goldenio.load('ref_vectors.json.gz')
+        pairs = golden['pairs']
+        for n in (1, 3, 37, 1500):
+            g1 = b''.join(hx(pairs[i %% len(pairs)]['g1']) for i in range(n)); g2 = b''.join(hx(pairs[(5 * i + 1) %% len(pairs)]['g2']) for i in range(n))
+            out, st = eng.pairing_batch(g1, g2, True, False)
+            ref, _ = oracle.pairing_batch(g1, g2, True, False, threads=16)
+            assert out == ref, n
+            assert eng.miller_product(g1, g2, True)[0] == oracle.miller_product(g1, g2, True), n
+        vb = golden['verify_batch']
+        assert eng.verify_batch(hx(vb['agg_sig']), [hx(m) for m in vb['msgs']], [hx(p) for p in vb['pks']]) is True
+        print('ok')
+    ''') % (ROOT, ROOT)
+    env = dict(os.environ, NBLS_SPLIT=split)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]

@@ -22,7 +22,8 @@ P = {n: i for i, n in enumerate(PROGS)}
 
 
 def load():
-    subprocess.check_call(['make', '-s', '-C', os.path.join(PKG, 'csrc'), '../libnbls_sim.so'])
+    if not os.environ.get('NBLS_SIM_NO_REBUILD'):   # set when a hand-built variant of the simulator is being checked
+        subprocess.check_call(['make', '-s', '-C', os.path.join(PKG, 'csrc'), '../libnbls_sim.so'])
     return C.CDLL(os.path.join(PKG, 'libnbls_sim.so'))
 
 
