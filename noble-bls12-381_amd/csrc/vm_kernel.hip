@@ -21,10 +21,11 @@ extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel(KernelArgs ka) {
   cx.live = inst_id < ka.G && cx.item < ka.n_items;
   if (ka.hwid_out && lane == 0) { ka.hwid_out[3 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); ka.hwid_out[3 * blockIdx.x + 1] = __builtin_readcyclecounter(); }   // HW_ID, XCC_ID, start tick (placement study)
   __syncthreads();   // single wave: orders the constant fill before first use
-  // Software-pipelined interpreter loop: the step header (scalar) and this lane's descriptor words for step s+1 are
-  // requested before step s executes, so the L2 latency of the descriptor fetch overlaps the arithmetic.
+  // Software-pipelined interpreter loop: this lane's descriptor words for step s+1 and the header of step s+2 are
+  // requested before step s executes, so their L2 latency overlaps the arithmetic.
   const uint4* descs4 = (const uint4*)ka.descs;
   Step st = ka.steps[0];
+  Step nst = ka.steps[ka.nsteps > 1 ? 1 : 0];
   uint4 d0 = make_uint4(0, 0, 0, 0), d1 = make_uint4(0, 0, 0, 0);
   if (lane_in < st.nlanes) {
     const u32 o = (st.desc_off + lane_in * st.stride) >> 2;
@@ -32,8 +33,11 @@ extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel(KernelArgs ka) {
     if (st.stride > 4) d1 = descs4[o + 1];
   }
   for (u32 s = 0; s < ka.nsteps; s++) {
-    const u32 sn = (s + 1 < ka.nsteps) ? s + 1 : s;
-    const Step nst = ka.steps[sn];
+    // header of step s+2 is requested now and first looked at one iteration later; the header of step s+1 arrived during
+    // the previous step, so the descriptor prefetch below does not wait on global memory (a lone wavefront has nobody to
+    // hide a ~2 us header round trip per step behind)
+    const u32 sn = (s + 2 < ka.nsteps) ? s + 2 : ka.nsteps - 1;
+    const Step nnst = ka.steps[sn];
     uint4 n0 = make_uint4(0, 0, 0, 0), n1 = make_uint4(0, 0, 0, 0);
     if (lane_in < nst.nlanes) {
       const u32 o = (nst.desc_off + lane_in * nst.stride) >> 2;
@@ -49,7 +53,7 @@ extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel(KernelArgs ka) {
         for (int i = 0; i < NL; i++) smem[dst + i] = res[i];
       }
     }
-    st = nst; d0 = n0; d1 = n1;
+    st = nst; nst = nnst; d0 = n0; d1 = n1;
   }
   if (ka.hwid_out && lane == 0) ka.hwid_out[3 * blockIdx.x + 2] = __builtin_readcyclecounter();
 }
@@ -76,6 +80,7 @@ extern "C" __global__ void __launch_bounds__(128) nbls_vm_kernel_split(KernelArg
   __syncthreads();
   const uint4* descs4 = (const uint4*)ka.descs;
   Step st = ka.steps[0];
+  Step nst = ka.steps[ka.nsteps > 1 ? 1 : 0];
   uint4 d0 = make_uint4(0, 0, 0, 0), d1 = make_uint4(0, 0, 0, 0);
   if (lane_in < st.nlanes) {
     const u32 o = (st.desc_off + lane_in * st.stride) >> 2;
@@ -83,8 +88,11 @@ extern "C" __global__ void __launch_bounds__(128) nbls_vm_kernel_split(KernelArg
     if (st.stride > 4) d1 = descs4[o + 1];
   }
   for (u32 s = 0; s < ka.nsteps; s++) {
-    const u32 sn = (s + 1 < ka.nsteps) ? s + 1 : s;
-    const Step nst = ka.steps[sn];
+    // header of step s+2 is requested now and first looked at one iteration later; the header of step s+1 arrived during
+    // the previous step, so the descriptor prefetch below does not wait on global memory (a lone wavefront has nobody to
+    // hide a ~2 us header round trip per step behind)
+    const u32 sn = (s + 2 < ka.nsteps) ? s + 2 : ka.nsteps - 1;
+    const Step nnst = ka.steps[sn];
     uint4 n0 = make_uint4(0, 0, 0, 0), n1 = make_uint4(0, 0, 0, 0);
     if (lane_in < nst.nlanes) {
       const u32 o = (nst.desc_off + lane_in * nst.stride) >> 2;
@@ -125,7 +133,7 @@ extern "C" __global__ void __launch_bounds__(128) nbls_vm_kernel_split(KernelArg
       }
     }
     __syncthreads();
-    st = nst; d0 = n0; d1 = n1;
+    st = nst; nst = nnst; d0 = n0; d1 = n1;
   }
 }
 
