@@ -107,6 +107,35 @@ def test_batch_4096_properties(eng, oracle):
     assert out == ref
 
 
+def test_batch_131072_properties(eng, oracle):
+    """BASELINE config 4 size per GPU (1M pairings over 8 GPUs): 131072 pairings in one call.  The oracle cannot follow at this
+    size, so: (i) the inputs cycle through 64 x 64 distinct (P_a, Q_b) combinations, every repetition of a combination must give
+    the identical 576 bytes wherever it sits in the batch; (ii) the 4096 distinct results are compared with the oracle;
+    (iii) e(P_a, Q_b) * e(-P_a, Q_b) == 1 over the whole batch through the shared-final-exponentiation path."""
+    n = 131072
+    base1, base2 = _rand_points(oracle, 64, 131)
+    idx = [((i * 13 + 5) % 64, (i // 64 + i * 7) % 64) for i in range(n)]
+    G1 = b''.join(base1[96 * a:96 * a + 96] for a, _ in idx)
+    G2 = b''.join(base2[192 * b:192 * b + 192] for _, b in idx)
+    out, st = eng.pairing_batch(G1, G2, True, False)
+    assert st == bytes(n)
+    first = {}
+    for i, key in enumerate(idx):
+        o = out[576 * i:576 * i + 576]
+        if key in first:
+            assert o == first[key], i
+        else:
+            first[key] = o
+    keys = sorted(first)
+    ref, _ = oracle.pairing_batch(b''.join(base1[96 * a:96 * a + 96] for a, _ in keys), b''.join(base2[192 * b:192 * b + 192] for _, b in keys), True, False,
+                                  threads=min(64, os.cpu_count() or 8))
+    assert b''.join(first[k] for k in keys) == ref
+    neg = b''.join(oracle.un('g1_neg_aff', base1[96 * a:96 * a + 96], 96) for a in range(64))
+    G1n = b''.join(neg[96 * a:96 * a + 96] for a, _ in idx)
+    prod, _ = eng.miller_product(G1 + G1n, G2 + G2, True)
+    assert prod == bytes(47) + b'\x01' + bytes(528)
+
+
 @pytest.mark.parametrize('split', ['0', '1'])
 def test_both_vm_kernels(split):
     """nbls_vm_kernel (one wavefront per workgroup) and nbls_vm_kernel_split (two wavefronts sharing every K_DOT lane-op, chosen
