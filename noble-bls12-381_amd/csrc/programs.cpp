@@ -188,9 +188,9 @@ static Program build(ProgId id) {
       outputw_fp12(trace_fe_easy(f, finv), 5, 0);
       return B.compile("fe_easy", 16);
     }
-    case P_EXPX: {
+    case P_EXPX: case P_EXPX12: {
       outputw_fp12(conj(cyclotomic_exp_x(inputw_fp12(3, 0))), 5, 0);
-      return B.compile("expx", EXPX_W);
+      return id == P_EXPX ? B.compile("expx", EXPX_W) : B.compile("expx12", 12);
     }
     case P_FE_MID1: {
       SFp12 a = inputw_fp12(3, 0), b = inputw_fp12(5, 0);

@@ -28,6 +28,8 @@ enum ProgId {
   P_T_SWU, P_T_ISO, P_T_CLEAR,   // test-only pieces of hash-to-G2 (unit parity against golden vectors): SWU map, 3-isogeny, cofactor clearing
   P_H2C_C,             // projective point (3) -> clearCofactor -> projective hash point (6), norm of Z (7)      (index.ts:489, 659-672)
   P_MILLER_RAW2,       // two (G1, G2) pairs per item -> raw Fp12 of millerLoop x millerLoop with a shared accumulator (one Fp12 squaring per bit)
+  P_EXPX12,            // EXPX compiled for 12 lanes per item (5 items per wave instead of 4): used when a launch is large enough to
+                       // keep >= 3 waves per SIMD anyway (an Fp12 op has exactly 12 lane-ops, so no lane idles)
   P_G1_MUL, P_G2_MUL,            // [k]P for per-item 256-bit scalars: point (buf 0 / 1), scalar 32 B (buf 2) -> projective (3), norm of Z (4)   (getPublicKey / sign, index.ts:738-752)
   P_COUNT
 };

@@ -178,3 +178,15 @@ def test_miller_shared_accumulator(sim, oracle, golden):
     for i in range(n):
         ref = oracle.miller_product(g1[192 * i:192 * i + 192], g2[384 * i:384 * i + 384], final_exp=False)
         assert out.raw[576 * i:576 * i + 576] == ref, i
+
+
+def test_expx_12_lane_variant(sim, oracle, golden):
+    """EXPX12 (12 lanes per item, 5 items per wave: the large-launch variant of the exponentiation by x) inside the full
+    final exponentiation; 7 items exercise a partially filled second wave"""
+    n = 7
+    g1, g2 = _points(golden, n)
+    F = C.create_string_buffer(vmsim_py.F12 * n); N = C.create_string_buffer(vmsim_py.RAW * n); out = C.create_string_buffer(576 * n)
+    vmsim_py.run(sim, 'MILLER_FE', n, {0: (C.create_string_buffer(g1, len(g1)), 96), 1: (C.create_string_buffer(g2, len(g2)), 192), 3: (F, vmsim_py.F12), 4: (N, vmsim_py.RAW)})
+    vmsim_py.final_exp(sim, n, F, N, out, expx='EXPX12')
+    for i in range(n):
+        assert out.raw[576 * i:576 * (i + 1)] == hx(golden['pairs'][i]['pairing']), i

@@ -17,7 +17,7 @@ def raw_elem(v):
 
 
 PROGS = ['MILLER_BYTES', 'MILLER_RAW', 'MILLER_FE', 'NORM_RAW', 'NORM_BYTES', 'FE_EASY', 'EXPX', 'FE_MID1', 'FE_MID2', 'FE_FINAL', 'MUL2', 'RAW_TO_BYTES', 'G1_VALIDATE', 'G2_VALIDATE', 'G1_DEC_A', 'G1_DEC_B', 'G2_DEC_A', 'G2_DEC_B', 'H2C_A', 'H2C_B',
-         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'G1_MUL', 'G2_MUL']
+         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'EXPX12', 'G1_MUL', 'G2_MUL']
 P = {n: i for i, n in enumerate(PROGS)}
 
 
@@ -38,19 +38,19 @@ def run(lib, prog, n, bufs):
     assert r == 0
 
 
-def final_exp(lib, n, F, N, out):
+def final_exp(lib, n, F, N, out, expx='EXPX'):
     """The launch sequence of final_exp_pipeline() in csrc/nbls_api.cpp, on the simulator."""
     NI = C.create_string_buffer(RAW * n)
     T = [C.create_string_buffer(F12 * n) for _ in range(7)]
     lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
     run(lib, 'FE_EASY', n, {3: (F, F12), 4: (NI, RAW), 5: (T[0], F12)})
-    run(lib, 'EXPX', n, {3: (T[0], F12), 5: (T[1], F12)})
+    run(lib, expx, n, {3: (T[0], F12), 5: (T[1], F12)})
     run(lib, 'FE_MID1', n, {3: (T[0], F12), 5: (T[1], F12), 6: (T[2], F12)})
-    run(lib, 'EXPX', n, {3: (T[2], F12), 5: (T[3], F12)})
-    run(lib, 'EXPX', n, {3: (T[3], F12), 5: (T[4], F12)})
-    run(lib, 'EXPX', n, {3: (T[4], F12), 5: (T[6], F12)})
+    run(lib, expx, n, {3: (T[2], F12), 5: (T[3], F12)})
+    run(lib, expx, n, {3: (T[3], F12), 5: (T[4], F12)})
+    run(lib, expx, n, {3: (T[4], F12), 5: (T[6], F12)})
     run(lib, 'FE_MID2', n, {3: (T[6], F12), 5: (T[1], F12), 6: (T[5], F12)})
-    run(lib, 'EXPX', n, {3: (T[5], F12), 5: (T[6], F12)})
+    run(lib, expx, n, {3: (T[5], F12), 5: (T[6], F12)})
     bufs = {i: (T[i], F12) for i in range(7)}
     bufs[7] = (out, 576)
     run(lib, 'FE_FINAL', n, bufs)
