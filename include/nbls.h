@@ -80,6 +80,12 @@ int nbls_hash_to_g2_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const ui
 int nbls_g1_sum(nbls_ctx* ctx, size_t n, const uint8_t* pts96, uint8_t* out96, int8_t* status);
 int nbls_g2_sum(nbls_ctx* ctx, size_t n, const uint8_t* pts192, uint8_t* out192, int8_t* status);
 
+/* PointG1.toHex(true) / toRawBytes(true) (index.ts:355-371) and PointG2.toSignature (index.ts:586-602) for n NON-ZERO affine points:
+ * x with the compression flag (bit 383) and the sign flag (bit 381) = floor(2y / p).  The zero point (not representable as
+ * affine wire bytes; the sum / multiplication calls report it as status 1) encodes as 0xc0 00...00 on the caller's side. */
+int nbls_g1_compress_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, uint8_t* out48);
+int nbls_g2_compress_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, uint8_t* out96);
+
 /* [k_i]P_i for per-item scalars (32 bytes big-endian each; any value, the reference reduces mod r first: normalizePrivKey
  * index.ts:269-279).  g1_aff == NULL multiplies the G1 generator: the core of getPublicKey / PointG1.fromPrivateKey
  * (index.ts:350-353, 738-740).  Double-and-add-always ladder: instruction stream and memory access pattern do not depend on

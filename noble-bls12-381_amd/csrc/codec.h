@@ -18,6 +18,20 @@ static inline SFp gt_half(const SFp& v_std) { return cmp_gt(v_std, raw_const(NBL
 static inline SFp2 fp2_b() { return {scale(fp_one(), 4), scale(fp_one(), 4)}; }
 static inline SFp2 mul_i(const SFp2& a) { return {-a.c1, a.c0}; }
 
+// ---------------------------------------------------------------- PointG1.toHex(true) / PointG2.toSignature of non-zero affine points
+// (index.ts:359-371, 586-602): x plus the compression flag 2^383 and the sign flag 2^381 * floor(2y / p)
+static inline void g1_compress(int in_buf, int out_buf) {
+  SFp x = input_raw(in_buf, 0), y = input_raw(in_buf, 48);
+  SFp flag = gt_half(y);
+  output_raw(x + select(flag, raw_const(NBLS_POW2_381_RAW), SFp()) + raw_const(NBLS_POW2_383_RAW), out_buf, 0);
+}
+static inline void g2_compress(int in_buf, int out_buf) {
+  SFp x0 = input_raw(in_buf, 0), x1 = input_raw(in_buf, 48), y0 = input_raw(in_buf, 96), y1 = input_raw(in_buf, 144);
+  SFp flag = select(is_zero(y1), gt_half(y0), gt_half(y1));      // tmp = y1 > 0 ? y1 * 2 : y0 * 2
+  output_raw(x1 + select(flag, raw_const(NBLS_POW2_381_RAW), SFp()) + raw_const(NBLS_POW2_383_RAW), out_buf, 0);
+  output_raw(x0, out_buf, 48);
+}
+
 // ---------------------------------------------------------------- PointG1.fromHex, 48-byte compressed (index.ts:301-315, 325)
 // phase A: x and x^3 + 4;  [kernel: (x^3+4)^((p+1)/4)];  phase B: check, sign, validity
 static inline void g1_decompress_A(int in_buf, int x_buf, int rhs_buf) {

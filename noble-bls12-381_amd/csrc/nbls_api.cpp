@@ -559,6 +559,19 @@ static int sum_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* pts, uint8_
 EXPORT int nbls_g1_sum(nbls_ctx* ctx, size_t n, const uint8_t* pts96, uint8_t* out96, int8_t* status) { return sum_host(ctx, false, n, pts96, out96, status); }
 EXPORT int nbls_g2_sum(nbls_ctx* ctx, size_t n, const uint8_t* pts192, uint8_t* out192, int8_t* status) { return sum_host(ctx, true, n, pts192, out192, status); }
 
+// PointG1.toHex(true) / PointG2.toSignature for non-zero affine points (index.ts:359-371, 586-602): bulk serialisation
+static int compress_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* aff, uint8_t* out) {
+  if (!ctx || (n && (!aff || !out))) return NBLS_EINVAL; if (!n) return NBLS_OK;
+  const size_t a = g2 ? 192 : 96, c = a / 2;
+  LOCKED(ctx); HostIO io{ctx}; void *d = io.alloc(n * a), *o = io.alloc(n * c); if (!d || !o) return NBLS_EHIP;
+  HIPCHK(hipMemcpyAsync(d, aff, n * a, hipMemcpyHostToDevice, s));
+  int r = run(ctx, g2 ? P_G2_COMPRESS : P_G1_COMPRESS, n, {B(0, d, a), B(2, o, c)}, s); if (r) return r;
+  HIPCHK(hipMemcpyAsync(out, o, n * c, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+  return NBLS_OK;
+}
+EXPORT int nbls_g1_compress_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, uint8_t* out48) { return compress_host(ctx, false, n, g1_aff, out48); }
+EXPORT int nbls_g2_compress_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, uint8_t* out96) { return compress_host(ctx, true, n, g2_aff, out96); }
+
 // [k_i]P_i for per-item 256-bit big-endian scalars (pt_stride 0 = one point for all items): ladder -> inversion -> affine
 static int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, size_t pt_stride, const void* d_scalars, void* d_out, void* d_status, hipStream_t s) {
   const size_t a = g2 ? 192 : 96, p = g2 ? 6 * RAW : 3 * RAW;

@@ -308,6 +308,8 @@ static Program build(ProgId id) {
       outputw(q.x.c0, 6, 0); outputw(q.x.c1, 6, 48); outputw(q.y.c0, 6, 96); outputw(q.y.c1, 6, 144); outputw(q.z.c0, 6, 192); outputw(q.z.c1, 6, 240);
       return B.compile(id == P_T_ISO ? "t_iso" : "t_clear", 8);
     }
+    case P_G1_COMPRESS: g1_compress(0, 2); return B.compile("g1_compress", 2);
+    case P_G2_COMPRESS: g2_compress(0, 2); return B.compile("g2_compress", 4);
     case P_G1_MUL: {
       SFp x = input(0, 0), y = input(0, 48);
       SFp k = input_raw(2, 0, 32);

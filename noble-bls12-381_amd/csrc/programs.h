@@ -30,6 +30,7 @@ enum ProgId {
   P_MILLER_RAW2,       // two (G1, G2) pairs per item -> raw Fp12 of millerLoop x millerLoop with a shared accumulator (one Fp12 squaring per bit)
   P_EXPX12,            // EXPX compiled for 12 lanes per item (5 items per wave instead of 4): used when a launch is large enough to
                        // keep >= 3 waves per SIMD anyway (an Fp12 op has exactly 12 lane-ops, so no lane idles)
+  P_G1_COMPRESS, P_G2_COMPRESS,   // affine wire point (buf 0) -> 48 / 96 compressed bytes (buf 2)   (PointG1.toHex(true) index.ts:359-371, PointG2.toSignature 586-602)
   P_G1_MUL, P_G2_MUL,            // [k]P for per-item 256-bit scalars: point (buf 0 / 1), scalar 32 B (buf 2) -> projective (3), norm of Z (4)   (getPublicKey / sign, index.ts:738-752)
   P_COUNT
 };

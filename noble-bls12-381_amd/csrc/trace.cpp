@@ -83,6 +83,12 @@ void output(const SFp& x, int buf, int off) {
   B->add_node(n);
 }
 
+// 48 big-endian bytes <- a raw integer below 2^384 held in a slot (no Montgomery conversion, no reduction mod p)
+void output_raw(const SFp& x, int buf, int off) {
+  Node n; n.kind = K_STORE; n.p0 = 1; n.a0 = materialize(x); n.buf = buf; n.off = off; n.live = true;
+  Builder::cur()->add_node(n);
+}
+
 int Builder::kp_atom(int k) {
   assert(k >= 1 && k <= 64);
   u32 P[NLIMBS] = NBLS_P_INIT, acc[NLIMBS] = {0};
@@ -288,7 +294,7 @@ Program Builder::compile(const std::string& name, int W) {
   // 4. list scheduling.  Ready queues per (kind, p0).
   // DOT lane-ops are bucketed by weight class so that a step's lanes do similar amounts of work (step time = max k)
   auto dot_class = [&](const Node& n) { size_t k = n.prods.size(); return k <= 2 ? 0 : 1; };
-  auto qkey = [&](const Node& n) { return (int)n.kind * 256 + ((n.kind == K_CMP || n.kind == K_FLAG || n.kind == K_LOAD) ? n.p0 : n.kind == K_DOT ? dot_class(n) : 0); };
+  auto qkey = [&](const Node& n) { return (int)n.kind * 256 + ((n.kind == K_CMP || n.kind == K_FLAG || n.kind == K_LOAD || n.kind == K_STORE) ? n.p0 : n.kind == K_DOT ? dot_class(n) : 0); };
   auto cmp = [&](int a, int b) { return nodes[a].height < nodes[b].height || (nodes[a].height == nodes[b].height && a > b); };
   typedef std::priority_queue<int, std::vector<int>, decltype(cmp)> PQ;
   std::map<int, PQ> ready;

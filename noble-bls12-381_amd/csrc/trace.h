@@ -196,6 +196,7 @@ static inline SFp constant(const u32* mont_limbs) {
   return SFp(B->const_atom(mont_limbs));
 }
 SFp input(int buf, int off);          // big-endian wire bytes -> Montgomery value
+void output_raw(const SFp& x, int buf, int off);       // raw integer (< 2^384) -> 48 big-endian bytes, no reduction
 SFp input_raw(int buf, int off, int nbytes = 48);   // big-endian integer of nbytes (multiple of 4, <= 48), NOT in Montgomery form
 SFp to_mont(const SFp& raw);          // raw integer (< 2^384) -> Montgomery value
 SFp raw_const(const u32* limbs);      // constant raw integer

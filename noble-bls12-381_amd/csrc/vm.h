@@ -18,7 +18,7 @@ enum StepKind : uint8_t {
   K_LOAD = 0,    // slot <- p0 (0 = 48) big-endian bytes of an input buffer (raw integer, < 2^384)
   K_MUL = 1,     // (retired: the first engine of this round; K_DOT subsumes it)
   K_LIN = 2,     // slot <- sum of up to 7 +-slots (a k*p constant term keeps it non-negative), optionally halved
-  K_STORE = 3,   // 48 big-endian bytes of an output buffer <- canonical(slot)   (slot must hold value/R already)
+  K_STORE = 3,   // 48 big-endian bytes of an output buffer <- canonical(slot)   (slot must hold value/R already); p0 = 1: the raw integer as is
   K_LOADW = 4,   // slot <- one raw element (14 limbs) of a scratch buffer
   K_STOREW = 5,  // scratch buffer <- the 14 limbs of slot
   K_ISZ = 6,     // slot <- (value == 0 mod p) ? 1 : 0   (raw integer flag)

@@ -304,7 +304,7 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, 
       u32 w0 = d[0], off = d[1];
       u32 X[NL], w[12];
       ld14(X, lds, slot_addr(w0 & 0xffff, cx.inst));
-      csub_p(X);
+      if (st.p0 == 0) csub_p(X);     // p0 = 1: raw 384-bit integer (compressed encodings carry flag bits above bit 380)
       limbs_to_words(w, X);
       if (cx.live) {
         const IOBuf& b = bufs[(w0 >> 16) & 7];

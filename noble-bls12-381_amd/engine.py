@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PROGRAMS = ['miller_bytes', 'miller_raw', 'miller_fe', 'norm_raw', 'norm_bytes', 'fe_easy', 'expx', 'fe_mid1', 'fe_mid2', 'fe_final', 'fp12_mul2', 'raw_to_bytes',
             'g1_validate', 'g2_validate', 'g1_dec_a', 'g1_dec_b', 'g2_dec_a', 'g2_dec_b', 'h2c_a', 'h2c_b',
-            'g1_to_proj', 'g1_add2', 'g1_norm', 'g1_to_affine', 'g2_to_proj', 'g2_add2', 'g2_norm', 'g2_to_affine', 't_swu', 't_iso', 't_clear', 'h2c_c', 'miller_raw2', 'expx12', 'g1_mul', 'g2_mul']
+            'g1_to_proj', 'g1_add2', 'g1_norm', 'g1_to_affine', 'g2_to_proj', 'g2_add2', 'g2_norm', 'g2_to_affine', 't_swu', 't_iso', 't_clear', 'h2c_c', 'miller_raw2', 'expx12', 'g1_compress', 'g2_compress', 'g1_mul', 'g2_mul']
 DST_DEFAULT = b'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_'   # htfDefaults.DST, reference index.ts:64
 
 
@@ -45,6 +45,8 @@ def load_library():
     lib.nbls_hash_to_g2_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp]
     lib.nbls_g1_sum.argtypes = [vp, sz, vp, vp, vp]
     lib.nbls_g2_sum.argtypes = [vp, sz, vp, vp, vp]
+    lib.nbls_g1_compress_batch.argtypes = [vp, sz, vp, vp]
+    lib.nbls_g2_compress_batch.argtypes = [vp, sz, vp, vp]
     lib.nbls_g1_mul_batch.argtypes = [vp, sz, vp, vp, vp, vp]
     lib.nbls_g2_mul_batch.argtypes = [vp, sz, vp, vp, vp, vp]
     lib.nbls_sign_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, vp]
@@ -165,12 +167,21 @@ class Engine:
         z1 = x1 + ((tmp // cls.P_MOD) << 381) + (1 << 383)
         return z1.to_bytes(48, 'big') + x0.to_bytes(48, 'big')
 
+    def compress_batch(self, aff, g2=False):
+        """PointG1.toHex(true) / PointG2.toSignature for a batch of non-zero affine points, on the GPU"""
+        sz = 192 if g2 else 96
+        n = len(aff) // sz
+        out = C.create_string_buffer(max(n * sz // 2, 1))
+        self._chk((self.lib.nbls_g2_compress_batch if g2 else self.lib.nbls_g1_compress_batch)(self.h, n, aff, out))
+        return out.raw[:n * sz // 2]
+
     def get_public_keys(self, keys):
         """getPublicKey for a batch of private keys -> list of 48-byte compressed keys; raises like the reference on a zero key"""
         aff, st = self.point_mul_batch(keys)
         if any(st):
             raise NblsError('Private key must be 0 < key < CURVE.r')
-        return [self.compress_g1(aff[96 * i:96 * i + 96]) for i in range(len(keys))]
+        c = self.compress_batch(aff)
+        return [c[48 * i:48 * i + 48] for i in range(len(keys))]
 
     def sign_batch_affine(self, msgs, keys, dst=DST_DEFAULT):
         """nbls_sign_batch as is: (n * 192 affine signature bytes, status bytes)"""
@@ -185,7 +196,8 @@ class Engine:
         aff, st = self.sign_batch_affine(msgs, keys, dst)
         if any(st):
             raise NblsError('Private key must be 0 < key < CURVE.r')
-        return [self.compress_g2(aff[192 * i:192 * i + 192]) for i in range(len(msgs))]
+        c = self.compress_batch(aff, g2=True)
+        return [c[96 * i:96 * i + 96] for i in range(len(msgs))]
 
     def verify_batch(self, sig96, msgs, pks48, dst=DST_DEFAULT):
         """-> True/False; raises NblsError where the reference throws while decoding its arguments"""

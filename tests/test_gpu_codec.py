@@ -115,3 +115,25 @@ def test_hash_to_g2_message_and_dst_lengths(eng, oracle):
         out = eng.hash_to_g2_batch(sub, dst)
         for i, m in enumerate(sub):
             assert out[192 * i:192 * i + 192] == oracle.hash_to_g2(m, dst)[1], (len(m), len(dst))
+
+
+def test_compress_on_device(eng, oracle, golden, testdata):
+    """nbls_g1_compress_batch / nbls_g2_compress_batch: the reference-generated codec vectors, the zkcrypto compressed
+    vectors (multiples of the generators), and decompress(compress(P)) == P on random points incl. both sign flags"""
+    for g2 in (False, True):
+        vs = [v for v in golden['codec']['g2' if g2 else 'g1'] if v['result'] == 'ok']
+        out = eng.compress_batch(b''.join(hx(v['aff']) for v in vs), g2)
+        e = 96 if g2 else 48
+        assert [out[e * i:e * i + e] for i in range(len(vs))] == [hx(v['hex']) for v in vs]
+    g1, g2g = oracle.g1_generator(), oracle.g2_generator()
+    pts1 = b''.join(oracle.g1_mul(g1, k)[1] for k in range(1, 40))
+    pts2 = b''.join(oracle.g2_mul(g2g, k)[1] for k in range(1, 40))
+    c1, c2 = eng.compress_batch(pts1), eng.compress_batch(pts2, True)
+    zk1 = hx(testdata['zk_g1_compressed']) if isinstance(testdata['zk_g1_compressed'], str) else b''.join(hx(x) for x in testdata['zk_g1_compressed'])
+    zk2 = hx(testdata['zk_g2_compressed']) if isinstance(testdata['zk_g2_compressed'], str) else b''.join(hx(x) for x in testdata['zk_g2_compressed'])
+    # the zkcrypto files start with the point at infinity, then 1*G, 2*G, ...
+    assert c1 == zk1[48:48 * 40] and c2 == zk2[96:96 * 40]
+    back1, st1 = eng.decompress_batch(c1)
+    back2, st2 = eng.decompress_batch(c2, True)
+    assert back1 == pts1 and back2 == pts2 and not any(st1) and not any(st2)
+    assert any(c[0] & 0x20 for c in (c1[48 * i:48 * i + 48] for i in range(39))) and any(not (c[0] & 0x20) for c in (c1[48 * i:48 * i + 48] for i in range(39)))

@@ -190,3 +190,14 @@ def test_expx_12_lane_variant(sim, oracle, golden):
     vmsim_py.final_exp(sim, n, F, N, out, expx='EXPX12')
     for i in range(n):
         assert out.raw[576 * i:576 * (i + 1)] == hx(golden['pairs'][i]['pairing']), i
+
+
+def test_compress_programs(sim, golden):
+    """PointG1.toHex(true) / PointG2.toSignature (index.ts:359-371, 586-602) against the reference-generated codec vectors"""
+    for g2 in (False, True):
+        vs = [v for v in golden['codec']['g2' if g2 else 'g1'] if v['result'] == 'ok']
+        assert len(vs) >= 4
+        out = vmsim_py.compress(sim, b''.join(hx(v['aff']) for v in vs), g2)
+        e = 96 if g2 else 48
+        for i, v in enumerate(vs):
+            assert out[e * i:e * i + e] == hx(v['hex']), (g2, i)

@@ -17,7 +17,7 @@ def raw_elem(v):
 
 
 PROGS = ['MILLER_BYTES', 'MILLER_RAW', 'MILLER_FE', 'NORM_RAW', 'NORM_BYTES', 'FE_EASY', 'EXPX', 'FE_MID1', 'FE_MID2', 'FE_FINAL', 'MUL2', 'RAW_TO_BYTES', 'G1_VALIDATE', 'G2_VALIDATE', 'G1_DEC_A', 'G1_DEC_B', 'G2_DEC_A', 'G2_DEC_B', 'H2C_A', 'H2C_B',
-         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'EXPX12', 'G1_MUL', 'G2_MUL']
+         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'EXPX12', 'G1_COMPRESS', 'G2_COMPRESS', 'G1_MUL', 'G2_MUL']
 P = {n: i for i, n in enumerate(PROGS)}
 
 
@@ -131,3 +131,11 @@ def point_mul(lib, pts, scalars32, g2=False):
     lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
     run(lib, pre + '_TO_AFFINE', n, {3: (Pj, psz), 4: (NI, RAW), 2: (out, sz), 7: (st, 1)})
     return out.raw, st.raw
+
+
+def compress(lib, aff, g2=False):
+    sz = 192 if g2 else 96
+    n = len(aff) // sz
+    out = buf(n * sz // 2)
+    run(lib, 'G2_COMPRESS' if g2 else 'G1_COMPRESS', n, {0: (buf(aff), sz), 2: (out, sz // 2)})
+    return out.raw

@@ -227,6 +227,8 @@ def emit(path, bits, fp_t, guard, qual, rbits=RBITS):
     fp('NBLS_TOP384', (1 << 384) * RM)     # montmul(t, TOP384) = t * 2^384 * R : high part of a 64-byte integer (hash_to_field)
     fp('NBLS_HALF_P_RAW', (P - 1) // 2, raw=True)   # v > (p-1)/2  <=>  floor(2v/p) = 1 (sign flags, index.ts:314)
     fp('NBLS_MASK381_RAW', (1 << 381) - 1, raw=True)
+    fp('NBLS_POW2_381_RAW', 1 << 381, raw=True)
+    fp('NBLS_POW2_383_RAW', 1 << 383, raw=True)
     a('#define NBLS_LIMB_BITS %d\n#define NBLS_NLIMBS %d\n#define NBLS_RBITS %d' % (bits, n, rbits))
     a('#define NBLS_N0_LIMB 0x%xu' % ((-pow(P, -1, 1 << bits)) % (1 << bits)))
     a('#define NBLS_N0_64 0x%016xull' % N0_64)
