@@ -83,6 +83,15 @@ class Oracle:
     def hash_to_g2(self, msg, dst=DST_DEFAULT):
         return self.call('hash_to_g2', 192, msg, C.c_size_t(len(msg)), dst, C.c_size_t(len(dst)))
 
+    def encode_to_g2(self, msg, dst=DST_DEFAULT):
+        return self.call('encode_to_g2', 192, msg, C.c_size_t(len(msg)), dst, C.c_size_t(len(dst)))
+
+    def hash_to_g1(self, msg, dst=DST_DEFAULT):
+        return self.call('hash_to_g1', 96, msg, C.c_size_t(len(msg)), dst, C.c_size_t(len(dst)))
+
+    def encode_to_g1(self, msg, dst=DST_DEFAULT):
+        return self.call('encode_to_g1', 96, msg, C.c_size_t(len(msg)), dst, C.c_size_t(len(dst)))
+
     def hash_to_field(self, msg, dst=DST_DEFAULT):
         return self.call('hash_to_field', 192, msg, C.c_size_t(len(msg)), dst, C.c_size_t(len(dst)))
 

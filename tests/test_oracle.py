@@ -225,3 +225,28 @@ def test_signatures(oracle, golden, testdata):
     for priv, msg, sig in testdata['sign_vectors'][:24]:
         st, s = o.sign(hx(msg), hx(priv.rjust(64, '0')))
         assert st == 0 and s == hx(sig)
+
+
+def _g2_tohex_to_wire(e):
+    """PointG2.toHex() order (x.c1 || x.c0 || y.c1 || y.c0) -> affine wire order (x.c0 || x.c1 || y.c0 || y.c1)"""
+    b = hx(e)
+    return b[48:96] + b[0:48] + b[144:192] + b[96:144]
+
+
+def test_hash_and_encode_to_curve_kats(oracle, golden, testdata):
+    """every hashToCurve / encodeToCurve known-answer block of the reference's test/hashToCurve.test.ts (RFC 9380 G1/G2 RO and
+    NU suites, kilic's TESTGEN suites) and the reference-run vectors for G1 hash / G1 encode / G2 encode"""
+    fn = {('g1', 'hash'): oracle.hash_to_g1, ('g1', 'encode'): oracle.encode_to_g1, ('g2', 'hash'): oracle.hash_to_g2, ('g2', 'encode'): oracle.encode_to_g2}
+    n = 0
+    for k in testdata['h2c_kats']:
+        for v in k['vectors']:
+            st, out = fn[(k['group'], k['kind'])](hx(v['msg']), k['dst'].encode())
+            assert st == 0
+            assert out == (hx(v['expected']) if k['group'] == 'g1' else _g2_tohex_to_wire(v['expected'])), (k['suite'], v['msg'][:16])
+            n += 1
+    assert n == 36
+    for v in golden['h2c_more']:
+        m, dst = hx(v['msg']), v['dst'].encode()
+        assert oracle.hash_to_g1(m, dst)[1] == hx(v['g1_hash'])
+        assert oracle.encode_to_g1(m, dst)[1] == hx(v['g1_encode'])
+        assert oracle.encode_to_g2(m, dst)[1] == hx(v['g2_encode'])

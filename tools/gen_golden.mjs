@@ -13,7 +13,7 @@ async function main() {
   const bls = await import(pathToFileURL(path.join(refDir, 'index.mjs')).href);
   const math = await import(pathToFileURL(path.join(refDir, 'math.mjs')).href);
   const { PointG1, PointG2, pairing, Fp, Fp2, Fp12, CURVE, utils } = bls;
-  const { Fp6, calcPairingPrecomputes, millerLoop, psi, psi2, map_to_curve_simple_swu_9mod16, isogenyMapG2 } = math;
+  const { Fp6, calcPairingPrecomputes, millerLoop, psi, psi2, map_to_curve_simple_swu_9mod16, isogenyMapG2, map_to_curve_simple_swu_3mod4, isogenyMapG1 } = math;
   const hex = (u8) => Buffer.from(u8).toString('hex');
   const sha = (u8) => createHash('sha256').update(u8).digest('hex');
 
@@ -208,6 +208,24 @@ async function main() {
     out.xmd_abc_32 = hex(xmd);
   }
   out.h2c = h2c;
+  // hash / encode to G1 and encode to G2 driven through the reference itself (default DST and the RFC G1 DST), with the
+  // SWU and isogeny intermediates of the first field element
+  {
+    const other = [];
+    const g1aff = (P) => { const [x, y] = P.toAffine(); return b(x) + b(y); };
+    const more = [Buffer.alloc(0), Buffer.from('abc'), rnd('g', 1), rnd('g', 31), rnd('g', 32), rnd('g', 55), rnd('g', 56), rnd('g', 64), rnd('g', 119), rnd('g', 300)];
+    for (const dst of [utils.getDSTLabel(), 'QUUX-V01-CS02-with-BLS12381G1_XMD:SHA-256_SSWU_RO_']) {
+      for (const m of more) {
+        const u = await utils.hashToField(m, 2, { m: 1, DST: dst });
+        const [x0, y0] = map_to_curve_simple_swu_3mod4(new Fp(u[0][0]));
+        const [xi, yi] = isogenyMapG1(x0, y0);
+        other.push({ msg: hex(m), dst, u: u.map((e) => e[0].toString(16).padStart(96, '0')).join(''), swu0: b(x0) + b(y0), iso0: b(xi) + b(yi),
+          g1_hash: g1aff(await PointG1.hashToCurve(m, { DST: dst })), g1_encode: g1aff(await PointG1.encodeToCurve(m, { DST: dst })),
+          g2_encode: g2aff(await PointG2.encodeToCurve(m, { DST: dst })) });
+      }
+    }
+    out.h2c_more = other;
+  }
   {
     const [bx, by] = PointG2.BASE.multiplyUnsafe(rScalar('cc')).toAffine();
     // clearCofactor on an E2 point outside the subgroup
