@@ -75,6 +75,12 @@ int nbls_g2_decompress_batch(nbls_ctx* ctx, size_t n, const uint8_t* in96, uint8
  * offsets[i+1]); SHA-256 expand_message_xmd (index.ts:207-231) and everything after it run on the GPU. */
 int nbls_hash_to_g2_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len, uint8_t* out192);
 
+/* PointG1.hashToCurve / PointG1.encodeToCurve (index.ts:331-350) and PointG2.encodeToCurve (index.ts:491-497): hash_to_field with
+ * (count, m) = (2, 1) / (1, 1) / (1, 2), simplified SWU on the isogenous curve, isogeny, cofactor clearing.  Messages as above. */
+int nbls_hash_to_g1_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len, uint8_t* out96);
+int nbls_encode_to_g1_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len, uint8_t* out96);
+int nbls_encode_to_g2_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len, uint8_t* out192);
+
 /* Sum of n affine points: the reduce step of aggregatePublicKeys / aggregateSignatures (index.ts:771-788). *status = 1 when
  * the sum is the zero point (output then all-zero). */
 int nbls_g1_sum(nbls_ctx* ctx, size_t n, const uint8_t* pts96, uint8_t* out96, int8_t* status);
@@ -113,7 +119,7 @@ int nbls_device_synchronize(nbls_ctx* ctx);
 /* Placement study (tools/placement.py): runs one step program on n scratch items; out_blocks[3b..3b+2] = HW_ID | XCC_ID << 32, start tick, end tick of workgroup b. */
 int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks);
 /* Per-kernel HIP-event timing (benchmark roofline leg): ms[i]/counts[i] for program i, last entry = inversion kernel. */
-#define NBLS_N_PROGRAMS 40
+#define NBLS_N_PROGRAMS 64
 int nbls_timing_enable(nbls_ctx* ctx, int on);
 int nbls_timing_read(nbls_ctx* ctx, float* ms /*[NBLS_N_PROGRAMS+1]*/, uint32_t* counts /*[NBLS_N_PROGRAMS+1]*/);
 

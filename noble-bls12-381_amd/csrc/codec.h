@@ -162,6 +162,52 @@ static inline Pt<SFp2> isogeny_g2_proj(const Pt<SFp2>& p) {
   SFp2 zxd = mat(mul(p.z, xd));
   return pt_mat<SFp2>({mul(mat(mul(xn, yd)), p.z), mul(mat(mul(p.y, yn)), xd), mul(zxd, yd)});
 }
+// ---------------------------------------------------------------- G1 hash-to-curve (index.ts:331-350)
+// map_to_curve_simple_swu_3mod4 (math.ts:1272-1313) split around its exponentiation tv4^((p-3)/4)
+struct Swu1State { SFp u, tv1, xNum1, xNum2, xDen, gxd, gx1, tv2, tv4; };
+static inline Swu1State swu1_prepare(const SFp& u) {
+  Swu1State s; s.u = u;
+  SFp A = fp_const(NBLS_G1_SWU_A), Bc = fp_const(NBLS_G1_SWU_B), Z = fp_const(NBLS_G1_SWU_Z);
+  s.tv1 = mat(sqr(u));
+  SFp tv3 = mat(mul(Z, s.tv1));
+  SFp xd0 = mat(sqr(tv3) + tv3);
+  s.xNum1 = mat(mul(xd0 + fp_one(), Bc));
+  s.xNum2 = mat(mul(tv3, s.xNum1));
+  SFp xd1 = mat(-mul(A, xd0));
+  s.xDen = select(is_zero(xd1), mat(mul(A, Z)), xd1);                          // exceptional case (math.ts:1288)
+  SFp xd2 = mat(sqr(s.xDen));
+  s.gxd = mat(mul(xd2, s.xDen));
+  s.gx1 = mat(mul(mat(sqr(s.xNum1) + mul(A, xd2)), s.xNum1) + mul(Bc, s.gxd));  // x1n^3 + A x1n xd^2 + B xd^3
+  s.tv2 = mat(mul(s.gx1, s.gxd));
+  s.tv4 = mat(mul(mat(sqr(s.gxd)), s.tv2));
+  return s;
+}
+// given pw = tv4^((p-3)/4): the point on E1' projectively, (X : Y : Z) = (xNum : y xDen : xDen)
+static inline Pt<SFp> swu1_finish(const Swu1State& s, const SFp& pw) {
+  SFp y1 = mat(mul(pw, s.tv2));
+  SFp y2 = mat(mul(mat(mul(mat(mul(y1, fp_const(NBLS_G1_SWU_C2))), s.tv1)), s.u));
+  SFp ok = is_zero(mul(mat(sqr(y1)), s.gxd) - s.gx1);                           // y1^2 gxd == gx1
+  SFp xNum = select(ok, s.xNum1, s.xNum2), yPos = select(ok, y1, y2);
+  SFp flip = f_xor(is_odd(std_canon(s.u)), is_odd(std_canon(yPos)));            // sgn0_m_eq_1 (math.ts:1187-1189)
+  SFp y = select(flip, mat(-yPos), yPos);
+  return pt_mat<SFp>({xNum, mul(y, s.xDen), s.xDen});
+}
+// isogenyMapG1 (11-isogeny, math.ts:1315-1327) on a projective point: homogenised Horner, h_j = h_(j-1) X + c_j Z^j
+static inline Pt<SFp> isogeny_g1_proj(const Pt<SFp>& p) {
+  std::vector<SFp> zp(16); zp[1] = p.z;
+  for (int j = 2; j <= 15; j++) zp[j] = mat(mul(zp[j - 1], p.z));
+  auto horner = [&](const u32 (*c)[NLIMBS], int d) {
+    SFp h = fp_const(c[0]);
+    for (int j = 1; j <= d; j++) h = mat(mul(h, p.x) + mul(fp_const(c[j]), zp[j]));
+    return h;
+  };
+  SFp xn = horner(NBLS_G1_ISO_XNUM, 11), xd = horner(NBLS_G1_ISO_XDEN, 10), yn = horner(NBLS_G1_ISO_YNUM, 15), yd = horner(NBLS_G1_ISO_YDEN, 15);
+  // x' = XN / (XD Z), y' = (Y / Z) YN / YD   (XN carries Z^11, XD Z^10, YN and YD Z^15)
+  return pt_mat<SFp>({mul(xn, yd), mul(mat(mul(p.y, yn)), xd), mul(mat(mul(xd, p.z)), yd)});
+}
+// PointG1.clearCofactor (index.ts:401-405): [|x|]P + P
+static inline Pt<SFp> clear_cofactor_g1(const Pt<SFp>& P) { return pt_add(pt_mul_u64(P, NBLS_X), P); }
+
 static inline Pt<SFp2> psi_proj(const Pt<SFp2>& p) { return pt_mat<SFp2>({mul(conj(p.x), fp2_const(NBLS_PSI_X)), mul(conj(p.y), fp2_const(NBLS_PSI_Y)), conj(p.z)}); }
 static inline Pt<SFp2> psi2_proj(const Pt<SFp2>& p) { return pt_mat<SFp2>({mul_fp(p.x, fp_const(NBLS_PSI2_C1)), -p.y, p.z}); }
 // PointG2.clearCofactor (index.ts:659-672)

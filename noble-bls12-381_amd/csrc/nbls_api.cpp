@@ -15,10 +15,11 @@
 
 extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream);
 extern "C" int nbls_fp_inv_launch(unsigned n, const void* in, void* out, void* stream);
-extern "C" int nbls_xmd256_launch(unsigned n, const void* msgs, const void* offsets, const void* dst, unsigned dst_len, void* out, void* stream);
+extern "C" int nbls_xmd_launch(unsigned n, const void* msgs, const void* offsets, const void* dst, unsigned dst_len, void* out, unsigned len_in_bytes, void* stream);
 extern "C" int nbls_fp_pow_launch(unsigned n, const void* in, void* out, const void* nibbles, int nnib, void* scratch, int is_fp2, void* stream);
 
 using namespace nbls;
+static_assert(P_COUNT <= NBLS_N_PROGRAMS, "nbls_timing_read's arrays (NBLS_N_PROGRAMS + 1 entries) must cover every step program");
 static const size_t RAW = RAW_FP_BYTES;     // one raw field element in HBM scratch (14 limbs + padding)
 static const size_t F12 = 12 * RAW;        // raw Fp12
 
@@ -40,7 +41,7 @@ struct nbls_ctx {
   // general scratch pool for the codec / hash / sum pipelines (grown on demand)
   static const int NSB = 14;
   uint8_t* sb[NSB] = {nullptr}; size_t sb_cap[NSB] = {0};
-  uint8_t* nib[3] = {nullptr, nullptr, nullptr}; int nnib[3] = {0, 0, 0};   // exponent nibbles: (p+1)/4, (p^2+7)/16, (p^2-9)/16
+  uint8_t* nib[4] = {nullptr, nullptr, nullptr, nullptr}; int nnib[4] = {0, 0, 0, 0};   // exponent nibbles: (p+1)/4, (p^2+7)/16, (p^2-9)/16, (p-3)/4
   uint8_t* neg_g1 = nullptr;    // -G1 generator, affine wire bytes (verify: e(-G, S))
   uint8_t* gen_g1 = nullptr;    // G1 generator, affine wire bytes (getPublicKey)
   // side stream for the one-element chains of verifyBatch (signature decompression: a 758-bit Fp2 exponentiation on a single
@@ -130,7 +131,7 @@ static int need(nbls_ctx* ctx, int i, size_t bytes, uint8_t** out) {
   return NBLS_OK;
 }
 static int run_pow(nbls_ctx* ctx, int which, size_t n, const void* in, void* out, hipStream_t s, uint8_t* scratch = nullptr) {
-  int is_fp2 = which != 0;
+  int is_fp2 = which == 1 || which == 2;
   if (!scratch) { int r = need(ctx, 11, n * 16 * (is_fp2 ? 2 : 1) * RAW, &scratch); if (r) return r; }
   int e = nbls_fp_pow_launch((unsigned)n, in, out, ctx->nib[which], ctx->nnib[which], scratch, is_fp2, s);
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
@@ -197,9 +198,9 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
   u32 one[12 * SLOT_WORDS]; memset(one, 0, sizeof one); memcpy(one, NBLS_R1, NLIMBS * 4);
   if (hipMalloc(&ctx->one12, F12) != hipSuccess || hipMemcpy(ctx->one12, one, F12, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   {
-    const uint64_t* exps[3] = {NBLS_EXP_P_PLUS_1_DIV_4, NBLS_EXP_P2_PLUS_7_DIV_16, NBLS_EXP_P2_MINUS_9_DIV_16};
-    const int bits[3] = {NBLS_P_PLUS_1_DIV_4_BITS, NBLS_P2_PLUS_7_DIV_16_BITS, NBLS_P2_MINUS_9_DIV_16_BITS};
-    for (int k = 0; k < 3; k++) {
+    const uint64_t* exps[4] = {NBLS_EXP_P_PLUS_1_DIV_4, NBLS_EXP_P2_PLUS_7_DIV_16, NBLS_EXP_P2_MINUS_9_DIV_16, NBLS_EXP_P_MINUS_3_DIV_4};
+    const int bits[4] = {NBLS_P_PLUS_1_DIV_4_BITS, NBLS_P2_PLUS_7_DIV_16_BITS, NBLS_P2_MINUS_9_DIV_16_BITS, NBLS_P_MINUS_3_DIV_4_BITS};
+    for (int k = 0; k < 4; k++) {
       int nn = (bits[k] + 3) / 4; std::vector<uint8_t> nb(nn);
       for (int j = 0; j < nn; j++) { int lo = 4 * (nn - 1 - j); uint8_t d = 0; for (int b = 3; b >= 0; b--) { int bit = lo + b; d = (uint8_t)((d << 1) | (bit < bits[k] ? (exps[k][bit >> 6] >> (bit & 63)) & 1 : 0)); } nb[j] = d; }
       ctx->nnib[k] = nn;
@@ -519,22 +520,22 @@ EXPORT int nbls_g1_decompress_batch(nbls_ctx* ctx, size_t n, const uint8_t* in48
 EXPORT int nbls_g2_decompress_batch(nbls_ctx* ctx, size_t n, const uint8_t* in96, uint8_t* out192, int8_t* status) { return decompress_host(ctx, true, n, in96, out192, status); }
 
 // expand_message_xmd for all messages on the device (xmd_kernel.hip): uploads the message blob, the n+1 offsets and the DST
-// into the scratch pool and leaves 256 uniform bytes per message in *d_uniform.  Only a DST longer than 255 bytes is touched
+// into the scratch pool and leaves len_in_bytes (64, 128 or 256) uniform bytes per message in *d_uniform.  Only a DST longer than 255 bytes is touched
 // on the host (RFC 9380 5.3.3: replaced by its SHA-256 digest), which is per call, not per message.
-static int dev_expand(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offs, const uint8_t* dst, size_t dst_len, uint8_t** d_uniform, hipStream_t s) {
+static int dev_expand(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offs, const uint8_t* dst, size_t dst_len, uint8_t** d_uniform, hipStream_t s, unsigned len_in_bytes = 256) {
   for (size_t i = 0; i < n; i++) if (offs[i + 1] < offs[i]) return NBLS_EINVAL;
   const size_t total = offs[n] - offs[0];
   uint8_t dst_hash[32];
   if (dst_len > 255) { Sha256 c; c.update((const uint8_t*)"H2C-OVERSIZE-DST-", 17); c.update(dst, dst_len); c.final(dst_hash); dst = dst_hash; dst_len = 32; }
   uint8_t *dm, *dofs, *dd, *du; int r;
-  if ((r = need(ctx, 7, total + 4, &dm)) || (r = need(ctx, 12, (n + 1) * 4 + 256, &dofs)) || (r = need(ctx, 8, n * 256, &du))) return r;
+  if ((r = need(ctx, 7, total + 4, &dm)) || (r = need(ctx, 12, (n + 1) * 4 + 256, &dofs)) || (r = need(ctx, 8, n * (size_t)len_in_bytes, &du))) return r;
   dd = dofs + (n + 1) * 4;
   std::vector<uint32_t> rel(n + 1); for (size_t i = 0; i <= n; i++) rel[i] = offs[i] - offs[0];
   if (total) HIPCHK(hipMemcpyAsync(dm, msgs + offs[0], total, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(dofs, rel.data(), (n + 1) * 4, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(dd, dst, dst_len, hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));     // `rel` and a hashed DST live on this stack frame
-  int e = nbls_xmd256_launch((unsigned)n, dm, dofs, dd, (unsigned)dst_len, du, s);
+  int e = nbls_xmd_launch((unsigned)n, dm, dofs, dd, (unsigned)dst_len, du, len_in_bytes, s);
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
   *d_uniform = du;
   return NBLS_OK;
@@ -558,6 +559,45 @@ static int sum_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* pts, uint8_
 }
 EXPORT int nbls_g1_sum(nbls_ctx* ctx, size_t n, const uint8_t* pts96, uint8_t* out96, int8_t* status) { return sum_host(ctx, false, n, pts96, out96, status); }
 EXPORT int nbls_g2_sum(nbls_ctx* ctx, size_t n, const uint8_t* pts192, uint8_t* out192, int8_t* status) { return sum_host(ctx, true, n, pts192, out192, status); }
+
+// PointG1.hashToCurve (count = 2) / PointG1.encodeToCurve (count = 1) on 64 * count uniform bytes per message (index.ts:331-350)
+static int dev_hash_to_g1(nbls_ctx* ctx, int count, size_t n, const void* d_uniform, void* d_out, hipStream_t s) {
+  uint8_t *U, *E, *Pw, *Q, *Q2, *N, *NI, *st; int r;
+  if ((r = need(ctx, 0, n * 2 * RAW, &U)) || (r = need(ctx, 1, n * 3 * RAW, &E)) || (r = need(ctx, 2, n * 2 * RAW, &Pw)) || (r = need(ctx, 3, n * 3 * RAW, &Q)) ||
+      (r = need(ctx, 4, n * RAW, &N)) || (r = need(ctx, 5, n * RAW, &NI)) || (r = need(ctx, 6, n, &st))) return r;
+  Q2 = E;   // E (the exponentiation inputs) is free again after the pow kernel
+  const size_t us = (size_t)count * RAW;
+  if ((r = run(ctx, count == 2 ? P_H2C1_A : P_ENC1_A, n, {B(0, d_uniform, 64 * (size_t)count), B(3, U, us), B(4, E, us)}, s))) return r;
+  if ((r = run_pow(ctx, 3, (size_t)count * n, E, Pw, s))) return r;
+  if ((r = run(ctx, count == 2 ? P_H2C1_B : P_ENC1_B, n, {B(3, U, us), B(5, Pw, us), B(6, Q, 3 * RAW)}, s))) return r;
+  if ((r = run(ctx, P_G1_CLEAR, n, {B(3, Q, 3 * RAW), B(6, Q2, 3 * RAW), B(7, N, RAW)}, s))) return r;
+  if ((r = run_inv_buf(ctx, n, N, NI, s))) return r;
+  return run(ctx, P_G1_TO_AFFINE, n, {B(3, Q2, 3 * RAW), B(4, NI, RAW), B(2, d_out, 96), B(7, st, 1)}, s);
+}
+// PointG2.encodeToCurve on 128 uniform bytes per message (index.ts:491-497)
+static int dev_encode_to_g2(nbls_ctx* ctx, size_t n, const void* d_uniform, void* d_out, hipStream_t s) {
+  uint8_t *T, *E, *Pw, *Q, *N, *NI, *st; int r;
+  if ((r = need(ctx, 0, n * 2 * RAW, &T)) || (r = need(ctx, 1, n * 6 * RAW, &E)) || (r = need(ctx, 2, n * 2 * RAW, &Pw)) || (r = need(ctx, 3, n * 6 * RAW, &Q)) ||
+      (r = need(ctx, 4, n * RAW, &N)) || (r = need(ctx, 5, n * RAW, &NI)) || (r = need(ctx, 6, n, &st))) return r;
+  if ((r = run(ctx, P_ENC2_A, n, {B(0, d_uniform, 128), B(3, T, 2 * RAW), B(4, E, 2 * RAW)}, s))) return r;
+  if ((r = run_pow(ctx, 2, n, E, Pw, s))) return r;
+  if ((r = run(ctx, P_ENC2_B, n, {B(3, T, 2 * RAW), B(5, Pw, 2 * RAW), B(6, E, 6 * RAW)}, s))) return r;
+  if ((r = run(ctx, P_H2C_C, n, {B(3, E, 6 * RAW), B(6, Q, 6 * RAW), B(7, N, RAW)}, s))) return r;
+  if ((r = run_inv_buf(ctx, n, N, NI, s))) return r;
+  return run(ctx, P_G2_TO_AFFINE, n, {B(3, Q, 6 * RAW), B(4, NI, RAW), B(2, d_out, 192), B(7, st, 1)}, s);
+}
+// mode: 0 = PointG1.hashToCurve, 1 = PointG1.encodeToCurve, 2 = PointG2.encodeToCurve
+static int hash_curve_host(nbls_ctx* ctx, int mode, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len, uint8_t* out) {
+  if (!ctx || (n && (!offsets || !out || !dst))) return NBLS_EINVAL; if (!n) return NBLS_OK;
+  const size_t a = mode == 2 ? 192 : 96;
+  LOCKED(ctx); HostIO io{ctx}; void* o = io.alloc(n * a); if (!o) return NBLS_EHIP;
+  uint8_t* d; int r = dev_expand(ctx, n, msgs, offsets, dst, dst_len, &d, s, mode == 1 ? 64 : 128); if (r) return r;
+  r = mode == 2 ? dev_encode_to_g2(ctx, n, d, o, s) : dev_hash_to_g1(ctx, mode == 0 ? 2 : 1, n, d, o, s); if (r) return r;
+  HIPCHK(hipMemcpyAsync(out, o, n * a, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); return NBLS_OK;
+}
+EXPORT int nbls_hash_to_g1_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len, uint8_t* out96) { return hash_curve_host(ctx, 0, n, msgs, offsets, dst, dst_len, out96); }
+EXPORT int nbls_encode_to_g1_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len, uint8_t* out96) { return hash_curve_host(ctx, 1, n, msgs, offsets, dst, dst_len, out96); }
+EXPORT int nbls_encode_to_g2_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len, uint8_t* out192) { return hash_curve_host(ctx, 2, n, msgs, offsets, dst, dst_len, out192); }
 
 // PointG1.toHex(true) / PointG2.toSignature for non-zero affine points (index.ts:359-371, 586-602): bulk serialisation
 static int compress_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* aff, uint8_t* out) {

@@ -308,6 +308,42 @@ static Program build(ProgId id) {
       outputw(q.x.c0, 6, 0); outputw(q.x.c1, 6, 48); outputw(q.y.c0, 6, 96); outputw(q.y.c1, 6, 144); outputw(q.z.c0, 6, 192); outputw(q.z.c1, 6, 240);
       return B.compile(id == P_T_ISO ? "t_iso" : "t_clear", 8);
     }
+    case P_H2C1_A: case P_ENC1_A: {
+      const int count = id == P_H2C1_A ? 2 : 1;
+      for (int k = 0; k < count; k++) {
+        SFp u = field_elem_from_64(0, 64 * k);
+        outputw(u, 3, 48 * k);
+        outputw(swu1_prepare(u).tv4, 4, 48 * k);
+      }
+      return B.compile(id == P_H2C1_A ? "h2c1_a" : "enc1_a", 4);
+    }
+    case P_H2C1_B: case P_ENC1_B: {
+      const int count = id == P_H2C1_B ? 2 : 1;
+      Pt<SFp> pts[2];
+      for (int k = 0; k < count; k++) pts[k] = swu1_finish(swu1_prepare(inputw(3, 48 * k)), inputw(5, 48 * k));
+      Pt<SFp> q = isogeny_g1_proj(count == 2 ? pt_add_generic(pts[0], pts[1]) : pts[0]);   // index.ts:336-337 / 348
+      outputw(q.x, 6, 0); outputw(q.y, 6, 48); outputw(q.z, 6, 96);
+      return B.compile(id == P_H2C1_B ? "h2c1_b" : "enc1_b", 8);
+    }
+    case P_G1_CLEAR: {
+      Pt<SFp> q = clear_cofactor_g1({inputw(3, 0), inputw(3, 48), inputw(3, 96)});
+      outputw(q.x, 6, 0); outputw(q.y, 6, 48); outputw(q.z, 6, 96);
+      outputw(q.z, 7, 0);
+      return B.compile("g1_clear", 8);
+    }
+    case P_ENC2_A: {
+      SFp2 t = {field_elem_from_64(0, 0), field_elem_from_64(0, 64)};
+      outputw(t.c0, 3, 0); outputw(t.c1, 3, 48);
+      SwuState st = swu_prepare(t);
+      outputw(st.uv15.c0, 4, 0); outputw(st.uv15.c1, 4, 48);
+      return B.compile("enc2_a", 8);
+    }
+    case P_ENC2_B: {
+      SFp2 t = {inputw(3, 0), inputw(3, 48)}, gp = {inputw(5, 0), inputw(5, 48)};
+      Pt<SFp2> q = isogeny_g2_proj(swu_finish(swu_prepare(t), gp));              // index.ts:494-495
+      outputw(q.x.c0, 6, 0); outputw(q.x.c1, 6, 48); outputw(q.y.c0, 6, 96); outputw(q.y.c1, 6, 144); outputw(q.z.c0, 6, 192); outputw(q.z.c1, 6, 240);
+      return B.compile("enc2_b", 8);
+    }
     case P_G1_COMPRESS: g1_compress(0, 2); return B.compile("g1_compress", 2);
     case P_G2_COMPRESS: g2_compress(0, 2); return B.compile("g2_compress", 4);
     case P_G1_MUL: {

@@ -31,6 +31,11 @@ enum ProgId {
   P_EXPX12,            // EXPX compiled for 12 lanes per item (5 items per wave instead of 4): used when a launch is large enough to
                        // keep >= 3 waves per SIMD anyway (an Fp12 op has exactly 12 lane-ops, so no lane idles)
   P_G1_COMPRESS, P_G2_COMPRESS,   // affine wire point (buf 0) -> 48 / 96 compressed bytes (buf 2)   (PointG1.toHex(true) index.ts:359-371, PointG2.toSignature 586-602)
+  // G1 hash-to-curve / encode-to-curve and G2 encode-to-curve (index.ts:331-350, 491-497); "count" field elements per message
+  P_H2C1_A, P_ENC1_A,   // 64 * count uniform bytes (buf 0) -> u (3), tv4 = gx1 gxd^3 (4)                              (math.ts:1272-1299)
+  P_H2C1_B, P_ENC1_B,   // u (3), tv4^((p-3)/4) (5) -> SWU point(s), sum on E1', 11-isogeny: projective point on E1 (6)  (math.ts:1300-1313, 1327)
+  P_G1_CLEAR,           // projective point (3) -> clearCofactor -> projective point (6), Z (7)                            (index.ts:401-405)
+  P_ENC2_A, P_ENC2_B,   // G2 encodeToCurve: 128 uniform bytes (0) -> u (3), SWU exponentiation input (4) ; u (3), power (5) -> projective point on E2 (6)
   P_G1_MUL, P_G2_MUL,            // [k]P for per-item 256-bit scalars: point (buf 0 / 1), scalar 32 B (buf 2) -> projective (3), norm of Z (4)   (getPublicKey / sign, index.ts:738-752)
   P_COUNT
 };

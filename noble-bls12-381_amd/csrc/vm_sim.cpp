@@ -54,7 +54,7 @@ __attribute__((visibility("default"))) int nbls_sim_run(int prog, unsigned n_ite
 __attribute__((visibility("default"))) void nbls_sim_fp_inv(unsigned n, const u32* in, u32* out) {
   for (unsigned k = 0; k < n; k++) { u32 r[NL]; fp_mont_inverse(r, in + SLOT_WORDS * k); memcpy(out + SLOT_WORDS * k, r, NL * 4); out[SLOT_WORDS * k + 14] = out[SLOT_WORDS * k + 15] = 0; }
 }
-// out = in^e; which: 0 = (p+1)/4 on Fp, 1 = (p^2+7)/16 on Fp2, 2 = (p^2-9)/16 on Fp2 (stand-ins for the pow kernels; raw elements of 16 words)
+// out = in^e; which: 0 = (p+1)/4 on Fp, 1 = (p^2+7)/16 on Fp2, 2 = (p^2-9)/16 on Fp2, 3 = (p-3)/4 on Fp (stand-ins for the pow kernels; raw elements of 16 words)
 static void mmh(u32* r, const u32* a, const u32* b) { u32 t[NL]; mont_mul28(t, a, b); memcpy(r, t, NL * 4); }
 static void addh(u32* r, const u32* a, const u32* b) { u32 t[NL]; for (int i = 0; i < NL; i++) t[i] = a[i] + b[i]; carry_norm(t); memcpy(r, t, NL * 4); }
 static void subh(u32* r, const u32* a, const u32* b) { const u32 BIAS[NL] = NBLS_BIAS16_28; u32 t[NL]; for (int i = 0; i < NL; i++) t[i] = a[i] + BIAS[i] - b[i]; carry_norm(t); memcpy(r, t, NL * 4); }
@@ -66,10 +66,10 @@ static void fp2mulh(u32* r, const u32* a, const u32* b) {   // elements: c0 at [
   memset(r, 0, 32 * 4); memcpy(r, r0, NL * 4); memcpy(r + 16, r1, NL * 4);
 }
 __attribute__((visibility("default"))) void nbls_sim_fp_pow(unsigned n, const u32* in, u32* out, int which) {
-  const uint64_t* e = which == 0 ? NBLS_EXP_P_PLUS_1_DIV_4 : which == 1 ? NBLS_EXP_P2_PLUS_7_DIV_16 : NBLS_EXP_P2_MINUS_9_DIV_16;
-  int bits = which == 0 ? NBLS_P_PLUS_1_DIV_4_BITS : which == 1 ? NBLS_P2_PLUS_7_DIV_16_BITS : NBLS_P2_MINUS_9_DIV_16_BITS;
+  const uint64_t* e = which == 0 ? NBLS_EXP_P_PLUS_1_DIV_4 : which == 1 ? NBLS_EXP_P2_PLUS_7_DIV_16 : which == 2 ? NBLS_EXP_P2_MINUS_9_DIV_16 : NBLS_EXP_P_MINUS_3_DIV_4;
+  int bits = which == 0 ? NBLS_P_PLUS_1_DIV_4_BITS : which == 1 ? NBLS_P2_PLUS_7_DIV_16_BITS : which == 2 ? NBLS_P2_MINUS_9_DIV_16_BITS : NBLS_P_MINUS_3_DIV_4_BITS;
   for (unsigned k = 0; k < n; k++) {
-    if (which == 0) {
+    if (which == 0 || which == 3) {
       u32 acc[16] = {0}; memcpy(acc, NBLS_R1, NL * 4);
       for (int i = bits - 1; i >= 0; i--) { mmh(acc, acc, acc); if ((e[i >> 6] >> (i & 63)) & 1) mmh(acc, acc, in + 16 * k); }
       memcpy(out + 16 * k, acc, 64);

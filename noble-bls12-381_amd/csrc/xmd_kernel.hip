@@ -62,9 +62,10 @@ struct DevSha {
   }
 };
 
-// out[256 * i ..] = expand_message_xmd(msg_i, DST, 256); dst_len <= 255 (longer DSTs are pre-hashed by the caller, RFC 9380 5.3.3)
-extern "C" __global__ void __launch_bounds__(64) nbls_xmd256_kernel(unsigned n, const uint8_t* __restrict__ msgs, const u32* __restrict__ offsets,
-                                                                    const uint8_t* __restrict__ dst, unsigned dst_len, uint8_t* __restrict__ out) {
+// out[len * i ..] = expand_message_xmd(msg_i, DST, len), len = 64, 128 or 256 (hash_to_field for G1 encode / G1 hash, G2 encode / G2 hash);
+// dst_len <= 255 (longer DSTs are pre-hashed by the caller, RFC 9380 5.3.3)
+extern "C" __global__ void __launch_bounds__(64) nbls_xmd_kernel(unsigned n, const uint8_t* __restrict__ msgs, const u32* __restrict__ offsets,
+                                                                 const uint8_t* __restrict__ dst, unsigned dst_len, uint8_t* __restrict__ out, unsigned len) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint8_t* m = msgs + offsets[i];
@@ -75,12 +76,12 @@ extern "C" __global__ void __launch_bounds__(64) nbls_xmd256_kernel(unsigned n, 
   c.init();
   for (int k = 0; k < 16; k++) c.word(0);
   for (u32 k = 0; k < mlen; k++) c.byte(m[k]);
-  c.byte(0x01); c.byte(0x00); c.byte(0x00);                     // len_in_bytes = 256, then I2OSP(0, 1)
+  c.byte(len >> 8); c.byte(len & 0xff); c.byte(0x00);           // I2OSP(len_in_bytes, 2), then I2OSP(0, 1)
   for (u32 k = 0; k < dst_len; k++) c.byte(dst[k]);
   c.byte(dst_len);
   c.finish(b0);
   // b_1 = H(b_0 || 1 || DST_prime) ; b_j = H((b_0 xor b_(j-1)) || j || DST_prime)
-  for (u32 j = 1; j <= 8; j++) {
+  for (u32 j = 1; j <= len / 32; j++) {
     c.init();
 #pragma unroll
     for (int k = 0; k < 8; k++) c.word(j == 1 ? b0[k] : (b0[k] ^ bi[k]));
@@ -88,15 +89,15 @@ extern "C" __global__ void __launch_bounds__(64) nbls_xmd256_kernel(unsigned n, 
     for (u32 k = 0; k < dst_len; k++) c.byte(dst[k]);
     c.byte(dst_len);
     c.finish(bi);
-    u32* o = (u32*)(out + 256 * (size_t)i + 32 * (j - 1));
+    u32* o = (u32*)(out + (size_t)len * i + 32 * (j - 1));
 #pragma unroll
     for (int k = 0; k < 8; k++) o[k] = __builtin_bswap32(bi[k]);
   }
 }
 }  // namespace nbls
 
-extern "C" int nbls_xmd256_launch(unsigned n, const void* msgs, const void* offsets, const void* dst, unsigned dst_len, void* out, void* stream) {
+extern "C" int nbls_xmd_launch(unsigned n, const void* msgs, const void* offsets, const void* dst, unsigned dst_len, void* out, unsigned len_in_bytes, void* stream) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(nbls::nbls_xmd256_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, (const uint8_t*)msgs, (const nbls::u32*)offsets, (const uint8_t*)dst, dst_len, (uint8_t*)out);
+  hipLaunchKernelGGL(nbls::nbls_xmd_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, (const uint8_t*)msgs, (const nbls::u32*)offsets, (const uint8_t*)dst, dst_len, (uint8_t*)out, len_in_bytes);
   return (int)hipGetLastError();
 }

@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PROGRAMS = ['miller_bytes', 'miller_raw', 'miller_fe', 'norm_raw', 'norm_bytes', 'fe_easy', 'expx', 'fe_mid1', 'fe_mid2', 'fe_final', 'fp12_mul2', 'raw_to_bytes',
             'g1_validate', 'g2_validate', 'g1_dec_a', 'g1_dec_b', 'g2_dec_a', 'g2_dec_b', 'h2c_a', 'h2c_b',
-            'g1_to_proj', 'g1_add2', 'g1_norm', 'g1_to_affine', 'g2_to_proj', 'g2_add2', 'g2_norm', 'g2_to_affine', 't_swu', 't_iso', 't_clear', 'h2c_c', 'miller_raw2', 'expx12', 'g1_compress', 'g2_compress', 'g1_mul', 'g2_mul']
+            'g1_to_proj', 'g1_add2', 'g1_norm', 'g1_to_affine', 'g2_to_proj', 'g2_add2', 'g2_norm', 'g2_to_affine', 't_swu', 't_iso', 't_clear', 'h2c_c', 'miller_raw2', 'expx12', 'g1_compress', 'g2_compress', 'h2c1_a', 'enc1_a', 'h2c1_b', 'enc1_b', 'g1_clear', 'enc2_a', 'enc2_b', 'g1_mul', 'g2_mul']
 DST_DEFAULT = b'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_'   # htfDefaults.DST, reference index.ts:64
 
 
@@ -43,6 +43,9 @@ def load_library():
     lib.nbls_g1_decompress_batch.argtypes = [vp, sz, vp, vp, vp]
     lib.nbls_g2_decompress_batch.argtypes = [vp, sz, vp, vp, vp]
     lib.nbls_hash_to_g2_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp]
+    lib.nbls_hash_to_g1_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp]
+    lib.nbls_encode_to_g1_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp]
+    lib.nbls_encode_to_g2_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp]
     lib.nbls_g1_sum.argtypes = [vp, sz, vp, vp, vp]
     lib.nbls_g2_sum.argtypes = [vp, sz, vp, vp, vp]
     lib.nbls_g1_compress_batch.argtypes = [vp, sz, vp, vp]
@@ -133,6 +136,17 @@ class Engine:
         out = C.create_string_buffer(max(192 * len(msgs), 1))
         self._chk(self.lib.nbls_hash_to_g2_batch(self.h, len(msgs), blob, offs, dst, len(dst), out))
         return out.raw[:192 * len(msgs)]
+
+    def hash_to_curve_batch(self, msgs, dst=DST_DEFAULT, g2=False, encode=False):
+        """PointG1/PointG2 .hashToCurve (encode=False) or .encodeToCurve (encode=True) -> affine wire bytes"""
+        if g2 and not encode:
+            return self.hash_to_g2_batch(msgs, dst)
+        blob, offs = self._pack(msgs)
+        sz = 192 if g2 else 96
+        out = C.create_string_buffer(max(sz * len(msgs), 1))
+        f = self.lib.nbls_encode_to_g2_batch if g2 else (self.lib.nbls_encode_to_g1_batch if encode else self.lib.nbls_hash_to_g1_batch)
+        self._chk(f(self.h, len(msgs), blob, offs, dst, len(dst), out))
+        return out.raw[:sz * len(msgs)]
 
     def point_sum(self, pts, g2=False):
         sz = 192 if g2 else 96

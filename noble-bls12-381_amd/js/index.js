@@ -57,6 +57,17 @@ class PointG1 {
   }
   isZero() { return this.zero; }
   // reference index.ts:298-327
+  // reference index.ts:331-350
+  static async hashToCurve(msg, options) {
+    msg = ensureBytes(msg); ensureInit();
+    const dst = stringToBytes((options && options.DST) || htfDefaults.DST);
+    return new PointG1(native.hashToCurve(0, msg, Uint32Array.from([0, msg.length]), dst));
+  }
+  static async encodeToCurve(msg, options) {
+    msg = ensureBytes(msg); ensureInit();
+    const dst = stringToBytes((options && options.DST) || htfDefaults.DST);
+    return new PointG1(native.hashToCurve(1, msg, Uint32Array.from([0, msg.length]), dst));
+  }
   static fromHex(bytes) {
     bytes = ensureBytes(bytes); ensureInit();
     if (bytes.length === 48) {
@@ -123,6 +134,12 @@ class PointG2 {
     msg = ensureBytes(msg); ensureInit();
     const dst = stringToBytes((options && options.DST) || htfDefaults.DST);
     return new PointG2(native.hashToG2(msg, Uint32Array.from([0, msg.length]), dst));
+  }
+  // reference index.ts:491-497
+  static async encodeToCurve(msg, options) {
+    msg = ensureBytes(msg); ensureInit();
+    const dst = stringToBytes((options && options.DST) || htfDefaults.DST);
+    return new PointG2(native.hashToCurve(2, msg, Uint32Array.from([0, msg.length]), dst));
   }
   // reference index.ts:500-530
   static fromSignature(hex) {

@@ -17,7 +17,7 @@ static void* lib;
 #define SYM(name) static __typeof__(&name) p_##name;
 SYM(nbls_init) SYM(nbls_destroy) SYM(nbls_strerror) SYM(nbls_pairing_batch) SYM(nbls_miller_product) SYM(nbls_final_exp_batch)
 SYM(nbls_g1_validate_batch) SYM(nbls_g2_validate_batch) SYM(nbls_g1_decompress_batch) SYM(nbls_g2_decompress_batch)
-SYM(nbls_hash_to_g2_batch) SYM(nbls_g1_sum) SYM(nbls_g2_sum) SYM(nbls_verify_batch) SYM(nbls_g1_mul_batch) SYM(nbls_g2_mul_batch) SYM(nbls_sign_batch)
+SYM(nbls_hash_to_g2_batch) SYM(nbls_g1_sum) SYM(nbls_g2_sum) SYM(nbls_verify_batch) SYM(nbls_g1_mul_batch) SYM(nbls_g2_mul_batch) SYM(nbls_sign_batch) SYM(nbls_hash_to_g1_batch) SYM(nbls_encode_to_g1_batch) SYM(nbls_encode_to_g2_batch)
 static nbls_ctx* ctx;
 
 #define CHECK(env, call) do { if ((call) != napi_ok) { napi_throw_error(env, NULL, "N-API call failed: " #call); return NULL; } } while (0)
@@ -105,6 +105,14 @@ static napi_value SignBatch(napi_env env, napi_callback_info info) {
   uint8_t *out, *st; napi_value vo = new_u8(env, n * 192, &out), vs = new_u8(env, n, &st);
   int r = p_nbls_sign_batch(ctx, n, msgs, (const uint32_t*)offs, dst, ld, keys, out, (int8_t*)st); if (r) return throw_code(env, r); return result2(env, vo, vs);
 }
+/* hashToCurve(mode, msgs, offsets, dst): mode 0 = G1 hashToCurve, 1 = G1 encodeToCurve, 2 = G2 encodeToCurve -> Uint8Array n*96 / n*192 */
+static napi_value HashToCurve(napi_env env, napi_callback_info info) {
+  ARGS(4); NEED_CTX(); int32_t mode = 0; napi_get_value_int32(env, argv[0], &mode); BYTES(1, msgs, lm); BYTES(2, offs, lo); BYTES(3, dst, ld); (void)lm;
+  size_t n = lo / 4 - 1, a = mode == 2 ? 192 : 96; uint8_t* out; napi_value vo = new_u8(env, n * a, &out);
+  int r = mode == 0 ? p_nbls_hash_to_g1_batch(ctx, n, msgs, (const uint32_t*)offs, dst, ld, out) : mode == 1 ? p_nbls_encode_to_g1_batch(ctx, n, msgs, (const uint32_t*)offs, dst, ld, out)
+                    : p_nbls_encode_to_g2_batch(ctx, n, msgs, (const uint32_t*)offs, dst, ld, out);
+  if (r) return throw_code(env, r); return vo;
+}
 /* verifyBatch(sig96, msgs, offsets, pks48, dst) -> {code, ok} */
 static napi_value VerifyBatch(napi_env env, napi_callback_info info) {
   ARGS(5); NEED_CTX(); BYTES(0, sig, ls); BYTES(1, msgs, lm); BYTES(2, offs, lo); BYTES(3, pks, lp); BYTES(4, dst, ld); (void)lm; (void)ls;
@@ -124,13 +132,14 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
 #define LOAD(name) p_##name = (__typeof__(p_##name))dlsym(lib, #name); if (!p_##name) { napi_throw_error(env, NULL, "libnbls.so lacks " #name); return exports; }
   LOAD(nbls_init) LOAD(nbls_destroy) LOAD(nbls_strerror) LOAD(nbls_pairing_batch) LOAD(nbls_miller_product) LOAD(nbls_final_exp_batch)
   LOAD(nbls_g1_validate_batch) LOAD(nbls_g2_validate_batch) LOAD(nbls_g1_decompress_batch) LOAD(nbls_g2_decompress_batch)
-  LOAD(nbls_hash_to_g2_batch) LOAD(nbls_g1_sum) LOAD(nbls_g2_sum) LOAD(nbls_verify_batch) LOAD(nbls_g1_mul_batch) LOAD(nbls_g2_mul_batch) LOAD(nbls_sign_batch)
+  LOAD(nbls_hash_to_g2_batch) LOAD(nbls_g1_sum) LOAD(nbls_g2_sum) LOAD(nbls_verify_batch) LOAD(nbls_g1_mul_batch) LOAD(nbls_g2_mul_batch) LOAD(nbls_sign_batch) LOAD(nbls_hash_to_g1_batch) LOAD(nbls_encode_to_g1_batch) LOAD(nbls_encode_to_g2_batch)
   napi_property_descriptor d[] = {
     {"init", 0, Init, 0, 0, 0, napi_enumerable, 0}, {"pairingBatch", 0, PairingBatch, 0, 0, 0, napi_enumerable, 0}, {"millerProduct", 0, MillerProduct, 0, 0, 0, napi_enumerable, 0},
     {"finalExpBatch", 0, FinalExpBatch, 0, 0, 0, napi_enumerable, 0}, {"g1Decompress", 0, G1Decompress, 0, 0, 0, napi_enumerable, 0}, {"g2Decompress", 0, G2Decompress, 0, 0, 0, napi_enumerable, 0},
     {"g1Validate", 0, G1Validate, 0, 0, 0, napi_enumerable, 0}, {"g2Validate", 0, G2Validate, 0, 0, 0, napi_enumerable, 0}, {"g1Sum", 0, G1Sum, 0, 0, 0, napi_enumerable, 0},
     {"g2Sum", 0, G2Sum, 0, 0, 0, napi_enumerable, 0}, {"hashToG2", 0, HashToG2, 0, 0, 0, napi_enumerable, 0}, {"verifyBatch", 0, VerifyBatch, 0, 0, 0, napi_enumerable, 0},
-    {"g1Mul", 0, G1Mul, 0, 0, 0, napi_enumerable, 0}, {"g2Mul", 0, G2Mul, 0, 0, 0, napi_enumerable, 0}, {"signBatch", 0, SignBatch, 0, 0, 0, napi_enumerable, 0}};
+    {"g1Mul", 0, G1Mul, 0, 0, 0, napi_enumerable, 0}, {"g2Mul", 0, G2Mul, 0, 0, 0, napi_enumerable, 0}, {"signBatch", 0, SignBatch, 0, 0, 0, napi_enumerable, 0},
+    {"hashToCurve", 0, HashToCurve, 0, 0, 0, napi_enumerable, 0}};
   napi_define_properties(env, exports, sizeof d / sizeof d[0], d);
   return exports;
 }

@@ -27,6 +27,11 @@ const hex = bls.utils.bytesToHex, un = bls.utils.hexToBytes;
   }
   // hashToCurve
   for (const v of gold.h2c.filter((x) => x.dst === bls.utils.getDSTLabel())) assert.strictEqual(hex((await bls.PointG2.hashToCurve(un(v.msg))).aff), v.aff);
+  // every hashToCurve / encodeToCurve known-answer block of the reference's test/hashToCurve.test.ts (G1 and G2, RO and NU)
+  for (const k of td.h2c_kats) {
+    const f = k.group === 'g1' ? (k.kind === 'hash' ? bls.PointG1.hashToCurve : bls.PointG1.encodeToCurve) : (k.kind === 'hash' ? bls.PointG2.hashToCurve : bls.PointG2.encodeToCurve);
+    for (const v of k.vectors) assert.strictEqual((await f(un(v.msg), { DST: k.dst })).toHex(), v.expected, k.suite);
+  }
   // verify on reference-produced signatures
   for (const s of gold.sigs) {
     assert.strictEqual(await bls.verify(s.sig, s.msg, s.pk), true);

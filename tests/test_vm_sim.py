@@ -201,3 +201,26 @@ def test_compress_programs(sim, golden):
         e = 96 if g2 else 48
         for i, v in enumerate(vs):
             assert out[e * i:e * i + e] == hx(v['hex']), (g2, i)
+
+
+def test_g1_hash_and_encode_programs(sim, oracle, golden, testdata):
+    """PointG1.hashToCurve / encodeToCurve and PointG2.encodeToCurve step programs (index.ts:331-350, 491-497) on the
+    reference's known-answer blocks (test/hashToCurve.test.ts) and the reference-run vectors"""
+    def g2wire(e):
+        b = hx(e); return b[48:96] + b[0:48] + b[144:192] + b[96:144]
+    for k in testdata['h2c_kats']:
+        if (k['group'], k['kind']) == ('g2', 'hash'):
+            continue
+        msgs = [hx(v['msg']) for v in k['vectors']]
+        ln = {('g1', 'hash'): 128, ('g1', 'encode'): 64, ('g2', 'encode'): 128}[(k['group'], k['kind'])]
+        uni = b''.join(oracle.expand_message_xmd(m, k['dst'].encode(), ln) for m in msgs)
+        if k['group'] == 'g1':
+            out = vmsim_py.hash_to_g1(sim, uni, 2 if k['kind'] == 'hash' else 1)
+            assert [out[96 * i:96 * i + 96] for i in range(len(msgs))] == [hx(v['expected']) for v in k['vectors']], k['suite']
+        else:
+            out = vmsim_py.encode_to_g2(sim, uni)
+            assert [out[192 * i:192 * i + 192] for i in range(len(msgs))] == [g2wire(v['expected']) for v in k['vectors']], k['suite']
+    vs = golden['h2c_more']
+    uni = b''.join(oracle.expand_message_xmd(hx(v['msg']), v['dst'].encode(), 128) for v in vs)
+    out = vmsim_py.hash_to_g1(sim, uni, 2)
+    assert [out[96 * i:96 * i + 96] for i in range(len(vs))] == [hx(v['g1_hash']) for v in vs]

@@ -17,7 +17,7 @@ def raw_elem(v):
 
 
 PROGS = ['MILLER_BYTES', 'MILLER_RAW', 'MILLER_FE', 'NORM_RAW', 'NORM_BYTES', 'FE_EASY', 'EXPX', 'FE_MID1', 'FE_MID2', 'FE_FINAL', 'MUL2', 'RAW_TO_BYTES', 'G1_VALIDATE', 'G2_VALIDATE', 'G1_DEC_A', 'G1_DEC_B', 'G2_DEC_A', 'G2_DEC_B', 'H2C_A', 'H2C_B',
-         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'EXPX12', 'G1_COMPRESS', 'G2_COMPRESS', 'G1_MUL', 'G2_MUL']
+         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'EXPX12', 'G1_COMPRESS', 'G2_COMPRESS', 'H2C1_A', 'ENC1_A', 'H2C1_B', 'ENC1_B', 'G1_CLEAR', 'ENC2_A', 'ENC2_B', 'G1_MUL', 'G2_MUL']
 P = {n: i for i, n in enumerate(PROGS)}
 
 
@@ -138,4 +138,30 @@ def compress(lib, aff, g2=False):
     n = len(aff) // sz
     out = buf(n * sz // 2)
     run(lib, 'G2_COMPRESS' if g2 else 'G1_COMPRESS', n, {0: (buf(aff), sz), 2: (out, sz // 2)})
+    return out.raw
+
+
+def hash_to_g1(lib, uniform, count):
+    """dev_hash_to_g1() of csrc/nbls_api.cpp on the simulator; uniform: n * 64 * count bytes of expand_message_xmd output"""
+    n = len(uniform) // (64 * count)
+    us = count * RAW
+    U, E, Pw, Q, Q2, N, NI, out, st = buf(us * n), buf(us * n), buf(us * n), buf(3 * RAW * n), buf(3 * RAW * n), buf(RAW * n), buf(RAW * n), buf(96 * n), buf(n)
+    run(lib, 'H2C1_A' if count == 2 else 'ENC1_A', n, {0: (buf(uniform), 64 * count), 3: (U, us), 4: (E, us)})
+    lib.nbls_sim_fp_pow(C.c_uint(count * n), E, Pw, 3)
+    run(lib, 'H2C1_B' if count == 2 else 'ENC1_B', n, {3: (U, us), 5: (Pw, us), 6: (Q, 3 * RAW)})
+    run(lib, 'G1_CLEAR', n, {3: (Q, 3 * RAW), 6: (Q2, 3 * RAW), 7: (N, RAW)})
+    lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
+    run(lib, 'G1_TO_AFFINE', n, {3: (Q2, 3 * RAW), 4: (NI, RAW), 2: (out, 96), 7: (st, 1)})
+    return out.raw
+
+
+def encode_to_g2(lib, uniform):
+    n = len(uniform) // 128
+    T, E, Pw, E2, Q, N, NI, out, st = buf(2 * RAW * n), buf(2 * RAW * n), buf(2 * RAW * n), buf(6 * RAW * n), buf(6 * RAW * n), buf(RAW * n), buf(RAW * n), buf(192 * n), buf(n)
+    run(lib, 'ENC2_A', n, {0: (buf(uniform), 128), 3: (T, 2 * RAW), 4: (E, 2 * RAW)})
+    lib.nbls_sim_fp_pow(C.c_uint(n), E, Pw, 2)
+    run(lib, 'ENC2_B', n, {3: (T, 2 * RAW), 5: (Pw, 2 * RAW), 6: (E2, 6 * RAW)})
+    run(lib, 'H2C_C', n, {3: (E2, 6 * RAW), 6: (Q, 6 * RAW), 7: (N, RAW)})
+    lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
+    run(lib, 'G2_TO_AFFINE', n, {3: (Q, 6 * RAW), 4: (NI, RAW), 2: (out, 192), 7: (st, 1)})
     return out.raw
