@@ -48,6 +48,14 @@ class Fp12 {
 }
 
 // ---- points: affine wire bytes, or the zero point
+// reference math.ts:1035-1043
+function validateScalar(n) {
+  if (typeof n === 'number') n = BigInt(n);
+  if (typeof n !== 'bigint' || n <= 0 || n > CURVE.r) throw new Error(`Point#multiply: invalid scalar, expected positive integer < CURVE.r. Got: ${n}`);
+  return n;
+}
+const scalarBytes = (n) => hexToBytes(validateScalar(n).toString(16).padStart(64, '0'));
+
 class PointG1 {
   constructor(aff, zero = false) { this.aff = aff; this.zero = zero; }
   static get ZERO() { return new PointG1(new Uint8Array(96), true); }
@@ -95,6 +103,19 @@ class PointG1 {
     return new PointG1(concat(this.aff.subarray(0, 48), hexToBytes(ny.toString(16).padStart(96, '0'))));
   }
   add(rhs) { return PointG1.sum([this, rhs]); }
+  subtract(rhs) { return this.add(rhs.negate()); }
+  double() { return this.add(this); }
+  // reference math.ts:1048-1167 (multiplyUnsafe / multiply / multiplyPrecomputed: same group element), the engine's ladder
+  multiply(scalar) {
+    const k = scalarBytes(scalar);
+    if (this.zero) return PointG1.ZERO;
+    ensureInit();
+    const { out, status } = native.g1Mul(this.aff, k);
+    return status[0] ? PointG1.ZERO : new PointG1(out);
+  }
+  multiplyUnsafe(scalar) { return this.multiply(scalar); }
+  multiplyPrecomputed(scalar) { return this.multiply(scalar); }
+  static fromPrivateKey(privateKey) { return PointG1.BASE.multiply(normalizePrivKey(privateKey)); }
   static sum(points) {
     ensureInit();
     const nz = points.filter((p) => !p.zero);
@@ -171,6 +192,23 @@ class PointG2 {
     return this;
   }
   add(rhs) { return PointG2.sum([this, rhs]); }
+  negate() {
+    if (this.zero) return this;
+    const neg = (b) => { const v = toBig(b); return hexToBytes((v === 0n ? 0n : CURVE.P - v).toString(16).padStart(96, '0')); };
+    return new PointG2(concat(this.aff.subarray(0, 96), neg(this.aff.subarray(96, 144)), neg(this.aff.subarray(144, 192))));
+  }
+  subtract(rhs) { return this.add(rhs.negate()); }
+  double() { return this.add(this); }
+  multiply(scalar) {
+    const k = scalarBytes(scalar);
+    if (this.zero) return PointG2.ZERO;
+    ensureInit();
+    const { out, status } = native.g2Mul(this.aff, k);
+    return status[0] ? PointG2.ZERO : new PointG2(out);
+  }
+  multiplyUnsafe(scalar) { return this.multiply(scalar); }
+  multiplyPrecomputed(scalar) { return this.multiply(scalar); }
+  static fromPrivateKey(privateKey) { return PointG2.BASE.multiply(normalizePrivKey(privateKey)); }
   static sum(points) {
     ensureInit();
     const nz = points.filter((p) => !p.zero);

@@ -49,6 +49,19 @@ const hex = bls.utils.bytesToHex, un = bls.utils.hexToBytes;
     const sp = await bls.sign(await bls.PointG2.hashToCurve(un(s.msg)), s.sk);        // point in, point out (index.ts:745, 751)
     assert.strictEqual(hex(sp.toSignature()), s.sig);
   }
+  // point arithmetic of the facade objects (reference test/point.test.ts style identities)
+  {
+    const G = bls.PointG1.BASE, H = bls.PointG2.BASE;
+    assert.ok(G.multiply(5n).equals(G.double().double().add(G)));
+    assert.ok(G.multiply(7n).subtract(G.multiply(3n)).equals(G.multiply(4n)));
+    assert.ok(G.multiply(bls.CURVE.r).isZero() && H.multiply(bls.CURVE.r).isZero());
+    assert.ok(H.multiply(6n).equals(H.double().add(H.double()).add(H.double())));
+    assert.ok(H.multiply(9n).subtract(H.multiply(2n)).equals(H.multiply(7n)));
+    assert.ok(bls.PointG1.fromPrivateKey(gold.sigs[0].sk).toHex(true) === gold.sigs[0].pk);
+    assert.throws(() => G.multiply(0n), /invalid scalar/);
+    // bilinearity through the facade: e(aG, bH) == e(G, abH)
+    assert.ok(bls.pairing(G.multiply(3n), H.multiply(5n)).equals(bls.pairing(G, H.multiply(15n))));
+  }
   assert.throws(() => bls.getPublicKey(0n), /Expected valid private key/);
   assert.throws(() => bls.getPublicKey(bls.CURVE.r), /Private key must be 0 < key < CURVE.r/);
   assert.throws(() => bls.getPublicKey('zz'), /Expected valid private key/);
