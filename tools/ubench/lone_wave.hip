@@ -2,6 +2,10 @@
 //   (a) 196 independent v_mad_i64_i32 (row-wise order: consecutive MADs hit different accumulators)
 //   (b) the same products ordered column-wise (each MAD consumes the previous MAD's result)
 //   (c) independent 32-bit adds
+//   (d) (a) + per block 16 ds_read_b128 from per-lane slots and 28 adds on the loaded words (operand formation)
+//   (e) (d) + lane-divergent branches around half of the adds (exec-mask juggling as in dot_operand)
+//   (f) (e) + one dependent global load per block (descriptor word)
+//   (g) (a) with the block replicated 24 times in straight-line code (~38 KB of instructions: the VM kernel's code footprint)
 // Prints clocks per instruction for 1, 2, 3 and 4 waves per SIMD (grid = waves x 1024 SIMDs).
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -10,7 +14,11 @@
 typedef long long i64; typedef int i32; typedef unsigned long long u64; typedef unsigned u32;
 
 template <int MODE>
-__global__ void __launch_bounds__(64) k(u32* out, u64* clk, int iters, u32 seed) {
+__global__ void __launch_bounds__(64) k(u32* out, u64* clk, int iters, u32 seed, const u32* gmem) {
+  __shared__ __attribute__((aligned(16))) u32 lds[64 * 16 * 4];
+  for (int i = threadIdx.x; i < 64 * 16 * 4; i += 64) lds[i] = i * seed;
+  __syncthreads();
+  u32 gi = threadIdx.x;
   i32 a[14], b[14]; i64 acc[28];
   for (int i = 0; i < 14; i++) { a[i] = (seed * (i + 1) + threadIdx.x) & 0xfffffff; b[i] = (seed * (i + 3) ^ threadIdx.x) & 0xfffffff; }
   for (int i = 0; i < 28; i++) acc[i] = 0;
@@ -26,6 +34,47 @@ __global__ void __launch_bounds__(64) k(u32* out, u64* clk, int iters, u32 seed)
       for (int c = 0; c < 27; c++)
 #pragma unroll
         for (int i = 0; i < 14; i++) { int j = c - i; if (j >= 0 && j < 14) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc[c]) : "v"(a[j]), "v"(b[i]) : "vcc"); }
+    } else if (MODE == 6) {
+#pragma unroll
+      for (int rep = 0; rep < 24; rep++) {
+#pragma unroll
+        for (int i = 0; i < 14; i++)
+#pragma unroll
+          for (int j = 0; j < 14; j++) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc[i + j]) : "v"(a[(j + rep) % 14]), "v"(b[i]) : "vcc");
+      }
+    } else if (MODE >= 3) {
+      // operand formation: four 14-limb loads (slot = f(lane, it)), combine, then the 196 MADs
+      u32 e = (MODE >= 5) ? gmem[gi & 1023] : (u32)it * 2654435761u;
+      if (MODE >= 5) gi = gi * 5 + e;
+      const uint4* L = (const uint4*)lds;
+      u32 x[16], y[16];
+      { uint4 q0 = L[((threadIdx.x + e) & 63) * 4 + 0], q1 = L[((threadIdx.x + e) & 63) * 4 + 1], q2 = L[((threadIdx.x + e) & 63) * 4 + 2], q3 = L[((threadIdx.x + e) & 63) * 4 + 3];
+        x[0]=q0.x;x[1]=q0.y;x[2]=q0.z;x[3]=q0.w;x[4]=q1.x;x[5]=q1.y;x[6]=q1.z;x[7]=q1.w;x[8]=q2.x;x[9]=q2.y;x[10]=q2.z;x[11]=q2.w;x[12]=q3.x;x[13]=q3.y;x[14]=q3.z;x[15]=q3.w; }
+      { uint4 q0 = L[((threadIdx.x * 3 + e) & 63) * 4 + 0], q1 = L[((threadIdx.x * 3 + e) & 63) * 4 + 1], q2 = L[((threadIdx.x * 3 + e) & 63) * 4 + 2], q3 = L[((threadIdx.x * 3 + e) & 63) * 4 + 3];
+        y[0]=q0.x;y[1]=q0.y;y[2]=q0.z;y[3]=q0.w;y[4]=q1.x;y[5]=q1.y;y[6]=q1.z;y[7]=q1.w;y[8]=q2.x;y[9]=q2.y;y[10]=q2.z;y[11]=q2.w;y[12]=q3.x;y[13]=q3.y;y[14]=q3.z;y[15]=q3.w; }
+      if (MODE >= 4) {
+        if ((threadIdx.x ^ e) & 1) {
+#pragma unroll
+          for (int i = 0; i < 14; i++) a[i] = (i32)(x[i] + y[i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 14; i++) a[i] = (i32)(x[i] - y[i]);
+        }
+        if ((threadIdx.x ^ e) & 2) {
+#pragma unroll
+          for (int i = 0; i < 14; i++) b[i] = (i32)(0u - y[i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 14; i++) b[i] = (i32)y[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 14; i++) { a[i] = (i32)(x[i] + y[i]); b[i] = (i32)(x[i] - y[i]); }
+      }
+#pragma unroll
+      for (int i = 0; i < 14; i++)
+#pragma unroll
+        for (int j = 0; j < 14; j++) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc[i + j]) : "v"(a[j]), "v"(b[i]) : "vcc");
     } else {
 #pragma unroll
       for (int r = 0; r < 7; r++)
@@ -42,18 +91,23 @@ __global__ void __launch_bounds__(64) k(u32* out, u64* clk, int iters, u32 seed)
 }
 int main() {
   const int iters = 2000;
-  for (int mode = 0; mode < 3; mode++) for (int wps = 1; wps <= 4; wps++) {
+  u32* gmem; hipMalloc(&gmem, 4096); hipMemset(gmem, 1, 4096);
+  for (int mode = 0; mode < 7; mode++) for (int wps = 1; wps <= 4; wps++) {
     int blocks = 1024 * wps; u32* out; u64* clk; hipMalloc(&out, blocks * 64 * 4); hipMalloc(&clk, blocks * 8);
     for (int rep = 0; rep < 2; rep++) {
-      if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(64), 0, 0, out, clk, iters, 12345u);
-      else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(64), 0, 0, out, clk, iters, 12345u);
-      else hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(64), 0, 0, out, clk, iters, 12345u);
+      if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(64), 0, 0, out, clk, iters, 12345u, gmem);
+      else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(64), 0, 0, out, clk, iters, 12345u, gmem);
+      else if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(64), 0, 0, out, clk, iters, 12345u, gmem);
+      else if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(64), 0, 0, out, clk, iters, 12345u, gmem);
+      else if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(64), 0, 0, out, clk, iters, 12345u, gmem);
+      else if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(64), 0, 0, out, clk, iters, 12345u, gmem);
+      else hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(64), 0, 0, out, clk, iters / 24, 12345u, gmem);
       hipDeviceSynchronize();
     }
     std::vector<u64> h(blocks); hipMemcpy(h.data(), clk, blocks * 8, hipMemcpyDeviceToHost);
     double avg = 0; for (auto v : h) avg += v; avg /= blocks;
-    printf("mode %d (%s) waves/SIMD %d: %.2f wave-clocks per instruction (196 instr per iteration), %.2f SIMD clocks per instruction\n", mode,
-           mode == 0 ? "mad row-wise" : mode == 1 ? "mad column-wise" : "add32", wps, avg / iters / 196.0, avg / iters / 196.0 / wps);
+    printf("mode %d (%s) waves/SIMD %d: %.0f ticks per block per wave, %.0f per SIMD (blocks of 196 MADs)\n", mode,
+           mode == 0 ? "mad row-wise" : mode == 1 ? "mad column-wise" : mode == 2 ? "add32" : mode == 3 ? "lds+adds+mad" : mode == 4 ? "lds+divergent adds+mad" : mode == 5 ? "global+lds+divergent+mad" : "mad, 38 KB straight-line (per 24 blocks)", wps, avg / iters, avg / iters / wps);
     hipFree(out); hipFree(clk);
   }
   return 0;
