@@ -389,14 +389,17 @@ EXPORT int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks) {
   if (!ctx || !n || !out_blocks) return NBLS_EINVAL;
   std::lock_guard<std::mutex> g(ctx->mu); HIPCHK(hipSetDevice(ctx->device));
   int r = ensure_scratch(ctx, n); if (r) return r;
-  r = upload(ctx, P_EXPX); if (r) return r;
-  const DevProgram& d = ctx->prog[P_EXPX];
+  if ((r = ensure_io(ctx, n))) return r;
+  const ProgId pid = getenv("NBLS_PROBE_MILLER") ? P_MILLER_FE : P_EXPX;   // NBLS_PROBE_MILLER: probe the (4x longer) Miller program instead
+  r = upload(ctx, pid); if (r) return r;
+  const DevProgram& d = ctx->prog[pid];
   const size_t blocks = (n + d.p->G - 1) / d.p->G;
   uint64_t* dbg = nullptr; HIPCHK(hipMalloc(&dbg, blocks * 24));
   KernelArgs ka; memset(&ka, 0, sizeof ka);
   ka.steps = d.steps; ka.descs = d.descs; ka.consts = d.consts;
   ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slots = d.p->slots; ka.n_items = (u32)n;
   ka.bufs[3].ptr = ctx->T[0]; ka.bufs[3].stride = F12; ka.bufs[5].ptr = ctx->T[1]; ka.bufs[5].stride = F12;
+  if (pid == P_MILLER_FE) { ka.bufs[0].ptr = ctx->io_g1; ka.bufs[0].stride = 96; ka.bufs[1].ptr = ctx->io_g2; ka.bufs[1].stride = 192; ka.bufs[4].ptr = ctx->N; ka.bufs[4].stride = RAW; }
   ka.hwid_out = dbg;
   HIPCHK(hipMemsetAsync(ctx->T[0], 0, n * F12, ctx->stream));
   int e = nbls_vm_launch(&ka, d.p->lds_bytes(), ctx->stream);

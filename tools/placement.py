@@ -23,5 +23,24 @@ print('n', n, 'workgroups', blocks, 'lds floor', os.environ.get('NBLS_LDS_FLOOR'
 print('  distinct CUs', len(cu), 'distinct SIMDs', len(simd))
 print('  workgroups per SIMD histogram', sorted(collections.Counter(simd.values()).items()))
 print('  workgroups per CU histogram  ', sorted(collections.Counter(cu.values()).items()))
+# co-residency: for SIMDs that received two workgroups, how much of their lifetimes overlapped (same XCD -> same counter)
+by_simd = collections.defaultdict(list)
+for b in range(blocks):
+    v = out[3 * b]; hw, xcc = v & 0xffffffff, (v >> 32) & 0xf
+    by_simd[(xcc, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 0xf, (hw >> 4) & 3)].append((out[3 * b + 1], out[3 * b + 2]))
+ov = []
+for iv in by_simd.values():
+    if len(iv) == 2:
+        (s0, e0), (s1, e1) = iv
+        ov.append(max(0, min(e0, e1) - max(s0, s1)) / max(e0 - s0, e1 - s1))
+if ov:
+    ov.sort(); print('  two-workgroup SIMDs: overlap fraction p10 %.2f p50 %.2f p90 %.2f' % (ov[len(ov) // 10], ov[len(ov) // 2], ov[9 * len(ov) // 10]))
+    ds = sorted(abs(iv[0][0] - iv[1][0]) for iv in by_simd.values() if len(iv) == 2)
+    print('  start-time difference of the two (ticks): p10 %d p50 %d p90 %d' % (ds[len(ds) // 10], ds[len(ds) // 2], ds[9 * len(ds) // 10]))
+# launch timeline inside XCD 0: start offsets (deciles) relative to its first wave, in units of the median wave lifetime
+x0 = sorted(out[3 * b + 1] for b in range(blocks) if ((out[3 * b] >> 32) & 0xf) == 0)
+if x0:
+    med = sorted(out[3 * b + 2] - out[3 * b + 1] for b in range(blocks))[blocks // 2]
+    print('  XCD 0: %d workgroups, start offsets / median life at deciles: %s' % (len(x0), ' '.join('%.2f' % ((x0[min(len(x0) - 1, len(x0) * d // 10)] - x0[0]) / med) for d in range(11))))
 q = lambda a, f: a[min(len(a) - 1, int(f * len(a)))]
 print('  ticks: start p50 %d p90 %d max %d | wave life p50 %d max %d | last end %d' % (q(starts, .5), q(starts, .9), starts[-1], q(lives, .5), lives[-1], ends[-1]))
