@@ -5,6 +5,7 @@
 // P = Q, P = -Q and the identity (0 : 1 : 0).  The reference's ProjectivePoint.add/double (math.ts:974-1025) branch on those
 // cases instead; the group elements produced are the same.
 #pragma once
+#include <cassert>
 #include "tower.h"
 
 namespace nbls {
@@ -59,20 +60,35 @@ template <class F> static inline Pt<F> pt_mul_u64(const Pt<F>& p, uint64_t k) {
   for (int i = top - 1; i >= 0; i--) { r = pt_dbl(r); if ((k >> i) & 1) r = pt_add(r, p); }
   return r;
 }
-// [k]P for a per-item scalar held in a raw integer slot (nbits processed MSB first): double-and-add-always with a
-// masked select per bit, so the instruction stream and the LDS access pattern are independent of k (the reference's
-// constant-time path is wNAF with precomputes, math.ts:1116-1157; the group element is the same).  The complete formulas
-// make the identity start value and every intermediate case valid.
+// [k]P for a per-item scalar held in a raw integer slot: fixed 3-bit windows, MSB first.  Per window: three doublings, a
+// table entry [0..7]P picked by a binary tree of masked selects on the three scalar bits (every entry is read, the K_SEL
+// lane-op merges both candidates under a mask), one complete addition (the entry may be the identity).  Instruction stream
+// and LDS access pattern are independent of k (the reference's constant-time path is wNAF with precomputes,
+// math.ts:1116-1157; the group element is the same).  The complete formulas make the identity start value and every
+// intermediate case valid.
 template <class F> static inline F sel(const SFp& f, const F& a, const F& b);
 template <> inline SFp sel<SFp>(const SFp& f, const SFp& a, const SFp& b) { return select(f, a, b); }
 template <> inline SFp2 sel<SFp2>(const SFp& f, const SFp2& a, const SFp2& b) { return {select(f, a.c0, b.c0), select(f, a.c1, b.c1)}; }
+template <class F> static inline Pt<F> pt_sel(const SFp& f, const Pt<F>& a, const Pt<F>& b) { return {sel<F>(f, a.x, b.x), sel<F>(f, a.y, b.y), sel<F>(f, a.z, b.z)}; }
 template <class F> static inline Pt<F> pt_mul_ladder(const Pt<F>& p, const SFp& k_raw, int nbits) {
-  Pt<F> r = pt_mat(pt_identity<F>());
-  for (int i = nbits - 1; i >= 0; i--) {
-    r = pt_dbl(r);
-    Pt<F> t = pt_add(r, p);
-    SFp b = bit_flag(k_raw, i);
-    r = {sel<F>(b, t.x, r.x), sel<F>(b, t.y, r.y), sel<F>(b, t.z, r.z)};
+  const int WIN = 3;
+  Pt<F> T[1 << WIN];
+  T[0] = pt_mat(pt_identity<F>()); T[1] = pt_mat(p); T[2] = pt_dbl(p);
+  for (int j = 3; j < (1 << WIN); j++) T[j] = pt_add(T[j - 1], T[1]);
+  Pt<F> r = T[0];
+  int hi = nbits;
+  const int top = nbits % WIN;                       // a short leading window (256 = 1 + 85 * 3)
+  if (top) {
+    assert(top == 1);
+    r = pt_sel<F>(bit_flag(k_raw, nbits - 1), T[1], T[0]);
+    hi = nbits - 1;
+  }
+  for (int lo = hi - WIN; lo >= 0; lo -= WIN) {
+    for (int i = 0; i < WIN; i++) r = pt_dbl(r);
+    SFp b0 = bit_flag(k_raw, lo), b1 = bit_flag(k_raw, lo + 1), b2 = bit_flag(k_raw, lo + 2);
+    Pt<F> u0 = pt_sel<F>(b0, T[1], T[0]), u1 = pt_sel<F>(b0, T[3], T[2]), u2 = pt_sel<F>(b0, T[5], T[4]), u3 = pt_sel<F>(b0, T[7], T[6]);
+    Pt<F> v0 = pt_sel<F>(b1, u1, u0), v1 = pt_sel<F>(b1, u3, u2);
+    r = pt_add(r, pt_sel<F>(b2, v1, v0));
   }
   return r;
 }
