@@ -94,7 +94,7 @@ int nbls_g2_compress_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, uint8
 
 /* [k_i]P_i for per-item scalars (32 bytes big-endian each; any value, the reference reduces mod r first: normalizePrivKey
  * index.ts:269-279).  g1_aff == NULL multiplies the G1 generator: the core of getPublicKey / PointG1.fromPrivateKey
-* (index.ts:350-353, 738-740).  Fixed-window ladder with masked table selection: instruction stream and memory access pattern do
+ * (index.ts:350-353, 738-740).  Fixed-window ladder with masked table selection: instruction stream and memory access pattern do
  * not depend on the scalar.  status: 0 ok, 1 result is the zero point, 5 scalar is 0 mod r (the reference throws). */
 int nbls_g1_mul_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff /* n*96 or NULL */, const uint8_t* scalars32, uint8_t* out96, int8_t* status);
 int nbls_g2_mul_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff /* n*192 */, const uint8_t* scalars32, uint8_t* out192, int8_t* status);
