@@ -107,6 +107,21 @@ def test_batch_4096_properties(eng, oracle):
     assert out == ref
 
 
+@pytest.mark.parametrize('n', [1023, 1024, 1025, 1029, 4095, 4097, 16383, 16384, 16385])
+def test_kernel_selection_boundaries(eng, oracle, n):
+    """batch sizes around the launch-shape decisions of the runtime: 256 workgroups (two-wave kernel vs one-wave kernel),
+    16384 items (EXPX in its 16-lane vs 12-lane build), partially filled last waves, odd / even pair counts of the shared
+    accumulator Miller program -- full comparison with the multi-threaded oracle"""
+    base1, base2 = _rand_points(oracle, 32, 4242)
+    G1 = b''.join(base1[96 * ((i * 5 + 1) % 32):96 * ((i * 5 + 1) % 32) + 96] for i in range(n))
+    G2 = b''.join(base2[192 * ((i // 32 + i * 3) % 32):192 * ((i // 32 + i * 3) % 32) + 192] for i in range(n))
+    out, _ = eng.pairing_batch(G1, G2, True, False)
+    ref, _ = oracle.pairing_batch(G1, G2, True, False, threads=min(64, os.cpu_count() or 8))
+    assert out == ref
+    if n <= 4097:      # the single-threaded oracle product is the slow part
+        assert eng.miller_product(G1, G2, True)[0] == oracle.miller_product(G1, G2, True)
+
+
 def test_batch_131072_properties(eng, oracle):
     """BASELINE config 4 size per GPU (1M pairings over 8 GPUs): 131072 pairings in one call.  The oracle cannot follow at this
     size, so: (i) the inputs cycle through 64 x 64 distinct (P_a, Q_b) combinations, every repetition of a combination must give
