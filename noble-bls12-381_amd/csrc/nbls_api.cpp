@@ -193,8 +193,6 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
   if (hipSetDevice(device_id) != hipSuccess) { delete ctx; return NBLS_ENOGPU; }
   if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   // Montgomery one as a raw Fp12 (pads odd-sized product reductions)
-  if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess || hipMalloc(&ctx->side_scratch, (6 + 32) * RAW) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   u32 one[12 * SLOT_WORDS]; memset(one, 0, sizeof one); memcpy(one, NBLS_R1, NLIMBS * 4);
   if (hipMalloc(&ctx->one12, F12) != hipSuccess || hipMemcpy(ctx->one12, one, F12, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   {
@@ -703,7 +701,13 @@ EXPORT int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_s
     uint8_t *G1, *G2, *ST, *O; int r;
     if ((r = need(ctx, 10, (n + 1) * (96 + 192) + (n + 1) + 576 + 64, &G1))) return r;
     G2 = G1 + (n + 1) * 96; O = G2 + (n + 1) * 192; ST = O + 576;
-    // normP2: PointG2.fromSignature for the ONE signature, on the side stream with its own scratch (overlaps everything below)
+    // normP2: PointG2.fromSignature for the ONE signature, on the side stream with its own scratch (overlaps everything below).
+    // The side stream is created on first use: HIP spreads streams over a few hardware queues in creation order, and contexts
+    // that only run pairing batches (noble-bls12-381_amd/pipeline.py keeps several in flight) should each get a queue of their own.
+    if (!ctx->side) {
+      if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess || hipMalloc(&ctx->side_scratch, (6 + 32) * RAW) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+    }
     {
       uint8_t *X = ctx->side_scratch, *Rr = X + 2 * RAW, *Cd = Rr + 2 * RAW, *pw = Cd + 2 * RAW;
       HIPCHK(hipEventRecord(ctx->ev_fork, s)); HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));

@@ -247,6 +247,9 @@ class Engine:
         keys = ['steps', 'dot_steps', 'lin_steps', 'dot_ops', 'products', 'lin_ops', 'slots', 'lds_bytes']
         return dict(zip(keys, list(o)))
 
+    def device_synchronize(self):
+        self._chk(self.lib.nbls_device_synchronize(self.h))
+
     def timing_enable(self, on=True):
         self._chk(self.lib.nbls_timing_enable(self.h, int(on)))
 
