@@ -178,3 +178,26 @@ def test_both_vm_kernels(split):
     env = dict(os.environ, NBLS_SPLIT=split)
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
+
+
+def test_batches_in_flight(oracle):
+    """PairingPipeline: several engine contexts, one stream each, batches submitted back to back without waiting -- every
+    batch's results must equal the oracle's although their kernels overlap on the GPU"""
+    import torch
+    pkg = importlib.import_module('noble-bls12-381_amd')
+    pipe = pkg.PairingPipeline(0, 3)
+    n, rounds = 700, 7
+    sets = [_rand_points(oracle, 16, 9000 + r) for r in range(rounds)]
+    ins, outs = [], []
+    for r in range(rounds):
+        G1 = b''.join(sets[r][0][96 * (i % 16):96 * (i % 16) + 96] for i in range(n))
+        G2 = b''.join(sets[r][1][192 * ((3 * i + 1) % 16):192 * ((3 * i + 1) % 16) + 192] for i in range(n))
+        ins.append((G1, G2, torch.frombuffer(bytearray(G1), dtype=torch.uint8).cuda(), torch.frombuffer(bytearray(G2), dtype=torch.uint8).cuda()))
+        outs.append(torch.empty(576 * n, dtype=torch.uint8, device='cuda'))
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        pipe.submit(n, ins[r][2].data_ptr(), ins[r][3].data_ptr(), outs[r].data_ptr(), True)
+    pipe.synchronize()
+    for r in range(rounds):
+        ref, _ = oracle.pairing_batch(ins[r][0], ins[r][1], True, False, threads=16)
+        assert bytes(outs[r].cpu().numpy().tobytes()) == ref, r
