@@ -162,17 +162,15 @@ static int reduce_product(nbls_ctx* ctx, size_t n, uint8_t** result, hipStream_t
 static int final_exp_pipeline(nbls_ctx* ctx, size_t n, uint8_t* f_raw, void* d_out, hipStream_t s) {
   int r;
   uint8_t** T = ctx->T;
-  // 12 lanes per item (5 items per wave) once the launch fills the chip three waves deep either way: +9 % on this program
-  const ProgId P_EXPX_SEL = n >= 16384 ? P_EXPX12 : P_EXPX;
   if ((r = run_inv(ctx, n, s))) return r;
   if ((r = run(ctx, P_FE_EASY, n, {B(3, f_raw, F12), B(4, ctx->NI, RAW), B(5, T[0], F12)}, s))) return r;
-  if ((r = run(ctx, P_EXPX_SEL, n, {B(3, T[0], F12), B(5, T[1], F12)}, s))) return r;                       // t2
+  if ((r = run(ctx, P_EXPX, n, {B(3, T[0], F12), B(5, T[1], F12)}, s))) return r;                       // t2
   if ((r = run(ctx, P_FE_MID1, n, {B(3, T[0], F12), B(5, T[1], F12), B(6, T[2], F12)}, s))) return r;   // t3
-  if ((r = run(ctx, P_EXPX_SEL, n, {B(3, T[2], F12), B(5, T[3], F12)}, s))) return r;                       // t4
-  if ((r = run(ctx, P_EXPX_SEL, n, {B(3, T[3], F12), B(5, T[4], F12)}, s))) return r;                       // t5
-  if ((r = run(ctx, P_EXPX_SEL, n, {B(3, T[4], F12), B(5, T[6], F12)}, s))) return r;                       // t6' (parked in T7's buffer)
+  if ((r = run(ctx, P_EXPX, n, {B(3, T[2], F12), B(5, T[3], F12)}, s))) return r;                       // t4
+  if ((r = run(ctx, P_EXPX, n, {B(3, T[3], F12), B(5, T[4], F12)}, s))) return r;                       // t5
+  if ((r = run(ctx, P_EXPX, n, {B(3, T[4], F12), B(5, T[6], F12)}, s))) return r;                       // t6' (parked in T7's buffer)
   if ((r = run(ctx, P_FE_MID2, n, {B(3, T[6], F12), B(5, T[1], F12), B(6, T[5], F12)}, s))) return r;   // t6
-  if ((r = run(ctx, P_EXPX_SEL, n, {B(3, T[5], F12), B(5, T[6], F12)}, s))) return r;                       // t7
+  if ((r = run(ctx, P_EXPX, n, {B(3, T[5], F12), B(5, T[6], F12)}, s))) return r;                       // t7
   return run(ctx, P_FE_FINAL, n, {B(0, T[0], F12), B(1, T[1], F12), B(2, T[2], F12), B(3, T[3], F12), B(4, T[4], F12), B(5, T[5], F12), B(6, T[6], F12), B(7, d_out, 576)}, s);
 }
 // one raw Fp12 -> final exponentiation (or plain encoding) -> wire bytes on device

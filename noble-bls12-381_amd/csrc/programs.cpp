@@ -140,7 +140,7 @@ static void load_points(SFp& Px, SFp& Py, SFp2& Qx, SFp2& Qy) {
 // lanes per work item (instances per wave = 64 / W): an Fp12 lane-op step has 12 heavy lanes
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
 static const int MILLER_W = env_int("NBLS_MILLER_W", 16);
-static const int EXPX_W = env_int("NBLS_EXPX_W", 16);
+static const int EXPX_W = env_int("NBLS_EXPX_W", 12);   // an Fp12 op has exactly 12 lane-ops: 5 items per wave, no idle lane (+5..9 % over 16 lanes once >= 2 waves share a SIMD)
 
 static Program build(ProgId id) {
   Builder B;
@@ -188,9 +188,9 @@ static Program build(ProgId id) {
       outputw_fp12(trace_fe_easy(f, finv), 5, 0);
       return B.compile("fe_easy", 16);
     }
-    case P_EXPX: case P_EXPX12: {
+    case P_EXPX: {
       outputw_fp12(conj(cyclotomic_exp_x(inputw_fp12(3, 0))), 5, 0);
-      return id == P_EXPX ? B.compile("expx", EXPX_W) : B.compile("expx12", 12);
+      return B.compile("expx", EXPX_W);
     }
     case P_FE_MID1: {
       SFp12 a = inputw_fp12(3, 0), b = inputw_fp12(5, 0);

@@ -28,8 +28,6 @@ enum ProgId {
   P_T_SWU, P_T_ISO, P_T_CLEAR,   // test-only pieces of hash-to-G2 (unit parity against golden vectors): SWU map, 3-isogeny, cofactor clearing
   P_H2C_C,             // projective point (3) -> clearCofactor -> projective hash point (6), norm of Z (7)      (index.ts:489, 659-672)
   P_MILLER_RAW2,       // two (G1, G2) pairs per item -> raw Fp12 of millerLoop x millerLoop with a shared accumulator (one Fp12 squaring per bit)
-  P_EXPX12,            // EXPX compiled for 12 lanes per item (5 items per wave instead of 4): used when a launch is large enough to
-                       // keep >= 3 waves per SIMD anyway (an Fp12 op has exactly 12 lane-ops, so no lane idles)
   P_G1_COMPRESS, P_G2_COMPRESS,   // affine wire point (buf 0) -> 48 / 96 compressed bytes (buf 2)   (PointG1.toHex(true) index.ts:359-371, PointG2.toSignature 586-602)
   // G1 hash-to-curve / encode-to-curve and G2 encode-to-curve (index.ts:331-350, 491-497); "count" field elements per message
   P_H2C1_A, P_ENC1_A,   // 64 * count uniform bytes (buf 0) -> u (3), tv4 = gx1 gxd^3 (4)                              (math.ts:1272-1299)

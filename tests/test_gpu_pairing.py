@@ -110,7 +110,7 @@ def test_batch_4096_properties(eng, oracle):
 @pytest.mark.parametrize('n', [1023, 1024, 1025, 1029, 4095, 4097, 16383, 16384, 16385])
 def test_kernel_selection_boundaries(eng, oracle, n):
     """batch sizes around the launch-shape decisions of the runtime: 256 workgroups (two-wave kernel vs one-wave kernel),
-    16384 items (EXPX in its 16-lane vs 12-lane build), partially filled last waves, odd / even pair counts of the shared
+    partially filled last waves (4 items per wave in the Miller programs, 5 in EXPX), odd / even pair counts of the shared
     accumulator Miller program -- full comparison with the multi-threaded oracle"""
     base1, base2 = _rand_points(oracle, 32, 4242)
     G1 = b''.join(base1[96 * ((i * 5 + 1) % 32):96 * ((i * 5 + 1) % 32) + 96] for i in range(n))

@@ -180,14 +180,13 @@ def test_miller_shared_accumulator(sim, oracle, golden):
         assert out.raw[576 * i:576 * i + 576] == ref, i
 
 
-def test_expx_12_lane_variant(sim, oracle, golden):
-    """EXPX12 (12 lanes per item, 5 items per wave: the large-launch variant of the exponentiation by x) inside the full
-    final exponentiation; 7 items exercise a partially filled second wave"""
+def test_partially_filled_waves(sim, oracle, golden):
+    """7 items: EXPX runs 5 items per wave (12 lanes each), the Miller programs 4 -- both leave a partially filled last wave"""
     n = 7
     g1, g2 = _points(golden, n)
     F = C.create_string_buffer(vmsim_py.F12 * n); N = C.create_string_buffer(vmsim_py.RAW * n); out = C.create_string_buffer(576 * n)
     vmsim_py.run(sim, 'MILLER_FE', n, {0: (C.create_string_buffer(g1, len(g1)), 96), 1: (C.create_string_buffer(g2, len(g2)), 192), 3: (F, vmsim_py.F12), 4: (N, vmsim_py.RAW)})
-    vmsim_py.final_exp(sim, n, F, N, out, expx='EXPX12')
+    vmsim_py.final_exp(sim, n, F, N, out)
     for i in range(n):
         assert out.raw[576 * i:576 * (i + 1)] == hx(golden['pairs'][i]['pairing']), i
 
