@@ -99,6 +99,16 @@ int nbls_g2_compress_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, uint8
 int nbls_g1_mul_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff /* n*96 or NULL */, const uint8_t* scalars32, uint8_t* out96, int8_t* status);
 int nbls_g2_mul_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff /* n*192 */, const uint8_t* scalars32, uint8_t* out192, int8_t* status);
 
+/* Multi-scalar multiplication sum_i [k_i]P_i (weighted form of the reference's aggregatePublicKeys / aggregateSignatures,
+ * index.ts:771-788, whose unweighted sums are nbls_g1_sum / nbls_g2_sum; the building block of random-linear-combination batch
+ * verification of distinct signatures).  Points: affine wire bytes in the prime-order subgroup (nbls_g*_validate_batch); scalars:
+ * 32 bytes big-endian each, any value.  Bucket method (12-bit windows) on the device; NOT constant time in the scalars (public
+ * coefficients), use nbls_g*_mul_batch for secret ones.  out: one affine point; status: 0 ok, 1 the sum is the zero point. */
+int nbls_g1_msm(nbls_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out96, int8_t* status);
+int nbls_g2_msm(nbls_ctx* ctx, size_t n, const uint8_t* pts192, const uint8_t* scalars32, uint8_t* out192, int8_t* status);
+/* the same with points, scalars, result and status resident in device memory; all scalars < 2^nbits (0 = 256) */
+int nbls_msm_dev(nbls_ctx* ctx, int g2, size_t n, const void* d_pts, const void* d_scalars32, unsigned nbits, void* d_out, void* d_status, void* stream);
+
 /* sign(message_i, privateKey_i) -- reference index.ts:744-752: PointG2.hashToCurve(message) multiplied by the key; output is
  * the affine signature point (192 B), which PointG2.toSignature (index.ts:586-602) compresses on the caller's side.
  * Messages as in nbls_hash_to_g2_batch. */

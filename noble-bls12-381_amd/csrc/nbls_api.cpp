@@ -16,6 +16,16 @@
 extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream);
 extern "C" int nbls_fp_inv_launch(unsigned n, const void* in, void* out, void* stream);
 extern "C" int nbls_xmd_launch(unsigned n, const void* msgs, const void* offsets, const void* dst, unsigned dst_len, void* out, unsigned len_in_bytes, void* stream);
+extern "C" int nbls_msm_keys_launch(unsigned n, unsigned nwin, const void* scalars, void* keys, void* vals, void* stream);
+extern "C" int nbls_msm_sort_launch(void* temp, size_t* temp_bytes, const void* keys_in, void* keys_out, const void* vals_in, void* vals_out, size_t m, int key_bits, void* stream);
+extern "C" int nbls_msm_gather_launch(size_t m, unsigned elem_bytes, const void* idx, const void* src, void* dst, void* stream);
+extern "C" int nbls_msm_rank_launch(size_t m, const void* keys, void* pos, void* maxrun_u32, void* stream);
+extern "C" int nbls_msm_pairs_launch(size_t m, unsigned d, const void* keys, const void* pos, void* list, void* count_u32, void* stream);
+extern "C" int nbls_msm_gather2_launch(size_t bound, const void* count_u32, unsigned elem_bytes, unsigned d, const void* list, const void* P, void* A, void* B, void* stream);
+extern "C" int nbls_msm_scatter_launch(size_t bound, const void* count_u32, unsigned elem_bytes, const void* list, const void* A, void* P, void* stream);
+extern "C" int nbls_msm_fill_launch(size_t count, unsigned elem_bytes, const void* ident, void* dst, void* stream);
+extern "C" int nbls_msm_heads_launch(size_t m, unsigned elem_bytes, const void* keys, const void* P, void* buckets, void* stream);
+extern "C" int nbls_msm_bitsel_launch(unsigned nwin, unsigned elem_bytes, const void* buckets, void* G, void* stream);
 extern "C" int nbls_fp_pow_launch(unsigned n, const void* in, void* out, const void* nibbles, int nnib, void* scratch, int is_fp2, void* stream);
 
 using namespace nbls;
@@ -71,12 +81,12 @@ static int upload(nbls_ctx* ctx, ProgId id) {
   return NBLS_OK;
 }
 
-static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pair<int, std::pair<const void*, size_t>>> bufs, hipStream_t s) {
+static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pair<int, std::pair<const void*, size_t>>> bufs, hipStream_t s, const uint32_t* n_dev = nullptr) {
   int r = upload(ctx, id); if (r) return r;
   const DevProgram& d = ctx->prog[id];
   KernelArgs ka; memset(&ka, 0, sizeof ka);
   ka.steps = d.steps; ka.descs = d.descs; ka.consts = d.consts;
-  ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slots = d.p->slots; ka.n_items = (u32)n;
+  ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slots = d.p->slots; ka.n_items = (u32)n; ka.n_items_dev = n_dev;
   for (auto& b : bufs) { ka.bufs[b.first].ptr = (uint8_t*)b.second.first; ka.bufs[b.first].stride = b.second.second; }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s); }
@@ -650,6 +660,101 @@ static int mul_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* pts, const 
 // PointG1.fromPrivateKey / getPublicKey core (index.ts:350-353, 738-740): [k_i]P_i, P = generator when g1_aff is NULL
 EXPORT int nbls_g1_mul_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, const uint8_t* scalars32, uint8_t* out96, int8_t* status) { return mul_host(ctx, false, n, g1_aff, scalars32, out96, status); }
 EXPORT int nbls_g2_mul_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, const uint8_t* scalars32, uint8_t* out192, int8_t* status) { return mul_host(ctx, true, n, g2_aff, scalars32, out192, status); }
+// ---- multi-scalar multiplication sum_i [k_i]P_i (the reference only has the unweighted sums aggregatePublicKeys /
+// aggregateSignatures, index.ts:771-788).  Bucket method with 12-bit windows, every group operation a complete addition run as
+// a step program over whole arrays:
+//   1. keys (window, digit) for every (point, window); device radix sort of the n * nwin keys (hipCUB); the points follow.
+//   2. segmented sum over the sorted list as a balanced tree inside every run of equal keys: in the round with stride d the
+//      elements whose rank in their run is a multiple of 2d absorb the element d further on.  The pairs of a round are
+//      listed by a compaction kernel (their number stays on the device: the step program reads it there), gathered, added,
+//      scattered back: n * nwin - (number of buckets hit) additions in total whatever the distribution of the digits;
+//      ceil(log2(longest run)) rounds -- the longest run is the one value read back.  The head of every run ends up as its bucket sum.
+//   3. sum_b b * B_b per window = sum_t 2^t * T_t with T_t = sum of the buckets whose index has bit t: 12 * 2^11 gathered
+//      points per window, a balanced tree of 11 rounds of pairwise additions (data independent).
+//   4. Horner over t inside every window (one item per window), then acc <- 2^12 * acc + S_w from the top window down.
+// Result: affine wire bytes + status (1 = the sum is the zero point).  nbits bounds the scalars (< 2^nbits), 0 = 256.
+#define MSMCHK(call) do { int e_ = (call); if (e_) { ctx->last_hip = e_; return NBLS_EHIP; } } while (0)
+static int dev_msm(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, const void* d_scalars, unsigned nbits, void* d_out, void* d_status, hipStream_t s) {
+  const size_t a = g2 ? 192 : 96, p = g2 ? 6 * RAW : 3 * RAW;
+  const unsigned C = MSM_WINDOW_BITS;
+  uint8_t* ident = g2 ? ctx->ident_g2 : ctx->ident_g1;
+  if (nbits == 0 || nbits > 256) nbits = 256;
+  const unsigned nwin = (nbits + C - 1) / C;
+  const size_t m = n * nwin, nb = (size_t)nwin << C, ng = ((size_t)nwin * C) << (C - 1);
+  if (n > ((size_t)1 << 24)) return NBLS_EINVAL;
+  uint8_t *Pj, *P, *A, *K, *tmp, *Bk, *G, *Gh, *N, *NI, *acc, *cnt; int r;
+  size_t tmp_bytes = 0;
+  if (m) MSMCHK(nbls_msm_sort_launch(nullptr, &tmp_bytes, nullptr, nullptr, nullptr, nullptr, m, 17, s));
+  const size_t half = m / 2 + 1;
+  if ((r = need(ctx, 0, (n + 1) * p, &Pj)) || (r = need(ctx, 1, (m + 1) * p, &P)) || (r = need(ctx, 2, 2 * std::max(half, (size_t)nwin) * p, &A)) || (r = need(ctx, 3, (m + 1) * 24, &K)) ||
+      (r = need(ctx, 4, RAW, &N)) || (r = need(ctx, 5, RAW, &NI)) || (r = need(ctx, 6, tmp_bytes + 16, &tmp)) || (r = need(ctx, 7, nb * p, &Bk)) || (r = need(ctx, 8, ng * p, &G)) ||
+      (r = need(ctx, 9, ng / 2 * p, &Gh)) || (r = need(ctx, 10, 2 * p, &acc)) || (r = need(ctx, 11, 64 * 4, &cnt))) return r;
+  uint8_t* Bv = A + half * p;
+  uint32_t *kin = (uint32_t*)K, *vin = kin + m, *kout = vin + m, *vout = kout + m, *pos = vout + m, *list = pos + m;
+  uint32_t* counters = (uint32_t*)cnt;    // [0] longest run, [1 + round] pairs of that round
+  MSMCHK(nbls_msm_fill_launch(nb, (unsigned)p, ident, Bk, s));
+  if (m) {
+    if ((r = run(ctx, g2 ? P_G2_TO_PROJ : P_G1_TO_PROJ, n, {B(g2 ? 1 : 0, d_pts, a), B(3, Pj, p)}, s))) return r;
+    MSMCHK(nbls_msm_keys_launch((unsigned)n, nwin, d_scalars, kin, vin, s));
+    MSMCHK(nbls_msm_sort_launch(tmp, &tmp_bytes, kin, kout, vin, vout, m, 17, s));
+    MSMCHK(nbls_msm_gather_launch(m, (unsigned)p, vout, Pj, P, s));
+    MSMCHK(nbls_msm_rank_launch(m, kout, pos, counters, s));
+    uint32_t maxrun = 0;
+    HIPCHK(hipMemcpyAsync(&maxrun, counters, 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+    int round = 0;
+    for (size_t d = 1; d < maxrun; d *= 2, round++) {
+      const size_t bound = m / (d + 1) + 1;      // every pair owns d + 1 list positions of its own
+      uint32_t* c = counters + 1 + round;
+      MSMCHK(nbls_msm_pairs_launch(m, (unsigned)d, kout, pos, list, c, s));
+      MSMCHK(nbls_msm_gather2_launch(bound, c, (unsigned)p, (unsigned)d, list, P, A, Bv, s));
+      if ((r = run(ctx, g2 ? P_G2_ADD_AB : P_G1_ADD_AB, bound, {B(3, A, p), B(4, Bv, p), B(5, A, p)}, s, c))) return r;
+      MSMCHK(nbls_msm_scatter_launch(bound, c, (unsigned)p, list, A, P, s));
+    }
+    MSMCHK(nbls_msm_heads_launch(m, (unsigned)p, kout, P, Bk, s));
+  }
+  MSMCHK(nbls_msm_bitsel_launch(nwin, (unsigned)p, Bk, G, s));
+  uint8_t *src = G, *dst = Gh;
+  for (size_t cnt = ng; cnt > (size_t)nwin * C; cnt /= 2) {
+    if ((r = run(ctx, g2 ? P_G2_ADD2 : P_G1_ADD2, cnt / 2, {B(3, src, 2 * p), B(5, dst, p)}, s))) return r;
+    std::swap(src, dst);
+  }
+  uint8_t* S = A;   // per-window sums
+  if ((r = run(ctx, g2 ? P_G2_HORNER : P_G1_HORNER, nwin, {B(3, src, C * p), B(5, S, p)}, s))) return r;
+  HIPCHK(hipMemcpyAsync(acc, S + (size_t)(nwin - 1) * p, p, hipMemcpyDeviceToDevice, s));
+  for (int w = (int)nwin - 2; w >= 0; w--)
+    if ((r = run(ctx, g2 ? P_G2_SHIFTADD : P_G1_SHIFTADD, 1, {B(3, acc, p), B(4, S + (size_t)w * p, p), B(5, acc, p)}, s))) return r;
+  if ((r = run(ctx, g2 ? P_G2_NORM : P_G1_NORM, 1, {B(3, acc, p), B(4, N, RAW)}, s))) return r;
+  if ((r = run_inv_buf(ctx, 1, N, NI, s))) return r;
+  return run(ctx, g2 ? P_G2_TO_AFFINE : P_G1_TO_AFFINE, 1, {B(3, acc, p), B(4, NI, RAW), B(2, d_out, a), B(7, d_status, 1)}, s);
+}
+static unsigned scalars_bit_length(size_t n, const uint8_t* k32) {   // max over the batch
+  int lead = 32;   // leading zero bytes common to all scalars
+  for (size_t i = 0; i < n && lead; i++) { int z = 0; while (z < lead && k32[32 * i + z] == 0) z++; lead = z; }
+  if (lead == 32) return 1;
+  uint8_t top = 0; for (size_t i = 0; i < n; i++) top |= k32[32 * i + lead];
+  unsigned bits = 8 * (31 - lead); while (top) { bits++; top >>= 1; }
+  return bits;
+}
+static int msm_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* pts, const uint8_t* scalars32, uint8_t* out, int8_t* status) {
+  if (!ctx || !out || (n && (!pts || !scalars32))) return NBLS_EINVAL;
+  const size_t a = g2 ? 192 : 96;
+  LOCKED(ctx); HostIO io{ctx}; void *dp = io.alloc(n * a), *dk = io.alloc(n * 32), *o = io.alloc(a), *st = io.alloc(1); if (!dp || !dk || !o || !st) return NBLS_EHIP;
+  if (n) { HIPCHK(hipMemcpyAsync(dp, pts, n * a, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(dk, scalars32, n * 32, hipMemcpyHostToDevice, s)); }
+  int r = dev_msm(ctx, g2, n, dp, dk, n ? scalars_bit_length(n, scalars32) : 1, o, st, s); if (r) return r;
+  int8_t z = 0; HIPCHK(hipMemcpyAsync(out, o, a, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(&z, st, 1, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+  if (status) *status = z;
+  return NBLS_OK;
+}
+EXPORT int nbls_g1_msm(nbls_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out96, int8_t* status) { return msm_host(ctx, false, n, pts96, scalars32, out96, status); }
+EXPORT int nbls_g2_msm(nbls_ctx* ctx, size_t n, const uint8_t* pts192, const uint8_t* scalars32, uint8_t* out192, int8_t* status) { return msm_host(ctx, true, n, pts192, scalars32, out192, status); }
+// device-resident variant: points (affine wire bytes), scalars (32 B big-endian, all < 2^nbits; nbits = 0 means 256), one affine result + int8 status
+// in device memory; enqueued on `stream` (NULL = the context's stream) except for one 4-byte read-back in the middle
+EXPORT int nbls_msm_dev(nbls_ctx* ctx, int g2, size_t n, const void* d_pts, const void* d_scalars32, unsigned nbits, void* d_out, void* d_status, void* stream) {
+  if (!ctx || !d_out || !d_status || (n && (!d_pts || !d_scalars32))) return NBLS_EINVAL;
+  std::lock_guard<std::mutex> g_(ctx->mu); HIPCHK(hipSetDevice(ctx->device));
+  return dev_msm(ctx, g2 != 0, n, d_pts, d_scalars32, nbits, d_out, d_status, stream ? (hipStream_t)stream : ctx->stream);
+}
+
 // sign(message_i, key_i) (index.ts:744-752): hashToCurve -> multiply by the key -> affine signature point (the caller
 // compresses, PointG2.toSignature index.ts:586-602).  status: 0 ok, 5 key is 0 mod r.
 EXPORT int nbls_sign_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len, const uint8_t* keys32, uint8_t* out192, int8_t* status) {

@@ -35,8 +35,13 @@ enum ProgId {
   P_G1_CLEAR,           // projective point (3) -> clearCofactor -> projective point (6), Z (7)                            (index.ts:401-405)
   P_ENC2_A, P_ENC2_B,   // G2 encodeToCurve: 128 uniform bytes (0) -> u (3), SWU exponentiation input (4) ; u (3), power (5) -> projective point on E2 (6)
   P_G1_MUL, P_G2_MUL,            // [k]P for per-item 256-bit scalars: point (buf 0 / 1), scalar 32 B (buf 2) -> projective (3), norm of Z (4)   (getPublicKey / sign, index.ts:738-752)
+  // multi-scalar multiplication (bucket method, 12-bit windows; nbls_api.cpp dev_msm): points are raw projective (3 / 6 field elements)
+  P_G1_ADD_AB, P_G2_ADD_AB,       // A[i] (buf 3) + B[i] (buf 4) -> buf 5 (may alias buf 3)
+  P_G1_HORNER, P_G2_HORNER,       // T[0..11] of one window (buf 3) -> sum_t 2^t T[t] (buf 5)
+  P_G1_SHIFTADD, P_G2_SHIFTADD,   // 2^12 * acc (buf 3) + S (buf 4) -> buf 5
   P_COUNT
 };
+static const int MSM_WINDOW_BITS = 12;
 const Program& get_program(ProgId id);
 void print_stats(const Program& p);
 }  // namespace nbls

@@ -10,6 +10,8 @@ namespace nbls {
 extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel(KernelArgs ka) {
   extern __shared__ __attribute__((aligned(16))) u32 smem[];
   const u32 lane = threadIdx.x;
+  u32 n_items = ka.n_items;
+  if (ka.n_items_dev) { const u32 v = *ka.n_items_dev; n_items = v < n_items ? v : n_items; if (blockIdx.x * ka.G >= n_items) return; }
   const u32 shared_words = ka.nconst * SLOT_WORDS;
   for (u32 i = lane; i < shared_words; i += 64) smem[i] = ka.consts[i];
   const u32 W = ka.W;
@@ -18,7 +20,7 @@ extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel(KernelArgs ka) {
   LaneCtx cx;
   cx.inst = shared_words + inst_id * ka.slots * SLOT_WORDS;
   cx.item = blockIdx.x * ka.G + inst_id;
-  cx.live = inst_id < ka.G && cx.item < ka.n_items;
+  cx.live = inst_id < ka.G && cx.item < n_items;
   if (ka.hwid_out && lane == 0) { ka.hwid_out[3 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); ka.hwid_out[3 * blockIdx.x + 1] = __builtin_readcyclecounter(); }   // HW_ID, XCC_ID, start tick (placement study)
   __syncthreads();   // single wave: orders the constant fill before first use
   // Software-pipelined interpreter loop: this lane's descriptor words for step s+1 and the header of step s+2 are
@@ -67,6 +69,8 @@ extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel(KernelArgs ka) {
 extern "C" __global__ void __launch_bounds__(128) nbls_vm_kernel_split(KernelArgs ka) {
   extern __shared__ __attribute__((aligned(16))) u32 smem[];
   const u32 tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  u32 n_items = ka.n_items;
+  if (ka.n_items_dev) { const u32 v = *ka.n_items_dev; n_items = v < n_items ? v : n_items; if (blockIdx.x * ka.G >= n_items) return; }
   const u32 shared_words = ka.nconst * SLOT_WORDS;
   for (u32 i = tid; i < shared_words; i += 128) smem[i] = ka.consts[i];
   const u32 W = ka.W;
@@ -75,7 +79,7 @@ extern "C" __global__ void __launch_bounds__(128) nbls_vm_kernel_split(KernelArg
   LaneCtx cx;
   cx.inst = shared_words + inst_id * ka.slots * SLOT_WORDS;
   cx.item = blockIdx.x * ka.G + inst_id;
-  cx.live = inst_id < ka.G && cx.item < ka.n_items;
+  cx.live = inst_id < ka.G && cx.item < n_items;
   u64* xch = (u64*)(smem + (ka.nconst + ka.G * ka.slots) * SLOT_WORDS);   // exchange area: 28 columns x 64 lanes, column-major (conflict-free)
   __syncthreads();
   const uint4* descs4 = (const uint4*)ka.descs;

@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PROGRAMS = ['miller_bytes', 'miller_raw', 'miller_fe', 'norm_raw', 'norm_bytes', 'fe_easy', 'expx', 'fe_mid1', 'fe_mid2', 'fe_final', 'fp12_mul2', 'raw_to_bytes',
             'g1_validate', 'g2_validate', 'g1_dec_a', 'g1_dec_b', 'g2_dec_a', 'g2_dec_b', 'h2c_a', 'h2c_b',
-            'g1_to_proj', 'g1_add2', 'g1_norm', 'g1_to_affine', 'g2_to_proj', 'g2_add2', 'g2_norm', 'g2_to_affine', 't_swu', 't_iso', 't_clear', 'h2c_c', 'miller_raw2', 'g1_compress', 'g2_compress', 'h2c1_a', 'enc1_a', 'h2c1_b', 'enc1_b', 'g1_clear', 'enc2_a', 'enc2_b', 'g1_mul', 'g2_mul']
+            'g1_to_proj', 'g1_add2', 'g1_norm', 'g1_to_affine', 'g2_to_proj', 'g2_add2', 'g2_norm', 'g2_to_affine', 't_swu', 't_iso', 't_clear', 'h2c_c', 'miller_raw2', 'g1_compress', 'g2_compress', 'h2c1_a', 'enc1_a', 'h2c1_b', 'enc1_b', 'g1_clear', 'enc2_a', 'enc2_b', 'g1_mul', 'g2_mul', 'g1_add_ab', 'g2_add_ab', 'g1_horner', 'g2_horner', 'g1_shiftadd', 'g2_shiftadd']
 DST_DEFAULT = b'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_'   # htfDefaults.DST, reference index.ts:64
 
 
@@ -52,6 +52,9 @@ def load_library():
     lib.nbls_g2_compress_batch.argtypes = [vp, sz, vp, vp]
     lib.nbls_g1_mul_batch.argtypes = [vp, sz, vp, vp, vp, vp]
     lib.nbls_g2_mul_batch.argtypes = [vp, sz, vp, vp, vp, vp]
+    lib.nbls_g1_msm.argtypes = [vp, sz, vp, vp, vp, vp]
+    lib.nbls_g2_msm.argtypes = [vp, sz, vp, vp, vp, vp]
+    lib.nbls_msm_dev.argtypes = [vp, i32, sz, vp, vp, C.c_uint32, vp, vp, vp]
     lib.nbls_sign_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, vp]
     lib.nbls_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, sz, C.POINTER(i32)]
     lib.nbls_verify_batch_dev_inputs.argtypes = [vp, sz, vp, vp, vp, C.POINTER(i32), vp, vp]
@@ -166,6 +169,20 @@ class Engine:
         f = self.lib.nbls_g2_mul_batch if g2 else self.lib.nbls_g1_mul_batch
         self._chk(f(self.h, n, pts, b''.join(scalars), out, st))
         return out.raw[:sz * n], st.raw[:n]
+
+    def msm(self, pts, scalars, g2=False):
+        """sum_i [k_i]P_i (bucket method on the GPU) -> (affine wire bytes, status); status 1 = the sum is the zero point.
+        pts: concatenated affine wire points, scalars: list of 32-byte big-endian strings"""
+        n = len(scalars)
+        sz = 192 if g2 else 96
+        assert len(pts) == sz * n
+        out = C.create_string_buffer(sz); st = C.c_int8(0)
+        f = self.lib.nbls_g2_msm if g2 else self.lib.nbls_g1_msm
+        self._chk(f(self.h, n, pts, b''.join(scalars), out, C.byref(st)))
+        return out.raw, st.value
+
+    def msm_dev(self, g2, n, d_pts, d_scalars, nbits, d_out, d_status, stream=0):
+        self._chk(self.lib.nbls_msm_dev(self.h, int(bool(g2)), n, d_pts, d_scalars, nbits, d_out, d_status, stream))
 
     @classmethod
     def compress_g1(cls, aff96):

@@ -166,6 +166,35 @@ def test_scalar_mul_programs(sim, oracle, golden):
     assert st[0] == 1
 
 
+def test_msm_pipeline(sim, oracle):
+    """the bucket-method multi-scalar multiplication (dev_msm in csrc/nbls_api.cpp: sort by window digit, segmented sums,
+    bit-sliced bucket weighting, Horner over the windows) with its step programs on the simulator, against the oracle's
+    sum of scalar multiples; scalars with repeated digits (long runs in one bucket), zero digits and zero scalars"""
+    import random
+    rnd = random.Random(381)
+    g1 = oracle.g1_generator()
+    pts = [oracle.g1_mul(g1, rnd.randrange(1, 1 << 64))[1] for _ in range(9)]
+    ks = [rnd.randrange(1, 1 << 24) for _ in range(5)] + [0x5005, 0x5005, 0, 0xfff000]
+    out, st = vmsim_py.msm(sim, b''.join(pts), b''.join(k.to_bytes(32, 'big') for k in ks), 24)
+    ref = oracle.g1_sum(b''.join(oracle.g1_mul(p, k)[1] for p, k in zip(pts, ks) if k))
+    assert st == 0 and out == ref[1]
+    # full-width scalars: 22 windows, incl. 2^256 - 1 and a multiple of the group order
+    r = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    kw = [rnd.randrange(0, 1 << 256) for _ in range(7)] + [(1 << 256) - 1, r]
+    out, st = vmsim_py.msm(sim, b''.join(pts), b''.join(k.to_bytes(32, 'big') for k in kw), 256)
+    ref = oracle.g1_sum(b''.join(oracle.g1_mul(p, k % r)[1] for p, k in zip(pts, kw) if k % r))
+    assert st == 0 and out == ref[1]
+    # G2, one window; the same point twice with k and 4096 - k... (digits sum to a multiple handled by the doublings)
+    g2 = oracle.g2_generator()
+    q = [oracle.g2_mul(g2, 3)[1], oracle.g2_mul(g2, 5)[1], g2]
+    ks2 = [7, 4095, 100]
+    out, st = vmsim_py.msm(sim, b''.join(q), b''.join(k.to_bytes(32, 'big') for k in ks2), 12, g2=True)
+    assert st == 0 and out == oracle.g2_mul(g2, 3 * 7 + 5 * 4095 + 100)[1]
+    # the sum is the zero point: k P + k (-P)
+    out, st = vmsim_py.msm(sim, pts[0] + oracle.un('g1_neg_aff', pts[0], 96), (5).to_bytes(32, 'big') * 2, 12)
+    assert st == 1
+
+
 def test_miller_shared_accumulator(sim, oracle, golden):
     """MILLER_RAW2: two pairs per item with one shared accumulator == product of the two separate Miller loops
     (the reference multiplies separate millerLoop values, index.ts:756-767, 810-817; same field element)"""

@@ -17,7 +17,7 @@ def raw_elem(v):
 
 
 PROGS = ['MILLER_BYTES', 'MILLER_RAW', 'MILLER_FE', 'NORM_RAW', 'NORM_BYTES', 'FE_EASY', 'EXPX', 'FE_MID1', 'FE_MID2', 'FE_FINAL', 'MUL2', 'RAW_TO_BYTES', 'G1_VALIDATE', 'G2_VALIDATE', 'G1_DEC_A', 'G1_DEC_B', 'G2_DEC_A', 'G2_DEC_B', 'H2C_A', 'H2C_B',
-         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'G1_COMPRESS', 'G2_COMPRESS', 'H2C1_A', 'ENC1_A', 'H2C1_B', 'ENC1_B', 'G1_CLEAR', 'ENC2_A', 'ENC2_B', 'G1_MUL', 'G2_MUL']
+         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'G1_COMPRESS', 'G2_COMPRESS', 'H2C1_A', 'ENC1_A', 'H2C1_B', 'ENC1_B', 'G1_CLEAR', 'ENC2_A', 'ENC2_B', 'G1_MUL', 'G2_MUL', 'G1_ADD_AB', 'G2_ADD_AB', 'G1_HORNER', 'G2_HORNER', 'G1_SHIFTADD', 'G2_SHIFTADD']
 P = {n: i for i, n in enumerate(PROGS)}
 
 
@@ -131,6 +131,77 @@ def point_mul(lib, pts, scalars32, g2=False):
     lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
     run(lib, pre + '_TO_AFFINE', n, {3: (Pj, psz), 4: (NI, RAW), 2: (out, sz), 7: (st, 1)})
     return out.raw, st.raw
+
+
+def msm(lib, pts, scalars32, nbits, g2=False):
+    """dev_msm() of csrc/nbls_api.cpp on the simulator; the data-movement kernels of msm_kernels.hip (window digits, sort,
+    gathers) are restated in Python, every group operation runs as a step program"""
+    WB = 12
+    sz, psz = (192, 6 * RAW) if g2 else (96, 3 * RAW)
+    pre = 'G2' if g2 else 'G1'
+    n = len(scalars32) // 32
+    nwin = (nbits + WB - 1) // WB
+    ident = bytearray(psz)
+    yo = (2 * RAW) if g2 else RAW
+    ident[yo:yo + RAW] = raw_elem(1)
+    ident = bytes(ident)
+    Pj = buf(psz * max(n, 1))
+    if n:
+        run(lib, pre + '_TO_PROJ', n, {(1 if g2 else 0): (buf(pts), sz), 3: (Pj, psz)})
+    ks = [int.from_bytes(scalars32[32 * i:32 * i + 32], 'big') for i in range(n)]
+    pairs = sorted(((w << WB) | ((ks[i] >> (WB * w)) & ((1 << WB) - 1)), w * n + i) for w in range(nwin) for i in range(n))   # stable: ties keep input order
+    keys = [k for k, _ in pairs]
+    m = len(pairs)
+    P = bytearray(b''.join(Pj.raw[psz * (v % n):psz * (v % n) + psz] for _, v in pairs)) if m else bytearray()
+    maxrun, j = 0, 0
+    while j < m:
+        e = j
+        while e < m and keys[e] == keys[j]:
+            e += 1
+        maxrun = max(maxrun, e - j); j = e
+    pos, j = [0] * m, 0
+    while j < m:
+        e = j
+        while e < m and keys[e] == keys[j]:
+            pos[e] = e - j; e += 1
+        j = e
+    d = 1
+    while d < maxrun:          # balanced tree inside every run: rank multiple of 2d absorbs the element d further on
+        lst = [j for j in range(m) if pos[j] % (2 * d) == 0 and j + d < m and keys[j + d] == keys[j]]
+        assert len(lst) <= m // (d + 1) + 1
+        A = buf(b''.join(bytes(P[psz * j:psz * j + psz]) for j in lst))
+        Bv = buf(b''.join(bytes(P[psz * (j + d):psz * (j + d) + psz]) for j in lst))
+        run(lib, pre + '_ADD_AB', len(lst), {3: (A, psz), 4: (Bv, psz), 5: (A, psz)})     # in place, as on the device
+        for i, j in enumerate(lst):
+            P[psz * j:psz * j + psz] = A.raw[psz * i:psz * i + psz]
+        d *= 2
+    buckets = [ident] * (nwin << WB)
+    for j in range(m):
+        if j == 0 or keys[j - 1] != keys[j]:
+            buckets[keys[j]] = bytes(P[psz * j:psz * j + psz])
+    G = []
+    for w in range(nwin):
+        for t in range(WB):
+            for jj in range(1 << (WB - 1)):
+                b = ((jj >> t) << (t + 1)) | (1 << t) | (jj & ((1 << t) - 1))
+                G.append(buckets[(w << WB) + b])
+    cnt = len(G)
+    src = buf(b''.join(G))
+    while cnt > nwin * WB:
+        dst = buf(psz * (cnt // 2))
+        run(lib, pre + '_ADD2', cnt // 2, {3: (src, 2 * psz), 5: (dst, psz)})
+        src = dst
+        cnt //= 2
+    S = buf(psz * nwin)
+    run(lib, pre + '_HORNER', nwin, {3: (src, WB * psz), 5: (S, psz)})
+    acc = buf(S.raw[psz * (nwin - 1):psz * nwin])
+    for w in range(nwin - 2, -1, -1):
+        run(lib, pre + '_SHIFTADD', 1, {3: (acc, psz), 4: (buf(S.raw[psz * w:psz * w + psz]), psz), 5: (acc, psz)})
+    N, NI, out, st = buf(RAW), buf(RAW), buf(sz), buf(1)
+    run(lib, pre + '_NORM', 1, {3: (acc, psz), 4: (N, RAW)})
+    lib.nbls_sim_fp_inv(C.c_uint(1), N, NI)
+    run(lib, pre + '_TO_AFFINE', 1, {3: (acc, psz), 4: (NI, RAW), 2: (out, sz), 7: (st, 1)})
+    return out.raw, st.raw[0]
 
 
 def compress(lib, aff, g2=False):
