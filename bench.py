@@ -63,6 +63,7 @@ def main():
     ap.add_argument('--inflight', type=int, default=5, help='batches kept in flight on separate HIP streams during the timed steps (1 = strictly one batch at a time)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--verify-batch', type=int, default=65536, help='signatures in the verifyBatch leg (BASELINE configs[2]); 0 disables')
+    ap.add_argument('--msm-points', type=int, default=65536, help='points in the multi-scalar multiplication leg (SURVEY 8(f).3); 0 disables')
     ap.add_argument('--sign-batch', type=int, default=8192, help='signatures produced in the sign leg (SURVEY 8(f).1); 0 disables')
     ap.add_argument('--product-terms', type=int, default=262144, help='terms of the sharded multi-pairing product leg (BASELINE configs[4]); 0 disables')
     args = ap.parse_args()
@@ -302,6 +303,33 @@ def main():
             sleg = {'metric': 'sign sigs/sec: nbls_sign_batch from host buffers (device SHA-256 expand_message_xmd + hash-to-G2 + constant-time G2 ladder + affine), compression not included', 'n': ns_, 'value': round(ns_ / sdt, 2), 'ms': round(sdt * 1e3, 3),
                     'g2_ladder_kernel_ms': round(stm.get('g2_mul', (0, 0))[0], 3), 'get_public_key_keys_per_s': round(ns_ / kdt, 2),
                     'cpu_baseline': {'value': round(1 / csdt, 2), 'unit': 'sigs/s', 'cores': 1, 'kind': 'port', 'sample': '16 signatures on one host thread (oracle/)'}}
+        mleg = None
+        if world == 1 and args.msm_points > 0:
+            nm = args.msm_points
+            R_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+            gen1 = oracle.g1_generator()
+            a64 = [int.from_bytes(hashlib.sha256(b'msm-a' + bytes([i])).digest(), 'big') % R_ORDER for i in range(64)]
+            p64 = [oracle.g1_mul(gen1, a)[1] for a in a64]
+            ks = [int.from_bytes(hashlib.sha256(b'msm-k' + i.to_bytes(4, 'big')).digest(), 'big') % R_ORDER for i in range(nm)]
+            Pm = b''.join(p64[i % 64] for i in range(nm)); Km = b''.join(k.to_bytes(32, 'big') for k in ks)
+            d_pm = torch.frombuffer(bytearray(Pm), dtype=torch.uint8).cuda(); d_km = torch.frombuffer(bytearray(Km), dtype=torch.uint8).cuda()
+            d_om = torch.empty(96, dtype=torch.uint8, device='cuda'); d_sm = torch.empty(1, dtype=torch.int8, device='cuda')
+            st_ = torch.cuda.current_stream().cuda_stream
+            eng.msm_dev(False, nm, d_pm.data_ptr(), d_km.data_ptr(), 255, d_om.data_ptr(), d_sm.data_ptr(), st_); torch.cuda.synchronize()
+            expect = oracle.g1_mul(gen1, sum(a64[i % 64] * k for i, k in enumerate(ks)) % R_ORDER)[1]      # parity: (sum a_i k_i) G with one oracle multiplication
+            assert bytes(d_om.cpu().numpy().tobytes()) == expect, 'msm parity check failed'
+            m0 = time.perf_counter()
+            for _ in range(5):
+                eng.msm_dev(False, nm, d_pm.data_ptr(), d_km.data_ptr(), 255, d_om.data_ptr(), d_sm.data_ptr(), st_)
+            torch.cuda.synchronize(); mdt = (time.perf_counter() - m0) / 5
+            h0 = time.perf_counter(); eng.msm(Pm, [Km[32 * i:32 * i + 32] for i in range(nm)]); hdt = time.perf_counter() - h0
+            nc = 256
+            c0 = time.perf_counter()
+            oracle.g1_sum(b''.join(oracle.g1_mul(p64[i % 64], ks[i])[1] for i in range(nc)))
+            cmdt = (time.perf_counter() - c0) / nc
+            mleg = {'metric': 'G1 multi-scalar multiplication points/sec (255-bit scalars, bucket method)', 'n': nm, 'value': round(nm / mdt, 2), 'ms': round(mdt * 1e3, 3),
+                    'host_call_points_per_s': round(nm / hdt, 2), 'note': 'value: points and scalars resident in HBM; host_call: nbls_g1_msm from host buffers incl. PCIe and Python marshalling',
+                    'cpu_baseline': {'value': round(1 / cmdt, 2), 'unit': 'points/s', 'cores': 1, 'kind': 'port', 'sample': '%d scalar multiplications + sum on one host thread (oracle/ double-and-add, no bucket method)' % nc}}
         line = {
             'metric': 'pairings/sec', 'value': round(value, 2), 'unit': 'pairings/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -309,7 +337,7 @@ def main():
             'config': {'workload': 'batch of %d independent BLS12-381 pairings per GPU (Miller loop + final exponentiation, inputs pre-validated, bit-exact vs reference), inputs/outputs resident in HBM' % n,
                        'batch_per_gpu': n, 'sharding': 'independent batches per rank, no collective', 'batches_in_flight': D},
             'single_stream': {'pairings_per_s': round(n * args.steps / dt_serial, 2), 'ms_per_batch': round(dt_serial / args.steps * 1e3, 4), 'note': 'one batch at a time on one stream (this rank): the latency of a 4096-pairing call'},
-            'roofline': roof, 'cpu_baseline': cpu, 'product': product, 'verify_batch': vbatch, 'sign': sleg,
+            'roofline': roof, 'cpu_baseline': cpu, 'product': product, 'verify_batch': vbatch, 'sign': sleg, 'msm': mleg,
         }
         print(json.dumps(line))
     if world > 1:

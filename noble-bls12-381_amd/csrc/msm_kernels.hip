@@ -30,6 +30,52 @@ __global__ void msm_keys_kernel(u32 n, u32 nwin, const uint8_t* __restrict__ sca
   }
 }
 
+// Scalar decomposition for the endomorphism split: k = a0 + a1 |z| + a2 |z|^2 + a3 |z|^3 in base |z| = 0xd201000000010000 (the
+// BLS parameter; a0..a2 < 2^64, a3 < 2^65 for k < 2^256).  dims = 4 (G2): the four digits; dims = 2 (G1): k mod z^2 = a0 + a1 |z|
+// and k div z^2 = a2 + a3 |z|.  Output: dims scalars per input scalar, 32 bytes big-endian each (the format msm_keys_kernel reads).
+__device__ inline u64 div_step(u64* limbs, int nl) {   // limbs (little-endian u64) /= |z|, returns the remainder; bitwise, |z| has its top bit set
+  const u64 Z = 0xd201000000010000ull;
+  u64 rem = 0;
+  for (int i = nl - 1; i >= 0; i--) {
+    u64 q = 0; const u64 v = limbs[i];
+    for (int b = 63; b >= 0; b--) {
+      const u64 carry = rem >> 63;
+      rem = (rem << 1) | ((v >> b) & 1);
+      const bool ge = carry || rem >= Z;
+      if (ge) rem -= Z;
+      q = (q << 1) | (u64)ge;
+    }
+    limbs[i] = q;
+  }
+  return rem;
+}
+__device__ inline void store_be(uint8_t* out, u64 l0, u64 l1, u64 l2) {   // 32-byte big-endian of l0 + l1 2^64 + l2 2^128
+  u32* o = (u32*)out;
+  o[0] = 0; o[1] = 0; o[2] = __builtin_bswap32((u32)(l2 >> 32)); o[3] = __builtin_bswap32((u32)l2);
+  o[4] = __builtin_bswap32((u32)(l1 >> 32)); o[5] = __builtin_bswap32((u32)l1); o[6] = __builtin_bswap32((u32)(l0 >> 32)); o[7] = __builtin_bswap32((u32)l0);
+}
+__global__ void msm_decompose_kernel(u32 n, u32 dims, const uint8_t* __restrict__ scalars, uint8_t* __restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32* k = (const u32*)(scalars + 32ull * i);
+  u64 l[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) l[j] = ((u64)__builtin_bswap32(k[6 - 2 * j]) << 32) | __builtin_bswap32(k[7 - 2 * j]);
+  const u64 a0 = div_step(l, 4);
+  const u64 a1 = div_step(l, 4);          // l = k div z^2 (< 2^129)
+  uint8_t* o = out + 32ull * dims * i;
+  if (dims == 2) {
+    const u64 Z = 0xd201000000010000ull;
+    const u64 lo = a1 * Z, hi = __umul64hi(a1, Z);
+    const u64 s0 = lo + a0, s1 = hi + (s0 < lo);
+    store_be(o, s0, s1, 0);
+    store_be(o + 32, l[0], l[1], l[2]);
+  } else {
+    const u64 a2 = div_step(l, 3);          // l = a3 (< 2^65)
+    store_be(o, a0, 0, 0); store_be(o + 32, a1, 0, 0); store_be(o + 64, a2, 0, 0); store_be(o + 96, l[0], l[1], 0);
+  }
+}
+
 // dst[j] = src[idx[j]]   (q = 16-byte vectors per element)
 __global__ void msm_gather_kernel(u64 m, u32 q, const u32* __restrict__ idx, const uint4* __restrict__ src, uint4* __restrict__ dst) {
   const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,6 +177,10 @@ inline unsigned blocks_for(u64 threads) { return (unsigned)((threads + 255) / 25
 extern "C" {
 int nbls_msm_keys_launch(unsigned n, unsigned nwin, const void* scalars, void* keys, void* vals, void* stream) {
   hipLaunchKernelGGL(msm_keys_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, n, nwin, (const uint8_t*)scalars, (u32*)keys, (u32*)vals);
+  return (int)hipGetLastError();
+}
+int nbls_msm_decompose_launch(unsigned n, unsigned dims, const void* scalars, void* out, void* stream) {
+  hipLaunchKernelGGL(msm_decompose_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, n, dims, (const uint8_t*)scalars, (uint8_t*)out);
   return (int)hipGetLastError();
 }
 // temp == NULL: returns the scratch size in *temp_bytes

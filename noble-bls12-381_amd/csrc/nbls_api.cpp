@@ -17,6 +17,7 @@ extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, vo
 extern "C" int nbls_fp_inv_launch(unsigned n, const void* in, void* out, void* stream);
 extern "C" int nbls_xmd_launch(unsigned n, const void* msgs, const void* offsets, const void* dst, unsigned dst_len, void* out, unsigned len_in_bytes, void* stream);
 extern "C" int nbls_msm_keys_launch(unsigned n, unsigned nwin, const void* scalars, void* keys, void* vals, void* stream);
+extern "C" int nbls_msm_decompose_launch(unsigned n, unsigned dims, const void* scalars, void* out, void* stream);
 extern "C" int nbls_msm_sort_launch(void* temp, size_t* temp_bytes, const void* keys_in, void* keys_out, const void* vals_in, void* vals_out, size_t m, int key_bits, void* stream);
 extern "C" int nbls_msm_gather_launch(size_t m, unsigned elem_bytes, const void* idx, const void* src, void* dst, void* stream);
 extern "C" int nbls_msm_rank_launch(size_t m, const void* keys, void* pos, void* maxrun_u32, void* stream);
@@ -679,10 +680,18 @@ static int dev_msm(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, const vo
   const unsigned C = MSM_WINDOW_BITS;
   uint8_t* ident = g2 ? ctx->ident_g2 : ctx->ident_g1;
   if (nbits == 0 || nbits > 256) nbits = 256;
+  if (n > ((size_t)1 << 22)) return NBLS_EINVAL;
+  // Wide scalars are split with the curve endomorphisms (GLV / GLS): k = sum_i a_i |z|^i, [|z|^i]P is one cheap map of P.  G1:
+  // 2 points with 129-bit scalars, G2: 4 points with 65-bit scalars -- the same number of bucket additions, but 10 / 5 instead
+  // of 21 rounds of "12 doublings + 1 addition" on a single point at the end (latency-bound: 0.11 ms each).
+  const bool split = nbits > 192;
+  const unsigned dims = split ? (g2 ? 4 : 2) : 1;
+  const size_t n_in = n;
+  if (split) { n *= dims; nbits = g2 ? 65 : 129; }
   const unsigned nwin = (nbits + C - 1) / C;
   const size_t m = n * nwin, nb = (size_t)nwin << C, ng = ((size_t)nwin * C) << (C - 1);
-  if (n > ((size_t)1 << 24)) return NBLS_EINVAL;
-  uint8_t *Pj, *P, *A, *K, *tmp, *Bk, *G, *Gh, *N, *NI, *acc, *cnt; int r;
+  uint8_t *Pj, *P, *A, *K, *tmp, *Bk, *G, *Gh, *N, *NI, *acc, *cnt, *Ks = nullptr; int r;
+  if (split && (r = need(ctx, 13, (n + 1) * 32, &Ks))) return r;
   size_t tmp_bytes = 0;
   if (m) MSMCHK(nbls_msm_sort_launch(nullptr, &tmp_bytes, nullptr, nullptr, nullptr, nullptr, m, 17, s));
   const size_t half = m / 2 + 1;
@@ -694,8 +703,11 @@ static int dev_msm(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, const vo
   uint32_t* counters = (uint32_t*)cnt;    // [0] longest run, [1 + round] pairs of that round
   MSMCHK(nbls_msm_fill_launch(nb, (unsigned)p, ident, Bk, s));
   if (m) {
-    if ((r = run(ctx, g2 ? P_G2_TO_PROJ : P_G1_TO_PROJ, n, {B(g2 ? 1 : 0, d_pts, a), B(3, Pj, p)}, s))) return r;
-    MSMCHK(nbls_msm_keys_launch((unsigned)n, nwin, d_scalars, kin, vin, s));
+    if (split) {
+      if ((r = run(ctx, g2 ? P_G2_MSM_PREP : P_G1_MSM_PREP, n_in, {B(g2 ? 1 : 0, d_pts, a), B(3, Pj, dims * p)}, s))) return r;
+      MSMCHK(nbls_msm_decompose_launch((unsigned)n_in, dims, d_scalars, Ks, s));
+    } else if ((r = run(ctx, g2 ? P_G2_TO_PROJ : P_G1_TO_PROJ, n, {B(g2 ? 1 : 0, d_pts, a), B(3, Pj, p)}, s))) return r;
+    MSMCHK(nbls_msm_keys_launch((unsigned)n, nwin, split ? Ks : (const uint8_t*)d_scalars, kin, vin, s));
     MSMCHK(nbls_msm_sort_launch(tmp, &tmp_bytes, kin, kout, vin, vout, m, 17, s));
     MSMCHK(nbls_msm_gather_launch(m, (unsigned)p, vout, Pj, P, s));
     MSMCHK(nbls_msm_rank_launch(m, kout, pos, counters, s));

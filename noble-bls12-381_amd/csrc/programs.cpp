@@ -364,6 +364,24 @@ static Program build(ProgId id) {
       B.sched_window = env_int("NBLS_MUL_WINDOW", 300);
       return B.compile("g2_mul", 16);
     }
+    case P_G1_MSM_PREP: {
+      // phi(x, y) = (beta x, y) acts on G1 as [-z^2] (the reference's subgroup check compares [-z^2]P with phi(P), index.ts:424-448)
+      SFp x = input(0, 0), y = input(0, 48);
+      outputw(x, 3, 0); outputw(y, 3, 48); outputw(fp_one(), 3, 96);
+      outputw(mul(x, fp_const(NBLS_BETA)), 3, 144); outputw(-y, 3, 192); outputw(fp_one(), 3, 240);
+      return B.compile("g1_msm_prep", 4);
+    }
+    case P_G2_MSM_PREP: {
+      // psi acts on G2 as [z] = [-|z|] (PointG2 subgroup check, index.ts:640-657): [|z|^i]Q = (-1)^i psi^i(Q)
+      Pt<SFp2> q = pt_affine(input_fp2(1, 0), input_fp2(1, 96));
+      Pt<SFp2> q1 = psi_proj(q), q2 = psi2_proj(q), q3 = psi_proj(q2);
+      Pt<SFp2> outs[4] = {q, pt_neg(q1), q2, pt_neg(q3)};
+      for (int k = 0; k < 4; k++) {
+        const Pt<SFp2>& r = outs[k]; const int o = 288 * k;
+        outputw(r.x.c0, 3, o); outputw(r.x.c1, 3, o + 48); outputw(r.y.c0, 3, o + 96); outputw(r.y.c1, 3, o + 144); outputw(r.z.c0, 3, o + 192); outputw(r.z.c1, 3, o + 240);
+      }
+      return B.compile("g2_msm_prep", 8);
+    }
     case P_G1_ADD_AB: case P_G1_HORNER: case P_G1_SHIFTADD: {
       auto ld = [&](int buf, int off) { return Pt<SFp>{inputw(buf, off), inputw(buf, off + 48), inputw(buf, off + 96)}; };
       Pt<SFp> r;

@@ -39,6 +39,8 @@ enum ProgId {
   P_G1_ADD_AB, P_G2_ADD_AB,       // A[i] (buf 3) + B[i] (buf 4) -> buf 5 (may alias buf 3)
   P_G1_HORNER, P_G2_HORNER,       // T[0..11] of one window (buf 3) -> sum_t 2^t T[t] (buf 5)
   P_G1_SHIFTADD, P_G2_SHIFTADD,   // 2^12 * acc (buf 3) + S (buf 4) -> buf 5
+  P_G1_MSM_PREP,                  // affine P (buf 0) -> P, [z^2]P = -phi(P) = (beta x, -y) as projective points (buf 3): scalars split in base z^2
+  P_G2_MSM_PREP,                  // affine Q (buf 1) -> Q, [|z|]Q = -psi(Q), [z^2]Q = psi^2(Q), [|z|^3]Q = -psi^3(Q) (buf 3): scalars split in base |z|
   P_COUNT
 };
 static const int MSM_WINDOW_BITS = 12;

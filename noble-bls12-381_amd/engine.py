@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PROGRAMS = ['miller_bytes', 'miller_raw', 'miller_fe', 'norm_raw', 'norm_bytes', 'fe_easy', 'expx', 'fe_mid1', 'fe_mid2', 'fe_final', 'fp12_mul2', 'raw_to_bytes',
             'g1_validate', 'g2_validate', 'g1_dec_a', 'g1_dec_b', 'g2_dec_a', 'g2_dec_b', 'h2c_a', 'h2c_b',
-            'g1_to_proj', 'g1_add2', 'g1_norm', 'g1_to_affine', 'g2_to_proj', 'g2_add2', 'g2_norm', 'g2_to_affine', 't_swu', 't_iso', 't_clear', 'h2c_c', 'miller_raw2', 'g1_compress', 'g2_compress', 'h2c1_a', 'enc1_a', 'h2c1_b', 'enc1_b', 'g1_clear', 'enc2_a', 'enc2_b', 'g1_mul', 'g2_mul', 'g1_add_ab', 'g2_add_ab', 'g1_horner', 'g2_horner', 'g1_shiftadd', 'g2_shiftadd']
+            'g1_to_proj', 'g1_add2', 'g1_norm', 'g1_to_affine', 'g2_to_proj', 'g2_add2', 'g2_norm', 'g2_to_affine', 't_swu', 't_iso', 't_clear', 'h2c_c', 'miller_raw2', 'g1_compress', 'g2_compress', 'h2c1_a', 'enc1_a', 'h2c1_b', 'enc1_b', 'g1_clear', 'enc2_a', 'enc2_b', 'g1_mul', 'g2_mul', 'g1_add_ab', 'g2_add_ab', 'g1_horner', 'g2_horner', 'g1_shiftadd', 'g2_shiftadd', 'g1_msm_prep', 'g2_msm_prep']
 DST_DEFAULT = b'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_'   # htfDefaults.DST, reference index.ts:64
 
 

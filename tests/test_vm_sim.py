@@ -190,6 +190,10 @@ def test_msm_pipeline(sim, oracle):
     ks2 = [7, 4095, 100]
     out, st = vmsim_py.msm(sim, b''.join(q), b''.join(k.to_bytes(32, 'big') for k in ks2), 12, g2=True)
     assert st == 0 and out == oracle.g2_mul(g2, 3 * 7 + 5 * 4095 + 100)[1]
+    # full-width scalars on G2: four points (-1)^i psi^i(Q) with the base-|z| digits of k
+    kq = [rnd.randrange(0, 1 << 256), (1 << 256) - 1, r - 1]
+    out, st = vmsim_py.msm(sim, b''.join(q), b''.join(k.to_bytes(32, 'big') for k in kq), 256, g2=True)
+    assert st == 0 and out == oracle.g2_mul(g2, (3 * kq[0] + 5 * kq[1] + kq[2]) % r)[1]
     # the sum is the zero point: k P + k (-P)
     out, st = vmsim_py.msm(sim, pts[0] + oracle.un('g1_neg_aff', pts[0], 96), (5).to_bytes(32, 'big') * 2, 12)
     assert st == 1

@@ -17,7 +17,7 @@ def raw_elem(v):
 
 
 PROGS = ['MILLER_BYTES', 'MILLER_RAW', 'MILLER_FE', 'NORM_RAW', 'NORM_BYTES', 'FE_EASY', 'EXPX', 'FE_MID1', 'FE_MID2', 'FE_FINAL', 'MUL2', 'RAW_TO_BYTES', 'G1_VALIDATE', 'G2_VALIDATE', 'G1_DEC_A', 'G1_DEC_B', 'G2_DEC_A', 'G2_DEC_B', 'H2C_A', 'H2C_B',
-         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'G1_COMPRESS', 'G2_COMPRESS', 'H2C1_A', 'ENC1_A', 'H2C1_B', 'ENC1_B', 'G1_CLEAR', 'ENC2_A', 'ENC2_B', 'G1_MUL', 'G2_MUL', 'G1_ADD_AB', 'G2_ADD_AB', 'G1_HORNER', 'G2_HORNER', 'G1_SHIFTADD', 'G2_SHIFTADD']
+         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'G1_COMPRESS', 'G2_COMPRESS', 'H2C1_A', 'ENC1_A', 'H2C1_B', 'ENC1_B', 'G1_CLEAR', 'ENC2_A', 'ENC2_B', 'G1_MUL', 'G2_MUL', 'G1_ADD_AB', 'G2_ADD_AB', 'G1_HORNER', 'G2_HORNER', 'G1_SHIFTADD', 'G2_SHIFTADD', 'G1_MSM_PREP', 'G2_MSM_PREP']
 P = {n: i for i, n in enumerate(PROGS)}
 
 
@@ -140,15 +140,25 @@ def msm(lib, pts, scalars32, nbits, g2=False):
     sz, psz = (192, 6 * RAW) if g2 else (96, 3 * RAW)
     pre = 'G2' if g2 else 'G1'
     n = len(scalars32) // 32
-    nwin = (nbits + WB - 1) // WB
     ident = bytearray(psz)
     yo = (2 * RAW) if g2 else RAW
     ident[yo:yo + RAW] = raw_elem(1)
     ident = bytes(ident)
-    Pj = buf(psz * max(n, 1))
-    if n:
-        run(lib, pre + '_TO_PROJ', n, {(1 if g2 else 0): (buf(pts), sz), 3: (Pj, psz)})
     ks = [int.from_bytes(scalars32[32 * i:32 * i + 32], 'big') for i in range(n)]
+    if nbits > 192:          # endomorphism split: k = sum a_i |z|^i, the points [|z|^i]P come from the PREP program
+        Z = 0xd201000000010000
+        dims = 4 if g2 else 2
+        Pj = buf(psz * dims * max(n, 1))
+        if n:
+            run(lib, pre + '_MSM_PREP', n, {(1 if g2 else 0): (buf(pts), sz), 3: (Pj, dims * psz)})
+        ks = [d for k in ks for d in ([k % Z, k // Z % Z, k // Z ** 2 % Z, k // Z ** 3] if g2 else [k % Z ** 2, k // Z ** 2])]
+        n *= dims
+        nbits = 65 if g2 else 129
+    else:
+        Pj = buf(psz * max(n, 1))
+        if n:
+            run(lib, pre + '_TO_PROJ', n, {(1 if g2 else 0): (buf(pts), sz), 3: (Pj, psz)})
+    nwin = (nbits + WB - 1) // WB
     pairs = sorted(((w << WB) | ((ks[i] >> (WB * w)) & ((1 << WB) - 1)), w * n + i) for w in range(nwin) for i in range(n))   # stable: ties keep input order
     keys = [k for k, _ in pairs]
     m = len(pairs)
