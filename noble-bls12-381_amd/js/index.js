@@ -123,6 +123,16 @@ class PointG1 {
     const { out, status } = native.g1Sum(concat(...nz.map((p) => p.aff)));
     return status[0] === 1 ? PointG1.ZERO : new PointG1(out);
   }
+  // sum_i [k_i]P_i on the GPU (bucket method); scalars: bigint | number, any non-negative value below 2^256.  Not in the reference
+  // (its aggregatePublicKeys is the unweighted sum): the building block of random-linear-combination batch verification
+  static msm(points, scalars) {
+    ensureInit();
+    if (points.length !== scalars.length) throw new Error('points / scalars length mismatch');
+    const keep = points.map((p, i) => i).filter((i) => !points[i].zero);
+    if (!keep.length) return PointG1.ZERO;
+    const { out, status } = native.g1Msm(concat(...keep.map((i) => points[i].aff)), concat(...keep.map((i) => hexToBytes(BigInt(scalars[i]).toString(16).padStart(64, '0')))));
+    return status[0] === 1 ? PointG1.ZERO : new PointG1(out);
+  }
   equals(rhs) { return this.zero === rhs.zero && (this.zero || bytesToHex(this.aff) === bytesToHex(rhs.aff)); }
   // reference index.ts:359-381
   toHex(isCompressed = false) {
@@ -214,6 +224,14 @@ class PointG2 {
     const nz = points.filter((p) => !p.zero);
     if (!nz.length) return PointG2.ZERO;
     const { out, status } = native.g2Sum(concat(...nz.map((p) => p.aff)));
+    return status[0] === 1 ? PointG2.ZERO : new PointG2(out);
+  }
+  static msm(points, scalars) {
+    ensureInit();
+    if (points.length !== scalars.length) throw new Error('points / scalars length mismatch');
+    const keep = points.map((p, i) => i).filter((i) => !points[i].zero);
+    if (!keep.length) return PointG2.ZERO;
+    const { out, status } = native.g2Msm(concat(...keep.map((i) => points[i].aff)), concat(...keep.map((i) => hexToBytes(BigInt(scalars[i]).toString(16).padStart(64, '0')))));
     return status[0] === 1 ? PointG2.ZERO : new PointG2(out);
   }
   equals(rhs) { return this.zero === rhs.zero && (this.zero || bytesToHex(this.aff) === bytesToHex(rhs.aff)); }

@@ -17,7 +17,7 @@ static void* lib;
 #define SYM(name) static __typeof__(&name) p_##name;
 SYM(nbls_init) SYM(nbls_destroy) SYM(nbls_strerror) SYM(nbls_pairing_batch) SYM(nbls_miller_product) SYM(nbls_final_exp_batch)
 SYM(nbls_g1_validate_batch) SYM(nbls_g2_validate_batch) SYM(nbls_g1_decompress_batch) SYM(nbls_g2_decompress_batch)
-SYM(nbls_hash_to_g2_batch) SYM(nbls_g1_sum) SYM(nbls_g2_sum) SYM(nbls_verify_batch) SYM(nbls_g1_mul_batch) SYM(nbls_g2_mul_batch) SYM(nbls_sign_batch) SYM(nbls_hash_to_g1_batch) SYM(nbls_encode_to_g1_batch) SYM(nbls_encode_to_g2_batch)
+SYM(nbls_hash_to_g2_batch) SYM(nbls_g1_sum) SYM(nbls_g2_sum) SYM(nbls_verify_batch) SYM(nbls_g1_mul_batch) SYM(nbls_g2_mul_batch) SYM(nbls_sign_batch) SYM(nbls_hash_to_g1_batch) SYM(nbls_encode_to_g1_batch) SYM(nbls_encode_to_g2_batch) SYM(nbls_g1_msm) SYM(nbls_g2_msm)
 static nbls_ctx* ctx;
 
 #define CHECK(env, call) do { if ((call) != napi_ok) { napi_throw_error(env, NULL, "N-API call failed: " #call); return NULL; } } while (0)
@@ -98,6 +98,17 @@ static napi_value G2Mul(napi_env env, napi_callback_info info) {
   uint8_t *out, *st; napi_value vo = new_u8(env, n * 192, &out), vs = new_u8(env, n, &st);
   int r = p_nbls_g2_mul_batch(ctx, n, pts, sc, out, (int8_t*)st); if (r) return throw_code(env, r); return result2(env, vo, vs);
 }
+/* g1Msm(points96, scalars32) / g2Msm(points192, scalars32) -> {out: one affine point, status}: sum_i [k_i]P_i (status 1 = zero point) */
+static napi_value G1Msm(napi_env env, napi_callback_info info) {
+  ARGS(2); NEED_CTX(); BYTES(0, pts, lp); BYTES(1, sc, ls); size_t n = ls / 32; if (lp != n * 96) { napi_throw_range_error(env, NULL, "bad point array length"); return NULL; }
+  uint8_t *out, *st; napi_value vo = new_u8(env, 96, &out), vs = new_u8(env, 1, &st);
+  int r = p_nbls_g1_msm(ctx, n, pts, sc, out, (int8_t*)st); if (r) return throw_code(env, r); return result2(env, vo, vs);
+}
+static napi_value G2Msm(napi_env env, napi_callback_info info) {
+  ARGS(2); NEED_CTX(); BYTES(0, pts, lp); BYTES(1, sc, ls); size_t n = ls / 32; if (lp != n * 192) { napi_throw_range_error(env, NULL, "bad point array length"); return NULL; }
+  uint8_t *out, *st; napi_value vo = new_u8(env, 192, &out), vs = new_u8(env, 1, &st);
+  int r = p_nbls_g2_msm(ctx, n, pts, sc, out, (int8_t*)st); if (r) return throw_code(env, r); return result2(env, vo, vs);
+}
 /* signBatch(msgs, offsets(Uint32Array n+1), dst, keys32) -> {out: n*192 affine signature points, status} */
 static napi_value SignBatch(napi_env env, napi_callback_info info) {
   ARGS(4); NEED_CTX(); BYTES(0, msgs, lm); BYTES(1, offs, lo); BYTES(2, dst, ld); BYTES(3, keys, lk); (void)lm;
@@ -132,14 +143,14 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
 #define LOAD(name) p_##name = (__typeof__(p_##name))dlsym(lib, #name); if (!p_##name) { napi_throw_error(env, NULL, "libnbls.so lacks " #name); return exports; }
   LOAD(nbls_init) LOAD(nbls_destroy) LOAD(nbls_strerror) LOAD(nbls_pairing_batch) LOAD(nbls_miller_product) LOAD(nbls_final_exp_batch)
   LOAD(nbls_g1_validate_batch) LOAD(nbls_g2_validate_batch) LOAD(nbls_g1_decompress_batch) LOAD(nbls_g2_decompress_batch)
-  LOAD(nbls_hash_to_g2_batch) LOAD(nbls_g1_sum) LOAD(nbls_g2_sum) LOAD(nbls_verify_batch) LOAD(nbls_g1_mul_batch) LOAD(nbls_g2_mul_batch) LOAD(nbls_sign_batch) LOAD(nbls_hash_to_g1_batch) LOAD(nbls_encode_to_g1_batch) LOAD(nbls_encode_to_g2_batch)
+  LOAD(nbls_hash_to_g2_batch) LOAD(nbls_g1_sum) LOAD(nbls_g2_sum) LOAD(nbls_verify_batch) LOAD(nbls_g1_mul_batch) LOAD(nbls_g2_mul_batch) LOAD(nbls_sign_batch) LOAD(nbls_hash_to_g1_batch) LOAD(nbls_encode_to_g1_batch) LOAD(nbls_encode_to_g2_batch) LOAD(nbls_g1_msm) LOAD(nbls_g2_msm)
   napi_property_descriptor d[] = {
     {"init", 0, Init, 0, 0, 0, napi_enumerable, 0}, {"pairingBatch", 0, PairingBatch, 0, 0, 0, napi_enumerable, 0}, {"millerProduct", 0, MillerProduct, 0, 0, 0, napi_enumerable, 0},
     {"finalExpBatch", 0, FinalExpBatch, 0, 0, 0, napi_enumerable, 0}, {"g1Decompress", 0, G1Decompress, 0, 0, 0, napi_enumerable, 0}, {"g2Decompress", 0, G2Decompress, 0, 0, 0, napi_enumerable, 0},
     {"g1Validate", 0, G1Validate, 0, 0, 0, napi_enumerable, 0}, {"g2Validate", 0, G2Validate, 0, 0, 0, napi_enumerable, 0}, {"g1Sum", 0, G1Sum, 0, 0, 0, napi_enumerable, 0},
     {"g2Sum", 0, G2Sum, 0, 0, 0, napi_enumerable, 0}, {"hashToG2", 0, HashToG2, 0, 0, 0, napi_enumerable, 0}, {"verifyBatch", 0, VerifyBatch, 0, 0, 0, napi_enumerable, 0},
     {"g1Mul", 0, G1Mul, 0, 0, 0, napi_enumerable, 0}, {"g2Mul", 0, G2Mul, 0, 0, 0, napi_enumerable, 0}, {"signBatch", 0, SignBatch, 0, 0, 0, napi_enumerable, 0},
-    {"hashToCurve", 0, HashToCurve, 0, 0, 0, napi_enumerable, 0}};
+    {"hashToCurve", 0, HashToCurve, 0, 0, 0, napi_enumerable, 0}, {"g1Msm", 0, G1Msm, 0, 0, 0, napi_enumerable, 0}, {"g2Msm", 0, G2Msm, 0, 0, 0, napi_enumerable, 0}};
   napi_define_properties(env, exports, sizeof d / sizeof d[0], d);
   return exports;
 }

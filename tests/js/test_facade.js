@@ -59,6 +59,12 @@ const hex = bls.utils.bytesToHex, un = bls.utils.hexToBytes;
     assert.ok(H.multiply(9n).subtract(H.multiply(2n)).equals(H.multiply(7n)));
     assert.ok(bls.PointG1.fromPrivateKey(gold.sigs[0].sk).toHex(true) === gold.sigs[0].pk);
     assert.throws(() => G.multiply(0n), /invalid scalar/);
+    // multi-scalar multiplication: sum_i [k_i]P_i against the scalar algebra on the generators
+    const k = [3n, (1n << 255n) + 12345n, bls.CURVE.r - 1n, 0xfff000n], a = [2n, 5n, 7n, 11n];
+    const t = k.reduce((acc, ki, i) => (acc + ki * a[i]) % bls.CURVE.r, 0n);
+    assert.ok(bls.PointG1.msm(a.map((x) => G.multiply(x)), k).equals(G.multiply(t)));
+    assert.ok(bls.PointG2.msm(a.map((x) => H.multiply(x)), k).equals(H.multiply(t)));
+    assert.ok(bls.PointG1.msm([G, G.negate()], [77n, 77n]).isZero());
     // bilinearity through the facade: e(aG, bH) == e(G, abH)
     assert.ok(bls.pairing(G.multiply(3n), H.multiply(5n)).equals(bls.pairing(G, H.multiply(15n))));
   }
