@@ -140,6 +140,11 @@ static void load_points(SFp& Px, SFp& Py, SFp2& Qx, SFp2& Qy) {
 // lanes per work item (instances per wave = 64 / W): an Fp12 lane-op step has 12 heavy lanes
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
 static const int MILLER_W = env_int("NBLS_MILLER_W", 16);
+// lanes per item of the point programs.  A G1 operation has at most ~4 independent field products per dependency level, so 4 lanes
+// per item take the same number of steps as 8 with twice the items per wavefront (G1 decode + subgroup check 5.6 -> 3.9 ms at
+// 65,536 keys); the G2 ladder at 8 lanes instead of 16: +9 % steps, twice the items (5.9 -> 4.5 ms at 8192 signatures).  The other
+// G2 programs stay at 8: at 4 lanes their LDS footprint (50 KB per wavefront) leaves less than one wavefront per SIMD.
+static const int G1_W = env_int("NBLS_G1_W", 4), G2_W = env_int("NBLS_G2_W", 8), G2MUL_W = env_int("NBLS_G2MUL_W", 8), G1MUL_W = env_int("NBLS_G1MUL_W", 4);
 static const int EXPX_W = env_int("NBLS_EXPX_W", 12);   // an Fp12 op has exactly 12 lane-ops: 5 items per wave, no idle lane (+5..9 % over 16 lanes once >= 2 waves share a SIMD)
 
 static Program build(ProgId id) {
@@ -220,18 +225,18 @@ static Program build(ProgId id) {
       SFp x = input(0, 0), y = input(0, 48), oc, sg;
       g1_validity_flags(x, y, oc, sg);
       status_out({{oc, 2}, {sg, 3}}, 7);
-      return B.compile("g1_validate", 8);
+      return B.compile("g1_validate", G1_W);
     }
     case P_G2_VALIDATE: {
       SFp2 x = input_fp2(1, 0), y = input_fp2(1, 96); SFp oc, sg;
       g2_validity_flags(x, y, oc, sg);
       status_out({{oc, 2}, {sg, 3}}, 7);
-      return B.compile("g2_validate", 8);
+      return B.compile("g2_validate", G2_W);
     }
     case P_G1_DEC_A: g1_decompress_A(0, 3, 4); return B.compile("g1_dec_a", 4);
-    case P_G1_DEC_B: g1_decompress_B(0, 3, 4, 5, 6, 7); return B.compile("g1_dec_b", 8);
+    case P_G1_DEC_B: g1_decompress_B(0, 3, 4, 5, 6, 7); return B.compile("g1_dec_b", G1_W);
     case P_G2_DEC_A: g2_decompress_A(0, 3, 4); return B.compile("g2_dec_a", 4);
-    case P_G2_DEC_B: g2_decompress_B(0, 3, 4, 5, 6, 7); return B.compile("g2_dec_b", 8);
+    case P_G2_DEC_B: g2_decompress_B(0, 3, 4, 5, 6, 7); return B.compile("g2_dec_b", G2_W);
     case P_H2C_A: {
       for (int k = 0; k < 2; k++) {
         SFp2 t = {field_elem_from_64(0, 128 * k), field_elem_from_64(0, 128 * k + 64)};
@@ -257,7 +262,7 @@ static Program build(ProgId id) {
       Pt<SFp2> q = clear_cofactor_g2(p);                               // index.ts:489, 659-672
       outputw(q.x.c0, 6, 0); outputw(q.x.c1, 6, 48); outputw(q.y.c0, 6, 96); outputw(q.y.c1, 6, 144); outputw(q.z.c0, 6, 192); outputw(q.z.c1, 6, 240);
       outputw(sqr(q.z.c0) + sqr(q.z.c1), 7, 0);
-      return B.compile("h2c_c", 8);
+      return B.compile("h2c_c", G2_W);
     }
     case P_G1_TO_PROJ: {
       outputw(input(0, 0), 3, 0); outputw(input(0, 48), 3, 48); outputw(fp_one(), 3, 96);
@@ -329,7 +334,7 @@ static Program build(ProgId id) {
       Pt<SFp> q = clear_cofactor_g1({inputw(3, 0), inputw(3, 48), inputw(3, 96)});
       outputw(q.x, 6, 0); outputw(q.y, 6, 48); outputw(q.z, 6, 96);
       outputw(q.z, 7, 0);
-      return B.compile("g1_clear", 8);
+      return B.compile("g1_clear", G1_W);
     }
     case P_ENC2_A: {
       SFp2 t = {field_elem_from_64(0, 0), field_elem_from_64(0, 64)};
@@ -353,7 +358,7 @@ static Program build(ProgId id) {
       outputw(r.x, 3, 0); outputw(r.y, 3, 48); outputw(r.z, 3, 96);
       outputw(r.z, 4, 0);
       B.sched_window = env_int("NBLS_MUL_WINDOW", 300);   // scalar bits are extracted just in time instead of all 256 up front (they would pin 256 LDS slots)
-      return B.compile("g1_mul", 8);
+      return B.compile("g1_mul", G1MUL_W);
     }
     case P_G2_MUL: {
       SFp2 x = input_fp2(1, 0), y = input_fp2(1, 96);
@@ -362,7 +367,7 @@ static Program build(ProgId id) {
       outputw(r.x.c0, 3, 0); outputw(r.x.c1, 3, 48); outputw(r.y.c0, 3, 96); outputw(r.y.c1, 3, 144); outputw(r.z.c0, 3, 192); outputw(r.z.c1, 3, 240);
       outputw(sqr(r.z.c0) + sqr(r.z.c1), 4, 0);      // Fp2 norm, inverted by the inversion kernel (Fp2.invert, math.ts:522-526)
       B.sched_window = env_int("NBLS_MUL_WINDOW", 300);
-      return B.compile("g2_mul", 16);
+      return B.compile("g2_mul", G2MUL_W);
     }
     case P_G1_MSM_PREP: {
       // phi(x, y) = (beta x, y) acts on G1 as [-z^2] (the reference's subgroup check compares [-z^2]P with phi(P), index.ts:424-448)
