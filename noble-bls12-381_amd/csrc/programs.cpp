@@ -149,6 +149,8 @@ static const int EXPX_W = env_int("NBLS_EXPX_W", 12);   // an Fp12 op has exactl
 
 static Program build(ProgId id) {
   Builder B;
+  if (id == P_MILLER_BYTES || id == P_MILLER_RAW || id == P_MILLER_RAW2 || id == P_MILLER_FE) B.max_dot = env_int("NBLS_MILLER_MAXDOT", 7);   // the Fp12 squaring has 6 coefficients of 7-8 products next to 6 of 6: capping at 7 shortens its step (-3 % instructions)
+  if (id == P_EXPX) B.max_dot = env_int("NBLS_EXPX_MAXDOT", 8);
   switch (id) {
     case P_MILLER_BYTES: {
       SFp Px, Py; SFp2 Qx, Qy; load_points(Px, Py, Qx, Qy);

@@ -234,10 +234,10 @@ int materialize(const SFp& x, bool halve_it) {
   } else {
     if ((int)lin.size() > MAX_DOT_LINEAR) { int a = emit_lin(B, lin, false); lin.clear(); lin.push_back({a, 1}); }
     // chunk the products: at most 8 per lane-op (column accumulators hold 112 limb products)
-    while (dps.size() > (size_t)MAX_DOT_PRODUCTS) {
-      std::vector<DotProduct> chunk(dps.begin(), dps.begin() + MAX_DOT_PRODUCTS);
+    while (dps.size() > (size_t)B->max_dot) {
+      std::vector<DotProduct> chunk(dps.begin(), dps.begin() + B->max_dot);
       int a = emit_dot(B, chunk, mult, {}, false);
-      dps.erase(dps.begin(), dps.begin() + MAX_DOT_PRODUCTS);
+      dps.erase(dps.begin(), dps.begin() + B->max_dot);
       if ((int)lin.size() >= MAX_DOT_LINEAR) { int l = emit_lin(B, lin, false); lin.clear(); lin.push_back({l, 1}); }
       lin.push_back({a, 1});
     }
@@ -407,6 +407,8 @@ Program Builder::compile(const std::string& name, int W) {
       pr = placed;
     }
     if (getenv("NBLS_DUMP_STEPS")) { fprintf(stderr, "%s dot step lanes=%zu k:", name.c_str(), L.size()); for (int c : L) fprintf(stderr, " %zu", nodes[c].prods.size()); fprintf(stderr, "\n"); }
+    if (getenv("NBLS_DUMP_NODES")) for (int c : L) { fprintf(stderr, "  node %d m=%d lin=%zu:", c, nodes[c].mult, nodes[c].lin.size()); for (auto& q : nodes[c].prods) fprintf(stderr, " (%d%s%d)x(%d%s%d)", q.a.s0, q.a.s1 < 0 ? "" : (q.a.n1 ? "-" : "+"), q.a.s1 < 0 ? 0 : q.a.s1, q.b.s0, q.b.s1 < 0 ? "" : (q.b.n1 ? "-" : "+"), q.b.s1 < 0 ? 0 : q.b.s1); fprintf(stderr, "\n"); }
+    if (getenv("NBLS_DUMP_FORMS")) { fprintf(stderr, "%s forms:", name.c_str()); for (size_t j = 0; j < mk; j++) fprintf(stderr, " %x/%x", ua[j], ub[j]); fprintf(stderr, "\n"); }
     // cost model of the step (VALU instructions per wavefront)
     double est = 310 + 80;
     for (size_t j = 0; j < mk; j++) est += 196 + 22 + form_cost(ua[j]) + form_cost(ub[j]);

@@ -81,6 +81,7 @@ struct Builder {
   std::map<int, int> contract_cache;                 // atom -> contracted atom
   int zero_atom = -1, one_atom = -1, r2_atom = -1, rawone_atom = -1;
   int TMAX = 12;         // soft cap on the size of a lazy form
+  int max_dot = MAX_DOT_PRODUCTS;   // products per lane-op: a lower cap splits heavy lane-ops (first chunk, then the rest + the first as a post-added term) so that the few heaviest lanes do not set the length of a step
   int sched_window = 0;  // scheduler look-ahead limit in critical-path units (0 = unlimited), see compile()
   static Builder*& cur() { static thread_local Builder* b = nullptr; return b; }
   Builder();

@@ -1,6 +1,9 @@
 """ctypes binding of libnbls.so (include/nbls.h).  Mirrors the reference's batched entry points:
 pairing (index.ts:715), the Miller-product core of verify/verifyBatch (index.ts:763-766, 811-816) and
-Fp12.finalExponentiate (math.ts:856)."""
+Fp12.finalExponentiate (math.ts:856).
+
+A process that also uses PyTorch-ROCm must import torch BEFORE the first Engine is created: the torch wheel bundles its own HIP
+runtime, libnbls.so binds to whichever runtime is already loaded, and torch loaded second reports "No HIP GPUs are available"."""
 import ctypes as C
 import os
 

@@ -1,6 +1,9 @@
 import os
 import sys
 import pytest
+# torch bundles its own HIP runtime: when a test uses both torch.cuda and libnbls.so in one process, torch has to be loaded first
+# (libnbls.so then binds to the runtime that is already there); loaded second, torch reports "No HIP GPUs are available"
+import torch  # noqa: F401
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
