@@ -123,6 +123,14 @@ int nbls_verify_batch(nbls_ctx* ctx, size_t n, const uint8_t* sig96, const uint8
 int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_sig96, const void* d_uniform256, const void* d_pk48, int* ok,
                                  int8_t* pk_status /* n, may be NULL */, void* stream);
 
+/* One rank's share of a verifyBatch spread over several GPUs (one process per GPU): the Miller product of this rank's n
+ * (key, message) pairs, times millerLoop(-G, S) on the ONE rank that passes the signature (d_sig96 = NULL elsewhere), WITHOUT the
+ * final exponentiation, as 576 wire bytes in device memory.  Ranks all-gather their partials and finish with
+ * nbls_fp12_product_final_dev (product + shared finalExponentiate, index.ts:811-817), then compare with Fp12.ONE.
+ * *zero_flag = 1: a zero point was met (verifyBatch answers false, d_out_fp12 not written).  NBLS_EDECODE as nbls_verify_batch. */
+int nbls_verify_batch_partial_dev(nbls_ctx* ctx, size_t n, const void* d_sig96 /* or NULL */, const void* d_uniform256, const void* d_pk48,
+                                  void* d_out_fp12, int* zero_flag, int8_t* pk_status /* n, may be NULL */, void* stream);
+
 /* Introspection for the benchmark / tests. */
 int nbls_program_stats(nbls_ctx* ctx, int prog, uint32_t* out8);   /* steps, mul_steps, lin_steps, mul_ops, lin_ops, lin_terms, slots, lds_bytes */
 int nbls_device_synchronize(nbls_ctx* ctx);

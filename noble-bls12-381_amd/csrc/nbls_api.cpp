@@ -697,7 +697,8 @@ static int dev_msm(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, const vo
   const size_t half = m / 2 + 1;
   if ((r = need(ctx, 0, (n + 1) * p, &Pj)) || (r = need(ctx, 1, (m + 1) * p, &P)) || (r = need(ctx, 2, 2 * std::max(half, (size_t)nwin) * p, &A)) || (r = need(ctx, 3, (m + 1) * 24, &K)) ||
       (r = need(ctx, 4, RAW, &N)) || (r = need(ctx, 5, RAW, &NI)) || (r = need(ctx, 6, tmp_bytes + 16, &tmp)) || (r = need(ctx, 7, nb * p, &Bk)) || (r = need(ctx, 8, ng * p, &G)) ||
-      (r = need(ctx, 9, ng / 2 * p, &Gh)) || (r = need(ctx, 10, 2 * p, &acc)) || (r = need(ctx, 11, 64 * 4, &cnt))) return r;
+      (r = need(ctx, 9, (ng / 2 + 2) * p, &Gh)) || (r = need(ctx, 11, 64 * 4, &cnt))) return r;
+  acc = Gh + ng / 2 * p;     // (slot 10 belongs to verifyBatch, which drops the context lock between its stages)
   uint8_t* Bv = A + half * p;
   uint32_t *kin = (uint32_t*)K, *vin = kin + m, *kout = vin + m, *vout = kout + m, *pos = vout + m, *list = pos + m;
   uint32_t* counters = (uint32_t*)cnt;    // [0] longest run, [1 + round] pairs of that round
@@ -806,16 +807,17 @@ EXPORT int nbls_verify_batch(nbls_ctx* ctx, size_t n, const uint8_t* sig96, cons
   return nbls_verify_batch_dev_inputs(ctx, n, d_sig, d_uni, d_pk, ok, nullptr, nullptr);
 }
 // Same with inputs resident in HBM: signature (96 B), expand_message_xmd outputs (256 B per message), public keys (48 B each).
-EXPORT int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_sig96, const void* d_uniform, const void* d_pk48, int* ok, int8_t* pk_status, void* stream) {
-  if (!ctx || !ok || !n || !d_sig96 || !d_uniform || !d_pk48) return NBLS_EINVAL;
-  std::vector<int8_t> st(n + 1);
-  uint8_t out[576];
-  {
-    std::lock_guard<std::mutex> g_(ctx->mu); HIPCHK(hipSetDevice(ctx->device));
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    uint8_t *G1, *G2, *ST, *O; int r;
-    if ((r = need(ctx, 10, (n + 1) * (96 + 192) + (n + 1) + 576 + 64, &G1))) return r;
-    G2 = G1 + (n + 1) * 96; O = G2 + (n + 1) * 192; ST = O + 576;
+// decode + hash stage shared by verifyBatch and its multi-GPU shard: keys -> G1 points, messages -> G2 hash points, and (when a
+// signature is given) the pair (-G, S) appended; the pairs land in scratch slot 10 (g1 | g2), statuses in st (n or n + 1 entries)
+static int verify_stage(nbls_ctx* ctx, size_t n, const void* d_sig96, const void* d_uniform, const void* d_pk48, std::vector<int8_t>& st, void* stream) {
+  const size_t np = n + (d_sig96 ? 1 : 0);
+  st.assign(np, 0);
+  std::lock_guard<std::mutex> g_(ctx->mu); HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  uint8_t *G1, *G2, *ST, *O; int r;
+  if ((r = need(ctx, 10, (n + 1) * (96 + 192) + (n + 1) + 576 + 64, &G1))) return r;
+  G2 = G1 + (n + 1) * 96; O = G2 + (n + 1) * 192; ST = O + 576;
+  if (d_sig96) {
     // normP2: PointG2.fromSignature for the ONE signature, on the side stream with its own scratch (overlaps everything below).
     // The side stream is created on first use: HIP spreads streams over a few hardware queues in creation order, and contexts
     // that only run pairing batches (noble-bls12-381_amd/pipeline.py keeps several in flight) should each get a queue of their own.
@@ -823,27 +825,34 @@ EXPORT int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_s
       if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess || hipMalloc(&ctx->side_scratch, (6 + 32) * RAW) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
     }
-    {
-      uint8_t *X = ctx->side_scratch, *Rr = X + 2 * RAW, *Cd = Rr + 2 * RAW, *pw = Cd + 2 * RAW;
-      HIPCHK(hipEventRecord(ctx->ev_fork, s)); HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-      if ((r = run(ctx, P_G2_DEC_A, 1, {B(0, d_sig96, 96), B(3, X, 2 * RAW), B(4, Rr, 2 * RAW)}, ctx->side))) return r;
-      if ((r = run_pow(ctx, 1, 1, Rr, Cd, ctx->side, pw))) return r;
-      if ((r = run(ctx, P_G2_DEC_B, 1, {B(0, d_sig96, 96), B(3, X, 2 * RAW), B(4, Rr, 2 * RAW), B(5, Cd, 2 * RAW), B(6, G2 + n * 192, 192), B(7, ST + n, 1)}, ctx->side))) return r;
-      HIPCHK(hipEventRecord(ctx->ev_join, ctx->side));
-    }
-    if ((r = dev_decompress(ctx, false, n, d_pk48, G1, ST, s))) return r;                       // normP1: PointG1.fromHex
-    if ((r = dev_hash_to_g2(ctx, n, d_uniform, G2, s))) return r;                               // normP2Hash: PointG2.hashToCurve
-    HIPCHK(hipMemcpyAsync(G1 + n * 96, ctx->neg_g1, 96, hipMemcpyDeviceToDevice, s));           // PointG1.BASE.negate()
-    HIPCHK(hipStreamWaitEvent(s, ctx->ev_join, 0));
-    HIPCHK(hipMemcpyAsync(st.data(), ST, n + 1, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    uint8_t *X = ctx->side_scratch, *Rr = X + 2 * RAW, *Cd = Rr + 2 * RAW, *pw = Cd + 2 * RAW;
+    HIPCHK(hipEventRecord(ctx->ev_fork, s)); HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    if ((r = run(ctx, P_G2_DEC_A, 1, {B(0, d_sig96, 96), B(3, X, 2 * RAW), B(4, Rr, 2 * RAW)}, ctx->side))) return r;
+    if ((r = run_pow(ctx, 1, 1, Rr, Cd, ctx->side, pw))) return r;
+    if ((r = run(ctx, P_G2_DEC_B, 1, {B(0, d_sig96, 96), B(3, X, 2 * RAW), B(4, Rr, 2 * RAW), B(5, Cd, 2 * RAW), B(6, G2 + n * 192, 192), B(7, ST + n, 1)}, ctx->side))) return r;
+    HIPCHK(hipEventRecord(ctx->ev_join, ctx->side));
   }
+  if ((r = dev_decompress(ctx, false, n, d_pk48, G1, ST, s))) return r;                       // normP1: PointG1.fromHex
+  if ((r = dev_hash_to_g2(ctx, n, d_uniform, G2, s))) return r;                               // normP2Hash: PointG2.hashToCurve
+  if (d_sig96) {
+    HIPCHK(hipMemcpyAsync(G1 + n * 96, ctx->neg_g1, 96, hipMemcpyDeviceToDevice, s));         // PointG1.BASE.negate()
+    HIPCHK(hipStreamWaitEvent(s, ctx->ev_join, 0));
+  }
+  HIPCHK(hipMemcpyAsync(st.data(), ST, np, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return NBLS_OK;
+}
+EXPORT int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_sig96, const void* d_uniform, const void* d_pk48, int* ok, int8_t* pk_status, void* stream) {
+  if (!ctx || !ok || !n || !d_sig96 || !d_uniform || !d_pk48) return NBLS_EINVAL;
+  std::vector<int8_t> st;
+  uint8_t out[576];
+  int r = verify_stage(ctx, n, d_sig96, d_uniform, d_pk48, st, stream); if (r) return r;
   if (pk_status) memcpy(pk_status, st.data(), n);
   for (size_t i = 0; i <= n; i++) if (st[i] > 1) return NBLS_EDECODE;       // the reference throws before its try block
   for (size_t i = 0; i <= n; i++) if (st[i] == 1) { *ok = 0; return NBLS_OK; }   // zero point -> pairing() throws -> false
   {
     uint8_t* base = ctx->sb[10];
-    int r = nbls_miller_product_dev(ctx, n + 1, base, base + (n + 1) * 96, 1, base + (n + 1) * 288, stream);
+    r = nbls_miller_product_dev(ctx, n + 1, base, base + (n + 1) * 96, 1, base + (n + 1) * 288, stream);
     if (r) return r;
     std::lock_guard<std::mutex> g_(ctx->mu);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
@@ -853,4 +862,21 @@ EXPORT int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_s
   bool one = out[47] == 1; for (int i = 0; i < 576 && one; i++) if (i != 47 && out[i]) one = false;   // exp.equals(Fp12.ONE)
   *ok = one ? 1 : 0;
   return NBLS_OK;
+}
+// One rank's share of a verifyBatch that is spread over several GPUs: the Miller product of this rank's n
+// (key, message) pairs -- times millerLoop(-G, S) on the one rank that passes the signature -- WITHOUT the final exponentiation,
+// as 576 wire bytes in device memory.  The ranks exchange their partials (one all-gather) and finish with
+// nbls_fp12_product_final_dev.  *zero_flag = 1 when a zero point was met (verifyBatch then answers false; d_out is not written).
+EXPORT int nbls_verify_batch_partial_dev(nbls_ctx* ctx, size_t n, const void* d_sig96, const void* d_uniform, const void* d_pk48, void* d_out_fp12, int* zero_flag, int8_t* pk_status, void* stream) {
+  if (!ctx || !zero_flag || !n || !d_uniform || !d_pk48 || !d_out_fp12) return NBLS_EINVAL;
+  std::vector<int8_t> st;
+  int r = verify_stage(ctx, n, d_sig96, d_uniform, d_pk48, st, stream); if (r) return r;
+  if (pk_status) memcpy(pk_status, st.data(), n);
+  for (int8_t v : st) if (v > 1) return NBLS_EDECODE;
+  *zero_flag = 0;
+  for (int8_t v : st) if (v == 1) { *zero_flag = 1; return NBLS_OK; }
+  const size_t np = st.size();
+  uint8_t* base = ctx->sb[10];
+  // the pairs sit at stride n + 1 inside the scratch block whether or not the signature pair is present
+  return nbls_miller_product_dev(ctx, np, base, base + (n + 1) * 96, 0, d_out_fp12, stream);
 }

@@ -61,6 +61,7 @@ def load_library():
     lib.nbls_sign_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, vp]
     lib.nbls_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, sz, C.POINTER(i32)]
     lib.nbls_verify_batch_dev_inputs.argtypes = [vp, sz, vp, vp, vp, C.POINTER(i32), vp, vp]
+    lib.nbls_verify_batch_partial_dev.argtypes = [vp, sz, vp, vp, vp, vp, C.POINTER(i32), vp, vp]
     lib.nbls_timing_enable.argtypes = [vp, i32]
     lib.nbls_timing_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     return lib
@@ -244,6 +245,13 @@ class Engine:
         ok = C.c_int(0)
         self._chk(self.lib.nbls_verify_batch_dev_inputs(self.h, n, d_sig, d_uniform, d_pk, C.byref(ok), None, stream))
         return bool(ok.value)
+
+    def verify_batch_partial_dev(self, n, d_sig, d_uniform, d_pk, d_out, stream=None):
+        """one rank's share of a multi-GPU verifyBatch: Miller product of its n pairs (plus (-G, S) when d_sig is not None/0) without
+        the final exponentiation -> 576 wire bytes at d_out; returns True when a zero point was met (the batch verifies false)"""
+        z = C.c_int(0)
+        self._chk(self.lib.nbls_verify_batch_partial_dev(self.h, n, d_sig or None, d_uniform, d_pk, d_out, C.byref(z), None, stream))
+        return bool(z.value)
 
     # ---- device-pointer entry points (torch uint8 CUDA tensors); enqueue on `stream` (int handle) or the context stream
     def pairing_batch_dev(self, n, d_g1, d_g2, d_out, with_final_exp=True, stream=None):

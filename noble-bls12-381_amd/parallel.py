@@ -22,6 +22,14 @@ class EngineBackend:
         self.eng.miller_product_dev(n, g1.data_ptr(), g2.data_ptr(), out.data_ptr(), final_exp=False, stream=torch.cuda.current_stream().cuda_stream)
         return out
 
+    def verify_partial(self, sig96, uniform, pks48):
+        """sig96: device tensor or None; uniform: n x 256 expand_message_xmd bytes; pks48: n x 48 compressed keys (device tensors)"""
+        n = pks48.numel() // 48
+        out = torch.zeros(576, dtype=torch.uint8, device=pks48.device)
+        zero = self.eng.verify_batch_partial_dev(n, sig96.data_ptr() if sig96 is not None else None, uniform.data_ptr(), pks48.data_ptr(), out.data_ptr(),
+                                                 stream=torch.cuda.current_stream().cuda_stream)
+        return out, zero
+
     def finish(self, partials, final_exp=True):
         w = partials.numel() // 576
         out = torch.empty(576, dtype=torch.uint8, device=partials.device)
@@ -46,3 +54,39 @@ def miller_product_sharded(backend, g1_local, g2_local, group=None, final_exp=Tr
     else:
         gathered = part
     return backend.finish(gathered, final_exp)
+
+
+ONE_FP12 = bytes(47) + b'\x01' + bytes(528)
+
+
+def verify_batch_sharded(backend, sig96, msgs_local, pks_local, group=None):
+    """verifyBatch (reference index.ts:792-821) with the (key, message) pairs sharded over the ranks: every rank decodes and hashes
+    its own shard and reduces it to one Fp12 partial; rank 0 also contributes millerLoop(-G, S).  ONE exchange: the all-gather of
+    the 576-byte partials (plus one scalar all-reduce carrying the "zero point met" flag); every rank then multiplies the partials,
+    runs the shared final exponentiation and compares with ONE.  msgs_local is whatever the backend's verify_partial takes
+    (EngineBackend: n x 256 expand_message_xmd bytes on the device)."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    rank = dist.get_rank(group) if multi else 0
+    err = None
+    try:
+        part, zero = backend.verify_partial(sig96 if rank == 0 else None, msgs_local, pks_local)
+    except Exception as e:      # an undecodable key / signature on this rank (the reference throws): every rank has to learn of it, or the others would wait in the collective
+        if not multi:
+            raise
+        err, zero, part = e, False, torch.zeros(576, dtype=torch.uint8, device=pks_local.device if hasattr(pks_local, 'device') else 'cpu')
+    if multi:
+        w = dist.get_world_size(group)
+        flag = torch.tensor([2 if err is not None else (1 if zero else 0)], dtype=torch.int32, device=part.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if int(flag.item()) == 2:
+            raise err if err is not None else RuntimeError('verify_batch_sharded: an input failed to decode on another rank')
+        zero = bool(flag.item())
+        gathered = torch.empty(w * 576, dtype=torch.uint8, device=part.device)
+        dist.all_gather_into_tensor(gathered, part, group=group)
+    else:
+        gathered = part
+    if zero:
+        return False
+    res = backend.finish(gathered, True)
+    return bytes(res.cpu().numpy().tobytes()) == ONE_FP12
