@@ -254,16 +254,18 @@ def main():
         # elements (768 B per Fp12, 64 B per Fp) every phase program reads and writes:
         # miller_fe W 832 | fp_inv R 64 W 64 | fe_easy R 832 W 768 | 4 x expx R 768 W 768 | fe_mid1/2 R 1536 W 768 | fe_final R 5376
         hbm_bytes = n * (288 + 832 + 128 + 832 + 768 + 4 * 1536 + 2 * 2304 + 5376 + 576)
-        traffic = None
+        traffic = None; valu_busy = None
         try:   # HBM bytes measured with rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, see profiles/README.md), same batch size only
             with open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')) as fh:
-                traffic = json.load(fh).get(str(n), {}).get('bytes_per_step')
+                prof = json.load(fh).get(str(n), {})
+                traffic = prof.get('bytes_per_step'); valu_busy = prof.get('valu_issue_busy')
         except OSError:
             pass
         roof = {
             'bound': 'valu-int32-mad', 'kernel': 'nbls_vm_kernel (all step programs of one pairing batch)',
             'achieved': round(achieved, 4), 'peak': round(PEAK_TMAD, 3), 'unit': 'TMAD32/s', 'frac': round(achieved / PEAK_TMAD, 4),
             'traffic': traffic,
+            'valu_issue_busy': valu_busy,    # SQ_INSTS_VALU x 4 clocks / (kernel time x 2.4 GHz x 1024 SIMDs) from the PMC pass in profiles/ (same batch size, one batch at a time)
             'frac_at_value': round(value / world * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL / 1e12 / PEAK_TMAD, 4),
             'frac_note': 'achieved/frac: the kernels of one batch running alone (HIP-event durations); frac_at_value: the same work at the rate of `value` (batches overlapping on %d streams)' % D,
             'kernel_ms': {k: round(v, 4) for k, v in per_step.items()},
