@@ -53,12 +53,41 @@ template <class F> static inline Pt<F> pt_dbl(const Pt<F>& p) {
   F a = mat(t0 - scale(t2, 3)), b = mat(t0 + t2);
   return pt_mat<F>({scale(mul(a, xy), 2), mul(a, b) + scale(mul(t0, t2), 8), scale(mul(t0, t1), 8)});
 }
+// The same doubling over Fp regrouped into two levels of products around one level of sums: 12 z^2 is ONE lane-op (3 * (2z)(2z)),
+// the factor 8 is carried by e = 2 t0 (a sum) and 4 e t = (e + e)(t + t), so no product has to be evaluated on its own
+// before it can be scaled.  2 DOT + 1 LIN steps per doubling instead of 3 + 1 (doubling chains: subgroup checks, cofactor
+// clearing, the ladders, the window shifts of the MSM).  Same projective point up to nothing: identical coordinates.
+template <> inline Pt<SFp> pt_dbl<SFp>(const Pt<SFp>& p) {
+  SFp t0 = mat(sqr(p.y)), t1 = mat(mul(p.y, p.z)), t2 = mat(mul_b3(sqr(p.z))), xy = mat(mul(p.x, p.y));
+  SFp a = mat(t0 - scale(t2, 3)), b = mat(t0 + t2), e = mat(scale(t0, 2));
+  return pt_mat<SFp>({scale(mul(a, xy), 2), mul(a, b) + scale(mul(e, t2), 4), scale(mul(e, t1), 4)});
+}
+// n successive doublings.  Over Fp2 the constant 3b = 12(1 + u) does not fit one lane-op (coefficients 12, 12, 24 on z0^2, z1^2,
+// z0 z1), but 3(1 + u) d^2 with d = 2z does (3, 3, 6 = multiplier 3, one operand doubled): a run of doublings therefore keeps
+// (x, y, d = 2z), on which a doubling is again two levels of products around one level of sums; t1 = y d = 2 y z, and the new
+// d is 2 * 8 t0 (y z) = 2 e t1 with e = 4 t0.  Entering costs one sum (d = z + z), leaving one (x, y doubled: (2x : 2y : d) is
+// the same projective point as (x : y : d / 2)).  A single doubling stays with pt_dbl.
+template <class F> static inline Pt<F> pt_dbl_n(const Pt<F>& p, int n) { Pt<F> r = p; for (int i = 0; i < n; i++) r = pt_dbl(r); return r; }
+template <> inline Pt<SFp2> pt_dbl_n<SFp2>(const Pt<SFp2>& p, int n) {
+  if (n < 2) return n ? pt_dbl(p) : p;
+  SFp2 x = p.x, y = p.y, d = mat(scale(p.z, 2));
+  for (int i = 0; i < n; i++) {
+    // n2 = -t2 = -3(1 + u) d^2: as POSITIVE terms of the sums a = t0 + 3 n2 and b' = -b = n2 - t0 it needs no bound contraction
+    // (a subtracted term must stay below 6p, and this lane-op's result is bounded by ~6.1p)
+    SFp2 t0 = mat(sqr(y)), t1 = mat(mul(y, d)), n2 = mat(-scale(mulnr(sqr(d)), 3)), xy = mat(mul(x, y));
+    SFp2 a = mat(t0 + scale(n2, 3)), nb = mat(n2 - t0), e = mat(scale(t0, 4));
+    SFp2 nx = mat(scale(mul(a, xy), 2)), ny = mat(-mul(a, nb) - scale(mul(e, n2), 2)), nd = mat(scale(mul(e, t1), 2));
+    x = nx; y = ny; d = nd;
+  }
+  return {mat(scale(x, 2)), mat(scale(y, 2)), d};
+}
 // [k]P for a public 64-bit constant k, MSB-first double-and-add (the reference's multiplyUnsafe, math.ts:1048-1058, is
 // LSB-first; the group element is the same)
 template <class F> static inline Pt<F> pt_mul_u64(const Pt<F>& p, uint64_t k) {
   Pt<F> r = p; int top = 63; while (top > 0 && !((k >> top) & 1)) top--;
-  for (int i = top - 1; i >= 0; i--) { r = pt_dbl(r); if ((k >> i) & 1) r = pt_add(r, p); }
-  return r;
+  int run = 0;
+  for (int i = top - 1; i >= 0; i--) { run++; if ((k >> i) & 1) { r = pt_add(pt_dbl_n(r, run), p); run = 0; } }
+  return pt_dbl_n(r, run);
 }
 // [k]P for a per-item scalar held in a raw integer slot: fixed 3-bit windows, MSB first.  Per window: three doublings, a
 // table entry [0..7]P picked by a binary tree of masked selects on the three scalar bits (every entry is read, the K_SEL
@@ -84,7 +113,7 @@ template <class F> static inline Pt<F> pt_mul_ladder(const Pt<F>& p, const SFp& 
     hi = nbits - 1;
   }
   for (int lo = hi - WIN; lo >= 0; lo -= WIN) {
-    for (int i = 0; i < WIN; i++) r = pt_dbl(r);
+    r = pt_dbl_n(r, WIN);
     SFp b0 = bit_flag(k_raw, lo), b1 = bit_flag(k_raw, lo + 1), b2 = bit_flag(k_raw, lo + 2);
     Pt<F> u0 = pt_sel<F>(b0, T[1], T[0]), u1 = pt_sel<F>(b0, T[3], T[2]), u2 = pt_sel<F>(b0, T[5], T[4]), u3 = pt_sel<F>(b0, T[7], T[6]);
     Pt<F> v0 = pt_sel<F>(b1, u1, u0), v1 = pt_sel<F>(b1, u3, u2);

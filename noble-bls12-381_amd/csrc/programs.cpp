@@ -394,7 +394,7 @@ static Program build(ProgId id) {
       Pt<SFp> r;
       if (id == P_G1_ADD_AB) r = pt_add(ld(3, 0), ld(4, 0));
       else if (id == P_G1_HORNER) { r = ld(3, 144 * (MSM_WINDOW_BITS - 1)); for (int t = MSM_WINDOW_BITS - 2; t >= 0; t--) r = pt_add(pt_dbl(r), ld(3, 144 * t)); }
-      else { r = ld(3, 0); for (int t = 0; t < MSM_WINDOW_BITS; t++) r = pt_dbl(r); r = pt_add(r, ld(4, 0)); }
+      else r = pt_add(pt_dbl_n(ld(3, 0), MSM_WINDOW_BITS), ld(4, 0));
       outputw(r.x, 5, 0); outputw(r.y, 5, 48); outputw(r.z, 5, 96);
       return B.compile(id == P_G1_ADD_AB ? "g1_add_ab" : id == P_G1_HORNER ? "g1_horner" : "g1_shiftadd", 4);
     }
@@ -403,7 +403,7 @@ static Program build(ProgId id) {
       Pt<SFp2> r;
       if (id == P_G2_ADD_AB) r = pt_add(ld(3, 0), ld(4, 0));
       else if (id == P_G2_HORNER) { r = ld(3, 288 * (MSM_WINDOW_BITS - 1)); for (int t = MSM_WINDOW_BITS - 2; t >= 0; t--) r = pt_add(pt_dbl(r), ld(3, 288 * t)); }
-      else { r = ld(3, 0); for (int t = 0; t < MSM_WINDOW_BITS; t++) r = pt_dbl(r); r = pt_add(r, ld(4, 0)); }
+      else r = pt_add(pt_dbl_n(ld(3, 0), MSM_WINDOW_BITS), ld(4, 0));
       outputw(r.x.c0, 5, 0); outputw(r.x.c1, 5, 48); outputw(r.y.c0, 5, 96); outputw(r.y.c1, 5, 144); outputw(r.z.c0, 5, 192); outputw(r.z.c1, 5, 240);
       return B.compile(id == P_G2_ADD_AB ? "g2_add_ab" : id == P_G2_HORNER ? "g2_horner" : "g2_shiftadd", 8);
     }

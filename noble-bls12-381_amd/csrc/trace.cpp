@@ -181,7 +181,7 @@ int materialize(const SFp& x, bool halve_it) {
   std::vector<std::pair<int, int>> atoms;   // (atom, coef)
   for (auto& t : x.f) {
     if (t.first >= PROD_BASE) prods.push_back({(int)(t.first - PROD_BASE), t.second});
-    else if (std::abs(t.second) > 3) {
+    else if (std::abs(t.second) > 4 || (std::abs(t.second) == 4 && !x.pure_atoms())) {   // 4 x as a pure sum stays a LIN lane-op (x + x + x + x)
       // large integer multiple of an atom: multiply by the constant inside the dot product instead of repeated addition
       Operand a; a.s0 = (int)t.first; Operand c; c.s0 = B->small_const(std::abs(t.second));
       prods.push_back({B->product(a, c), t.second > 0 ? 1 : -1});
@@ -195,7 +195,7 @@ int materialize(const SFp& x, bool halve_it) {
     bool ok = true;
     for (auto& p : prods) {
       int q = std::abs(p.second) / m; const ProdKey& k = B->prods[p.first];
-      if (!(q == 1 || (q == 2 && (k.a.s1 < 0 || k.b.s1 < 0)))) { ok = false; break; }
+      if (!(q == 1 || (q == 2 && (k.a.s1 < 0 || k.b.s1 < 0)) || (q == 4 && k.a.s1 < 0 && k.b.s1 < 0))) { ok = false; break; }
     }
     if (ok) { mult = m; break; }
   }
@@ -203,7 +203,8 @@ int materialize(const SFp& x, bool halve_it) {
   for (auto& p : prods) {
     ProdKey k = B->prods[p.first];
     int q = std::abs(p.second) / mult; bool neg = p.second < 0;
-    if (q == 2 && k.a.s1 < 0) { k.a.s1 = k.a.s0; k.a.n1 = false; q = 1; }
+    if (q == 4 && k.a.s1 < 0 && k.b.s1 < 0) { k.a.s1 = k.a.s0; k.a.n1 = false; k.b.s1 = k.b.s0; k.b.n1 = false; q = 1; }   // 4 x y = (x + x)(y + y)
+    else if (q == 2 && k.a.s1 < 0) { k.a.s1 = k.a.s0; k.a.n1 = false; q = 1; }
     else if (q == 2 && k.b.s1 < 0) { k.b.s1 = k.b.s0; k.b.n1 = false; q = 1; }
     if (q == 1) dps.push_back({k.a, k.b, neg});
     else {
