@@ -84,7 +84,12 @@ static inline SFp12 mul_by_014(const SFp12& a, const SFp2& o0, const SFp2& o1, c
           {mul(y.c0, o0) + mul(xy2, o1) + mul(xx2, o4), mul(y.c0, o1) + mul(y.c1, o0) + mul(x.c0, o4), mul(y.c1, o1) + mul(y.c2, o0) + mul(x.c1, o4)}};
 }
 static inline SFp12 sqr(const SFp12& a) {                         // = math.ts:783-791: (c0^2 + v c1^2, 2 c0 c1)
-  return {sqr(a.c0) + mulnr(sqr(a.c1)), scale(mul(a.c0, a.c1), 2)};
+  // v * c1^2 = (xi * w.c2, w.c0, w.c1) with w = c1^2; xi * w.c2 is written with the non-residue folded into operands
+  // (xi * (2 x y) = 2 (xi x) y: two products per coefficient where xi applied to the pending form would take four)
+  const SFp6& b = a.c1;
+  SFp6 s = sqr(a.c0), w = sqr(b);
+  SFp2 xw2 = mulnr(sqr(b.c1)) + scale(mul(mulnr(b.c0), b.c2), 2);
+  return {{s.c0 + xw2, s.c1 + w.c0, s.c2 + w.c1}, scale(mul(a.c0, a.c1), 2)};
 }
 static inline SFp12 conj(const SFp12& a) { return {a.c0, -a.c1}; }                             // math.ts:799-801
 static inline SFp12 frob(const SFp12& a, int power) {             // math.ts:804-809
@@ -99,7 +104,10 @@ static inline SFp12 cyclotomic_sqr(const SFp12& x) {              // math.ts:824
   fp4_square(x.c0.c0, x.c1.c1, t3, t4);
   fp4_square(x.c1.c0, x.c0.c2, t5, t6);
   fp4_square(x.c0.c1, x.c1.c2, t7, t8);
-  SFp2 t9 = mulnr(t8);
+  // (1 + u) * t8 with the non-residue folded into an operand ((xi a) b: two products per coefficient; xi applied to the pending
+  // product form would expand to four) -- the same field element
+  SFp2 t9 = scale(mul(mulnr(x.c0.c1), x.c1.c2), 2);
+  (void)t8;
   return {{scale(t3 - x.c0.c0, 2) + t3, scale(t5 - x.c0.c1, 2) + t5, scale(t7 - x.c0.c2, 2) + t7},
           {scale(t9 + x.c1.c0, 2) + t9, scale(t4 + x.c1.c1, 2) + t4, scale(t6 + x.c1.c2, 2) + t6}};
 }
