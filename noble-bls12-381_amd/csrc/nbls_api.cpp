@@ -210,6 +210,9 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
     for (int k = 0; k < 4; k++) {
       int nn = (bits[k] + 3) / 4; std::vector<uint8_t> nb(nn);
       for (int j = 0; j < nn; j++) { int lo = 4 * (nn - 1 - j); uint8_t d = 0; for (int b = 3; b >= 0; b--) { int bit = lo + b; d = (uint8_t)((d << 1) | (bit < bits[k] ? (exps[k][bit >> 6] >> (bit & 63)) & 1 : 0)); } nb[j] = d; }
+      // the two Fp2 exponents go through the Frobenius split e = c0 + c1 p (pow_kernels.hip): joint 2-bit digits from tools/gen_consts.py
+      if (k == 1) { nb.assign(NBLS_JOINT_P2_PLUS_7_DIV_16, NBLS_JOINT_P2_PLUS_7_DIV_16 + sizeof NBLS_JOINT_P2_PLUS_7_DIV_16); nn = (int)nb.size(); }
+      if (k == 2) { nb.assign(NBLS_JOINT_P2_MINUS_9_DIV_16, NBLS_JOINT_P2_MINUS_9_DIV_16 + sizeof NBLS_JOINT_P2_MINUS_9_DIV_16); nn = (int)nb.size(); }
       ctx->nnib[k] = nn;
       if (hipMalloc(&ctx->nib[k], nn) != hipSuccess || hipMemcpy(ctx->nib[k], nb.data(), nn, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
     }

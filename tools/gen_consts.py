@@ -327,6 +327,14 @@ def emit(path, bits, fp_t, guard, qual, rbits=RBITS):
         a('#define NBLS_%s_BITS %d' % (name, e.bit_length()))
         a('%s uint64_t NBLS_EXP_%s[%d] = {%s};' % (qual, name, nw, ','.join('0x%016xull' % ((e >> (64 * i)) & (2 ** 64 - 1)) for i in range(nw))))
 
+    def joint_digits(name, e):
+        # e = c0 + c1 * p: a^e = a^c0 * conj(a)^c1 in Fp2 (a^p = conj(a)); joint 2-bit windows, most significant first, digit = c1_bits << 2 | c0_bits
+        c0, c1 = e % P, e // P
+        assert c0 + c1 * P == e and c1 < P
+        nwin = (max(c0.bit_length(), c1.bit_length()) + 1) // 2
+        ds = [(((c1 >> (2 * w)) & 3) << 2) | ((c0 >> (2 * w)) & 3) for w in reversed(range(nwin))]
+        a('%s unsigned char NBLS_JOINT_%s[%d] = {%s};' % (qual, name, nwin, ','.join(str(d) for d in ds)))
+
     fp('NBLS_P', P, raw=True)
     fp('NBLS_2P', 2 * P, raw=True)
     fp('NBLS_R1', 1)            # Montgomery one
@@ -379,6 +387,8 @@ def emit(path, bits, fp_t, guard, qual, rbits=RBITS):
     fparr('NBLS_G1_ISO_YDEN', G1_ISO_YDEN)
     for k, v in EXP.items():
         exp(k, v)
+        if v > P:
+            joint_digits(k, v)
     rw = [(R_ORDER >> (64 * i)) & (2 ** 64 - 1) for i in range(4)]
     a('%s uint64_t NBLS_R_ORDER[4] = {%s};' % (qual, ','.join('0x%016xull' % x for x in rw)))
     a('#endif')
