@@ -50,7 +50,7 @@ struct nbls_ctx {
   uint8_t *F = nullptr, *F2 = nullptr, *N = nullptr, *NI = nullptr, *io_g1 = nullptr, *io_g2 = nullptr, *io_f12 = nullptr, *one12 = nullptr;
   uint8_t* T[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // t1..t7 of the final exponentiation, raw Fp12
   // general scratch pool for the codec / hash / sum pipelines (grown on demand)
-  static const int NSB = 14;
+  static const int NSB = 20;
   uint8_t* sb[NSB] = {nullptr}; size_t sb_cap[NSB] = {0};
   uint8_t* nib[4] = {nullptr, nullptr, nullptr, nullptr}; int nnib[4] = {0, 0, 0, 0};   // exponent nibbles: (p+1)/4, (p^2+7)/16, (p^2-9)/16, (p-3)/4
   uint8_t* neg_g1 = nullptr;    // -G1 generator, affine wire bytes (verify: e(-G, S))
@@ -58,6 +58,7 @@ struct nbls_ctx {
   // side stream for the one-element chains of verifyBatch (signature decompression: a 758-bit Fp2 exponentiation on a single
   // lane is ~4 ms of pure latency) so that they overlap the batch-wide kernels instead of serialising with them
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; uint8_t* side_scratch = nullptr;
+  hipStream_t side2 = nullptr; hipEvent_t ev_join2 = nullptr;   // verifyBatch: key decoding runs beside message hashing (their exponentiation kernels are latency-bound and leave issue slots free)
   uint8_t* ident_g1 = nullptr; uint8_t* ident_g2 = nullptr;   // projective identity (0 : 1 : 0), raw
   size_t cap_F = 0, cap_io = 0;
   int last_hip = 0;
@@ -242,6 +243,9 @@ EXPORT void nbls_destroy(nbls_ctx* ctx) {
   for (uint8_t* p : ctx->sb) if (p) hipFree(p);
   for (uint8_t* p : ctx->nib) if (p) hipFree(p);
   for (uint8_t* p : {ctx->neg_g1, ctx->ident_g1, ctx->ident_g2}) if (p) hipFree(p);
+  if (ctx->side) hipStreamDestroy(ctx->side);
+  if (ctx->side2) hipStreamDestroy(ctx->side2);
+  for (hipEvent_t e : {ctx->ev_fork, ctx->ev_join, ctx->ev_join2}) if (e) hipEventDestroy(e);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -457,12 +461,14 @@ static int dev_validate(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, voi
   return g2 ? run(ctx, P_G2_VALIDATE, n, {B(1, d_pts, 192), B(7, d_status, 1)}, s) : run(ctx, P_G1_VALIDATE, n, {B(0, d_pts, 96), B(7, d_status, 1)}, s);
 }
 // PointG1.fromHex (48 B) / PointG2.fromSignature (96 B): compressed -> affine wire bytes + status
-static int dev_decompress(nbls_ctx* ctx, bool g2, size_t n, const void* d_in, void* d_out, void* d_status, hipStream_t s) {
+// slot0 / pow_slot: scratch-pool slots used (three from slot0, one for the exponentiation table), so that two chains can run on
+// different streams at the same time
+static int dev_decompress(nbls_ctx* ctx, bool g2, size_t n, const void* d_in, void* d_out, void* d_status, hipStream_t s, int slot0 = 0, int pow_slot = 11) {
   const size_t e = g2 ? 96 : 48, q = g2 ? 2 * RAW : RAW;
-  uint8_t *X, *R, *Cd; int r;
-  if ((r = need(ctx, 0, n * q, &X)) || (r = need(ctx, 1, n * q, &R)) || (r = need(ctx, 2, n * q, &Cd))) return r;
+  uint8_t *X, *R, *Cd, *pw; int r;
+  if ((r = need(ctx, slot0, n * q, &X)) || (r = need(ctx, slot0 + 1, n * q, &R)) || (r = need(ctx, slot0 + 2, n * q, &Cd)) || (r = need(ctx, pow_slot, n * 16 * (g2 ? 2 : 1) * RAW, &pw))) return r;
   if ((r = run(ctx, g2 ? P_G2_DEC_A : P_G1_DEC_A, n, {B(0, d_in, e), B(3, X, q), B(4, R, q)}, s))) return r;
-  if ((r = run_pow(ctx, g2 ? 1 : 0, n, R, Cd, s))) return r;
+  if ((r = run_pow(ctx, g2 ? 1 : 0, n, R, Cd, s, pw))) return r;
   return run(ctx, g2 ? P_G2_DEC_B : P_G1_DEC_B, n, {B(0, d_in, e), B(3, X, q), B(4, R, q), B(5, Cd, q), B(6, d_out, 2 * e), B(7, d_status, 1)}, s);
 }
 // 256 uniform bytes per message (expand_message_xmd output) -> hash point, affine wire bytes (PointG2.hashToCurve, index.ts:481-490)
@@ -825,7 +831,7 @@ static int verify_stage(nbls_ctx* ctx, size_t n, const void* d_sig96, const void
     // The side stream is created on first use: HIP spreads streams over a few hardware queues in creation order, and contexts
     // that only run pairing batches (noble-bls12-381_amd/pipeline.py keeps several in flight) should each get a queue of their own.
     if (!ctx->side) {
-      if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess || (!ctx->ev_fork && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) ||
           hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess || hipMalloc(&ctx->side_scratch, (6 + 32) * RAW) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
     }
     uint8_t *X = ctx->side_scratch, *Rr = X + 2 * RAW, *Cd = Rr + 2 * RAW, *pw = Cd + 2 * RAW;
@@ -835,8 +841,23 @@ static int verify_stage(nbls_ctx* ctx, size_t n, const void* d_sig96, const void
     if ((r = run(ctx, P_G2_DEC_B, 1, {B(0, d_sig96, 96), B(3, X, 2 * RAW), B(4, Rr, 2 * RAW), B(5, Cd, 2 * RAW), B(6, G2 + n * 192, 192), B(7, ST + n, 1)}, ctx->side))) return r;
     HIPCHK(hipEventRecord(ctx->ev_join, ctx->side));
   }
-  if ((r = dev_decompress(ctx, false, n, d_pk48, G1, ST, s))) return r;                       // normP1: PointG1.fromHex
-  if ((r = dev_hash_to_g2(ctx, n, d_uniform, G2, s))) return r;                               // normP2Hash: PointG2.hashToCurve
+  // normP1 (PointG1.fromHex of the keys) on a second stream beside normP2Hash (PointG2.hashToCurve of the messages): both chains
+  // contain a per-lane exponentiation kernel that fills the chip only two wavefronts deep and issues at half rate, so running
+  // them side by side costs little more than the longer one.  Scratch slots 14..16 / 17 for the key chain (0..6 / 11 belong to the hash,
+  // 7..9 / 12 hold the staged messages, keys and expand_message_xmd output of the host-buffer entry point).
+  static const bool overlap = !getenv("NBLS_VERIFY_NO_OVERLAP");
+  if (overlap) {
+    if (!ctx->side2 && (hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming) != hipSuccess)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+    if (!ctx->ev_fork && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+    HIPCHK(hipEventRecord(ctx->ev_fork, s)); HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));
+    if ((r = dev_decompress(ctx, false, n, d_pk48, G1, ST, ctx->side2, 14, 17))) return r;
+    HIPCHK(hipEventRecord(ctx->ev_join2, ctx->side2));
+    if ((r = dev_hash_to_g2(ctx, n, d_uniform, G2, s))) return r;
+    HIPCHK(hipStreamWaitEvent(s, ctx->ev_join2, 0));
+  } else {
+    if ((r = dev_decompress(ctx, false, n, d_pk48, G1, ST, s))) return r;                       // normP1: PointG1.fromHex
+    if ((r = dev_hash_to_g2(ctx, n, d_uniform, G2, s))) return r;                               // normP2Hash: PointG2.hashToCurve
+  }
   if (d_sig96) {
     HIPCHK(hipMemcpyAsync(G1 + n * 96, ctx->neg_g1, 96, hipMemcpyDeviceToDevice, s));         // PointG1.BASE.negate()
     HIPCHK(hipStreamWaitEvent(s, ctx->ev_join, 0));
