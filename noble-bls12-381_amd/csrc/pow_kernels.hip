@@ -94,51 +94,95 @@ extern "C" __global__ void __launch_bounds__(64) nbls_fp_pow_kernel(unsigned n, 
 // a^e in Fp2 for e up to ~2^762, as a^c0 * conj(a)^c1 with e = c0 + c1 p (a^p = conj(a): the Frobenius is free), joint 2-bit windows:
 // 2 squarings + at most one multiplication by a^i conj(a)^j per window, 191 windows -- 382 squarings instead of the 757 of a plain
 // left-to-right exponentiation (same field element).  digits[w] = c1 bits << 2 | c0 bits, most significant window first.
-extern "C" __global__ void __launch_bounds__(64) nbls_fp2_pow_kernel(unsigned n, const u32* __restrict__ in, u32* __restrict__ out, const unsigned char* __restrict__ digits, int nwin, u32* __restrict__ scratch) {
-  unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// TWO LANES PER ELEMENT: lane parity r owns component c_r of every Fp2 value and computes component r of every product (both
+// components cost the same: two limb products + one reduction for a multiplication, one + one for a squaring); the partner's
+// component arrives by a DPP lane swap.  Half the instructions per lane and twice the wavefronts of the one-lane-per-element
+// form, which at 131,072 elements filled the chip only two wavefronts deep and was latency-bound (5.4 ms).
+__device__ __forceinline__ void swap_pair(u32* p, const u32* x) {
+#pragma unroll
+  for (int k = 0; k < NL; k++) p[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)x[k], 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
+}
+// component r of a * b; X, U: own components of a, b
+__device__ __forceinline__ void fp2_mul_2l(u32* res, const u32* X, const u32* U, bool r) {
   const u32 BIAS[NL] = NBLS_BIAS16_28;
-  u32* tab = scratch + (size_t)i * 16 * 32;     // tab[j << 2 | i] = a^i conj(a)^j
-  Fp2r pw[4], acc, t;
+  u32 Y[NL], V[NL], B1[NL], B2[NL], A2[NL];
+  swap_pair(Y, X); swap_pair(V, U);
 #pragma unroll
-  for (int k = 0; k < NL; k++) { pw[1].c0[k] = in[32 * i + k]; pw[1].c1[k] = in[32 * i + 16 + k]; pw[0].c0[k] = NBLS_R1[k]; pw[0].c1[k] = 0; }
-  fp2_sqr_r(pw[2], pw[1]); fp2_mul_r(pw[3], pw[2], pw[1]);
-  for (int jj = 0; jj < 4; jj++) {
-    Fp2r cj = pw[jj];                            // conj(a^j) = conj(a)^j: (c0, 16p - c1), normalised
-    if (jj) {
+  for (int k = 0; k < NL; k++) { B1[k] = r ? V[k] : U[k]; B2[k] = r ? U[k] : V[k]; A2[k] = r ? Y[k] : BIAS[k] - Y[k]; }   // r = 0: a0 b0 - a1 b1 ; r = 1: a1 b0 + a0 b1
+  carry_norm(A2);
+  u64 acc[2 * NL];
 #pragma unroll
-      for (int k = 0; k < NL; k++) cj.c1[k] = BIAS[k] - pw[jj].c1[k];
-      carry_norm(cj.c1);
-    }
-    for (int ii = 0; ii < 4; ii++) {
-      Fp2r u;
-      if (ii == 0) u = cj; else if (jj == 0) u = pw[ii]; else fp2_mul_r(u, pw[ii], cj);
-      const int d = (jj << 2) | ii;
+  for (int k = 0; k < 2 * NL; k++) acc[k] = 0;
+  mac28(acc, X, B1); mac28(acc, A2, B2);
+  redc28(res, acc);
+}
+// component r of a^2 (math.ts:477-484): r = 0: (a0 + a1)(a0 - a1) ; r = 1: (2 a0) a1
+__device__ __forceinline__ void fp2_sqr_2l(u32* res, const u32* X, bool r) {
+  const u32 BIAS[NL] = NBLS_BIAS16_28;
+  u32 Y[NL], o1[NL], o2[NL];
+  swap_pair(Y, X);
 #pragma unroll
-      for (int k = 0; k < NL; k++) { tab[32 * d + k] = u.c0[k]; tab[32 * d + 16 + k] = u.c1[k]; }
+  for (int k = 0; k < NL; k++) { o1[k] = (r ? Y[k] : X[k]) + Y[k]; o2[k] = r ? X[k] : X[k] + BIAS[k] - Y[k]; }
+  carry_norm(o1); carry_norm(o2);
+  mont_mul28(res, o1, o2);
+}
+extern "C" __global__ void __launch_bounds__(64) nbls_fp2_pow_kernel(unsigned n, const u32* __restrict__ in, u32* __restrict__ out, const unsigned char* __restrict__ digits, int nwin, u32* __restrict__ scratch) {
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x, i = t >> 1;
+  const bool r = t & 1;
+  if (i >= n) return;                              // both lanes of a pair leave together
+  const u32 BIAS[NL] = NBLS_BIAS16_28;
+  u32* tab = scratch + (size_t)t * 16 * 16;        // tab[j << 2 | i] = own component of a^i conj(a)^j
+  u32 acc[NL], tt[NL];
+  // table: powers a^0..a^3 first (kept in the table, not in registers), then the three conjugate rows from them
+  {
+    u32 p1[NL], pk[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) { p1[k] = in[32 * i + 16 * r + k]; acc[k] = r ? 0u : NBLS_R1[k]; tab[k] = acc[k]; tab[16 + k] = p1[k]; }
+    fp2_sqr_2l(pk, p1, r);
+#pragma unroll
+    for (int k = 0; k < NL; k++) tab[32 + k] = pk[k];
+    fp2_mul_2l(tt, pk, p1, r);
+#pragma unroll
+    for (int k = 0; k < NL; k++) tab[48 + k] = tt[k];
+  }
+  for (int jj = 1; jj < 4; jj++) {
+    u32 cj[NL];                                    // own component of conj(a^j) = conj(a)^j: (c0, 16p - c1)
+#pragma unroll
+    for (int k = 0; k < NL; k++) { const u32 v = tab[16 * jj + k]; cj[k] = r ? BIAS[k] - v : v; }
+    carry_norm(cj);
+#pragma unroll
+    for (int k = 0; k < NL; k++) tab[16 * (jj << 2) + k] = cj[k];
+    for (int ii = 1; ii < 4; ii++) {
+      u32 pi[NL];
+#pragma unroll
+      for (int k = 0; k < NL; k++) pi[k] = tab[16 * ii + k];
+      fp2_mul_2l(tt, pi, cj, r);
+#pragma unroll
+      for (int k = 0; k < NL; k++) tab[16 * ((jj << 2) | ii) + k] = tt[k];
     }
   }
-  acc = pw[0];
   for (int w = 0; w < nwin; w++) {
-    if (w) { fp2_sqr_r(t, acc); fp2_sqr_r(acc, t); }
-    const unsigned d = digits[w];
+    if (w) { fp2_sqr_2l(tt, acc, r); fp2_sqr_2l(acc, tt, r); }
+    const unsigned d = digits[w];                   // uniform
     if (d) {
-      Fp2r e;
+      u32 e[NL];
 #pragma unroll
-      for (int k = 0; k < NL; k++) { e.c0[k] = tab[32 * d + k]; e.c1[k] = tab[32 * d + 16 + k]; }
-      fp2_mul_r(t, acc, e); acc = t;
+      for (int k = 0; k < NL; k++) e[k] = tab[16 * d + k];
+      fp2_mul_2l(tt, acc, e, r);
+#pragma unroll
+      for (int k = 0; k < NL; k++) acc[k] = tt[k];
     }
   }
 #pragma unroll
-  for (int k = 0; k < NL; k++) { out[32 * i + k] = acc.c0[k]; out[32 * i + 16 + k] = acc.c1[k]; }
-  out[32 * i + 14] = out[32 * i + 15] = out[32 * i + 30] = out[32 * i + 31] = 0;
+  for (int k = 0; k < NL; k++) out[32 * i + 16 * r + k] = acc[k];
+  out[32 * i + 16 * r + 14] = 0; out[32 * i + 16 * r + 15] = 0;
 }
 
 }  // namespace nbls
 
 extern "C" int nbls_fp_pow_launch(unsigned n, const void* in, void* out, const void* nibbles, int nnib, void* scratch, int is_fp2, void* stream) {
   if (n == 0) return 0;
-  if (is_fp2) hipLaunchKernelGGL(nbls::nbls_fp2_pow_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, (const nbls::u32*)in, (nbls::u32*)out, (const unsigned char*)nibbles, nnib, (nbls::u32*)scratch);
+  if (is_fp2) hipLaunchKernelGGL(nbls::nbls_fp2_pow_kernel, dim3((2 * n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, (const nbls::u32*)in, (nbls::u32*)out, (const unsigned char*)nibbles, nnib, (nbls::u32*)scratch);
   else hipLaunchKernelGGL(nbls::nbls_fp_pow_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, (const nbls::u32*)in, (nbls::u32*)out, (const unsigned char*)nibbles, nnib, (nbls::u32*)scratch);
   return (int)hipGetLastError();
 }
