@@ -2,6 +2,7 @@
 import hashlib
 import importlib
 import pytest
+from ctypes import c_int as C_int
 from goldenio import hx
 
 pytestmark = pytest.mark.gpu
@@ -170,3 +171,43 @@ def test_hash_and_encode_to_curve_kats(eng, oracle, golden, testdata):
         assert enc2[192 * i:192 * i + 192] == oracle.encode_to_g2(m, dst)[1]
     # outputs are in the prime-order subgroup
     assert eng.validate_batch(out, False) == [0] * len(msgs) and eng.validate_batch(enc2, True) == [0] * len(msgs)
+
+
+def test_decode_validate_large_mixed_batch(eng, oracle):
+    """3001 compressed G1 keys and 1001 compressed G2 signatures (ragged last wavefronts at 16 / 8 items per wave), valid and
+    invalid encodings mixed: decode status and affine bytes against the oracle item by item; the decoded points through the
+    validity programs again; and 1999 hash-to-G2 outputs against the oracle"""
+    import hashlib
+    import random
+    rnd = random.Random(2024)
+    g1, g2 = oracle.g1_generator(), oracle.g2_generator()
+    n1, n2 = 3001, 1001
+    base1 = [oracle.call('g1_compress', 48, oracle.g1_mul(g1, rnd.randrange(1, 1 << 200))[1], C_int(0))[1] for _ in range(40)]
+    base2 = [oracle.call('g2_compress', 96, oracle.g2_mul(g2, rnd.randrange(1, 1 << 200))[1], C_int(0))[1] for _ in range(24)]
+    keys = []
+    for i in range(n1):
+        k = bytearray(base1[i % 40])
+        if i % 7 == 3:
+            k[47 - (i % 5)] ^= 1 + (i % 200)          # another x: no square root, or a point outside the subgroup, or (rarely) valid
+        keys.append(bytes(k))
+    sigs = []
+    for i in range(n2):
+        s = bytearray(base2[i % 24])
+        if i % 5 == 2:
+            s[95 - (i % 3)] ^= 1 + (i % 100)
+        sigs.append(bytes(s))
+    for comp, is_g2, sz in ((keys, False, 96), (sigs, True, 192)):
+        out, st = eng.decompress_batch(b''.join(comp), g2=is_g2)
+        ok_pts = []
+        for i, c in enumerate(comp):
+            rs, ro = oracle.call('g2_decompress' if is_g2 else 'g1_decompress', sz, c)
+            assert st[i] == rs, (is_g2, i, st[i], rs)
+            if rs == 0:
+                assert out[sz * i:sz * i + sz] == ro, (is_g2, i)
+                ok_pts.append(ro)
+        assert len(ok_pts) > len(comp) // 2
+        assert eng.validate_batch(b''.join(ok_pts), g2=is_g2) == [0] * len(ok_pts)
+    msgs = [hashlib.sha256(b'h2c-large-%d' % i).digest()[:1 + i % 32] for i in range(1999)]
+    out = eng.hash_to_g2_batch(msgs)
+    for i in range(0, 1999, 37):
+        assert out[192 * i:192 * i + 192] == oracle.hash_to_g2(msgs[i])[1], i
