@@ -50,8 +50,13 @@ NBLS_HD void carry_norm(u32* x) {
 
 template <typename LDSP>
 NBLS_HD void ld14(u32* x, LDSP lds, u32 off) {
+#if defined(NBLS_EXP_NOLDS)     // timing experiment only (tools/exp_variants.sh): operands made up from the address, no LDS traffic; results are garbage
+#pragma unroll
+  for (int i = 0; i < NL; i++) x[i] = (off * 2654435761u + i * 40503u) & LMASK;
+#else
 #pragma unroll
   for (int i = 0; i < NL; i++) x[i] = lds[off + i];
+#endif
 }
 // word offset of an operand's slot: constants live at the start of the LDS image, everything else in the instance region
 NBLS_HD u32 slot_addr(u32 op, u32 inst) {
