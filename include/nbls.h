@@ -134,7 +134,7 @@ int nbls_verify_batch_partial_dev(nbls_ctx* ctx, size_t n, const void* d_sig96 /
 /* Introspection for the benchmark / tests. */
 int nbls_program_stats(nbls_ctx* ctx, int prog, uint32_t* out8);   /* steps, mul_steps, lin_steps, mul_ops, lin_ops, lin_terms, slots, lds_bytes */
 int nbls_device_synchronize(nbls_ctx* ctx);
-/* Placement study (tools/placement.py): runs one step program on n scratch items; out_blocks[3b..3b+2] = HW_ID | XCC_ID << 32, start tick, end tick of workgroup b. */
+/* Placement study (tools/placement.py): runs one step program on n scratch items; out_blocks[5b..5b+4] = HW_ID | XCC_ID << 32, start tick, end tick (s_memtime), start, end time (s_memrealtime, 100 MHz) of workgroup b. */
 int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks);
 /* Per-kernel HIP-event timing (benchmark roofline leg): ms[i]/counts[i] for program i, last entry = inversion kernel. */
 #define NBLS_N_PROGRAMS 64

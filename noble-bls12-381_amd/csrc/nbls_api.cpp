@@ -408,7 +408,7 @@ EXPORT int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks) {
   r = upload(ctx, pid); if (r) return r;
   const DevProgram& d = ctx->prog[pid];
   const size_t blocks = (n + d.p->G - 1) / d.p->G;
-  uint64_t* dbg = nullptr; HIPCHK(hipMalloc(&dbg, blocks * 24));
+  uint64_t* dbg = nullptr; HIPCHK(hipMalloc(&dbg, blocks * 40));
   KernelArgs ka; memset(&ka, 0, sizeof ka);
   ka.steps = d.steps; ka.descs = d.descs; ka.consts = d.consts;
   ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slots = d.p->slots; ka.n_items = (u32)n;
@@ -418,7 +418,7 @@ EXPORT int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks) {
   HIPCHK(hipMemsetAsync(ctx->T[0], 0, n * F12, ctx->stream));
   int e = nbls_vm_launch(&ka, d.p->lds_bytes(), ctx->stream);
   if (e) { hipFree(dbg); ctx->last_hip = e; return NBLS_EHIP; }
-  HIPCHK(hipMemcpyAsync(out_blocks, dbg, blocks * 24, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpyAsync(out_blocks, dbg, blocks * 40, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
   hipFree(dbg);
   return NBLS_OK;
 }

@@ -7,7 +7,7 @@
 
 namespace nbls {
 
-extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel(KernelArgs ka) {
+template <bool FAIR> __device__ __forceinline__ void vm_kernel_body(const KernelArgs& ka) {
   extern __shared__ __attribute__((aligned(16))) u32 smem[];
   const u32 lane = threadIdx.x;
   u32 n_items = ka.n_items;
@@ -21,7 +21,7 @@ extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel(KernelArgs ka) {
   cx.inst = shared_words + inst_id * ka.slots * SLOT_WORDS;
   cx.item = blockIdx.x * ka.G + inst_id;
   cx.live = inst_id < ka.G && cx.item < n_items;
-  if (ka.hwid_out && lane == 0) { ka.hwid_out[3 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); ka.hwid_out[3 * blockIdx.x + 1] = __builtin_readcyclecounter(); }   // HW_ID, XCC_ID, start tick (placement study)
+  if (ka.hwid_out && lane == 0) { ka.hwid_out[5 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); ka.hwid_out[5 * blockIdx.x + 1] = __builtin_readcyclecounter(); ka.hwid_out[5 * blockIdx.x + 3] = wall_clock64(); }   // HW_ID, XCC_ID, start tick (s_memtime), start time (s_memrealtime, 100 MHz): placement study
   __syncthreads();   // single wave: orders the constant fill before first use
   // Software-pipelined interpreter loop: this lane's descriptor words for step s+1 and the header of step s+2 are
   // requested before step s executes, so their L2 latency overlaps the arithmetic.
@@ -34,7 +34,18 @@ extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel(KernelArgs ka) {
     d0 = descs4[o];
     if (st.stride > 4) d1 = descs4[o + 1];
   }
+  // Fairness between the wavefronts that share a SIMD: the issue arbiter prefers the oldest wavefront, which then runs at ~94 % of
+  // its lone speed while a second one gets ~55 % and a third ~23 % (tools/placement.py), so the youngest finishes long after the
+  // others and runs the tail alone.  Lowering the own priority with progress lets the wavefront that is behind catch up: +8..10 %
+  // for launches that put 2-4 wavefronts on every SIMD in a single round (8192..16384 pairings).  The launcher picks the FAIR instantiation only
+  // for those: with one wavefront per SIMD there is nothing to balance, and in steady state (many rounds, or several batches in
+  // flight) the priorities cost ~2 %.
+  // Two instantiations: even a never-taken priority test in this loop costs a lone wavefront 5 % (measured), so the variant without
+  // the priority code is a kernel of its own.
+  const u32 quarter = (ka.nsteps >> 2) + 1;
+  if (FAIR) __builtin_amdgcn_s_setprio(3);
   for (u32 s = 0; s < ka.nsteps; s++) {
+    if (FAIR) { if (s == quarter) __builtin_amdgcn_s_setprio(2); else if (s == 3 * quarter) __builtin_amdgcn_s_setprio(1); }
     // header of step s+2 is requested now and first looked at one iteration later; the header of step s+1 arrived during
     // the previous step, so the descriptor prefetch below does not wait on global memory (a lone wavefront has nobody to
     // hide a ~2 us header round trip per step behind)
@@ -57,8 +68,10 @@ extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel(KernelArgs ka) {
     }
     st = nst; nst = nnst; d0 = n0; d1 = n1;
   }
-  if (ka.hwid_out && lane == 0) ka.hwid_out[3 * blockIdx.x + 2] = __builtin_readcyclecounter();
+  if (ka.hwid_out && lane == 0) { ka.hwid_out[5 * blockIdx.x + 2] = __builtin_readcyclecounter(); ka.hwid_out[5 * blockIdx.x + 4] = wall_clock64(); }
 }
+extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel(KernelArgs ka) { vm_kernel_body<false>(ka); }
+extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel_fair(KernelArgs ka) { vm_kernel_body<true>(ka); }
 
 // Two-wave variant for small batches.  A lone wavefront per SIMD issues at ~1/3 of the VALU rate (every instruction waits
 // for the previous one; tools/ubench/lone_wave.hip) and a second wavefront on the same SIMD runs at full speed beside it,
@@ -154,6 +167,7 @@ extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, vo
   static const int split_mode = getenv("NBLS_SPLIT") ? atoi(getenv("NBLS_SPLIT")) : -1;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)nbls_vm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)nbls_vm_kernel_fair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)nbls_vm_kernel_split, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
@@ -161,6 +175,11 @@ extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, vo
   if (lds_bytes < lds_floor) lds_bytes = lds_floor;
   const bool split = split_mode == 1 || (split_mode < 0 && blocks <= 256);
   if (split) hipLaunchKernelGGL(nbls_vm_kernel_split, dim3(blocks), dim3(128), lds_bytes + 2 * NLIMBS * 64 * 8, (hipStream_t)stream, *ka);
-  else hipLaunchKernelGGL(nbls_vm_kernel, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, *ka);
+  else {
+    static const int fair_mode = getenv("NBLS_FAIR") ? atoi(getenv("NBLS_FAIR")) : -1;   // 0 never, 1 always, unset: launches of 2..4 wavefronts per SIMD
+    const bool fair = fair_mode >= 0 ? fair_mode != 0 : (blocks > 1024 && blocks <= 4096);
+    if (fair) hipLaunchKernelGGL(nbls_vm_kernel_fair, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, *ka);
+    else hipLaunchKernelGGL(nbls_vm_kernel, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, *ka);
+  }
   return (int)hipGetLastError();
 }

@@ -8,10 +8,12 @@ pkg = importlib.import_module('noble-bls12-381_amd')
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 eng = pkg.Engine(0)
 blocks = (n + 3) // 4
-out = (C.c_uint64 * (3 * blocks))()
+out5 = (C.c_uint64 * (5 * blocks))()
 eng.lib.nbls_placement_probe.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
-r = eng.lib.nbls_placement_probe(eng.h, n, out)
+r = eng.lib.nbls_placement_probe(eng.h, n, out5)
 assert r == 0, r
+out = [v for b in range(blocks) for v in out5[5 * b:5 * b + 3]]      # (hw id, start tick, end tick) per workgroup
+real = [(out5[5 * b + 3], out5[5 * b + 4]) for b in range(blocks)]     # s_memrealtime (100 MHz) at start / end
 simd = collections.Counter(); cu = collections.Counter()
 t0 = min(out[3 * b + 1] for b in range(blocks))
 starts = sorted(out[3 * b + 1] - t0 for b in range(blocks)); ends = sorted(out[3 * b + 2] - t0 for b in range(blocks)); lives = sorted(out[3 * b + 2] - out[3 * b + 1] for b in range(blocks))
@@ -44,3 +46,10 @@ if x0:
     print('  XCD 0: %d workgroups, start offsets / median life at deciles: %s' % (len(x0), ' '.join('%.2f' % ((x0[min(len(x0) - 1, len(x0) * d // 10)] - x0[0]) / med) for d in range(11))))
 q = lambda a, f: a[min(len(a) - 1, int(f * len(a)))]
 print('  ticks: start p50 %d p90 %d max %d | wave life p50 %d max %d | last end %d' % (q(starts, .5), q(starts, .9), starts[-1], q(lives, .5), lives[-1], ends[-1]))
+
+# real time (100 MHz counter, common to the whole device): when do the workgroups start and end, and how fast does s_memtime tick meanwhile
+r0 = min(a for a, _ in real)
+st = sorted((a - r0) / 100.0 for a, _ in real); en = sorted((e - r0) / 100.0 for _, e in real); lf = sorted((e - a) / 100.0 for a, e in real)
+print('  real time (us): start p10 %.1f p50 %.1f p90 %.1f max %.1f | end p10 %.1f p50 %.1f max %.1f | life p10 %.1f p50 %.1f p90 %.1f' % (q(st, .1), q(st, .5), q(st, .9), st[-1], q(en, .1), q(en, .5), en[-1], q(lf, .1), q(lf, .5), q(lf, .9)))
+rates = sorted((out5[5 * b + 2] - out5[5 * b + 1]) / max(1, (out5[5 * b + 4] - out5[5 * b + 3])) * 100.0 for b in range(blocks))
+print('  s_memtime ticks per microsecond of real time: p10 %.0f p50 %.0f p90 %.0f' % (q(rates, .1), q(rates, .5), q(rates, .9)))
