@@ -361,6 +361,19 @@ def main():
             sleg = {'metric': 'sign sigs/sec: nbls_sign_batch from host buffers (device SHA-256 expand_message_xmd + hash-to-G2 + constant-time G2 ladder + affine), compression not included', 'n': ns_, 'value': round(ns_ / sdt, 2), 'ms': round(sdt * 1e3, 3),
                     'g2_ladder_kernel_ms': round(stm.get('g2_mul', (0, 0))[0], 3), 'get_public_key_keys_per_s': round(ns_ / kdt, 2),
                     'cpu_baseline': {'value': round(1 / csdt, 2), 'unit': 'sigs/s', 'cores': 1, 'kind': 'port', 'sample': '16 signatures on one host thread (oracle/)'}}
+        aleg = None
+        if world == 1 and args.sign_batch > 0:
+            # aggregatePublicKeys / aggregateSignatures (index.ts:771-788; benchmark.js sizes 8..2048) on affine points from host buffers
+            na = 2048
+            g1p = synth_points(oracle, 64, seed=5)[0]; g2p = synth_points(oracle, 64, seed=6)[1]
+            P1 = (g1p * (na // 64))[:96 * na]; P2 = (g2p * (na // 64))[:192 * na]
+            assert eng.point_sum(P1[:96 * 8])[0] == oracle.g1_sum(P1[:96 * 8])[1] and eng.point_sum(P2[:192 * 8], g2=True)[0] == oracle.g2_sum(P2[:192 * 8])[1], 'aggregate parity check failed'
+            eng.point_sum(P1); eng.point_sum(P2, g2=True)
+            a0 = time.perf_counter(); eng.point_sum(P1); a1 = time.perf_counter(); eng.point_sum(P2, g2=True); a2 = time.perf_counter()
+            big = (g1p * 1024)[:96 * 65536]
+            eng.point_sum(big); a3 = time.perf_counter(); eng.point_sum(big); a4 = time.perf_counter()
+            aleg = {'aggregate_public_keys_2048_ms': round((a1 - a0) * 1e3, 3), 'aggregate_signatures_2048_ms': round((a2 - a1) * 1e3, 3),
+                    'aggregate_public_keys_65536_ms': round((a4 - a3) * 1e3, 3), 'note': 'affine points in host memory -> one affine sum (tree of complete additions on the GPU)'}
         mleg = None
         if world == 1 and args.msm_points > 0:
             nm = args.msm_points
@@ -395,7 +408,7 @@ def main():
             'config': {'workload': 'batch of %d independent BLS12-381 pairings per GPU (Miller loop + final exponentiation, inputs pre-validated, bit-exact vs reference), inputs/outputs resident in HBM' % n,
                        'batch_per_gpu': n, 'sharding': 'independent batches per rank, no collective', 'batches_in_flight': D},
             'single_stream': {'pairings_per_s': round(n * args.steps / dt_serial, 2), 'ms_per_batch': round(dt_serial / args.steps * 1e3, 4), 'note': 'one batch at a time on one stream (this rank): the latency of a 4096-pairing call'},
-            'roofline': roof, 'cpu_baseline': cpu, 'product': product, 'verify_batch': vbatch if vbatch is not None else vshard, 'verify_batch_sharded': vshard if vbatch is not None else None, 'sign': sleg, 'msm': mleg,
+            'roofline': roof, 'cpu_baseline': cpu, 'product': product, 'verify_batch': vbatch if vbatch is not None else vshard, 'verify_batch_sharded': vshard if vbatch is not None else None, 'sign': sleg, 'aggregate': aleg, 'msm': mleg,
         }
         print(json.dumps(line))
     if world > 1:
