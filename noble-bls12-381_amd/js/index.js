@@ -4,17 +4,31 @@
  * the reference; the arithmetic runs on the GPU.  Additive batched entry points: pairingBatch, millerProduct.
  *
  * getPublicKey / sign run the double-and-add-always ladders of the engine (SURVEY 8(f).1); additive: getPublicKeys, signBatch.
- * The reference's re-exported field classes (Fp, Fr, Fp2) are host-side bigint helpers outside the hot path and are not
- * provided; Fp12 is a thin byte-backed wrapper (toBytes / equals / multiply / finalExponentiate).
+ * The reference's re-exported field classes Fp, Fr, Fp2 (index.ts:22) are single-element bigint helpers outside the batched hot
+ * path: fields.js provides them on the host; Fp12 is a thin byte-backed wrapper (toBytes / equals / finalExponentiate).
  */
 'use strict';
 const path = require('path');
 const native = require(path.join(__dirname, 'nbls_napi.node'));
+const { Fp, Fr, Fp2 } = require('./fields.js');
 
+// curve parameters under the reference's key names (math.ts:13-63).  h = (z - 1)^2 / 3 and h2 = (z^8 - 4z^7 + 5z^6 - 4z^4 + 6z^3 - 4z^2 - 4z + 13) / 9
+// with z = -x; h2Eff is the effective G2 cofactor of RFC 9380 section 8.8.2; P2 is p^2 - 1 as in the reference.
+const P_ = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaabn;
 const CURVE = {
-  P: 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaabn,
+  P: P_,
   r: 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001n,
+  h: 0x396c8c005555e1568c00aaab0000aaabn,
+  Gx: 0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bbn,
+  Gy: 0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1n,
+  b: 4n,
+  P2: P_ ** 2n - 1n,
+  h2: 0x5d543a95414e7f1091d50792876a202cd91de4547085abaa68a205b2e5a7ddfa628f1cb4d9e82ef21537e293a6691ae1616ec6e786f0c70cf1c38e31c7238e5n,
+  G2x: [0x024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8n, 0x13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7en],
+  G2y: [0x0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801n, 0x0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79ben],
+  b2: [4n, 4n],
   x: 0xd201000000010000n,
+  h2Eff: 0xbc69f08f2ee75b3584c6a0ea91b352888e2a8e9145ad7689986ff031508ffe1329c2f178731db956d82bf015d1212b02ec0ec69d7477c1ae954cbc06689f6a359894c0adebbf6b4e8020005aaa95551n,
 };
 const htfDefaults = { DST: 'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_' };      // reference index.ts:60-81
 let inited = false;
@@ -386,5 +400,5 @@ const utils = {
   },
 };
 
-module.exports = { CURVE, Fp12, PointG1, PointG2, pairing, pairingBatch, millerProduct, getPublicKey, getPublicKeys, sign, signBatch, verify, verifyBatch,
+module.exports = { CURVE, Fp, Fr, Fp2, Fp12, PointG1, PointG2, pairing, pairingBatch, millerProduct, getPublicKey, getPublicKeys, sign, signBatch, verify, verifyBatch,
   aggregatePublicKeys, aggregateSignatures, utils, init: (dev) => { native.init(dev || 0); inited = true; } };

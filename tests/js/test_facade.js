@@ -71,6 +71,30 @@ const hex = bls.utils.bytesToHex, un = bls.utils.hexToBytes;
   assert.throws(() => bls.getPublicKey(0n), /Expected valid private key/);
   assert.throws(() => bls.getPublicKey(bls.CURVE.r), /Private key must be 0 < key < CURVE.r/);
   assert.throws(() => bls.getPublicKey('zz'), /Expected valid private key/);
+  // field classes re-exported by the reference (Fp, Fr, Fp2): values produced by the reference itself under Node (tools/gen_golden.mjs
+  // environment; which square root is returned matters), plus algebraic identities
+  {
+    const { Fp, Fr, Fp2 } = bls;
+    const KAT = [{"a": "6db81c7c3bb8001a70db6825237a68d16afbe3ef96ff20d09f166f6fa64fbc0f74b64f128ab6978006d1c34c1c30898", "b": "1443e64d873318f63ccb594417232f71634dc5dfb781376bd86e4d5f55134f5d035f1309be5fc1357a580b18313fb18d", "c": "2d468a88aca03e5eb9dbf78cc5f44c92b506d77fbba72c1e58edcfb825e39e7e", "fp_sqrt_of_square": "6db81c7c3bb8001a70db6825237a68d16afbe3ef96ff20d09f166f6fa64fbc0f74b64f128ab6978006d1c34c1c30898", "fr_sqrt_of_square": "2d468a88aca03e5eb9dbf78cc5f44c92b506d77fbba72c1e58edcfb825e39e7e", "fr_sqrt": null, "fp2_sqrt": ["dddcf5cb8350cc85f0ff240bb335215cad168a568a0da66bea228a73f657b82256a8a023397f1ed138ab3247372e685", "16c51d24f20c1a9767d7932911baa8f2d7f312b2965e085c399cb50f5a1c44f875a2037200cb7963f0d47a25dbbabb24"], "fp2_sqrt_of_square": ["6db81c7c3bb8001a70db6825237a68d16afbe3ef96ff20d09f166f6fa64fbc0f74b64f128ab6978006d1c34c1c30898", "1443e64d873318f63ccb594417232f71634dc5dfb781376bd86e4d5f55134f5d035f1309be5fc1357a580b18313fb18d"], "fp2_inv": ["d03dac58e0765a784312f19e7ae790c3453d32959c359c5a819b5f15abd6bccc6e9eb48a625cb70d35ea532a62b13f9", "155c4bfaf04f9da958711a7537e4dd7b55e6a279a405e3441c8a08dcbe06c7f7a0b2cf704b065d930443a45c476d01ae"], "fp_div": "153a8c5d13453a4b38f4b4b74b8f9426ede543dcda1946e374f2b623f8f5c4f6e9e3bfabd005a6d4721d2f5e7af8bf4b"}, {"a": "30c200e8a22e36adad8e4586ae7a3f97ad4aaa338ca9f0c35ab60b911c9dd31c02e7b7eb80eb3ea51ab325b69ec9f7", "b": "55599e8869490c15daa5045056940efe235038593a3ad78c82e6e7e7612aa1dc68d7c58fec3cb71e4b224519db7ebff", "c": "35622a117accb8f34bdb6d535a052c95635bcc4a450217a341c24439fd08ba1d", "fp_sqrt_of_square": "19d04fe950ddb8639d6e1970bc9d3297ccca00dabff868cea3d61c956594585102a91846c5d314c114e44cda4960e0b4", "fr_sqrt_of_square": "35622a117accb8f34bdb6d535a052c95635bcc4a450217a341c24439fd08ba1d", "fr_sqrt": null, "fp2_sqrt": ["faee05e96dbe63b7b07225d2e2b49dfdd1e0c14da372b72d44c4d4dd6c70b6d24b5b483436969df7ee3ceeb273bda8d", "d314c32b24f433d5710445438268bfc061fdf134769f527b526d1da58e07b1f3286c66f4a2e1e29a62f5e8f8127aac0"], "fp2_sqrt_of_square": ["19d04fe950ddb8639d6e1970bc9d3297ccca00dabff868cea3d61c956594585102a91846c5d314c114e44cda4960e0b4", "14ab7801b2eb55d8ed7157713de26be7824247ff5fe165469f026422809e4c06581e83a5b290348dd54cdbae6247beac"], "fp2_inv": ["c877ae1592afe694586aa8b7996014290e3f768d239b1a7bbacc488e72edfad120533aa392a6c7da9f70989a2e0cb29", "c5674761fc1f999304857aa872d4ac80ce4dfee4dd92e35abb3c8106a257960f75716d320f55d558d7b47220d32b682"], "fp_div": "50b5b2048185d5ea0d5d46ddb4653bfd2b909fdce00e6bbbe7200ca9956209b1d7888cea244dbc7a09b527be9c8be9d"}, {"a": "19cb36f11763bec08aa94fd5c0bf780fd5e6b9583c45725158e4711ead88b2cdce5aa6ccb35ad31e3c87a37c3f6c7f66", "b": "56e8e51b187c6f232a59abc75f6f44e3412e951be10401fb043c9c3d5c797a99ceeb384c34f7e34867ee0b2f4aa74ea", "c": "6db17ed227d658a2678c54caa51f1aacc340168d165974882f8d8c962970ce90", "fp_sqrt_of_square": "35daf9221c27d9c07257e0828c34c78e90922cb73fa06e0e4c61824928435650515931fdf92ce17d775c83c0932b45", "fr_sqrt_of_square": "6db17ed227d658a2678c54caa51f1aacc340168d165974882f8d8c962970ce90", "fr_sqrt": "6a940374128dab090a51cc5ff7698768f5c9f1fdc37750ec69a9bf57d733c0bd", "fp2_sqrt": ["1471e9edd6bf4c55d75e056a0f964ac1867fd9fa1f0b2f922cea8f4ccd5dd8085b8c9b44a57e10e0f5fa797f7e3a7067", "142a632148692db7d3818ca240ec386724a7e332db6621f46c8e8679f1fbae64b9a4c336ac522047facc4b98d4c9ec37"], "fp2_sqrt_of_square": ["35daf9221c27d9c07257e0828c34c78e90922cb73fa06e0e4c61824928435650515931fdf92ce17d775c83c0932b45", "1492839887f81fa818760cf9cd54b889306462333574d29fb6ed08dd20e95e7a81bd4c79ee0481cb33801f4d0b5535c1"], "fp2_inv": ["907ab06a8064f0b9324c12e34d9b440f86eef354f9149e0f16c6e9c2ac5141545bc20dbbf2bbe906f8781b71f55394d", "11caa470ea4316e37a2d48e753ae826b2a2b428fe892a585109f94a16a1902623ccd01cb051e1dcb85cb72d0489984e7"], "fp_div": "1515bc6dee2926b2f779fb6d87c4ac092d27d049b58968a8a6b13b5165407301620d71d441abe37d54905bda19c4c11b"}, {"a": "4a89f1b2c2e7fc525b0e7682e913b8e7f0da47dcd56e5b6047bdb0121ba2280db77320bd22687ab86aad588cf39ba2e", "b": "3f57552e0bcf8366eb948a9017b65b9dbef4d964d98db859cad15b814654bcd2c5255bf82b984256c68586f17a96d8e", "c": "3e9ea9ed5f0111856cef067c0a13db244de795c310a49798eeb778e21a3fe8ca", "fp_sqrt_of_square": "155872cf0d5166d5256ac04e14ba7148e569a707262e2d0962b4f79fd4f6d3a34334cdf2df2d785433542a7730c5f07d", "fr_sqrt_of_square": "3e9ea9ed5f0111856cef067c0a13db244de795c310a49798eeb778e21a3fe8ca", "fr_sqrt": "63dbaf4e8e09ae7236e6f0b07383a33b3d7cc8743383292bea8f7c1ed4ae776b", "fp2_sqrt": ["109e41de364bf504efbd9a40af951f3914272351aa981d6cfa807971e0f1cd34076aae924b9273ecdb48eba918ffb79", "edef1a2b953e9e32d7d1db2bc1c9b7e2ac244149e6f4777313bdbe7292c6aed932a789bfc8b0b93ff2b245ccd83850a"], "fp2_sqrt_of_square": ["155872cf0d5166d5256ac04e14ba7148e569a707262e2d0962b4f79fd4f6d3a34334cdf2df2d785433542a7730c5f07d", "160b9c9758c2ee63dc625f0d41d0471d8887fdeea5ec3739ca83bce8e24baa56f259aa3f2e9a7bda4d96a790e8563d1d"], "fp2_inv": ["13c54bd48921112a4e0ba83c78866d65381a912bf0fcf618995911b9a49235b7e393dfc1e26f3cc9cc82189085465d7b", "177ffbc26f87289c13c07d2bdb3028498b21965cebbe3a6ad9ca86b2fe65b1b3057810745f89d908ee599c0ba5afffd2"], "fp_div": "11db0a7bf032c48412a85f35d1c0138e4bb4312b8ba964fcc9f77d363311b28e8e430fe2cf0946a7575255f3b6ed900a"}, {"a": "56bd2891a44c6f21cfa73267f577253ac233882ad8fdff7713fb5c59dc14bdf6980c9f1fe8ff60bcce5350ee95cf3ab", "b": "1ec8a011f798c6152095f866c7ecf4a4969f4eea35fa624d8707419dc143c203dce5012d83ddc98efdd25e8d305130d", "c": "65813fba1798b3abe1df8d1662bcbf04e89d63a73b344808c670c13fd6083b6d", "fp_sqrt_of_square": "14953f611f3b1fa82e21348fc3f43a83b854130245f532c7f5f11cdb58efaa44b52b360cb2c409f3ed19caf116a2b700", "fr_sqrt_of_square": "e6c67991204c99c515a4af1a6e519006b20405bc4ca13f6398f3ebf29f7c494", "fr_sqrt": "52c29eaae3ad4c9f7eb6aa8468264ca6962ab66d1f0d935bea19c4ef1f7f524e", "fp2_sqrt": ["15ea2f1973040eef9a744eb099dcfe755a90e8cc73509179dbfadf4b0fa555cd0664c6626eff60c9bbb938fee30d0b1c", "10fa37e8713a458f909c39cf0c0e22053d0db97bfe22631fab3a65b2b455f44cd3e443b67f279a0641ac739aa89b14c9"], "fp2_sqrt_of_square": ["14953f611f3b1fa82e21348fc3f43a83b854130245f532c7f5f11cdb58efaa44b52b360cb2c409f3ed19caf116a2b700", "181487e91a065a38f912482fd6ccdd8d1b0d569650256c9a8ec05e871a9cba03e0ddafebd9162366ca21da172cfa979e"], "fp2_inv": ["26360366bc4ad86772f383d29cd13421584ff41fb22c0783c3121eef38b5cc3685736218356d7bab4c6a6e5d5bc6c5b", "16a3d8ac8d63a1f140b32159f9819245534f6a06c83f848afeab3b8fe3fca0e1bbd2e2c8cd5b6aa41d86e6ba18914323"], "fp_div": "1fed9d55b6e5832fe5574bce6e85db44fdfe85c212a32bcb51c3e19234815dd844c2d69475ac4cf135421c841f20127"}, {"a": "f283201353fe94507405ffe9b31d8df9cb7ce4d948fc1ca47eeb0e83d25bcd58b1a2acf2e64803fc38f31d57c3f75d8", "b": "e0eb5d1f5efd4c188bb5a989f1393ee43088c03e71f8e571982fdcecb122103dc4cf2b4b6369e27ed8d544d44f46e2a", "c": "491132c71c63f191d4ecde98ed4e5575bd6871c500a82c42fe275cf3c488d4e3", "fp_sqrt_of_square": "ad8dfe9043ffd5543db47b7a819d3f7c7bf7d375ef550f51f4221b8b98b394e9391d52f82ef7fbff66fce2a83c034d3", "fr_sqrt_of_square": "491132c71c63f191d4ecde98ed4e5575bd6871c500a82c42fe275cf3c488d4e3", "fr_sqrt": "701f1e6dace483e818f67fb1edc5039e45a3024853617ca0ac38bab76c0a886f", "fp2_sqrt": ["15c617950589f5baaf74565e1e907ed7c397c5c201e48996829cfc33185163c99dae0990905a83b39ebb8fb35200968a", "17952092484638e27fdb0a0ed34c467c6390e34c6bf8c9407dd6ea39250bdd5cef9216ca8b1fe7890135a3468058bab7"], "fp2_sqrt_of_square": ["f283201353fe94507405ffe9b31d8df9cb7ce4d948fc1ca47eeb0e83d25bcd58b1a2acf2e64803fc38f31d57c3f75d8", "e0eb5d1f5efd4c188bb5a989f1393ee43088c03e71f8e571982fdcecb122103dc4cf2b4b6369e27ed8d544d44f46e2a"], "fp2_inv": ["6998decd77b4571ba2e208ed9dd9d03eb40eeebb67a3f0c8b12cdddd3fdf466c614b4216ae83524824a504a85e2184e", "920ad18056b6caa770623c43fb529c3c2d6e7fb6e5cb074865ab3cb223a0f9c665f3d4f88aceff771242d96f1f8ccd2"], "fp_div": "197441b89e269250a4caeb7e81e301be77a12f20a44169c57be39d23c888702332551d1ac3d75b405d62ea7ef1eaef99"}];
+    for (const k of KAT) {
+      const a = BigInt('0x' + k.a), b = BigInt('0x' + k.b), c = BigInt('0x' + k.c);
+      assert.strictEqual(new Fp(a).square().sqrt().value.toString(16), k.fp_sqrt_of_square);
+      assert.strictEqual(new Fp(a).div(new Fp(b)).value.toString(16), k.fp_div);
+      const fs = new Fr(c).sqrt();
+      assert.strictEqual(fs ? fs.value.toString(16) : null, k.fr_sqrt);
+      assert.strictEqual(new Fr(c).square().sqrt().value.toString(16), k.fr_sqrt_of_square);
+      const X = Fp2.fromBigTuple([a, b]), s = X.sqrt(), ss = X.square().sqrt(), inv = X.invert();
+      assert.deepStrictEqual(s ? [s.c0.value.toString(16), s.c1.value.toString(16)] : null, k.fp2_sqrt);
+      assert.deepStrictEqual([ss.c0.value.toString(16), ss.c1.value.toString(16)], k.fp2_sqrt_of_square);
+      assert.deepStrictEqual([inv.c0.value.toString(16), inv.c1.value.toString(16)], k.fp2_inv);
+      assert.ok(X.multiply(inv).equals(Fp2.ONE) && X.pow(Fp2.ORDER).equals(Fp2.ONE) && X.frobeniusMap(1).equals(X.pow(bls.CURVE.P)));
+      assert.ok(Fp2.fromBytes(X.toBytes()).equals(X) && Fp.fromBytes(new Fp(a).toBytes()).equals(new Fp(a)));
+    }
+    assert.strictEqual(Fp.BYTES_LEN, 48); assert.strictEqual(Fp2.BYTES_LEN, 96); assert.strictEqual(Fp.MAX_BITS, 381);
+    assert.strictEqual(bls.CURVE.h * bls.CURVE.r, bls.CURVE.P + bls.CURVE.x);             // #E(Fp) = p + 1 - t with t = z + 1, z = -x
+    assert.throws(() => new Fp(0n).invert(), /invert: expected positive integers/);
+    assert.throws(() => new Fp2(1n, 2n), /c0: Expected Fp/);
+  }
   // aggregate + verifyBatch
   const vb = gold.verify_batch;
   assert.strictEqual(hex(bls.aggregatePublicKeys(vb.pks)), vb.agg_pk);
