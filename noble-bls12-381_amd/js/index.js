@@ -391,7 +391,46 @@ async function verifyBatch(signature, messages, publicKeys) {
   }
 }
 
+// ---- utils (reference index.ts:94-149): host-side helpers around the signature API
+const nodeCrypto = require('crypto');
+const sha256 = async (message) => Uint8Array.from(nodeCrypto.createHash('sha256').update(message).digest());
+const modBig = (a, b) => { const r = a % b; return r >= 0n ? r : b + r; };
+// expand_message_xmd of RFC 9380 section 5.3.1 (reference index.ts:207-231); H is an async digest with 32-byte output and 64-byte blocks
+async function expandMessageXMD(msg, DST, lenInBytes, H = sha256) {
+  if (DST.length > 255) DST = await H(concat(stringToBytes('H2C-OVERSIZE-DST-'), DST));
+  const bInBytes = 32, rInBytes = 64, ell = Math.ceil(lenInBytes / bInBytes);
+  if (ell > 255) throw new Error('Invalid xmd length');
+  const dstPrime = concat(DST, Uint8Array.of(DST.length));
+  const lib = Uint8Array.of((lenInBytes >> 8) & 0xff, lenInBytes & 0xff);
+  const b0 = await H(concat(new Uint8Array(rInBytes), msg, lib, Uint8Array.of(0), dstPrime));
+  const blocks = [await H(concat(b0, Uint8Array.of(1), dstPrime))];
+  for (let i = 2; i <= ell; i++) blocks.push(await H(concat(b0.map((v, k) => v ^ blocks[i - 2][k]), Uint8Array.of(i), dstPrime)));
+  return concat(...blocks).slice(0, lenInBytes);
+}
+// hash_to_field (reference index.ts:236-267): count elements of F_{p^m}, each coordinate from L = ceil((log2 p + k) / 8) uniform bytes
+async function hashToField(msg, count, options = {}) {
+  const o = { DST: htfDefaults.DST, p: CURVE.P, m: 2, k: 128, expand: true, hash: sha256, ...options };
+  const L = Math.ceil((o.p.toString(2).length + o.k) / 8), len = count * o.m * L;
+  const bytes = o.expand ? await expandMessageXMD(msg, stringToBytes(o.DST), len, o.hash) : msg;
+  const u = [];
+  for (let i = 0; i < count; i++) {
+    const e = [];
+    for (let j = 0; j < o.m; j++) { const off = L * (j + i * o.m); e.push(modBig(toBig(bytes.subarray(off, off + L)), o.p)); }
+    u.push(e);
+  }
+  return u;
+}
 const utils = {
+  hashToField, expandMessageXMD, sha256, mod: modBig,
+  hashToPrivateKey: (hash) => {          // FIPS 186 B.1.1: 40..1024 uniform bytes -> key (reference index.ts:105-113)
+    hash = ensureBytes(hash);
+    if (hash.length < 40 || hash.length > 1024) throw new Error('Expected 40-1024 bytes of private key as per FIPS 186');
+    const num = modBig(toBig(hash), CURVE.r);
+    if (num === 0n || num === 1n) throw new Error('Invalid private key');
+    return hexToBytes(num.toString(16).padStart(64, '0'));
+  },
+  randomBytes: (bytesLength = 32) => Uint8Array.from(nodeCrypto.randomBytes(bytesLength)),
+  randomPrivateKey: () => utils.hashToPrivateKey(utils.randomBytes(40)),
   bytesToHex, hexToBytes, stringToBytes,
   getDSTLabel() { return htfDefaults.DST; },
   setDSTLabel(newLabel) {

@@ -95,6 +95,23 @@ const hex = bls.utils.bytesToHex, un = bls.utils.hexToBytes;
     assert.throws(() => new Fp(0n).invert(), /invert: expected positive integers/);
     assert.throws(() => new Fp2(1n, 2n), /c0: Expected Fp/);
   }
+  // utils: expand_message_xmd / hash_to_field on the host against the device path (hashToCurve of the same message goes through the
+  // device SHA-256), key derivation helpers
+  {
+    const msg = un('abcdef0123456789');
+    const xmd = await bls.utils.expandMessageXMD(msg, bls.utils.stringToBytes('QUUX-V01-CS02-with-expander-SHA256-128'), 0x20);
+    assert.strictEqual(hex(await bls.utils.expandMessageXMD(bls.utils.stringToBytes('abc'), bls.utils.stringToBytes('QUUX-V01-CS02-with-expander-SHA256-128'), 0x20)),
+      'd8ccab23b5985ccea865c6c97b6e5b8350e794e603b4b97902f53a8a0d605615');       // RFC 9380 appendix K.1
+    assert.strictEqual(xmd.length, 32);
+    const u = await bls.utils.hashToField(msg, 2);
+    assert.ok(u.length === 2 && u[0].length === 2 && u.every((e) => e.every((v) => typeof v === 'bigint' && v < bls.CURVE.P)));
+    const k = bls.utils.hashToPrivateKey(new Uint8Array(40).fill(7));
+    assert.ok(k.length === 32 && hex(bls.getPublicKey(k)).length === 96);
+    assert.throws(() => bls.utils.hashToPrivateKey(new Uint8Array(39)), /Expected 40-1024 bytes/);
+    assert.strictEqual(bls.utils.randomPrivateKey().length, 32);
+    assert.strictEqual(bls.utils.mod(-1n, 5n), 4n);
+    assert.strictEqual(hex(await bls.utils.sha256(bls.utils.stringToBytes('abc'))), 'ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad');
+  }
   // aggregate + verifyBatch
   const vb = gold.verify_batch;
   assert.strictEqual(hex(bls.aggregatePublicKeys(vb.pks)), vb.agg_pk);
