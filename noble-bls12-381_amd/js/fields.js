@@ -145,4 +145,84 @@ Fp2.BYTES_LEN = 2 * Fp.BYTES_LEN;     // two 48-byte field elements (math.ts:540
 Fp2.ZERO = new Fp2(Fp.ZERO, Fp.ZERO);
 Fp2.ONE = new Fp2(Fp.ONE, Fp.ZERO);
 
-module.exports = { Fp, Fr, Fp2 };
+// ---- Fp6 = Fp2[v] / (v^3 - (1 + u)),  Fp12 = Fp6[w] / (w^2 - v): single-element host arithmetic for the results the engine hands back
+// (products / inverses of a few pairing values; anything batched goes to the GPU).  Coordinates as in the reference's classes
+// (math.ts:554-885): Fp6(c0, c1, c2), Fp12(c0, c1); bytes = coordinates in that order, 48 bytes each.
+const XI = new Fp2(Fp.ONE, Fp.ONE);
+class Fp6 {
+  constructor(c0, c1, c2) { this.c0 = c0; this.c1 = c1; this.c2 = c2; }
+  static fromBigSix(t) { return new Fp6(Fp2.fromBigTuple(t.slice(0, 2)), Fp2.fromBigTuple(t.slice(2, 4)), Fp2.fromBigTuple(t.slice(4, 6))); }
+  one() { return Fp6.ONE; }
+  isZero() { return this.c0.isZero() && this.c1.isZero() && this.c2.isZero(); }
+  equals(r) { return this.c0.equals(r.c0) && this.c1.equals(r.c1) && this.c2.equals(r.c2); }
+  negate() { return new Fp6(this.c0.negate(), this.c1.negate(), this.c2.negate()); }
+  add(r) { return new Fp6(this.c0.add(r.c0), this.c1.add(r.c1), this.c2.add(r.c2)); }
+  subtract(r) { return new Fp6(this.c0.subtract(r.c0), this.c1.subtract(r.c1), this.c2.subtract(r.c2)); }
+  toString() { return `Fp6(${this.c0} + ${this.c1} * v, ${this.c2} * v^2)`; }
+  multiply(r) {
+    if (typeof r === 'bigint') return new Fp6(this.c0.multiply(r), this.c1.multiply(r), this.c2.multiply(r));
+    const { c0: a0, c1: a1, c2: a2 } = this, { c0: b0, c1: b1, c2: b2 } = r;      // schoolbook, v^3 = xi
+    return new Fp6(a0.multiply(b0).add(a1.multiply(b2).add(a2.multiply(b1)).mulByNonresidue()),
+      a0.multiply(b1).add(a1.multiply(b0)).add(a2.multiply(b2).mulByNonresidue()),
+      a0.multiply(b2).add(a1.multiply(b1)).add(a2.multiply(b0)));
+  }
+  square() { return this.multiply(this); }
+  mulByNonresidue() { return new Fp6(this.c2.mulByNonresidue(), this.c0, this.c1); }     // * v
+  pow(n) { return powGeneric(this, Fp6.ONE, n); }
+  invert() {
+    const { c0, c1, c2 } = this;
+    const t0 = c0.square().subtract(c2.multiply(c1).mulByNonresidue()), t1 = c2.square().mulByNonresidue().subtract(c0.multiply(c1)), t2 = c1.square().subtract(c0.multiply(c2));
+    const d = c2.multiply(t1).add(c1.multiply(t2)).mulByNonresidue().add(c0.multiply(t0)).invert();
+    return new Fp6(d.multiply(t0), d.multiply(t1), d.multiply(t2));
+  }
+  div(r) { return this.multiply(typeof r === 'bigint' ? new Fp(r).invert().value : r.invert()); }
+  frobeniusMap(power) { return new Fp6(this.c0.frobeniusMap(power), this.c1.frobeniusMap(power).multiply(FROB6_1[power % 6]), this.c2.frobeniusMap(power).multiply(FROB6_2[power % 6])); }
+  static fromBytes(b) { if (b.length !== Fp6.BYTES_LEN) throw new Error(`fromBytes wrong length=${b.length}`); return new Fp6(Fp2.fromBytes(b.subarray(0, 96)), Fp2.fromBytes(b.subarray(96, 192)), Fp2.fromBytes(b.subarray(192, 288))); }
+  toBytes() { const o = new Uint8Array(288); o.set(this.c0.toBytes(), 0); o.set(this.c1.toBytes(), 96); o.set(this.c2.toBytes(), 192); return o; }
+}
+function powGeneric(base, one, n) {
+  n = BigInt(n);
+  if (n < 0n) throw new Error('Expected power > 0');
+  let r = one, b = base;
+  for (; n > 0n; n >>= 1n) { if (n & 1n) r = r.multiply(b); b = b.square(); }
+  return r;
+}
+Fp6.BYTES_LEN = 3 * Fp2.BYTES_LEN;
+Fp6.ZERO = new Fp6(Fp2.ZERO, Fp2.ZERO, Fp2.ZERO);
+Fp6.ONE = new Fp6(Fp2.ONE, Fp2.ZERO, Fp2.ZERO);
+// Frobenius constants: xi^((p^k - 1) / 3), xi^(2 (p^k - 1) / 3), xi^((p^k - 1) / 6)
+const FROB6_1 = [], FROB6_2 = [], FROB12 = [];
+for (let k = 0; k < 12; k++) { const e = P ** BigInt(k) - 1n; if (k < 6) { FROB6_1.push(XI.pow(e / 3n)); FROB6_2.push(XI.pow(2n * e / 3n)); } FROB12.push(XI.pow(e / 6n)); }
+
+class Fp12 {
+  constructor(c0, c1) { this.c0 = c0; this.c1 = c1; }
+  static fromBigTwelve(t) { return new Fp12(Fp6.fromBigSix(t.slice(0, 6)), Fp6.fromBigSix(t.slice(6, 12))); }
+  one() { return Fp12.ONE; }
+  isZero() { return this.c0.isZero() && this.c1.isZero(); }
+  equals(r) { return this.c0.equals(r.c0) && this.c1.equals(r.c1); }
+  negate() { return new Fp12(this.c0.negate(), this.c1.negate()); }
+  add(r) { return new Fp12(this.c0.add(r.c0), this.c1.add(r.c1)); }
+  subtract(r) { return new Fp12(this.c0.subtract(r.c0), this.c1.subtract(r.c1)); }
+  toString() { return `Fp12(${this.c0} + ${this.c1} * w)`; }
+  multiply(r) {
+    if (typeof r === 'bigint') return new Fp12(this.c0.multiply(r), this.c1.multiply(r));
+    const t0 = this.c0.multiply(r.c0), t1 = this.c1.multiply(r.c1);                // w^2 = v
+    return new Fp12(t0.add(t1.mulByNonresidue()), this.c0.add(this.c1).multiply(r.c0.add(r.c1)).subtract(t0.add(t1)));
+  }
+  square() { return this.multiply(this); }
+  pow(n) { return powGeneric(this, Fp12.ONE, n); }
+  invert() { const t = this.c0.square().subtract(this.c1.square().mulByNonresidue()).invert(); return new Fp12(this.c0.multiply(t), this.c1.multiply(t).negate()); }
+  div(r) { return this.multiply(typeof r === 'bigint' ? new Fp(r).invert().value : r.invert()); }
+  conjugate() { return new Fp12(this.c0, this.c1.negate()); }
+  frobeniusMap(power) {
+    const r0 = this.c0.frobeniusMap(power), { c0, c1, c2 } = this.c1.frobeniusMap(power), k = FROB12[power % 12];
+    return new Fp12(r0, new Fp6(c0.multiply(k), c1.multiply(k), c2.multiply(k)));
+  }
+  static fromBytes(b) { if (b.length !== Fp12.BYTES_LEN) throw new Error(`fromBytes wrong length=${b.length}`); return new Fp12(Fp6.fromBytes(b.subarray(0, 288)), Fp6.fromBytes(b.subarray(288, 576))); }
+  toBytes() { const o = new Uint8Array(576); o.set(this.c0.toBytes(), 0); o.set(this.c1.toBytes(), 288); return o; }
+}
+Fp12.BYTES_LEN = 2 * Fp6.BYTES_LEN;
+Fp12.ZERO = new Fp12(Fp6.ZERO, Fp6.ZERO);
+Fp12.ONE = new Fp12(Fp6.ONE, Fp6.ZERO);
+
+module.exports = { Fp, Fr, Fp2, Fp6, Fp12 };

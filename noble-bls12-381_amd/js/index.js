@@ -5,12 +5,12 @@
  *
  * getPublicKey / sign run the double-and-add-always ladders of the engine (SURVEY 8(f).1); additive: getPublicKeys, signBatch.
  * The reference's re-exported field classes Fp, Fr, Fp2 (index.ts:22) are single-element bigint helpers outside the batched hot
- * path: fields.js provides them on the host; Fp12 is a thin byte-backed wrapper (toBytes / equals / finalExponentiate).
+ * path: fields.js provides them on the host, together with Fp6 and Fp12 (finalExponentiate goes to the GPU).
  */
 'use strict';
 const path = require('path');
 const native = require(path.join(__dirname, 'nbls_napi.node'));
-const { Fp, Fr, Fp2 } = require('./fields.js');
+const { Fp, Fr, Fp2, Fp6, Fp12 } = require('./fields.js');
 
 // curve parameters under the reference's key names (math.ts:13-63).  h = (z - 1)^2 / 3 and h2 = (z^8 - 4z^7 + 5z^6 - 4z^4 + 6z^3 - 4z^2 - 4z + 13) / 9
 // with z = -x; h2Eff is the effective G2 cofactor of RFC 9380 section 8.8.2; P2 is p^2 - 1 as in the reference.
@@ -52,14 +52,8 @@ function isZeroBytes(u8) { for (let i = 0; i < u8.length; i++) if (u8[i]) return
 const G1_STATUS = { 2: 'Invalid G1 point: not on curve Fp', 3: 'Invalid G1 point: must be of prime-order subgroup', 4: 'Invalid compressed G1 point' };
 const G2_STATUS = { 2: 'Invalid G2 point: not on curve Fp2', 3: 'Invalid G2 point: must be of prime-order subgroup', 4: 'Failed to find a square root' };
 
-// ---- Fp12: byte-backed (Fp12.toBytes order, reference math.ts:875-884)
-class Fp12 {
-  constructor(bytes) { this.bytes = bytes; }
-  toBytes() { return Uint8Array.from(this.bytes); }
-  equals(rhs) { return bytesToHex(this.bytes) === bytesToHex(rhs.bytes); }
-  finalExponentiate() { ensureInit(); return new Fp12(native.finalExpBatch(this.bytes)); }
-  static get ONE() { const b = new Uint8Array(576); b[47] = 1; return new Fp12(b); }
-}
+// ---- Fp12: the host class of fields.js (coordinates, math.ts:705-885 method names); the final exponentiation runs on the GPU
+Fp12.prototype.finalExponentiate = function () { ensureInit(); return Fp12.fromBytes(native.finalExpBatch(this.toBytes())); };
 
 // ---- points: affine wire bytes, or the zero point
 // reference math.ts:1035-1043
@@ -273,7 +267,7 @@ function pairing(P, Q, withFinalExponent = true) {
   ensureInit();
   const { out, status } = native.pairingBatch(P.aff, Q.aff, withFinalExponent, true);
   if (status[0]) throw new Error(status[0] >= 10 ? G2_STATUS[status[0] - 10] : G1_STATUS[status[0]]);
-  return new Fp12(out);
+  return Fp12.fromBytes(out);
 }
 // additive: n independent pairings in one call; points are PointG1[] / PointG2[] or packed affine byte arrays
 function pairingBatch(Ps, Qs, withFinalExponent = true, validate = true) {
@@ -341,7 +335,7 @@ async function verify(signature, message, publicKey) {
   if (P.isZero() || Hm.isZero() || S.isZero()) throw new Error('No pairings at point of Infinity');
   const r = native.millerProduct(concat(P.negate().aff, PointG1.BASE.aff), concat(Hm.aff, S.aff), true, true);
   if (r.code) { const st = r.status[0] || r.status[1]; throw new Error(st >= 10 ? G2_STATUS[st - 10] : G1_STATUS[st]); }
-  return new Fp12(r.out).equals(Fp12.ONE);
+  return Fp12.fromBytes(r.out).equals(Fp12.ONE);
 }
 // reference index.ts:771-788
 function aggregatePublicKeys(publicKeys) {
@@ -385,7 +379,7 @@ async function verifyBatch(signature, messages, publicKeys) {
     g1.push(PointG1.BASE.negate()); g2.push(sig);
     const r = native.millerProduct(concat(...g1.map((p) => p.aff)), concat(...g2.map((p) => p.aff)), true, true);
     if (r.code) throw new Error('invalid point');
-    return new Fp12(r.out).equals(Fp12.ONE);
+    return Fp12.fromBytes(r.out).equals(Fp12.ONE);
   } catch (e) {
     return false;
   }
@@ -439,5 +433,5 @@ const utils = {
   },
 };
 
-module.exports = { CURVE, Fp, Fr, Fp2, Fp12, PointG1, PointG2, pairing, pairingBatch, millerProduct, getPublicKey, getPublicKeys, sign, signBatch, verify, verifyBatch,
+module.exports = { CURVE, Fp, Fr, Fp2, Fp6, Fp12, PointG1, PointG2, pairing, pairingBatch, millerProduct, getPublicKey, getPublicKeys, sign, signBatch, verify, verifyBatch,
   aggregatePublicKeys, aggregateSignatures, utils, init: (dev) => { native.init(dev || 0); inited = true; } };

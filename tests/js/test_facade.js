@@ -12,7 +12,7 @@ const hex = bls.utils.bytesToHex, un = bls.utils.hexToBytes;
   const e = bls.pairing(bls.PointG1.BASE, bls.PointG2.BASE);
   assert.strictEqual(hex(e.toBytes()), td.e_G1_G2);
   assert.strictEqual(hex(bls.pairing(bls.PointG1.BASE, bls.PointG2.BASE, false).toBytes()), gold.pairs[0].miller);
-  assert.strictEqual(hex(new bls.Fp12(un(td.finalexp_in)).finalExponentiate().toBytes()), td.finalexp_out);
+  assert.strictEqual(hex(bls.Fp12.fromBytes(un(td.finalexp_in)).finalExponentiate().toBytes()), td.finalexp_out);
   assert.throws(() => bls.pairing(bls.PointG1.ZERO, bls.PointG2.BASE), /No pairings at point of Infinity/);
   // codecs
   for (const v of gold.codec.g1) {
@@ -94,6 +94,16 @@ const hex = bls.utils.bytesToHex, un = bls.utils.hexToBytes;
     assert.strictEqual(bls.CURVE.h * bls.CURVE.r, bls.CURVE.P + bls.CURVE.x);             // #E(Fp) = p + 1 - t with t = z + 1, z = -x
     assert.throws(() => new Fp(0n).invert(), /invert: expected positive integers/);
     assert.throws(() => new Fp2(1n, 2n), /c0: Expected Fp/);
+  }
+  // Fp12 on the host against the GPU: e(P, Q)^2 = e(2P, Q) = e(P, Q) * e(P, Q); inverse = conjugate for pairing values; Frobenius
+  {
+    const G = bls.PointG1.BASE, H = bls.PointG2.BASE;
+    const e1 = bls.pairing(G.multiply(3n), H), e2 = bls.pairing(G.multiply(6n), H);
+    assert.ok(e1.multiply(e1).equals(e2) && e1.square().equals(e2) && e1.pow(2n).equals(e2));
+    assert.ok(e1.invert().equals(e1.conjugate()) && e1.multiply(e1.invert()).equals(bls.Fp12.ONE));
+    assert.ok(e1.frobeniusMap(12).equals(e1) && e1.frobeniusMap(1).equals(e1.pow(bls.CURVE.P)));
+    assert.ok(bls.pairing(G, H, false).finalExponentiate().equals(bls.pairing(G, H)));
+    assert.ok(bls.Fp12.fromBytes(e1.toBytes()).equals(e1) && !e1.isZero());
   }
   // utils: expand_message_xmd / hash_to_field on the host against the device path (hashToCurve of the same message goes through the
   // device SHA-256), key derivation helpers
