@@ -64,8 +64,31 @@ function validateScalar(n) {
 }
 const scalarBytes = (n) => hexToBytes(validateScalar(n).toString(16).padStart(64, '0'));
 
+// Points are held as affine wire bytes (what the engine consumes) or as the zero point.  The reference's constructor form
+// new PointG1(x: Fp, y: Fp, z?: Fp) (index.ts:291) is accepted too: the projective triple is made affine on the host.
 class PointG1 {
-  constructor(aff, zero = false) { this.aff = aff; this.zero = zero; }
+  constructor(aff, zero = false, z) {
+    if (aff instanceof Fp) {
+      const x = aff, y = zero; z = z === undefined ? Fp.ONE : z;
+      if (!(y instanceof Fp) || !(z instanceof Fp)) throw new Error('Expected Fp coordinates');
+      if (z.isZero()) { this.aff = new Uint8Array(96); this.zero = true; return; }
+      const zi = z.invert();
+      this.aff = concat(x.multiply(zi).toBytes(), y.multiply(zi).toBytes()); this.zero = false; return;
+    }
+    this.aff = aff; this.zero = zero;
+  }
+  // coordinates as the reference exposes them (affine representative, z = 1; the zero point is (1, 1, 0) as getZero(), math.ts:910-912)
+  get x() { return this.zero ? Fp.ONE : Fp.fromBytes(this.aff.subarray(0, 48)); }
+  get y() { return this.zero ? Fp.ONE : Fp.fromBytes(this.aff.subarray(48)); }
+  get z() { return this.zero ? Fp.ZERO : Fp.ONE; }
+  getZero() { return PointG1.ZERO; }
+  fromAffineTuple(xy) { return new PointG1(xy[0], xy[1], Fp.ONE); }
+  toAffineBatch(points) { return points.map((p) => p.toAffine()); }
+  normalizeZ(points) { return points; }
+  toString() { return this.zero ? 'Point<Zero>' : `Point<x=${this.x}, y=${this.y}>`; }
+  millerLoop(Q) { return pairing(this, Q, false); }                                        // index.ts:395-397 (line precomputation happens on the GPU)
+  clearCofactor() { return this.zero ? this : this.multiply(CURVE.x).add(this); }         // [x]P + P with x = |z| (index.ts:401-405)
+  calcMultiplyPrecomputes() {} clearMultiplyPrecomputes() {}                               // window tables of the reference's host ladder: nothing to cache here
   static get ZERO() { return new PointG1(new Uint8Array(96), true); }
   static get BASE() {
     return new PointG1(hexToBytes('17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb' +
@@ -155,11 +178,31 @@ class PointG1 {
     return bytesToHex(this.aff);
   }
   toRawBytes(isCompressed = false) { return hexToBytes(this.toHex(isCompressed)); }
-  toAffine() { return [toBig(this.aff.subarray(0, 48)), toBig(this.aff.subarray(48))]; }
+  toAffine() { return [this.x, this.y]; }     // [Fp, Fp] (math.ts:949-958); the zero point gives (1, 1) scaled by an undefined inverse in the reference: not meaningful
 }
 
 class PointG2 {
-  constructor(aff, zero = false) { this.aff = aff; this.zero = zero; }   // aff = x.c0 || x.c1 || y.c0 || y.c1
+  constructor(aff, zero = false, z) {      // aff = x.c0 || x.c1 || y.c0 || y.c1 (192 bytes), or the reference's (x: Fp2, y: Fp2, z?: Fp2) (index.ts:472)
+    if (aff instanceof Fp2) {
+      const x = aff, y = zero; z = z === undefined ? Fp2.ONE : z;
+      if (!(y instanceof Fp2) || !(z instanceof Fp2)) throw new Error('Expected Fp2 coordinates');
+      if (z.isZero()) { this.aff = new Uint8Array(192); this.zero = true; return; }
+      const zi = z.invert();
+      this.aff = concat(x.multiply(zi).toBytes(), y.multiply(zi).toBytes()); this.zero = false; return;
+    }
+    this.aff = aff; this.zero = zero;
+  }
+  get x() { return this.zero ? Fp2.ONE : Fp2.fromBytes(this.aff.subarray(0, 96)); }
+  get y() { return this.zero ? Fp2.ONE : Fp2.fromBytes(this.aff.subarray(96)); }
+  get z() { return this.zero ? Fp2.ZERO : Fp2.ONE; }
+  getZero() { return PointG2.ZERO; }
+  fromAffineTuple(xy) { return new PointG2(xy[0], xy[1], Fp2.ONE); }
+  toAffine() { return [this.x, this.y]; }
+  toAffineBatch(points) { return points.map((p) => p.toAffine()); }
+  normalizeZ(points) { return points; }
+  toString() { return this.zero ? 'Point<Zero>' : `Point<x=${this.x}, y=${this.y}>`; }
+  clearPairingPrecomputes() {} calcMultiplyPrecomputes() {} clearMultiplyPrecomputes() {}      // caches of the reference's host path
+  pairingPrecomputes() { throw new Error('pairingPrecomputes: the line coefficients are computed inside the Miller-loop kernel and never leave the GPU'); }
   static get ZERO() { return new PointG2(new Uint8Array(192), true); }
   static get BASE() {
     return new PointG2(hexToBytes('024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8' +

@@ -105,6 +105,20 @@ const hex = bls.utils.bytesToHex, un = bls.utils.hexToBytes;
     assert.ok(bls.pairing(G, H, false).finalExponentiate().equals(bls.pairing(G, H)));
     assert.ok(bls.Fp12.fromBytes(e1.toBytes()).equals(e1) && !e1.isZero());
   }
+  // the reference's coordinate view of points: constructor from field elements (projective), x / y / z, toAffine
+  {
+    const { Fp, Fp2, PointG1, PointG2, CURVE } = bls;
+    const G = new PointG1(new Fp(CURVE.Gx), new Fp(CURVE.Gy));
+    assert.ok(G.equals(PointG1.BASE) && G.x.value === CURVE.Gx && G.z.equals(Fp.ONE));
+    const lam = new Fp(12345n);
+    assert.ok(new PointG1(G.x.multiply(lam), G.y.multiply(lam), lam).equals(G));         // (lx : ly : l) is the same point
+    assert.ok(new PointG1(Fp.ONE, Fp.ONE, Fp.ZERO).isZero() && PointG1.ZERO.z.isZero());
+    const H = new PointG2(Fp2.fromBigTuple(CURVE.G2x), Fp2.fromBigTuple(CURVE.G2y), Fp2.ONE);
+    assert.ok(H.equals(PointG2.BASE) && H.toAffine()[0].equals(Fp2.fromBigTuple(CURVE.G2x)));
+    assert.ok(H.fromAffineTuple(H.double().toAffine()).equals(H.multiply(2n)));
+    assert.ok(G.millerLoop(H).finalExponentiate().equals(bls.pairing(G, H)));
+    assert.ok(G.multiply(5n).clearCofactor().equals(G.multiply(5n * (CURVE.x + 1n) % CURVE.r)));
+  }
   // utils: expand_message_xmd / hash_to_field on the host against the device path (hashToCurve of the same message goes through the
   // device SHA-256), key derivation helpers
   {
