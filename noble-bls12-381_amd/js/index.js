@@ -404,7 +404,7 @@ async function verifyBatch(signature, messages, publicKeys) {
     // fast path: one engine call (hex inputs hash to distinct message objects in the reference, so no grouping applies)
     const msgs = messages.map(ensureBytes);
     const offs = new Uint32Array(msgs.length + 1); msgs.forEach((m, i) => { offs[i + 1] = offs[i] + m.length; });
-    const r = native.verifyBatch(ensureBytes(signature), concat(...msgs), offs, concat(...publicKeys.map(ensureBytes)), stringToBytes(htfDefaults.DST));
+    const r = await native.verifyBatchAsync(ensureBytes(signature), concat(...msgs), offs, concat(...publicKeys.map(ensureBytes)), stringToBytes(htfDefaults.DST));   // worker thread: the event loop keeps running
     if (r.code) { normP2(signature); publicKeys.forEach(normP1); throw new Error('invalid point'); }   // re-derive the reference's exception
     return r.ok;
   }

@@ -2,8 +2,8 @@
  * nbls_napi.c -- thin N-API addon: exposes the C ABI of libnbls.so (include/nbls.h) to Node.  No arithmetic here.
  * libnbls.so is loaded with dlopen at module init so the addon builds with plain gcc (no HIP needed):
  *     gcc -shared -fPIC -I/usr/include/node -I../../include nbls_napi.c -o nbls_napi.node -ldl
- * All calls are synchronous (they block for the duration of the GPU work); index.js wraps the reference's async functions
- * (verify, verifyBatch) in Promises.  Typed arrays are passed by reference (napi_get_typedarray_info), no copies.
+ * Calls are synchronous (they block for the duration of the GPU work) except verifyBatchAsync, which runs on a libuv worker thread
+ * (napi_create_async_work) and resolves a Promise: the facade's verifyBatch uses it for wire-format inputs (the calls that can take tens of milliseconds).  Typed arrays are passed by reference (napi_get_typedarray_info), no copies.
  */
 #include <node_api.h>
 #include <dlfcn.h>
@@ -134,6 +134,40 @@ static napi_value VerifyBatch(napi_env env, napi_callback_info info) {
   napi_set_named_property(env, o, "code", c); napi_set_named_property(env, o, "ok", k); return o;
 }
 
+/* verifyBatchAsync(sig96, msgs, offsets, pks48, dst) -> Promise<{code, ok}>: the same call on a libuv worker thread (napi_create_async_work),
+ * so that the event loop keeps running during the ~1-100 ms a batch takes.  The typed arrays are kept alive by references until
+ * the work completes; the engine context serialises concurrent calls itself. */
+typedef struct {
+  napi_async_work work; napi_deferred deferred; napi_ref refs[5];
+  const uint8_t *sig, *msgs, *pks, *dst; const uint32_t* offs; size_t n, dst_len;
+  int rc, ok;
+} verify_job;
+static void verify_execute(napi_env env, void* data) { verify_job* j = (verify_job*)data; (void)env;
+  j->rc = p_nbls_verify_batch(ctx, j->n, j->sig, j->msgs, j->offs, j->pks, j->dst, j->dst_len, &j->ok); }
+static void verify_complete(napi_env env, napi_status status, void* data) {
+  verify_job* j = (verify_job*)data;
+  for (int i = 0; i < 5; i++) napi_delete_reference(env, j->refs[i]);
+  if (status != napi_ok || (j->rc && j->rc != NBLS_EDECODE)) {
+    char m[128]; snprintf(m, sizeof m, "nbls: %s (code %d)", p_nbls_strerror ? p_nbls_strerror(j->rc) : "error", j->rc);
+    napi_value msg, err; napi_create_string_utf8(env, m, NAPI_AUTO_LENGTH, &msg); napi_create_error(env, NULL, msg, &err); napi_reject_deferred(env, j->deferred, err);
+  } else {
+    napi_value o, c, k; napi_create_object(env, &o); napi_create_int32(env, j->rc, &c); napi_get_boolean(env, j->ok != 0, &k);
+    napi_set_named_property(env, o, "code", c); napi_set_named_property(env, o, "ok", k); napi_resolve_deferred(env, j->deferred, o);
+  }
+  napi_delete_async_work(env, j->work); free(j);
+}
+static napi_value VerifyBatchAsync(napi_env env, napi_callback_info info) {
+  ARGS(5); NEED_CTX(); BYTES(0, sig, ls); BYTES(1, msgs, lm); BYTES(2, offs, lo); BYTES(3, pks, lp); BYTES(4, dst, ld); (void)lm; (void)ls;
+  size_t n = lo / 4 - 1; if (lp != n * 48) { napi_throw_range_error(env, NULL, "bad public key array length"); return NULL; }
+  verify_job* j = (verify_job*)calloc(1, sizeof *j); if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+  j->sig = sig; j->msgs = msgs; j->offs = (const uint32_t*)offs; j->pks = pks; j->dst = dst; j->dst_len = ld; j->n = n;
+  for (int i = 0; i < 5; i++) napi_create_reference(env, argv[i], 1, &j->refs[i]);
+  napi_value promise, name; napi_create_promise(env, &j->deferred, &promise); napi_create_string_utf8(env, "nbls_verify_batch", NAPI_AUTO_LENGTH, &name);
+  if (napi_create_async_work(env, NULL, name, verify_execute, verify_complete, j, &j->work) != napi_ok || napi_queue_async_work(env, j->work) != napi_ok) {
+    for (int i = 0; i < 5; i++) napi_delete_reference(env, j->refs[i]); free(j); napi_throw_error(env, NULL, "napi_create_async_work failed"); return NULL; }
+  return promise;
+}
+
 static napi_value ModuleInit(napi_env env, napi_value exports) {
   const char* path = getenv("NBLS_LIB");
   char buf[4096];
@@ -150,7 +184,7 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
     {"g1Validate", 0, G1Validate, 0, 0, 0, napi_enumerable, 0}, {"g2Validate", 0, G2Validate, 0, 0, 0, napi_enumerable, 0}, {"g1Sum", 0, G1Sum, 0, 0, 0, napi_enumerable, 0},
     {"g2Sum", 0, G2Sum, 0, 0, 0, napi_enumerable, 0}, {"hashToG2", 0, HashToG2, 0, 0, 0, napi_enumerable, 0}, {"verifyBatch", 0, VerifyBatch, 0, 0, 0, napi_enumerable, 0},
     {"g1Mul", 0, G1Mul, 0, 0, 0, napi_enumerable, 0}, {"g2Mul", 0, G2Mul, 0, 0, 0, napi_enumerable, 0}, {"signBatch", 0, SignBatch, 0, 0, 0, napi_enumerable, 0},
-    {"hashToCurve", 0, HashToCurve, 0, 0, 0, napi_enumerable, 0}, {"g1Msm", 0, G1Msm, 0, 0, 0, napi_enumerable, 0}, {"g2Msm", 0, G2Msm, 0, 0, 0, napi_enumerable, 0}};
+    {"hashToCurve", 0, HashToCurve, 0, 0, 0, napi_enumerable, 0}, {"g1Msm", 0, G1Msm, 0, 0, 0, napi_enumerable, 0}, {"g2Msm", 0, G2Msm, 0, 0, 0, napi_enumerable, 0}, {"verifyBatchAsync", 0, VerifyBatchAsync, 0, 0, 0, napi_enumerable, 0}};
   napi_define_properties(env, exports, sizeof d / sizeof d[0], d);
   return exports;
 }
