@@ -24,6 +24,15 @@ def test_addon_builds_and_exports():
 
 
 @needs_node
+def test_host_side_of_the_facade():
+    """field classes, utils and coordinate constructors: pure host code, no GPU call (values pinned on the reference)"""
+    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'noble-bls12-381_amd', 'csrc'), '../libnbls.so'])
+    _build()
+    out = subprocess.run(['node', os.path.join(ROOT, 'tests', 'js', 'test_host.js')], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'JS host ok' in out.stdout, out.stdout + out.stderr
+
+
+@needs_node
 @pytest.mark.gpu
 def test_facade_on_gpu():
     _build()
