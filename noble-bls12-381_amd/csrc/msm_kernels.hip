@@ -84,22 +84,32 @@ __global__ void msm_gather_kernel(u64 m, u32 q, const u32* __restrict__ idx, con
   dst[t] = src[(u64)idx[e] * q + part];
 }
 
-// rank of every element inside its run of equal keys (binary search for the run's first element); the last element of a
-// run reports the run length, the longest one bounds the number of rounds of the segmented sum
-__global__ void msm_rank_kernel(u64 m, const u32* __restrict__ keys, u32* __restrict__ pos, u32* __restrict__ maxrun) {
+// rank of every element inside its run of equal keys: starts[j] = j at the head of a run, else 0; an inclusive max-scan (hipCUB)
+// turns that into the index of the run's head, rank = j - head.  The last element of a run reports the run length; the longest
+// run bounds the number of rounds of the segmented sum.
+__global__ void msm_heads_flag_kernel(u64 m, const u32* __restrict__ keys, u32* __restrict__ starts) {
   const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m) return;
-  const u32 key = keys[j];
-  u64 lo = 0, hi = j;                          // first index with keys[idx] == key
-  while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
-  const u32 r = (u32)(j - lo);
-  pos[j] = r;
-  if (j + 1 == m || keys[j + 1] != key) atomicMax(maxrun, r + 1);
+  starts[j] = (j > 0 && keys[j - 1] != keys[j]) ? (u32)j : 0u;
+}
+__global__ void msm_rank_kernel(u64 m, const u32* __restrict__ keys, u32* __restrict__ pos /* in: head index, out: rank */, u32* __restrict__ maxrun) {
+  __shared__ u32 blockmax;                       // one global atomic per workgroup (same-address atomics serialise: one per run cost 0.24 ms at 90 k runs)
+  if (threadIdx.x == 0) blockmax = 0;
+  __syncthreads();
+  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < m) {
+    const u32 r = (u32)j - pos[j];
+    pos[j] = r;
+    if (j + 1 == m || keys[j + 1] != keys[j]) atomicMax(&blockmax, r + 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && blockmax) atomicMax(maxrun, blockmax);
 }
 
 // Segmented sum over the sorted list as a balanced tree inside every run: in the round with stride d the elements whose rank
 // is a multiple of 2d absorb the element d places further on (when it is in the same run).  This kernel lists those
-// elements (ballot + prefix counts).  The order of the list is irrelevant: every pair is independent.
+// elements (ballot + prefix counts); the addition program then addresses its operands through the list (KernelArgs.item_index).
+// The order of the list is irrelevant: every pair is independent.
 __global__ void __launch_bounds__(1024) msm_pairs_kernel(u64 m, u32 d, const u32* __restrict__ keys, const u32* __restrict__ pos, u32* __restrict__ list, u32* __restrict__ count) {
   // 4096 elements per workgroup, ONE global atomic per workgroup (same-address atomics serialise: one per wavefront cost 1.5 ms at 2^24 elements)
   __shared__ u32 wbase[4][16];
@@ -125,23 +135,6 @@ __global__ void __launch_bounds__(1024) msm_pairs_kernel(u64 m, u32 d, const u32
 #pragma unroll
   for (int it = 0; it < 4; it++)
     if (act[it]) list[wbase[it][wave] + (u32)__popcll(mask[it] & ((1ull << lane) - 1))] = (u32)(j0 + it * 1024);
-}
-
-// A[i] = P[list[i]], B[i] = P[list[i] + d] for i < *count
-__global__ void msm_gather2_kernel(const u32* __restrict__ count, u32 q, u32 d, const u32* __restrict__ list, const uint4* __restrict__ P, uint4* __restrict__ A, uint4* __restrict__ B) {
-  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (u64)*count * q) return;
-  const u64 e = t / q; const u32 part = (u32)(t - e * q);
-  const u64 j = list[e];
-  A[t] = P[j * q + part];
-  B[t] = P[(j + d) * q + part];
-}
-// P[list[i]] = A[i] for i < *count
-__global__ void msm_scatter_kernel(const u32* __restrict__ count, u32 q, const u32* __restrict__ list, const uint4* __restrict__ A, uint4* __restrict__ P) {
-  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (u64)*count * q) return;
-  const u64 e = t / q; const u32 part = (u32)(t - e * q);
-  P[(u64)list[e] * q + part] = A[t];
 }
 
 __global__ void msm_fill_kernel(u64 count, u32 q, const uint4* __restrict__ ident, uint4* __restrict__ dst) {
@@ -192,25 +185,19 @@ int nbls_msm_gather_launch(size_t m, unsigned elem_bytes, const void* idx, const
   hipLaunchKernelGGL(msm_gather_kernel, dim3(blocks_for((u64)m * q)), dim3(256), 0, (hipStream_t)stream, (u64)m, q, (const u32*)idx, (const uint4*)src, (uint4*)dst);
   return (int)hipGetLastError();
 }
-int nbls_msm_rank_launch(size_t m, const void* keys, void* pos, void* maxrun_u32, void* stream) {
+// temp == NULL: returns the scan's scratch size in *temp_bytes
+int nbls_msm_rank_launch(void* temp, size_t* temp_bytes, size_t m, const void* keys, void* pos, void* maxrun_u32, void* stream) {
+  if (!temp) return (int)hipcub::DeviceScan::InclusiveScan(nullptr, *temp_bytes, (const u32*)pos, (u32*)pos, hipcub::Max(), (int)m, (hipStream_t)stream);
   hipMemsetAsync(maxrun_u32, 0, 4, (hipStream_t)stream);
+  hipLaunchKernelGGL(msm_heads_flag_kernel, dim3(blocks_for(m)), dim3(256), 0, (hipStream_t)stream, (u64)m, (const u32*)keys, (u32*)pos);
+  int e = (int)hipcub::DeviceScan::InclusiveScan(temp, *temp_bytes, (const u32*)pos, (u32*)pos, hipcub::Max(), (int)m, (hipStream_t)stream);
+  if (e) return e;
   hipLaunchKernelGGL(msm_rank_kernel, dim3(blocks_for(m)), dim3(256), 0, (hipStream_t)stream, (u64)m, (const u32*)keys, (u32*)pos, (u32*)maxrun_u32);
   return (int)hipGetLastError();
 }
 int nbls_msm_pairs_launch(size_t m, unsigned d, const void* keys, const void* pos, void* list, void* count_u32, void* stream) {
   hipMemsetAsync(count_u32, 0, 4, (hipStream_t)stream);
   hipLaunchKernelGGL(msm_pairs_kernel, dim3((unsigned)((m + 4095) / 4096)), dim3(1024), 0, (hipStream_t)stream, (u64)m, d, (const u32*)keys, (const u32*)pos, (u32*)list, (u32*)count_u32);
-  return (int)hipGetLastError();
-}
-// bound = upper limit of *count (sizes the launch)
-int nbls_msm_gather2_launch(size_t bound, const void* count_u32, unsigned elem_bytes, unsigned d, const void* list, const void* P, void* A, void* B, void* stream) {
-  const u32 q = elem_bytes / 16;
-  hipLaunchKernelGGL(msm_gather2_kernel, dim3(blocks_for((u64)bound * q)), dim3(256), 0, (hipStream_t)stream, (const u32*)count_u32, q, d, (const u32*)list, (const uint4*)P, (uint4*)A, (uint4*)B);
-  return (int)hipGetLastError();
-}
-int nbls_msm_scatter_launch(size_t bound, const void* count_u32, unsigned elem_bytes, const void* list, const void* A, void* P, void* stream) {
-  const u32 q = elem_bytes / 16;
-  hipLaunchKernelGGL(msm_scatter_kernel, dim3(blocks_for((u64)bound * q)), dim3(256), 0, (hipStream_t)stream, (const u32*)count_u32, q, (const u32*)list, (const uint4*)A, (uint4*)P);
   return (int)hipGetLastError();
 }
 int nbls_msm_fill_launch(size_t count, unsigned elem_bytes, const void* ident, void* dst, void* stream) {

@@ -20,10 +20,8 @@ extern "C" int nbls_msm_keys_launch(unsigned n, unsigned nwin, const void* scala
 extern "C" int nbls_msm_decompose_launch(unsigned n, unsigned dims, const void* scalars, void* out, void* stream);
 extern "C" int nbls_msm_sort_launch(void* temp, size_t* temp_bytes, const void* keys_in, void* keys_out, const void* vals_in, void* vals_out, size_t m, int key_bits, void* stream);
 extern "C" int nbls_msm_gather_launch(size_t m, unsigned elem_bytes, const void* idx, const void* src, void* dst, void* stream);
-extern "C" int nbls_msm_rank_launch(size_t m, const void* keys, void* pos, void* maxrun_u32, void* stream);
+extern "C" int nbls_msm_rank_launch(void* temp, size_t* temp_bytes, size_t m, const void* keys, void* pos, void* maxrun_u32, void* stream);
 extern "C" int nbls_msm_pairs_launch(size_t m, unsigned d, const void* keys, const void* pos, void* list, void* count_u32, void* stream);
-extern "C" int nbls_msm_gather2_launch(size_t bound, const void* count_u32, unsigned elem_bytes, unsigned d, const void* list, const void* P, void* A, void* B, void* stream);
-extern "C" int nbls_msm_scatter_launch(size_t bound, const void* count_u32, unsigned elem_bytes, const void* list, const void* A, void* P, void* stream);
 extern "C" int nbls_msm_fill_launch(size_t count, unsigned elem_bytes, const void* ident, void* dst, void* stream);
 extern "C" int nbls_msm_heads_launch(size_t m, unsigned elem_bytes, const void* keys, const void* P, void* buckets, void* stream);
 extern "C" int nbls_msm_bitsel_launch(unsigned nwin, unsigned elem_bytes, const void* buckets, void* G, void* stream);
@@ -83,12 +81,12 @@ static int upload(nbls_ctx* ctx, ProgId id) {
   return NBLS_OK;
 }
 
-static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pair<int, std::pair<const void*, size_t>>> bufs, hipStream_t s, const uint32_t* n_dev = nullptr) {
+static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pair<int, std::pair<const void*, size_t>>> bufs, hipStream_t s, const uint32_t* n_dev = nullptr, const uint32_t* item_index = nullptr) {
   int r = upload(ctx, id); if (r) return r;
   const DevProgram& d = ctx->prog[id];
   KernelArgs ka; memset(&ka, 0, sizeof ka);
   ka.steps = d.steps; ka.descs = d.descs; ka.consts = d.consts;
-  ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slots = d.p->slots; ka.n_items = (u32)n; ka.n_items_dev = n_dev;
+  ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slots = d.p->slots; ka.n_items = (u32)n; ka.n_items_dev = n_dev; ka.item_index = item_index;
   for (auto& b : bufs) { ka.bufs[b.first].ptr = (uint8_t*)b.second.first; ka.bufs[b.first].stride = b.second.second; }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s); }
@@ -676,8 +674,8 @@ EXPORT int nbls_g2_mul_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, con
 //   1. keys (window, digit) for every (point, window); device radix sort of the n * nwin keys (hipCUB); the points follow.
 //   2. segmented sum over the sorted list as a balanced tree inside every run of equal keys: in the round with stride d the
 //      elements whose rank in their run is a multiple of 2d absorb the element d further on.  The pairs of a round are
-//      listed by a compaction kernel (their number stays on the device: the step program reads it there), gathered, added,
-//      scattered back: n * nwin - (number of buckets hit) additions in total whatever the distribution of the digits;
+//      listed by a compaction kernel (their number stays on the device: the step program reads it there) and added in place,
+//      the step program addressing its operands through the list: n * nwin - (number of buckets hit) additions in total whatever the distribution of the digits;
 //      ceil(log2(longest run)) rounds -- the longest run is the one value read back.  The head of every run ends up as its bucket sum.
 //   3. sum_b b * B_b per window = sum_t 2^t * T_t with T_t = sum of the buckets whose index has bit t: 12 * 2^11 gathered
 //      points per window, a balanced tree of 11 rounds of pairwise additions (data independent).
@@ -702,13 +700,12 @@ static int dev_msm(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, const vo
   uint8_t *Pj, *P, *A, *K, *tmp, *Bk, *G, *Gh, *N, *NI, *acc, *cnt, *Ks = nullptr; int r;
   if (split && (r = need(ctx, 13, (n + 1) * 32, &Ks))) return r;
   size_t tmp_bytes = 0;
-  if (m) MSMCHK(nbls_msm_sort_launch(nullptr, &tmp_bytes, nullptr, nullptr, nullptr, nullptr, m, 17, s));
-  const size_t half = m / 2 + 1;
-  if ((r = need(ctx, 0, (n + 1) * p, &Pj)) || (r = need(ctx, 1, (m + 1) * p, &P)) || (r = need(ctx, 2, 2 * std::max(half, (size_t)nwin) * p, &A)) || (r = need(ctx, 3, (m + 1) * 24, &K)) ||
+  size_t scan_bytes = 0;
+  if (m) { MSMCHK(nbls_msm_sort_launch(nullptr, &tmp_bytes, nullptr, nullptr, nullptr, nullptr, m, 17, s)); MSMCHK(nbls_msm_rank_launch(nullptr, &scan_bytes, m, nullptr, nullptr, nullptr, s)); tmp_bytes = std::max(tmp_bytes, scan_bytes); }
+  if ((r = need(ctx, 0, (n + 1) * p, &Pj)) || (r = need(ctx, 1, (m + 1) * p, &P)) || (r = need(ctx, 2, ((size_t)nwin + 1) * p, &A)) || (r = need(ctx, 3, (m + 1) * 24, &K)) ||
       (r = need(ctx, 4, RAW, &N)) || (r = need(ctx, 5, RAW, &NI)) || (r = need(ctx, 6, tmp_bytes + 16, &tmp)) || (r = need(ctx, 7, nb * p, &Bk)) || (r = need(ctx, 8, ng * p, &G)) ||
       (r = need(ctx, 9, (ng / 2 + 2) * p, &Gh)) || (r = need(ctx, 11, 64 * 4, &cnt))) return r;
   acc = Gh + ng / 2 * p;     // (slot 10 belongs to verifyBatch, which drops the context lock between its stages)
-  uint8_t* Bv = A + half * p;
   uint32_t *kin = (uint32_t*)K, *vin = kin + m, *kout = vin + m, *vout = kout + m, *pos = vout + m, *list = pos + m;
   uint32_t* counters = (uint32_t*)cnt;    // [0] longest run, [1 + round] pairs of that round
   MSMCHK(nbls_msm_fill_launch(nb, (unsigned)p, ident, Bk, s));
@@ -720,7 +717,7 @@ static int dev_msm(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, const vo
     MSMCHK(nbls_msm_keys_launch((unsigned)n, nwin, split ? Ks : (const uint8_t*)d_scalars, kin, vin, s));
     MSMCHK(nbls_msm_sort_launch(tmp, &tmp_bytes, kin, kout, vin, vout, m, 17, s));
     MSMCHK(nbls_msm_gather_launch(m, (unsigned)p, vout, Pj, P, s));
-    MSMCHK(nbls_msm_rank_launch(m, kout, pos, counters, s));
+    MSMCHK(nbls_msm_rank_launch(tmp, &scan_bytes, m, kout, pos, counters, s));
     uint32_t maxrun = 0;
     HIPCHK(hipMemcpyAsync(&maxrun, counters, 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
     int round = 0;
@@ -728,9 +725,9 @@ static int dev_msm(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, const vo
       const size_t bound = m / (d + 1) + 1;      // every pair owns d + 1 list positions of its own
       uint32_t* c = counters + 1 + round;
       MSMCHK(nbls_msm_pairs_launch(m, (unsigned)d, kout, pos, list, c, s));
-      MSMCHK(nbls_msm_gather2_launch(bound, c, (unsigned)p, (unsigned)d, list, P, A, Bv, s));
-      if ((r = run(ctx, g2 ? P_G2_ADD_AB : P_G1_ADD_AB, bound, {B(3, A, p), B(4, Bv, p), B(5, A, p)}, s, c))) return r;
-      MSMCHK(nbls_msm_scatter_launch(bound, c, (unsigned)p, list, A, P, s));
+      // P[j] += P[j + d] for the listed j, in place: the step program addresses its buffers through the list (KernelArgs.item_index);
+      // a listed element is never the partner of another one (ranks are multiples of 2d), so no pair touches another pair's points
+      if ((r = run(ctx, g2 ? P_G2_ADD_AB : P_G1_ADD_AB, bound, {B(3, P, p), B(4, P + d * p, p), B(5, P, p)}, s, c, list))) return r;
     }
     MSMCHK(nbls_msm_heads_launch(m, (unsigned)p, kout, P, Bk, s));
   }

@@ -71,6 +71,7 @@ struct KernelArgs {
   uint32_t slots;           // LDS slots per instance
   uint32_t n_items;
   IOBuf bufs[MAX_BUFS];
+  const uint32_t* item_index;    // optional (NULL): buffers are addressed with item_index[item] instead of item (gathered operands, results scattered back in place)
   const uint32_t* n_items_dev;   // optional (NULL): the item count lives in device memory (min with n_items, which then only sizes the launch)
   uint64_t* hwid_out;       // optional (NULL): per workgroup, HW_ID | XCC_ID << 32 of its wavefront -- placement studies (tools/placement.py)
 };

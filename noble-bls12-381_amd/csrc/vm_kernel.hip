@@ -21,6 +21,7 @@ template <bool FAIR> __device__ __forceinline__ void vm_kernel_body(const Kernel
   cx.inst = shared_words + inst_id * ka.slots * SLOT_WORDS;
   cx.item = blockIdx.x * ka.G + inst_id;
   cx.live = inst_id < ka.G && cx.item < n_items;
+  if (ka.item_index && cx.live) cx.item = ka.item_index[cx.item];
   if (ka.hwid_out && lane == 0) { ka.hwid_out[5 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); ka.hwid_out[5 * blockIdx.x + 1] = __builtin_readcyclecounter(); ka.hwid_out[5 * blockIdx.x + 3] = wall_clock64(); }   // HW_ID, XCC_ID, start tick (s_memtime), start time (s_memrealtime, 100 MHz): placement study
   __syncthreads();   // single wave: orders the constant fill before first use
   // Software-pipelined interpreter loop: this lane's descriptor words for step s+1 and the header of step s+2 are
@@ -93,6 +94,7 @@ extern "C" __global__ void __launch_bounds__(128) nbls_vm_kernel_split(KernelArg
   cx.inst = shared_words + inst_id * ka.slots * SLOT_WORDS;
   cx.item = blockIdx.x * ka.G + inst_id;
   cx.live = inst_id < ka.G && cx.item < n_items;
+  if (ka.item_index && cx.live) cx.item = ka.item_index[cx.item];
   u64* xch = (u64*)(smem + (ka.nconst + ka.G * ka.slots) * SLOT_WORDS);   // exchange area: 28 columns x 64 lanes, column-major (conflict-free)
   __syncthreads();
   const uint4* descs4 = (const uint4*)ka.descs;
