@@ -412,7 +412,7 @@ def main():
         line = {
             'metric': 'pairings/sec', 'value': round(value, 2), 'unit': 'pairings/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'i64 column accumulators over 14 x 28-bit limbs (v_mad_i64_i32), 381-bit Fp in Montgomery form R=2^392', 'data': 'synthetic',
+            'dtype': 'int64', 'dtype_detail': 'signed 64-bit column accumulators over 14 x 28-bit limbs (v_mad_i64_i32), 381-bit Fp in Montgomery form R = 2^392; results bit-exact', 'data': 'synthetic',
             'config': {'workload': 'batch of %d independent BLS12-381 pairings per GPU (Miller loop + final exponentiation, inputs pre-validated, bit-exact vs reference), inputs/outputs resident in HBM' % n,
                        'batch_per_gpu': n, 'sharding': 'independent batches per rank, no collective', 'batches_in_flight': D},
             'single_stream': {'pairings_per_s': round(n * args.steps / dt_serial, 2), 'ms_per_batch': round(dt_serial / args.steps * 1e3, 4), 'note': 'one batch at a time on one stream (this rank): the latency of a 4096-pairing call'},
