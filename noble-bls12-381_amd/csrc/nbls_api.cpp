@@ -86,7 +86,7 @@ static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pa
   const DevProgram& d = ctx->prog[id];
   KernelArgs ka; memset(&ka, 0, sizeof ka);
   ka.steps = d.steps; ka.descs = d.descs; ka.consts = d.consts;
-  ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slots = d.p->slots; ka.n_items = (u32)n; ka.n_items_dev = n_dev; ka.item_index = item_index;
+  ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slot_bytes = d.p->slot_bytes; ka.inst_bytes = d.p->inst_bytes(); ka.n_items = (u32)n; ka.n_items_dev = n_dev; ka.item_index = item_index;
   for (auto& b : bufs) { ka.bufs[b.first].ptr = (uint8_t*)b.second.first; ka.bufs[b.first].stride = b.second.second; }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s); }
@@ -409,7 +409,7 @@ EXPORT int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks) {
   uint64_t* dbg = nullptr; HIPCHK(hipMalloc(&dbg, blocks * 40));
   KernelArgs ka; memset(&ka, 0, sizeof ka);
   ka.steps = d.steps; ka.descs = d.descs; ka.consts = d.consts;
-  ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slots = d.p->slots; ka.n_items = (u32)n;
+  ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slot_bytes = d.p->slot_bytes; ka.inst_bytes = d.p->inst_bytes(); ka.n_items = (u32)n;
   ka.bufs[3].ptr = ctx->T[0]; ka.bufs[3].stride = F12; ka.bufs[5].ptr = ctx->T[1]; ka.bufs[5].stride = F12;
   if (pid == P_MILLER_FE) { ka.bufs[0].ptr = ctx->io_g1; ka.bufs[0].stride = 96; ka.bufs[1].ptr = ctx->io_g2; ka.bufs[1].stride = 192; ka.bufs[4].ptr = ctx->N; ka.bufs[4].stride = RAW; }
   ka.hwid_out = dbg;

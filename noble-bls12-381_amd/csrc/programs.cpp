@@ -424,9 +424,9 @@ const Program& get_program(ProgId id) {
 }
 
 void print_stats(const Program& p) {
-  printf("%-14s W=%2u G=%u steps=%5zu (dot %4u, lin %4u, other %3u)  dot_ops=%6u products=%6u (product-slot fill %.2f)  lin_ops=%6u terms=%6u  slots=%4u  lds=%6u B  descs=%zu KB  operands: combined %u normalised %u negated %u  est_valu=%.0fk\n",
+  printf("%-14s W=%2u G=%u steps=%5zu (dot %4u, lin %4u, other %3u)  dot_ops=%6u products=%6u (product-slot fill %.2f)  lin_ops=%6u terms=%6u  slots=%4u  lds=%6u B  descs=%zu KB  operands: combined %u normalised %u; round operands %u: single %u sum %u diff %u mixed %u norm %u  est_valu=%.0fk\n",
          p.name.c_str(), p.W, p.G, p.steps.size(), p.n_dot_steps, p.n_lin_steps, p.n_other_steps, p.n_dot_ops, p.n_products,
-         p.n_prod_slots ? (double)p.n_products / p.n_prod_slots : 0.0, p.n_lin_ops, p.n_lin_terms, p.slots, p.lds_bytes(), p.descs.size() * 4 / 1024, p.n_comb_operands, p.n_norm_operands, p.n_neg_operands, p.est_valu / 1e3);
+         p.n_prod_slots ? (double)p.n_products / p.n_prod_slots : 0.0, p.n_lin_ops, p.n_lin_terms, p.slots, p.lds_bytes(), p.descs.size() * 4 / 1024, p.n_comb_operands, p.n_norm_operands, p.n_round_ops, p.n_op_mode[0], p.n_op_mode[1], p.n_op_mode[2], p.n_op_mode[3], p.n_op_norm, p.est_valu / 1e3);
 }
 
 }  // namespace nbls

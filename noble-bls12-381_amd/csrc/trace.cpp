@@ -354,22 +354,25 @@ Program Builder::compile(const std::string& name, int W) {
     remaining -= (int)chosen.size();
     for (int c : chosen) for (int u : nodes[c].users) if (--nodes[u].ndeps == 0) ready.emplace(qkey(nodes[u]), PQ(cmp)).first->second.push(u);
   }
-  // 4b. operand forms.  A product's minus sign goes where it is free (reverse a difference), else onto a single-slot
-  // operand.  Then, because every lane of a wavefront walks the same product loop, the products of each lane-op are
-  // permuted (and their operands swapped) so that product index i has the same operand shape in as many lanes of the
-  // step as possible: the kernel's per-shape branches (second term, subtract, normalise, negate) are taken only where
-  // some lane needs them.
-  auto form_mask = [](const Operand& o, bool norm, bool neg) { return (o.s1 >= 0 ? (o.n1 ? 2 : 1) : 0) | (norm ? 4 : 0) | (neg ? 8 : 0); };
-  auto form_cost = [](int m) { return (m ? 6 : 0) + ((m & 3) ? 11 : 0) + ((m & 1) ? 14 : 0) + ((m & 2) ? 14 : 0) + ((m & 4) ? 41 : 0) + ((m & 8) ? 14 : 0); };
-  for (auto& L : step_nodes) {
+  // 4b. operand shapes.  A product's minus sign goes where it is free: reverse a difference, else turn a single slot x into 0 - x
+  // (a difference with the zero constant).  Then, because every lane of a wavefront walks the same product rounds and the kernel
+  // branches on the shape of a ROUND (uniform, in the step header), the products of each lane-op are permuted (and their operands
+  // swapped) so that round i has the same operand shape in as many lanes of the step as possible: a second term costs 14 limb
+  // additions for the whole wavefront as soon as ANY lane has one (the others add the zero constant), mixed signs cost three times
+  // that, a normalisation 41 instructions.
+  auto form_mask = [](const Operand& o, bool norm, bool neg0) { return (o.s1 >= 0 ? (o.n1 ? 2 : 1) : 0) | (norm ? 4 : 0) | (neg0 ? 8 : 0); };
+  auto form_cost = [](int m) { return (((m & 3) == 3 || (m & 8)) ? 46 : (m & 3) ? 18 : 0) + ((m & 4) ? 41 : 0); };
+  std::vector<std::vector<std::pair<int, int>>> step_shapes(step_nodes.size());   // per DOT step: (shape of A, shape of B) per round
+  for (size_t si = 0; si < step_nodes.size(); si++) {
+    auto& L = step_nodes[si];
     if (nodes[L[0]].kind != K_DOT) continue;
     for (int c : L) for (auto& p : nodes[c].prods) {
       if (!p.neg) continue;
       if (p.a.s1 >= 0 && p.a.n1) std::swap(p.a.s0, p.a.s1);
       else if (p.b.s1 >= 0 && p.b.n1) std::swap(p.b.s0, p.b.s1);
-      else if (p.a.s1 < 0) p.neg_a = true;
-      else if (p.b.s1 < 0) p.neg_b = true;
-      else p.neg_a = true;
+      else if (p.a.s1 < 0) { p.a.s1 = p.a.s0; p.a.s0 = zero_atom; p.a.n1 = true; }
+      else if (p.b.s1 < 0) { p.b.s1 = p.b.s0; p.b.s0 = zero_atom; p.b.n1 = true; }
+      else { p.a.n1 = true; p.neg0_a = true; }   // -(x + y) = (-x) - y: both signs per lane (shape mode 3)
       p.neg = false;
     }
     size_t mk = 0; for (int c : L) mk = std::max(mk, nodes[c].prods.size());
@@ -380,16 +383,16 @@ Program Builder::compile(const std::string& name, int W) {
       auto& pr = nodes[c].prods;
       std::vector<DotProduct> placed(mk); std::vector<char> used(mk, 0);
       std::vector<size_t> idx(pr.size()); for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
-      auto weight = [&](const DotProduct& p) { return form_cost(form_mask(p.a, p.norm_a, p.neg_a)) + form_cost(form_mask(p.b, p.norm_b, p.neg_b)); };
+      auto weight = [&](const DotProduct& p) { return form_cost(form_mask(p.a, p.norm_a, p.neg0_a)) + form_cost(form_mask(p.b, p.norm_b, p.neg0_b)); };
       std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return weight(pr[x]) > weight(pr[y]); });
       size_t hi = 0;
       for (size_t i : idx) {
         const DotProduct& p = pr[i];
-        int ma = form_mask(p.a, p.norm_a, p.neg_a), mb = form_mask(p.b, p.norm_b, p.neg_b);
+        int ma = form_mask(p.a, p.norm_a, p.neg0_a), mb = form_mask(p.b, p.norm_b, p.neg0_b);
         int best = -1, best_cost = 1 << 30; bool best_swap = false;
         for (size_t j = 0; j < mk; j++) {
           if (used[j]) continue;
-          if (j >= pr.size() && j > hi) break;   // keep the lane's products packed at the low indices (k = number of products)
+          if (j >= pr.size() && j > hi) break;   // keep the lane's products packed at the low rounds
           for (int sw = 0; sw < 2; sw++) {
             int xa = sw ? mb : ma, xb = sw ? ma : mb;
             int inc = form_cost(ua[j] | xa) - form_cost(ua[j]) + form_cost(ub[j] | xb) - form_cost(ub[j]);
@@ -400,29 +403,31 @@ Program Builder::compile(const std::string& name, int W) {
         if (getenv("NBLS_NO_ALIGN")) { best = (int)i; best_swap = false; }
         if (best < 0) { for (size_t j = 0; j < pr.size(); j++) if (!used[j]) { best = (int)j; break; } best_swap = false; }
         DotProduct q = p;
-        if (best_swap) { std::swap(q.a, q.b); std::swap(q.norm_a, q.norm_b); std::swap(q.neg_a, q.neg_b); }
+        if (best_swap) { std::swap(q.a, q.b); std::swap(q.norm_a, q.norm_b); std::swap(q.neg0_a, q.neg0_b); }
         placed[best] = q; used[best] = 1; hi = std::max(hi, (size_t)best + 1);
-        ua[best] |= form_mask(q.a, q.norm_a, q.neg_a); ub[best] |= form_mask(q.b, q.norm_b, q.neg_b);
+        ua[best] |= form_mask(q.a, q.norm_a, q.neg0_a); ub[best] |= form_mask(q.b, q.norm_b, q.neg0_b);
       }
       placed.resize(pr.size());
       pr = placed;
     }
+    for (size_t j = 0; j < mk; j++) { step_shapes[si].push_back({ua[j], ub[j]}); P.n_round_ops += 2; P.n_op_mode[(ua[j] & 8) ? 3 : (ua[j] & 3)]++; P.n_op_mode[(ub[j] & 8) ? 3 : (ub[j] & 3)]++; P.n_op_norm += ((ua[j] >> 2) & 1) + ((ub[j] >> 2) & 1); }
     if (getenv("NBLS_DUMP_STEPS")) { fprintf(stderr, "%s dot step lanes=%zu k:", name.c_str(), L.size()); for (int c : L) fprintf(stderr, " %zu", nodes[c].prods.size()); fprintf(stderr, "\n"); }
     if (getenv("NBLS_DUMP_NODES")) for (int c : L) { fprintf(stderr, "  node %d m=%d lin=%zu:", c, nodes[c].mult, nodes[c].lin.size()); for (auto& q : nodes[c].prods) fprintf(stderr, " (%d%s%d)x(%d%s%d)", q.a.s0, q.a.s1 < 0 ? "" : (q.a.n1 ? "-" : "+"), q.a.s1 < 0 ? 0 : q.a.s1, q.b.s0, q.b.s1 < 0 ? "" : (q.b.n1 ? "-" : "+"), q.b.s1 < 0 ? 0 : q.b.s1); fprintf(stderr, "\n"); }
     if (getenv("NBLS_DUMP_FORMS")) { fprintf(stderr, "%s forms:", name.c_str()); for (size_t j = 0; j < mk; j++) fprintf(stderr, " %x/%x", ua[j], ub[j]); fprintf(stderr, "\n"); }
-    // cost model of the step (VALU instructions per wavefront)
-    double est = 310 + 80;
-    for (size_t j = 0; j < mk; j++) est += 196 + 22 + form_cost(ua[j]) + form_cost(ub[j]);
-    size_t ml = 0; bool any_mult = false, any_halve = false;
-    for (int c : L) { ml = std::max(ml, nodes[c].lin.size()); any_mult |= nodes[c].mult > 1; any_halve |= nodes[c].halve; }
-    est += ml * 30 + (any_mult ? 14 : 0) + ((any_mult || ml) ? 41 : 0) + (any_halve ? 60 : 0);
+    // cost model of the step (VALU instructions per wavefront): rounds of 196 multiply-adds + 4 address additions + the shape work, one
+    // reduction (196 + ~100), post-processing
+    double est = 60 + 196 + 100;
+    for (size_t j = 0; j < mk; j++) est += 196 + 4 + form_cost(ua[j]) + form_cost(ub[j]);
+    size_t mp = 0, mn = 0; bool any_mult = false, any_halve = false;
+    for (int c : L) { size_t np = 0, nn = 0; for (auto& t : nodes[c].lin) (t.second < 0 ? nn : np)++; mp = std::max(mp, np); mn = std::max(mn, nn); any_mult |= nodes[c].mult > 1; any_halve |= nodes[c].halve; }
+    est += (mp + mn) * 16 + (any_mult ? 28 : 0) + ((any_mult || mp + mn) ? 41 : 0) + (any_halve ? 60 : 0);
     P.est_valu += est;
   }
   for (auto& L : step_nodes) {
     const Node& n0 = nodes[L[0]];
     if (n0.kind == K_DOT) continue;
-    if (n0.kind == K_LIN) { size_t mx = 0; bool h = false; for (int c : L) { mx = std::max(mx, nodes[c].lin.size()); h |= nodes[c].halve; } P.est_valu += 80 + mx * 30 + 41 + (h ? 60 : 0); }
-    else P.est_valu += 150;
+    if (n0.kind == K_LIN) { size_t mp = 0, mn = 0; bool h = false; for (int c : L) { size_t np = 0, nn = 0; for (auto& t : nodes[c].lin) (t.second < 0 ? nn : np)++; mp = std::max(mp, np); mn = std::max(mn, nn); h |= nodes[c].halve; } P.est_valu += 50 + (mp + mn) * 16 + 41 + (h ? 60 : 0); }
+    else P.est_valu += 120;
   }
   // 5. slot allocation (linear scan; a destination may reuse a slot whose last read is in the same step)
   for (int i = 0; i < N; i++) { Node& n = nodes[i]; if (!n.live || n.kind == 0xff) continue; for (int u : n.users) n.last_use = std::max(n.last_use, nodes[u].step); }
@@ -438,40 +443,51 @@ Program Builder::compile(const std::string& name, int W) {
       if (nodes[c].last_use < 0) free_slots.push_back(nodes[c].slot);   // defensive: result never read
     }
   }
-  assert(nslots <= (int)OP_SLOT_MASK);
   P.slots = nslots;
+  P.nconst = (u32)const_words.size() / SLOT_WORDS;
+  // LDS layout: every instance region holds the constants (replicated, so that an operand address is base + offset whatever it
+  // names) followed by the slots.  Slot stride 80 bytes makes the 16-byte reads of 16 lanes that name 16 different slots conflict-free
+  // (bank group (5 k + c) mod 16; with 64 bytes only 4 of the 16 groups are ever hit by the same chunk c); it is used when the LDS
+  // footprint still allows 12 wavefronts per CU (3 per SIMD, the VGPR limit), else 64.
+  {
+    const char* e = getenv("NBLS_SLOT_BYTES");
+    u32 sb = e && *e ? (u32)atoi(e) : 0;
+    if (sb != 64 && sb != 80) sb = (u64)P.G * (P.nconst + P.slots) * 80 <= 163840 / 12 ? 80 : 64;
+    P.slot_bytes = sb;
+  }
+  assert(P.inst_bytes() < 65536);
   // 6. emit
-  auto op = [&](int atom) -> u32 {
-    if (atom < 0) return OP_CONST | 0;   // const slot 0 is zero
+  auto op = [&](int atom) -> u32 {   // LDS byte offset inside the instance region
+    if (atom < 0) return 0;   // const slot 0 is zero
     const Node& n = nodes[atom];
-    if (n.kind == 0xff) { assert(n.const_idx < (int)OP_SLOT_MASK); return OP_CONST | (u32)n.const_idx; }
+    if (n.kind == 0xff) return (u32)n.const_idx * P.slot_bytes;
     assert(n.slot >= 0);
-    return (u32)n.slot;
+    return (P.nconst + (u32)n.slot) * P.slot_bytes;
   };
-  auto enc_operand = [&](const Operand& o, bool negate, bool norm) -> u32 {
-    u32 e0 = op(o.s0) | (negate ? OP_NEG : 0u) | (norm ? OP_NORM : 0u);
-    u32 e1 = o.s1 >= 0 ? (op(o.s1) | (o.n1 ? OP_NEG : 0u) | OP_PRESENT) : 0u;
-    return e0 | (e1 << 16);
-  };
-  auto enc_product = [&](const DotProduct& p, u32& wa, u32& wb) {
-    wa = enc_operand(p.a, p.neg_a, p.norm_a); wb = enc_operand(p.b, p.neg_b, p.norm_b);
-    P.n_norm_operands += p.norm_a + p.norm_b; P.n_neg_operands += p.neg_a + p.neg_b; P.n_comb_operands += (p.a.s1 >= 0) + (p.b.s1 >= 0);
-  };
+  auto put16 = [](std::vector<u32>& w, int first, int t, u32 v) { w[first + t / 2] |= (v & 0xffffu) << (16 * (t & 1)); };
   for (size_t s = 0; s < step_nodes.size(); s++) {
     const std::vector<int>& L = step_nodes[s];
     const Node& n0 = nodes[L[0]];
     Step st; memset(&st, 0, sizeof st);
     st.kind = n0.kind; st.nlanes = (uint8_t)L.size(); st.desc_off = (u32)P.descs.size();
     st.stride = 4;
+    size_t mp = 0, mn = 0;   // DOT / LIN: added and subtracted terms, max over the lanes
+    if (n0.kind == K_LIN || n0.kind == K_DOT) for (int c : L) { size_t np = 0, nn = 0; for (auto& t : nodes[c].lin) (t.second < 0 ? nn : np)++; mp = std::max(mp, np); mn = std::max(mn, nn); }
     if (n0.kind == K_LIN) {
-      size_t mx = 0; for (int c : L) mx = std::max(mx, nodes[c].lin.size());
-      st.p0 = (uint8_t)mx; st.stride = mx > 6 ? 8 : 4;
+      assert(mp <= (size_t)MAX_LIN_TERMS && mn <= (size_t)MAX_LIN_TERMS);
+      st.p0 = (uint8_t)mp; st.p1 = (uint8_t)mn; st.stride = mp + mn > 6 ? 8 : 4;
       P.n_lin_steps++; P.n_lin_ops += (u32)L.size();
     } else if (n0.kind == K_DOT) {
-      size_t mk = 0, ml = 0;
-      for (int c : L) { mk = std::max(mk, nodes[c].prods.size()); ml = std::max(ml, nodes[c].lin.size()); P.n_products += (u32)nodes[c].prods.size(); }
-      st.p0 = (uint8_t)mk; st.pad = (u32)ml;
-      st.stride = (u32)((4 + 2 * mk + 3) / 4 * 4);
+      size_t mk = step_shapes[s].size();
+      for (int c : L) { P.n_products += (u32)nodes[c].prods.size(); if (nodes[c].mult > 1) st.p1 |= DOTF_MULT; if (nodes[c].halve) st.p1 |= DOTF_HALVE; if (nodes[c].offs > 0) st.p1 |= DOTF_OFFS; }
+      assert(mk <= (size_t)MAX_DOT_PRODUCTS && mp <= (size_t)MAX_DOT_LINEAR && mn <= (size_t)MAX_DOT_LINEAR);
+      st.p0 = (uint8_t)mk; st.lin = (u32)mp | ((u32)mn << 4);
+      for (size_t j = 0; j < mk; j++) {
+        auto sh3 = [](int m) { return (u32)(((m & 8) ? 3 : (m & 3)) | (m & 4)); };
+        const u32 sh = sh3(step_shapes[s][j].first) | (sh3(step_shapes[s][j].second) << SH_B_SHIFT);
+        st.shape[j / 4] |= sh << (8 * (j & 3));
+      }
+      st.stride = (u32)(DOT_HDR_WORDS + DOT_ROUND_WORDS * mk);
       P.n_dot_steps++; P.n_dot_ops += (u32)L.size(); P.n_prod_slots += (u32)(mk * W);
     } else {
       st.p0 = n0.p0; P.n_other_steps++;
@@ -480,30 +496,36 @@ Program Builder::compile(const std::string& name, int W) {
     for (int c : L) {
       const Node& n = nodes[c];
       std::vector<u32> w(st.stride, 0);
+      auto put_lin = [&](int first) {   // added terms first, then subtracted ones, each group padded with the zero constant (offset 0)
+        int ia = 0, is = 0;
+        for (auto& t : n.lin) { if (t.second > 0) put16(w, first, ia++, op(t.first)); else put16(w, first, (int)mp + is++, op(t.first)); }
+      };
       switch (n.kind) {
         case K_DOT:
           assert(n.prods.size() <= (size_t)MAX_DOT_PRODUCTS && n.lin.size() <= (size_t)MAX_DOT_LINEAR && n.mult >= 1 && n.mult <= 4);
-          w[0] = (u32)n.slot | ((u32)n.prods.size() << 16) | ((u32)n.lin.size() << 20) | ((u32)n.mult << 24) | (n.halve ? (1u << 27) : 0u) | ((u32)n.offs << 28);
-          for (size_t t = 0; t < n.lin.size(); t++) {
-            u32 term = op(n.lin[t].first) | (n.lin[t].second < 0 ? (1u << OP_MODE_SHIFT) : 0u);
-            w[2 + t / 2] |= term << (16 * (t & 1));
+          w[0] = op(c) | ((u32)n.mult << 16) | (n.halve ? (1u << 19) : 0u) | ((u32)n.offs << 20);
+          put_lin(4);
+          for (size_t i = 0; i < n.prods.size(); i++) {
+            const DotProduct& p = n.prods[i];
+            u32* r = &w[DOT_HDR_WORDS + DOT_ROUND_WORDS * i];
+            const int sa = step_shapes[s][i].first, sb = step_shapes[s][i].second;
+            const bool ma = (sa & 3) == 3 || (sa & 8), mb = (sb & 3) == 3 || (sb & 8);   // per-lane signs in bit 0 of the offsets
+            r[0] = op(p.a.s0) | ((ma && p.neg0_a) ? 1u : 0u); r[1] = p.a.s1 >= 0 ? (op(p.a.s1) | ((ma && p.a.n1) ? 1u : 0u)) : 0u;
+            r[2] = op(p.b.s0) | ((mb && p.neg0_b) ? 1u : 0u); r[3] = p.b.s1 >= 0 ? (op(p.b.s1) | ((mb && p.b.n1) ? 1u : 0u)) : 0u;
+            P.n_norm_operands += p.norm_a + p.norm_b; P.n_comb_operands += (p.a.s1 >= 0) + (p.b.s1 >= 0);
           }
-          for (size_t i = 0; i < n.prods.size(); i++) enc_product(n.prods[i], w[4 + 2 * i], w[5 + 2 * i]);
           break;
         case K_LIN:
-          w[0] = (u32)n.slot | ((u32)n.lin.size() << 16) | (n.halve ? (1u << 24) : 0u);
-          for (size_t t = 0; t < n.lin.size(); t++) {
-            u32 term = op(n.lin[t].first) | (n.lin[t].second < 0 ? (1u << OP_MODE_SHIFT) : 0u);
-            w[1 + t / 2] |= term << (16 * (t & 1));
-          }
+          w[0] = op(c) | (n.halve ? (1u << 16) : 0u);
+          put_lin(1);
           P.n_lin_terms += (u32)n.lin.size();
           break;
-        case K_LOAD: case K_LOADW: w[0] = (u32)n.slot | ((u32)n.buf << 16); w[1] = (u32)n.off; break;
+        case K_LOAD: case K_LOADW: w[0] = op(c) | ((u32)n.buf << 16); w[1] = (u32)n.off; break;
         case K_STORE: case K_STOREW: w[0] = op(n.a0) | ((u32)n.buf << 16); w[1] = (u32)n.off; break;
-        case K_ISZ: case K_CANON: w[0] = (u32)n.slot | (op(n.a0) << 16); break;
-        case K_SEL: w[0] = (u32)n.slot | (op(n.b0) << 16); w[1] = op(n.a0) | (op(n.a1) << 16); break;
-        case K_CMP: case K_FLAG: case K_BITAND: w[0] = (u32)n.slot; w[1] = op(n.a0) | (op(n.a1) << 16); break;
-        case K_BIT: w[0] = (u32)n.slot | (op(n.a0) << 16); w[1] = (u32)n.off; break;
+        case K_ISZ: case K_CANON: w[0] = op(c) | (op(n.a0) << 16); break;
+        case K_SEL: w[0] = op(c) | (op(n.b0) << 16); w[1] = op(n.a0) | (op(n.a1) << 16); break;
+        case K_CMP: case K_FLAG: case K_BITAND: w[0] = op(c); w[1] = op(n.a0) | (op(n.a1) << 16); break;
+        case K_BIT: w[0] = op(c) | (op(n.a0) << 16); w[1] = (u32)n.off; break;
         case K_STATUS:
           assert(n.stat.size() <= 7);
           w[0] = (u32)n.stat.size() | ((u32)n.buf << 16);
@@ -515,7 +537,6 @@ Program Builder::compile(const std::string& name, int W) {
     }
     P.steps.push_back(st);
   }
-  P.nconst = (u32)const_words.size() / SLOT_WORDS;
   P.consts = const_words;
   return P;
 }

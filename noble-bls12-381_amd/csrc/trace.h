@@ -29,12 +29,15 @@ struct Program {
   std::string name;
   std::vector<Step> steps;
   std::vector<u32> descs;
-  std::vector<u32> consts;   // nconst * SLOT_WORDS words
+  std::vector<u32> consts;   // nconst * RAW_WORDS words
   u32 nconst = 0, W = 64, G = 1, slots = 0;
+  u32 slot_bytes = 64;       // LDS slot stride chosen for this program (Builder::compile)
   // statistics
   u32 n_dot_steps = 0, n_lin_steps = 0, n_other_steps = 0, n_dot_ops = 0, n_products = 0, n_prod_slots = 0, n_lin_ops = 0, n_lin_terms = 0, n_norm_operands = 0, n_neg_operands = 0, n_comb_operands = 0;
+  u32 n_round_ops = 0, n_op_mode[4] = {0, 0, 0, 0}, n_op_norm = 0;   // product-round operands (two per round) by shape
   double est_valu = 0;       // cost-model estimate of VALU instructions per wave (see Builder::compile)
-  u32 lds_bytes() const { return lds_words(nconst, G, slots) * 4; }
+  u32 inst_bytes() const { return (nconst + slots) * slot_bytes; }   // one instance region: constants (replicated per instance) + slots
+  u32 lds_bytes() const { return G * inst_bytes(); }
 };
 
 // operand of a pending product: s0 (never negated after canonicalisation) and optional s1 with sign
@@ -49,7 +52,7 @@ typedef long long TermKey;                         // atom id, or PROD_BASE + pr
 static const TermKey PROD_BASE = 1LL << 40;
 typedef std::vector<std::pair<TermKey, int>> Form;   // sorted by key, no zero coefficients
 
-struct DotProduct { Operand a, b; bool neg; bool norm_a = false, norm_b = false; bool neg_a = false, neg_b = false; };   // neg: the product enters with a minus sign; norm_*: normalise that (sum) operand first
+struct DotProduct { Operand a, b; bool neg; bool norm_a = false, norm_b = false; bool neg0_a = false, neg0_b = false; };   // neg: the product enters with a minus sign (resolved into an operand shape by compile()); norm_*: normalise that (sum) operand first; neg0_*: the operand's first term is negated too (-(x + y), per-lane signs)
 
 struct Node {
   uint8_t kind = 0;        // StepKind, or 0xff for constants

@@ -48,44 +48,52 @@ NBLS_HD void carry_norm(u32* x) {
   x[NL - 1] = (u32)((i32)x[NL - 1] + c);
 }
 
+// LDS access: `lds` is a byte pointer to the workgroup's LDS image (device) or to a plain array (simulator); slots are
+// 16-byte aligned, so a slot is read with three 16-byte accesses and one 8-byte access (ds_read_b128 x 3 + ds_read_b64).
+struct alignas(16) V4 { u32 x, y, z, w; };
+struct alignas(8) V2 { u32 x, y; };
 template <typename LDSP>
-NBLS_HD void ld14(u32* x, LDSP lds, u32 off) {
-#if defined(NBLS_EXP_NOLDS)     // timing experiment only (tools/exp_variants.sh): operands made up from the address, no LDS traffic; results are garbage
-#pragma unroll
-  for (int i = 0; i < NL; i++) x[i] = (off * 2654435761u + i * 40503u) & LMASK;
-#else
-#pragma unroll
-  for (int i = 0; i < NL; i++) x[i] = lds[off + i];
-#endif
+NBLS_HD void ld14(u32* x, LDSP lds, u32 addr) {
+  const V4 a = *(const V4*)(lds + addr), b = *(const V4*)(lds + addr + 16), c = *(const V4*)(lds + addr + 32);
+  const V2 d = *(const V2*)(lds + addr + 48);
+  x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+  x[8] = c.x; x[9] = c.y; x[10] = c.z; x[11] = c.w; x[12] = d.x; x[13] = d.y;
 }
-// word offset of an operand's slot: constants live at the start of the LDS image, everything else in the instance region
-NBLS_HD u32 slot_addr(u32 op, u32 inst) {
-  const u32 is_const = (u32)((i32)(op << 18) >> 31);   // OP_CONST (bit 13) -> all ones
-  return (inst & ~is_const) + ((op & OP_SLOT_MASK) << 4);
+template <typename LDSP>
+NBLS_HD void st14(LDSP lds, u32 addr, const u32* x) {
+  V4 a = {x[0], x[1], x[2], x[3]}, b = {x[4], x[5], x[6], x[7]}, c = {x[8], x[9], x[10], x[11]};
+  V2 d = {x[12], x[13]};
+  *(V4*)(lds + addr) = a; *(V4*)(lds + addr + 16) = b; *(V4*)(lds + addr + 32) = c; *(V2*)(lds + addr + 48) = d;
 }
+template <typename LDSP>
+NBLS_HD u32 ld1(LDSP lds, u32 addr) { return *(const u32*)(lds + addr); }
 
-// operand of a DOT product, as signed limbs: x, x + y or x - y, optionally normalised (sums only), optionally negated
+// operand of a DOT product round, as signed limbs: x, x + y or x - y (f0, f1: byte offsets inside the instance region), optionally
+// normalised.  `shape` (3 bits: mode, normalise) is uniform for the wavefront, so these are scalar branches; a lane that has no second
+// term where another lane has one points f1 at the zero constant.  Mode 3: the signs of both terms are per lane (bit 0 of f0 / f1).
 template <typename LDSP>
-NBLS_HD void dot_operand(u32* A, u32 enc, LDSP lds, u32 inst) {
-  const u32 e0 = enc & 0xffff, e1 = enc >> 16;
-  ld14(A, lds, slot_addr(e0, inst));
-  if ((enc & (OP_NEG | OP_NORM | (OP_PRESENT << 16))) == 0) return;   // plain slot: the common case
-  if (e1 & OP_PRESENT) {
+NBLS_HD void dot_operand(u32* A, u32 f0, u32 f1, u32 shape, LDSP lds, u32 inst) {
+  const u32 mode = shape & 3;
+  if (mode != 3) ld14(A, lds, inst + f0);
+  if (mode) {
     u32 X[NL];
-    ld14(X, lds, slot_addr(e1, inst));
-    if (e1 & OP_NEG) {
-#pragma unroll
-      for (int i = 0; i < NL; i++) A[i] -= X[i];
-    } else {
+    if (mode == 1) {
+      ld14(X, lds, inst + f1);
 #pragma unroll
       for (int i = 0; i < NL; i++) A[i] += X[i];
+    } else if (mode == 2) {
+      ld14(X, lds, inst + f1);
+#pragma unroll
+      for (int i = 0; i < NL; i++) A[i] -= X[i];
+    } else {   // per-lane signs on both terms (bit 0 of the offsets): +-x +- y
+      ld14(A, lds, inst + (f0 & ~1u));
+      ld14(X, lds, inst + (f1 & ~1u));
+      const u32 m0 = 0u - (f0 & 1u), m1 = 0u - (f1 & 1u), c = (f0 & 1u) + (f1 & 1u);
+#pragma unroll
+      for (int i = 0; i < NL; i++) A[i] = (A[i] ^ m0) + (X[i] ^ m1) + c;
     }
   }
-  if (e0 & OP_NORM) carry_norm(A);
-  if (e0 & OP_NEG) {
-#pragma unroll
-    for (int i = 0; i < NL; i++) A[i] = 0u - A[i];
-  }
+  if (shape & 4) carry_norm(A);
 }
 
 // acc[i+j] += a[j] * b[i] on signed limbs: 196 in-place v_mad_i64_i32, no carries
@@ -175,116 +183,108 @@ NBLS_HD void halve28(u32* r) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Per-lane step execution.  `lds` is the workgroup's LDS image (device) or a plain array (simulator):
-//   words [0, nconst*16)            program constants (shared by all instances)
-//   words [inst, inst + slots*16)   this instance's slots
-// The function reads operands, computes, and returns the result in `res` (14 limbs) together with the destination
-// word offset (or 0xffffffff when the step has no LDS destination); the caller commits the limbs afterwards, so that
+// Per-lane step execution.  `lds` is the workgroup's LDS image (device) or a plain array (simulator), addressed in bytes:
+//   [inst, inst + inst_bytes)   this instance's region: the program's constants first, then its slots
+// The functions read operands, compute, and return the result in `res` (14 limbs) together with the destination byte
+// address (or 0xffffffff when the step has no LDS destination); the caller commits the limbs afterwards, so that
 // every read of a step precedes every write of that step (in-order LDS within a wavefront; explicit two-phase loop in
 // the simulator).
 struct LaneCtx {
-  u32 inst;       // word offset of the instance region
+  u32 inst;       // byte offset of the instance region
   u32 item;       // global work-item index
   bool live;      // item < n_items (dead instances compute on zeros but never touch global memory)
 };
+NBLS_HD u32 slot_addr(u32 field, u32 inst) { return inst + (field & 0xffffu); }
+// 16-bit offset number t of a packed list that starts at word `first` of the descriptor
+NBLS_HD u32 field16(const u32* d, int first, int t) { return (d[first + t / 2] >> (16 * (t & 1))) & 0xffffu; }
 
-// K_DOT in two pieces so that the two-wave kernel (vm_kernel.hip, small batches) can split the products of a lane-op
-// between two wavefronts: dot_products accumulates products [lo, hi) of this lane's descriptor into the 28 signed
-// columns; dot_result reduces the columns and applies multiplier, post-added slots, normalisation and halving.
-template <typename LDSP>
-NBLS_HD void dot_products(u64* acc, const Step& st, const u32* d, const u32* __restrict__ gd, LDSP lds, const LaneCtx& cx, u32 lo, u32 hi) {
-  const u32 k = (d[0] >> 16) & 0xf;
-  u32 na, nb;
-  if (lo == 0) { na = d[4]; nb = d[5]; } else if (lo < hi) { na = gd[4 + 2 * lo]; nb = gd[5 + 2 * lo]; } else { na = 0; nb = 0; }
-  for (u32 i = lo; i < hi; i++) {   // uniform trip count; next product's operand words are fetched ahead
-    const u32 ea = na, eb = nb;
-    if (i + 1 < hi) { na = gd[6 + 2 * i]; nb = gd[7 + 2 * i]; }
-    if (i < k) {
-      u32 A[NL], B[NL];
-      dot_operand(A, ea, lds, cx.inst);
-      dot_operand(B, eb, lds, cx.inst);
-      mac28(acc, A, B);
-    }
+// K_DOT in three pieces so that the two-wave kernel (vm_kernel.hip, small batches) can split the product rounds of a step
+// between two wavefronts: dot_init loads the bias, dot_round accumulates one product of this lane into the 28 signed
+// columns, dot_finish reduces the columns and applies multiplier, post-added slots, normalisation and halving.
+NBLS_HD void dot_init(u64* acc, const Step& st, u32 w0) {
+  if (st.p1 & DOTF_OFFS) acc_init(acc, (w0 >> 20) & 0xf);
+  else {
+#pragma unroll
+    for (int i = 0; i < 2 * NL; i++) acc[i] = 0;
   }
 }
+NBLS_HD u32 round_shape(const Step& st, u32 r) { return ((r < 4 ? st.shape[0] : st.shape[1]) >> (8 * (r & 3))) & 0xffu; }
 template <typename LDSP>
-NBLS_HD u32 dot_result(u32* res, u64* acc, bool have_products, const Step& st, const u32* d, LDSP lds, const LaneCtx& cx) {
+NBLS_HD void dot_round(u64* acc, u32 shape, u32 a0, u32 a1, u32 b0, u32 b1, LDSP lds, const LaneCtx& cx) {
+  u32 A[NL], B[NL];
+  dot_operand(A, a0, a1, shape & 7, lds, cx.inst);
+  dot_operand(B, b0, b1, (shape >> SH_B_SHIFT) & 7, lds, cx.inst);
+  mac28(acc, A, B);
+}
+template <typename LDSP>
+NBLS_HD u32 dot_finish(u32* res, u64* acc, const Step& st, const u32* d /* the 8 header words */, LDSP lds, const LaneCtx& cx) {
   const u32 w0 = d[0];
-  const u32 L = (w0 >> 20) & 0xf, mult = (w0 >> 24) & 0x7;
   u32 r[NL];
-  if (have_products) redc28(r, acc);
+  if (st.p0 > 0) redc28(r, acc);
   else {
 #pragma unroll
     for (int i = 0; i < NL; i++) r[i] = 0;
   }
-  if (mult > 1) {
+  if (st.p1 & DOTF_MULT) {   // m in 1..4 as shift and add; with <= 4 post-added terms the limb sums stay inside (-2^31, 2^31)
+    const u32 mult = (w0 >> 16) & 7, sh = mult >> 1, m3 = mult == 3 ? 0xffffffffu : 0u;
 #pragma unroll
-    for (int i = 0; i < NL; i++) r[i] *= mult;     // m <= 4; with <= 4 linear terms the limb sums stay inside (-2^31, 2^31)
+    for (int i = 0; i < NL; i++) r[i] = (r[i] << sh) + (r[i] & m3);
   }
+  const int nadd = (int)(st.lin & 7), nsub = (int)((st.lin >> 4) & 7);
 #pragma unroll
   for (int t = 0; t < MAX_DOT_LINEAR; t++) {
-    if (t < (int)st.pad) {   // uniform
-      u32 term = (d[2 + t / 2] >> (16 * (t & 1))) & 0xffff;
-      if ((u32)t < L) {
-        u32 X[NL];
-        ld14(X, lds, slot_addr(term, cx.inst));
-        if (term & OP_NEG) {
+    if (t < nadd) {   // uniform
+      u32 X[NL];
+      ld14(X, lds, slot_addr(field16(d, 4, t), cx.inst));
 #pragma unroll
-          for (int i = 0; i < NL; i++) r[i] -= X[i];
-        } else {
-#pragma unroll
-          for (int i = 0; i < NL; i++) r[i] += X[i];
-        }
-      }
+      for (int i = 0; i < NL; i++) r[i] += X[i];
     }
   }
-  if (mult > 1 || st.pad > 0) carry_norm(r);
-  if (w0 & (1u << 27)) halve28(r);
+#pragma unroll
+  for (int t = 0; t < 2 * MAX_DOT_LINEAR; t++) {
+    if (t >= nadd && t < nadd + nsub) {   // uniform
+      u32 X[NL];
+      ld14(X, lds, slot_addr(field16(d, 4, t), cx.inst));
+#pragma unroll
+      for (int i = 0; i < NL; i++) r[i] -= X[i];
+    }
+  }
+  if ((st.p1 & DOTF_MULT) || st.lin) carry_norm(r);
+  if (st.p1 & DOTF_HALVE) { if (w0 & (1u << 19)) halve28(r); }
 #pragma unroll
   for (int i = 0; i < NL; i++) res[i] = r[i];
-  return slot_addr(w0 & 0xffff, cx.inst);
+  return slot_addr(w0, cx.inst);
 }
 
+// every step kind except K_DOT
 template <typename LDSP>
-NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, already loaded */, const u32* __restrict__ gd /* this lane's descriptor in global memory */,
-                      LDSP lds, const LaneCtx& cx, const IOBuf* bufs, u32* res) {
+NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words */, LDSP lds, const LaneCtx& cx, const IOBuf* bufs, u32* res) {
   switch (st.kind) {
-    case K_DOT: {
-      u64 acc[2 * NL];
-      if (st.p0 > 0) {   // uniform
-        acc_init(acc, d[0] >> 28);
-        dot_products(acc, st, d, gd, lds, cx, 0, st.p0);
-      }
-      return dot_result(res, acc, st.p0 > 0, st, d, lds, cx);
-    }
     case K_LIN: {
       const u32 w0 = d[0];
-      const u32 nt = (w0 >> 16) & 0xff;
+      const int nadd = st.p0, nsub = st.p1;
       u32 r[NL];
 #pragma unroll
       for (int i = 0; i < NL; i++) r[i] = 0;
 #pragma unroll
-      for (int t = 0; t < MAX_LIN_TERMS; t++) {
-        if (t < (int)st.p0) {   // uniform
-          u32 term = (d[1 + t / 2] >> (16 * (t & 1))) & 0xffff;
-          if ((u32)t < nt) {
-            u32 X[NL];
-            ld14(X, lds, slot_addr(term, cx.inst));
-            if (term & OP_NEG) {
+      for (int t = 0; t < 2 * MAX_LIN_TERMS; t++) {
+        if (t < nadd + nsub) {   // uniform
+          u32 X[NL];
+          ld14(X, lds, slot_addr(field16(d, 1, t), cx.inst));
+          if (t < nadd) {
 #pragma unroll
-              for (int i = 0; i < NL; i++) r[i] -= X[i];
-            } else {
+            for (int i = 0; i < NL; i++) r[i] += X[i];
+          } else {
 #pragma unroll
-              for (int i = 0; i < NL; i++) r[i] += X[i];
-            }
+            for (int i = 0; i < NL; i++) r[i] -= X[i];
           }
         }
       }
       carry_norm(r);
-      if (w0 & (1u << 24)) halve28(r);
+      if (w0 & (1u << 16)) halve28(r);
 #pragma unroll
       for (int i = 0; i < NL; i++) res[i] = r[i];
-      return slot_addr(w0 & 0xffff, cx.inst);
+      return slot_addr(w0, cx.inst);
     }
     case K_LOAD: {
       u32 w0 = d[0], off = d[1];
@@ -295,7 +295,7 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, 
 #pragma unroll
       for (int i = 0; i < 12; i++) w[i] = (cx.live && i < nw) ? bswap32(src[nw - 1 - i]) : 0u;
       words_to_limbs(res, w);
-      return slot_addr(w0 & 0xffff, cx.inst);
+      return slot_addr(w0, cx.inst);
     }
     case K_LOADW: {
       u32 w0 = d[0], off = d[1];
@@ -303,12 +303,12 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, 
       const u32* src = (const u32*)(b.ptr + (u64)cx.item * b.stride + off);
 #pragma unroll
       for (int i = 0; i < NL; i++) res[i] = cx.live ? src[i] : 0u;
-      return slot_addr(w0 & 0xffff, cx.inst);
+      return slot_addr(w0, cx.inst);
     }
     case K_STORE: {
       u32 w0 = d[0], off = d[1];
       u32 X[NL], w[12];
-      ld14(X, lds, slot_addr(w0 & 0xffff, cx.inst));
+      ld14(X, lds, slot_addr(w0, cx.inst));
       if (st.p0 == 0) csub_p(X);     // p0 = 1: raw 384-bit integer (compressed encodings carry flag bits above bit 380)
       limbs_to_words(w, X);
       if (cx.live) {
@@ -322,7 +322,7 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, 
     case K_STOREW: {
       u32 w0 = d[0], off = d[1];
       u32 X[NL];
-      ld14(X, lds, slot_addr(w0 & 0xffff, cx.inst));
+      ld14(X, lds, slot_addr(w0, cx.inst));
       if (cx.live) {
         const IOBuf& b = bufs[(w0 >> 16) & 7];
         u32* dst = (u32*)(b.ptr + (u64)cx.item * b.stride + off);
@@ -340,30 +340,30 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, 
 #pragma unroll
       for (int i = 0; i < NL; i++) res[i] = 0;
       res[0] = z ? 1u : 0u;
-      return slot_addr(w0 & 0xffff, cx.inst);
+      return slot_addr(w0, cx.inst);
     }
     case K_SEL: {
       u32 w0 = d[0], w1 = d[1];
       // both sources are read and merged with a mask: the LDS access pattern does not depend on the flag (the flag
       // can be a secret scalar bit in the sign / getPublicKey ladders)
-      const u32 m = 0u - (lds[slot_addr(w0 >> 16, cx.inst)] != 0 ? 1u : 0u);
+      const u32 m = 0u - (ld1(lds, slot_addr(w0 >> 16, cx.inst)) != 0 ? 1u : 0u);
       u32 Xa[NL], Xb[NL];
-      ld14(Xa, lds, slot_addr(w1 & 0xffff, cx.inst));
+      ld14(Xa, lds, slot_addr(w1, cx.inst));
       ld14(Xb, lds, slot_addr(w1 >> 16, cx.inst));
 #pragma unroll
       for (int i = 0; i < NL; i++) res[i] = (Xa[i] & m) | (Xb[i] & ~m);
-      return slot_addr(w0 & 0xffff, cx.inst);
+      return slot_addr(w0, cx.inst);
     }
     case K_CANON: {
       u32 w0 = d[0];
       ld14(res, lds, slot_addr(w0 >> 16, cx.inst));
       csub_p(res);
-      return slot_addr(w0 & 0xffff, cx.inst);
+      return slot_addr(w0, cx.inst);
     }
     case K_CMP: {
       u32 w0 = d[0], w1 = d[1];
       u32 X[NL], Y[NL];
-      ld14(X, lds, slot_addr(w1 & 0xffff, cx.inst));
+      ld14(X, lds, slot_addr(w1, cx.inst));
       u32 f;
       if (st.p0 == 0) {   // X > Y  <=>  Y - X borrows (normalised limbs)
         ld14(Y, lds, slot_addr(w1 >> 16, cx.inst));
@@ -377,40 +377,40 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words, 
 #pragma unroll
       for (int i = 0; i < NL; i++) res[i] = 0;
       res[0] = f;
-      return slot_addr(w0 & 0xffff, cx.inst);
+      return slot_addr(w0, cx.inst);
     }
     case K_BIT: {
       u32 w0 = d[0], bit = d[1];
-      u32 w = lds[slot_addr(w0 >> 16, cx.inst) + bit / 28];
+      u32 w = ld1(lds, slot_addr(w0 >> 16, cx.inst) + 4 * (bit / 28));
 #pragma unroll
       for (int i = 0; i < NL; i++) res[i] = 0;
       res[0] = (w >> (bit % 28)) & 1;
-      return slot_addr(w0 & 0xffff, cx.inst);
+      return slot_addr(w0, cx.inst);
     }
     case K_BITAND: {
       u32 w0 = d[0], w1 = d[1];
       u32 X[NL], Y[NL];
-      ld14(X, lds, slot_addr(w1 & 0xffff, cx.inst));
+      ld14(X, lds, slot_addr(w1, cx.inst));
       ld14(Y, lds, slot_addr(w1 >> 16, cx.inst));
 #pragma unroll
       for (int i = 0; i < NL; i++) res[i] = X[i] & Y[i];
-      return slot_addr(w0 & 0xffff, cx.inst);
+      return slot_addr(w0, cx.inst);
     }
     case K_FLAG: {
       u32 w0 = d[0], w1 = d[1];
-      u32 a = lds[slot_addr(w1 & 0xffff, cx.inst)] & 1, b = lds[slot_addr(w1 >> 16, cx.inst)] & 1;
+      u32 a = ld1(lds, slot_addr(w1, cx.inst)) & 1, b = ld1(lds, slot_addr(w1 >> 16, cx.inst)) & 1;
       u32 f = st.p0 == 0 ? (a & b) : st.p0 == 1 ? (a | b) : st.p0 == 2 ? (a ^ b) : (a & (b ^ 1));
 #pragma unroll
       for (int i = 0; i < NL; i++) res[i] = 0;
       res[0] = f;
-      return slot_addr(w0 & 0xffff, cx.inst);
+      return slot_addr(w0, cx.inst);
     }
     case K_STATUS: {
       u32 w0 = d[0];
       u32 n = w0 & 0xff, code = 0;
       for (int k = (int)n - 1; k >= 0; k--) {
         u32 e = d[1 + k];
-        if ((lds[slot_addr(e & 0xffff, cx.inst)] & 1) == 0) code = e >> 16;
+        if ((ld1(lds, slot_addr(e, cx.inst)) & 1) == 0) code = e >> 16;
       }
       if (cx.live) { const IOBuf& b = bufs[(w0 >> 16) & 7]; ((int8_t*)b.ptr)[(u64)cx.item * b.stride] = (int8_t)code; }
       return 0xffffffffu;

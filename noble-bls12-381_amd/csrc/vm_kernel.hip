@@ -1,39 +1,62 @@
 // vm_kernel.hip -- the gfx950 wave-VM kernel: one wavefront (= one workgroup of 64 lanes) interprets a compiled
 // step list for G work items at once; see vm.h / vm_exec.h.  Integer VALU work (v_mad_i64_i32 into lazy 64-bit columns):
 // no MFMA by construction (independent 381-bit products are not a dense contraction).
+//
+// Control flow is scalar throughout: the step header (kind, product rounds, operand shapes, post-added terms) is uniform
+// for the wavefront and is read with scalar loads, so the product loop contains no per-lane flag test and no exec-mask
+// juggling -- a round is: four address additions, the LDS reads, the limb-wise combine the round's shape asks for, 196
+// multiply-adds.  Per-lane data (LDS byte offsets) comes from the lane descriptors, fetched one round / one step ahead.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <mutex>
 #include "vm_exec.h"
 
 namespace nbls {
 
-template <bool FAIR> __device__ __forceinline__ void vm_kernel_body(const KernelArgs& ka) {
-  extern __shared__ __attribute__((aligned(16))) u32 smem[];
-  const u32 lane = threadIdx.x;
+struct LaneSetup { u32 lane_in; LaneCtx cx; };
+
+__device__ __forceinline__ u32 kernel_prologue(const KernelArgs& ka, char* lds, u32 tid, u32 nthreads, u32 lane, LaneSetup& ls, bool& exit_now) {
   u32 n_items = ka.n_items;
-  if (ka.n_items_dev) { const u32 v = *ka.n_items_dev; n_items = v < n_items ? v : n_items; if (blockIdx.x * ka.G >= n_items) return; }
-  const u32 shared_words = ka.nconst * SLOT_WORDS;
-  for (u32 i = lane; i < shared_words; i += 64) smem[i] = ka.consts[i];
+  exit_now = false;
+  if (ka.n_items_dev) { const u32 v = *ka.n_items_dev; n_items = v < n_items ? v : n_items; if (blockIdx.x * ka.G >= n_items) { exit_now = true; return 0; } }
+  // constants: replicated at the start of every instance region
+  const u32 per_inst = ka.nconst * NL;
+  for (u32 i = tid; i < ka.G * per_inst; i += nthreads) {
+    const u32 g = i / per_inst, r = i - g * per_inst, c = r / NL, l = r - c * NL;
+    *(u32*)(lds + g * ka.inst_bytes + c * ka.slot_bytes + 4 * l) = ka.consts[c * RAW_WORDS + l];
+  }
   const u32 W = ka.W;
   const u32 inst_id = lane / W;
-  const u32 lane_in = (inst_id < ka.G) ? (lane - inst_id * W) : 0xffffu;
-  LaneCtx cx;
-  cx.inst = shared_words + inst_id * ka.slots * SLOT_WORDS;
-  cx.item = blockIdx.x * ka.G + inst_id;
-  cx.live = inst_id < ka.G && cx.item < n_items;
-  if (ka.item_index && cx.live) cx.item = ka.item_index[cx.item];
+  ls.lane_in = (inst_id < ka.G) ? (lane - inst_id * W) : 0xffffu;
+  ls.cx.inst = (inst_id < ka.G ? inst_id : 0) * ka.inst_bytes;
+  ls.cx.item = blockIdx.x * ka.G + inst_id;
+  ls.cx.live = inst_id < ka.G && ls.cx.item < n_items;
+  if (ka.item_index && ls.cx.live) ls.cx.item = ka.item_index[ls.cx.item];
+  return n_items;
+}
+
+template <bool FAIR> __device__ __forceinline__ void vm_kernel_body(const KernelArgs& ka) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds = smem;
+  const u32 lane = threadIdx.x;
+  LaneSetup ls; bool exit_now;
+  kernel_prologue(ka, lds, lane, 64, lane, ls, exit_now);
+  if (exit_now) return;
+  const u32 lane_in = ls.lane_in;
+  const LaneCtx cx = ls.cx;
   if (ka.hwid_out && lane == 0) { ka.hwid_out[5 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); ka.hwid_out[5 * blockIdx.x + 1] = __builtin_readcyclecounter(); ka.hwid_out[5 * blockIdx.x + 3] = wall_clock64(); }   // HW_ID, XCC_ID, start tick (s_memtime), start time (s_memrealtime, 100 MHz): placement study
   __syncthreads();   // single wave: orders the constant fill before first use
-  // Software-pipelined interpreter loop: this lane's descriptor words for step s+1 and the header of step s+2 are
-  // requested before step s executes, so their L2 latency overlaps the arithmetic.
+  // Software-pipelined interpreter loop: the header of step s+2 (scalar), this lane's descriptor header and first product round of
+  // step s+1 (vector) are requested before step s executes, so their latency overlaps the arithmetic.
   const uint4* descs4 = (const uint4*)ka.descs;
   Step st = ka.steps[0];
   Step nst = ka.steps[ka.nsteps > 1 ? 1 : 0];
-  uint4 d0 = make_uint4(0, 0, 0, 0), d1 = make_uint4(0, 0, 0, 0);
+  uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0, dr = d0;
   if (lane_in < st.nlanes) {
     const u32 o = (st.desc_off + lane_in * st.stride) >> 2;
     d0 = descs4[o];
     if (st.stride > 4) d1 = descs4[o + 1];
+    if (st.stride > 8) dr = descs4[o + 2];
   }
   // Fairness between the wavefronts that share a SIMD: the issue arbiter prefers the oldest wavefront, which then runs at ~94 % of
   // its lone speed while a second one gets ~55 % and a third ~23 % (tools/placement.py), so the youngest finishes long after the
@@ -41,95 +64,102 @@ template <bool FAIR> __device__ __forceinline__ void vm_kernel_body(const Kernel
   // for launches that put 2-4 wavefronts on every SIMD in a single round (8192..16384 pairings).  The launcher picks the FAIR instantiation only
   // for those: with one wavefront per SIMD there is nothing to balance, and in steady state (many rounds, or several batches in
   // flight) the priorities cost ~2 %.
-  // Two instantiations: even a never-taken priority test in this loop costs a lone wavefront 5 % (measured), so the variant without
-  // the priority code is a kernel of its own.
   const u32 quarter = (ka.nsteps >> 2) + 1;
   if (FAIR) __builtin_amdgcn_s_setprio(3);
   for (u32 s = 0; s < ka.nsteps; s++) {
     if (FAIR) { if (s == quarter) __builtin_amdgcn_s_setprio(2); else if (s == 3 * quarter) __builtin_amdgcn_s_setprio(1); }
-    // header of step s+2 is requested now and first looked at one iteration later; the header of step s+1 arrived during
-    // the previous step, so the descriptor prefetch below does not wait on global memory (a lone wavefront has nobody to
-    // hide a ~2 us header round trip per step behind)
     const u32 sn = (s + 2 < ka.nsteps) ? s + 2 : ka.nsteps - 1;
     const Step nnst = ka.steps[sn];
-    uint4 n0 = make_uint4(0, 0, 0, 0), n1 = make_uint4(0, 0, 0, 0);
+    uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, nr = n0;
     if (lane_in < nst.nlanes) {
       const u32 o = (nst.desc_off + lane_in * nst.stride) >> 2;
       n0 = descs4[o];
       if (nst.stride > 4) n1 = descs4[o + 1];
+      if (nst.stride > 8) nr = descs4[o + 2];
     }
     if (lane_in < st.nlanes) {
-      u32 d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+      const u32 d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
       u32 res[NL];
-      u32 dst = exec_lane(st, d, ka.descs + st.desc_off + lane_in * st.stride, smem, cx, ka.bufs, res);
-      if (dst != 0xffffffffu) {
-#pragma unroll
-        for (int i = 0; i < NL; i++) smem[dst + i] = res[i];
+      u32 dst;
+      if (st.kind == K_DOT) {   // uniform
+        u64 acc[2 * NL];
+        dot_init(acc, st, d[0]);
+        const uint4* gr = descs4 + ((st.desc_off + lane_in * st.stride) >> 2) + 3;   // descriptor of round 1
+        uint4 cur = dr;
+        for (u32 r = 0; r < st.p0; r++) {   // uniform trip count; the next round's offsets are fetched ahead
+          uint4 nx = cur;
+          if (r + 1 < st.p0) nx = gr[r];
+          dot_round(acc, round_shape(st, r), cur.x, cur.y, cur.z, cur.w, lds, cx);
+          cur = nx;
+        }
+        dst = dot_finish(res, acc, st, d, lds, cx);
+      } else {
+        dst = exec_lane(st, d, lds, cx, ka.bufs, res);
       }
+      if (dst != 0xffffffffu) st14(lds, dst, res);
     }
-    st = nst; nst = nnst; d0 = n0; d1 = n1;
+    st = nst; nst = nnst; d0 = n0; d1 = n1; dr = nr;
   }
   if (ka.hwid_out && lane == 0) { ka.hwid_out[5 * blockIdx.x + 2] = __builtin_readcyclecounter(); ka.hwid_out[5 * blockIdx.x + 4] = wall_clock64(); }
 }
 extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel(KernelArgs ka) { vm_kernel_body<false>(ka); }
 extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel_fair(KernelArgs ka) { vm_kernel_body<true>(ka); }
 
-// Two-wave variant for small batches.  A lone wavefront per SIMD issues at ~1/3 of the VALU rate (every instruction waits
-// for the previous one; tools/ubench/lone_wave.hip) and a second wavefront on the same SIMD runs at full speed beside it,
-// so when a launch has no more workgroups than the chip has SIMDs each workgroup gets TWO wavefronts that share the work
-// of every K_DOT lane-op: wave 0 accumulates the first half of the products, wave 1 the second half; wave 1 hands its 28
-// column accumulators over through LDS, wave 0 adds them, reduces once and finishes the lane-op.  Same instances, same
-// slots, same results (integer sums in a different order); ~0.65x the instructions per wavefront.
+// Two-wave variant for small batches.  A lone wavefront per SIMD issues at ~1/2 of the VALU rate (tools/ubench/lone_wave.hip)
+// and a second wavefront on the same SIMD runs beside it, so when a launch has no more workgroups than the chip has CUs each
+// workgroup gets TWO wavefronts that share the work of every K_DOT step: wave 0 accumulates the first half of the product
+// rounds, wave 1 the second half; wave 1 hands its 28 column accumulators over through LDS, wave 0 adds them, reduces once and
+// finishes the lane-op.  Same instances, same slots, same results (integer sums in a different order).
 extern "C" __global__ void __launch_bounds__(128) nbls_vm_kernel_split(KernelArgs ka) {
-  extern __shared__ __attribute__((aligned(16))) u32 smem[];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds = smem;
   const u32 tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  u32 n_items = ka.n_items;
-  if (ka.n_items_dev) { const u32 v = *ka.n_items_dev; n_items = v < n_items ? v : n_items; if (blockIdx.x * ka.G >= n_items) return; }
-  const u32 shared_words = ka.nconst * SLOT_WORDS;
-  for (u32 i = tid; i < shared_words; i += 128) smem[i] = ka.consts[i];
-  const u32 W = ka.W;
-  const u32 inst_id = lane / W;
-  const u32 lane_in = (inst_id < ka.G) ? (lane - inst_id * W) : 0xffffu;
-  LaneCtx cx;
-  cx.inst = shared_words + inst_id * ka.slots * SLOT_WORDS;
-  cx.item = blockIdx.x * ka.G + inst_id;
-  cx.live = inst_id < ka.G && cx.item < n_items;
-  if (ka.item_index && cx.live) cx.item = ka.item_index[cx.item];
-  u64* xch = (u64*)(smem + (ka.nconst + ka.G * ka.slots) * SLOT_WORDS);   // exchange area: 28 columns x 64 lanes, column-major (conflict-free)
+  LaneSetup ls; bool exit_now;
+  kernel_prologue(ka, lds, tid, 128, lane, ls, exit_now);
+  if (exit_now) return;
+  const u32 lane_in = ls.lane_in;
+  const LaneCtx cx = ls.cx;
+  u64* xch = (u64*)(lds + ka.G * ka.inst_bytes);   // exchange area: 28 columns x 64 lanes, column-major (conflict-free)
   __syncthreads();
   const uint4* descs4 = (const uint4*)ka.descs;
   Step st = ka.steps[0];
   Step nst = ka.steps[ka.nsteps > 1 ? 1 : 0];
-  uint4 d0 = make_uint4(0, 0, 0, 0), d1 = make_uint4(0, 0, 0, 0);
+  uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0;
   if (lane_in < st.nlanes) {
     const u32 o = (st.desc_off + lane_in * st.stride) >> 2;
     d0 = descs4[o];
     if (st.stride > 4) d1 = descs4[o + 1];
   }
   for (u32 s = 0; s < ka.nsteps; s++) {
-    // header of step s+2 is requested now and first looked at one iteration later; the header of step s+1 arrived during
-    // the previous step, so the descriptor prefetch below does not wait on global memory (a lone wavefront has nobody to
-    // hide a ~2 us header round trip per step behind)
     const u32 sn = (s + 2 < ka.nsteps) ? s + 2 : ka.nsteps - 1;
     const Step nnst = ka.steps[sn];
-    uint4 n0 = make_uint4(0, 0, 0, 0), n1 = make_uint4(0, 0, 0, 0);
+    uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
     if (lane_in < nst.nlanes) {
       const u32 o = (nst.desc_off + lane_in * nst.stride) >> 2;
       n0 = descs4[o];
       if (nst.stride > 4) n1 = descs4[o + 1];
     }
     const bool active = lane_in < st.nlanes;
-    u32 d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-    const u32* gd = ka.descs + st.desc_off + lane_in * st.stride;
-    if (st.kind == K_DOT && st.p0 >= 2) {        // uniform: split the product loop between the two waves
+    const u32 d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    const uint4* gr = descs4 + ((st.desc_off + lane_in * st.stride) >> 2) + 2;   // descriptor of round 0
+    if (st.kind == K_DOT && st.p0 >= 2) {        // uniform: split the product rounds between the two waves
       const u32 h = (st.p0 + 1) / 2;
       u64 acc[2 * NL];
       if (active) {
-        if (wave == 0) { acc_init(acc, d[0] >> 28); dot_products(acc, st, d, gd, smem, cx, 0, h); }
+        const u32 lo = wave == 0 ? 0 : h, hi = wave == 0 ? h : st.p0;
+        if (wave == 0) dot_init(acc, st, d[0]);
         else {
 #pragma unroll
           for (int c = 0; c < 2 * NL; c++) acc[c] = 0;
-          dot_products(acc, st, d, gd, smem, cx, h, st.p0);
+        }
+        uint4 cur = gr[lo];
+        for (u32 r = lo; r < hi; r++) {
+          uint4 nx = cur;
+          if (r + 1 < hi) nx = gr[r + 1];
+          dot_round(acc, round_shape(st, r), cur.x, cur.y, cur.z, cur.w, lds, cx);
+          cur = nx;
+        }
+        if (wave == 1) {
 #pragma unroll
           for (int c = 0; c < 2 * NL; c++) xch[c * 64 + lane] = acc[c];
         }
@@ -139,17 +169,19 @@ extern "C" __global__ void __launch_bounds__(128) nbls_vm_kernel_split(KernelArg
 #pragma unroll
         for (int c = 0; c < 2 * NL; c++) acc[c] += xch[c * 64 + lane];
         u32 res[NL];
-        const u32 dst = dot_result(res, acc, true, st, d, smem, cx);
-#pragma unroll
-        for (int i = 0; i < NL; i++) smem[dst + i] = res[i];
+        const u32 dst = dot_finish(res, acc, st, d, lds, cx);
+        st14(lds, dst, res);
       }
     } else if (active && wave == 0) {
       u32 res[NL];
-      const u32 dst = exec_lane(st, d, gd, smem, cx, ka.bufs, res);
-      if (dst != 0xffffffffu) {
-#pragma unroll
-        for (int i = 0; i < NL; i++) smem[dst + i] = res[i];
-      }
+      u32 dst;
+      if (st.kind == K_DOT) {
+        u64 acc[2 * NL];
+        dot_init(acc, st, d[0]);
+        for (u32 r = 0; r < st.p0; r++) { const uint4 cur = gr[r]; dot_round(acc, round_shape(st, r), cur.x, cur.y, cur.z, cur.w, lds, cx); }
+        dst = dot_finish(res, acc, st, d, lds, cx);
+      } else dst = exec_lane(st, d, lds, cx, ka.bufs, res);
+      if (dst != 0xffffffffu) st14(lds, dst, res);
     }
     __syncthreads();
     st = nst; nst = nnst; d0 = n0; d1 = n1;
@@ -163,16 +195,23 @@ extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, vo
   using namespace nbls;
   if (ka->n_items == 0) return 0;
   unsigned blocks = (ka->n_items + ka->G - 1) / ka->G;
-  static bool attr_set = false;
+  // the dynamic-LDS limit is a per-device function attribute: set it once on every device a launch is made on
+  static std::mutex attr_mu;
+  static bool attr_set[64] = {false};
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    std::lock_guard<std::mutex> g(attr_mu);
+    if (!attr_set[dev]) {
+      hipFuncSetAttribute((const void*)nbls_vm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute((const void*)nbls_vm_kernel_fair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute((const void*)nbls_vm_kernel_split, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set[dev] = true;
+    }
+  }
   // NBLS_SPLIT: 0 = never, 1 = always, unset = for launches of at most 256 workgroups (one per CU): measured 18 % lower latency
   // there, break-even at 512 workgroups, a loss beyond (two co-resident wavefronts per CU contend for LDS)
   static const int split_mode = getenv("NBLS_SPLIT") ? atoi(getenv("NBLS_SPLIT")) : -1;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)nbls_vm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)nbls_vm_kernel_fair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)nbls_vm_kernel_split, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
   static const unsigned lds_floor = getenv("NBLS_LDS_FLOOR") ? (unsigned)atoi(getenv("NBLS_LDS_FLOOR")) : 0u;   // placement studies: caps workgroups per CU at 160 KB / floor
   if (lds_bytes < lds_floor) lds_bytes = lds_floor;
   const bool split = split_mode == 1 || (split_mode < 0 && blocks <= 256);

@@ -13,12 +13,13 @@
 using namespace nbls;
 
 static void sim_run(const Program& p, unsigned n_items, const IOBuf* bufs) {
-  const unsigned shared = p.nconst * SLOT_WORDS;
-  std::vector<u32> lds(lds_words(p.nconst, p.G, p.slots));
+  const unsigned inst_bytes = p.inst_bytes();
+  std::vector<V4> lds4((size_t)p.G * inst_bytes / 16 + 1);
+  char* lds = (char*)lds4.data();
   unsigned blocks = (n_items + p.G - 1) / p.G;
   for (unsigned blk = 0; blk < blocks; blk++) {
-    std::fill(lds.begin(), lds.end(), 0xdeadbeefu);
-    memcpy(lds.data(), p.consts.data(), shared * 4);
+    memset(lds, 0xde, (size_t)p.G * inst_bytes);
+    for (unsigned g = 0; g < p.G; g++) for (unsigned c = 0; c < p.nconst; c++) memcpy(lds + g * inst_bytes + c * p.slot_bytes, p.consts.data() + c * RAW_WORDS, NL * 4);
     for (size_t s = 0; s < p.steps.size(); s++) {
       const Step& st = p.steps[s];
       struct Pending { u32 dst; u32 v[NL]; };
@@ -28,15 +29,20 @@ static void sim_run(const Program& p, unsigned n_items, const IOBuf* bufs) {
         if (inst >= p.G) continue;
         unsigned lane_in = lane - inst * p.W;
         if (lane_in >= st.nlanes) continue;
-        LaneCtx cx; cx.inst = shared + inst * p.slots * SLOT_WORDS; cx.item = blk * p.G + inst; cx.live = cx.item < n_items;
+        LaneCtx cx; cx.inst = inst * inst_bytes; cx.item = blk * p.G + inst; cx.live = cx.item < n_items;
         Pending pd;
         u32 dw[8] = {0};
         const u32* gd = p.descs.data() + st.desc_off + lane_in * st.stride;
         memcpy(dw, gd, (st.stride < 8 ? st.stride : 8) * 4);
-        pd.dst = exec_lane(st, dw, gd, lds.data(), cx, bufs, pd.v);
+        if (st.kind == K_DOT) {
+          u64 acc[2 * NL];
+          dot_init(acc, st, dw[0]);
+          for (u32 r = 0; r < st.p0; r++) { const u32* rd = gd + DOT_HDR_WORDS + DOT_ROUND_WORDS * r; dot_round(acc, round_shape(st, r), rd[0], rd[1], rd[2], rd[3], lds, cx); }
+          pd.dst = dot_finish(pd.v, acc, st, dw, lds, cx);
+        } else pd.dst = exec_lane(st, dw, lds, cx, bufs, pd.v);
         if (pd.dst != 0xffffffffu) pend.push_back(pd);
       }
-      for (auto& pd : pend) memcpy(&lds[pd.dst], pd.v, NL * 4);
+      for (auto& pd : pend) st14(lds, pd.dst, pd.v);
     }
   }
 }
