@@ -54,6 +54,26 @@ int nbls_miller_product(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, const ui
                         uint8_t* out_fp12, int8_t* status);
 int nbls_miller_product_dev(nbls_ctx* ctx, size_t n, const void* d_g1_aff, const void* d_g2_aff, int final_exp, void* d_out_fp12, void* stream);
 
+/* Prepared G2 points.  PointG2.pairingPrecomputes() (index.ts:703-711) memoises calcPairingPrecomputes (math.ts:1331-1371): the 68 line
+ * triples [Fp2, Fp2, Fp2] of the Miller loop, which depend on Q alone; PointG1.millerLoop (index.ts:452-454) then runs millerLoop
+ * (math.ts:1373-1388) over them.  A table lives on the device in the engine's raw limb format (NBLS_LINE_TABLE_BYTES per point) or
+ * crosses the ABI as the reference's value, 68 x (c0 || c1 || c2) in Fp2.toBytes order (NBLS_LINE_WIRE_BYTES per point).  Many P
+ * against one Q (one message signed by many keys, index.ts:804-812) pass table_stride = 0 / n_tables = 1. */
+#define NBLS_LINE_TABLE_BYTES 26112
+#define NBLS_LINE_WIRE_BYTES 19584
+int nbls_g2_prepare(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, uint8_t* out_tables_wire);
+int nbls_g2_prepare_dev(nbls_ctx* ctx, size_t n, const void* d_g2_aff, void* d_tables, void* stream);
+int nbls_lines_to_wire_dev(nbls_ctx* ctx, size_t n, const void* d_tables, void* d_tables_wire, void* stream);
+int nbls_lines_from_wire_dev(nbls_ctx* ctx, size_t n, const void* d_tables_wire, void* d_tables, void* stream);
+/* pairing(P_i, Q_i) / prod_i millerLoop(P_i, Q_i) with prepared Q: table_stride = NBLS_LINE_TABLE_BYTES (a table per item) or 0 (one table) */
+int nbls_pairing_prepared_dev(nbls_ctx* ctx, size_t n, const void* d_g1_aff, const void* d_tables, size_t table_stride, int with_final_exp,
+                              void* d_out_fp12, void* stream);
+int nbls_miller_product_prepared_dev(nbls_ctx* ctx, size_t n, const void* d_g1_aff, const void* d_tables, size_t table_stride, int final_exp,
+                                     void* d_out_fp12, void* stream);
+/* host buffers: n_tables = n or 1 tables in wire form; product != 0 returns ONE Fp12 (the product, optionally final-exponentiated) */
+int nbls_pairing_prepared(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, const uint8_t* tables_wire, size_t n_tables, int with_final_exp,
+                          int product, uint8_t* out_fp12);
+
 /* Fp12.finalExponentiate for n elements -- reference math.ts:856-874. */
 int nbls_final_exp_batch(nbls_ctx* ctx, size_t n, const uint8_t* in_fp12, uint8_t* out_fp12);
 int nbls_final_exp_batch_dev(nbls_ctx* ctx, size_t n, const void* d_in_fp12, void* d_out_fp12, void* stream);
@@ -137,7 +157,9 @@ int nbls_device_synchronize(nbls_ctx* ctx);
 /* Placement study (tools/placement.py): runs one step program on n scratch items; out_blocks[5b..5b+4] = HW_ID | XCC_ID << 32, start tick, end tick (s_memtime), start, end time (s_memrealtime, 100 MHz) of workgroup b. */
 int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks);
 /* Per-kernel HIP-event timing (benchmark roofline leg): ms[i]/counts[i] for program i, last entry = inversion kernel. */
-#define NBLS_N_PROGRAMS 64
+#define NBLS_N_PROGRAMS 96
+int nbls_program_count(void);                 /* number of step programs; timing slot nbls_program_count() = the inversion kernel */
+const char* nbls_program_name(int prog);
 int nbls_timing_enable(nbls_ctx* ctx, int on);
 int nbls_timing_read(nbls_ctx* ctx, float* ms /*[NBLS_N_PROGRAMS+1]*/, uint32_t* counts /*[NBLS_N_PROGRAMS+1]*/);
 

@@ -31,8 +31,12 @@ using namespace nbls;
 static_assert(P_COUNT <= NBLS_N_PROGRAMS, "nbls_timing_read's arrays (NBLS_N_PROGRAMS + 1 entries) must cover every step program");
 static const size_t RAW = RAW_FP_BYTES;     // one raw field element in HBM scratch (14 limbs + padding)
 static const size_t F12 = 12 * RAW;        // raw Fp12
+static const size_t LINE_BYTES = (size_t)LINE_ELEMS * RAW;   // one line table: 68 triples of Fp2 as raw elements (26,112 B)
+static const size_t SPLIT_MILLER_MIN = 16384;   // pairs from which the Miller loop runs as LINES + ACC (see nbls_pairing_batch_dev)
+static const size_t LINES_CHUNK = 65536;   // pairs whose line tables are in HBM at a time (1.7 GB); larger batches run chunk by chunk on the same stream
 
 #define EXPORT extern "C" __attribute__((visibility("default")))
+static std::recursive_mutex g_null_mu;   // locked in place of a context's mutex when the caller passed no context (the call then fails with NBLS_EINVAL)
 
 struct DevProgram {
   Step* steps = nullptr; u32* descs = nullptr; u32* consts = nullptr;
@@ -42,7 +46,7 @@ struct DevProgram {
 struct nbls_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  std::mutex mu;
+  std::recursive_mutex mu;   // held for the whole of every exported call (host-level calls re-enter it through the *_dev entry points)
   DevProgram prog[P_COUNT];
   // scratch (device)
   uint8_t *F = nullptr, *F2 = nullptr, *N = nullptr, *NI = nullptr, *io_g1 = nullptr, *io_g2 = nullptr, *io_f12 = nullptr, *one12 = nullptr;
@@ -59,6 +63,9 @@ struct nbls_ctx {
   hipStream_t side2 = nullptr; hipEvent_t ev_join2 = nullptr;   // verifyBatch: key decoding runs beside message hashing (their exponentiation kernels are latency-bound and leave issue slots free)
   uint8_t* ident_g1 = nullptr; uint8_t* ident_g2 = nullptr;   // projective identity (0 : 1 : 0), raw
   size_t cap_F = 0, cap_io = 0;
+  uint8_t* L = nullptr; size_t cap_L = 0;   // line tables of the Miller loop (LINE_BYTES each), at most LINES_CHUNK of them
+  // the scratch above is shared by every call on this context: a call that uses another stream than its predecessor waits for it (StreamOrder)
+  hipStream_t last_stream = nullptr; hipEvent_t ev_last = nullptr; bool ev_last_set = false;
   int last_hip = 0;
   // optional per-kernel timing (HIP events on the launch stream); slot P_COUNT = inversion kernel
   bool timing = false;
@@ -107,8 +114,8 @@ static int run_inv(nbls_ctx* ctx, size_t n, hipStream_t s) {
 static int ensure_scratch(nbls_ctx* ctx, size_t n) {
   if (n <= ctx->cap_F) return NBLS_OK;
   size_t cap = n + n / 8 + 64;
-  if (ctx->F) { hipFree(ctx->F); hipFree(ctx->F2); hipFree(ctx->N); hipFree(ctx->NI); for (auto& t : ctx->T) hipFree(t); }
-  ctx->cap_F = 0;
+  if (ctx->F) { hipFree(ctx->F); hipFree(ctx->F2); hipFree(ctx->N); hipFree(ctx->NI); for (auto& t : ctx->T) { hipFree(t); t = nullptr; } }
+  ctx->F = ctx->F2 = ctx->N = ctx->NI = nullptr; ctx->cap_F = 0;
   HIPCHK(hipMalloc(&ctx->F, (cap + 2) * F12));
   HIPCHK(hipMalloc(&ctx->F2, (cap / 2 + 2) * F12));
   HIPCHK(hipMalloc(&ctx->N, cap * RAW));
@@ -121,7 +128,7 @@ static int ensure_io(nbls_ctx* ctx, size_t n) {
   if (n <= ctx->cap_io) return NBLS_OK;
   size_t cap = n + 64;
   if (ctx->io_g1) { hipFree(ctx->io_g1); hipFree(ctx->io_g2); hipFree(ctx->io_f12); }
-  ctx->cap_io = 0;
+  ctx->io_g1 = ctx->io_g2 = ctx->io_f12 = nullptr; ctx->cap_io = 0;
   HIPCHK(hipMalloc(&ctx->io_g1, cap * 96));
   HIPCHK(hipMalloc(&ctx->io_g2, cap * 192));
   HIPCHK(hipMalloc(&ctx->io_f12, cap * 576));
@@ -129,6 +136,16 @@ static int ensure_io(nbls_ctx* ctx, size_t n) {
   return NBLS_OK;
 }
 
+static int ensure_lines(nbls_ctx* ctx, size_t n) {
+  if (n > LINES_CHUNK) n = LINES_CHUNK;
+  if (n <= ctx->cap_L) return NBLS_OK;
+  size_t cap = n + n / 8 + 8; if (cap > LINES_CHUNK) cap = LINES_CHUNK;
+  if (ctx->L) hipFree(ctx->L);
+  ctx->L = nullptr; ctx->cap_L = 0;
+  HIPCHK(hipMalloc(&ctx->L, cap * LINE_BYTES));
+  ctx->cap_L = cap;
+  return NBLS_OK;
+}
 static int need(nbls_ctx* ctx, int i, size_t bytes, uint8_t** out) {
   if (bytes > ctx->sb_cap[i]) {
     if (ctx->sb[i]) hipFree(ctx->sb[i]);
@@ -152,6 +169,18 @@ static int run_inv_buf(nbls_ctx* ctx, size_t n, const void* in, void* out, hipSt
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
   return NBLS_OK;
 }
+
+
+// Calls on one context share its scratch buffers.  The mutex serialises the host side; on the device, work submitted to the
+// SAME stream is ordered anyway, and a call that names a different stream than its predecessor is made to wait for it.
+struct StreamOrder {
+  nbls_ctx* ctx; hipStream_t s;
+  StreamOrder(nbls_ctx* c, hipStream_t st) : ctx(c), s(st) {
+    if (!ctx->ev_last) hipEventCreateWithFlags(&ctx->ev_last, hipEventDisableTiming);
+    if (ctx->ev_last && ctx->ev_last_set && ctx->last_stream != s) hipStreamWaitEvent(s, ctx->ev_last, 0);
+  }
+  ~StreamOrder() { if (ctx->ev_last && hipEventRecord(ctx->ev_last, s) == hipSuccess) { ctx->ev_last_set = true; ctx->last_stream = s; } }
+};
 
 typedef std::pair<int, std::pair<const void*, size_t>> BufArg;
 static inline BufArg B(int idx, const void* p, size_t stride) { return {idx, {p, stride}}; }
@@ -236,14 +265,14 @@ EXPORT void nbls_destroy(nbls_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   for (auto& d : ctx->prog) { if (d.steps) hipFree(d.steps); if (d.descs) hipFree(d.descs); if (d.consts) hipFree(d.consts); }
-  for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->gen_g1, ctx->side_scratch}) if (p) hipFree(p);
+  for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->gen_g1, ctx->side_scratch, ctx->L}) if (p) hipFree(p);
   for (uint8_t* p : ctx->T) if (p) hipFree(p);
   for (uint8_t* p : ctx->sb) if (p) hipFree(p);
   for (uint8_t* p : ctx->nib) if (p) hipFree(p);
   for (uint8_t* p : {ctx->neg_g1, ctx->ident_g1, ctx->ident_g2}) if (p) hipFree(p);
   if (ctx->side) hipStreamDestroy(ctx->side);
   if (ctx->side2) hipStreamDestroy(ctx->side2);
-  for (hipEvent_t e : {ctx->ev_fork, ctx->ev_join, ctx->ev_join2}) if (e) hipEventDestroy(e);
+  for (hipEvent_t e : {ctx->ev_fork, ctx->ev_join, ctx->ev_join2, ctx->ev_last}) if (e) hipEventDestroy(e);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -265,17 +294,40 @@ EXPORT int nbls_device_synchronize(nbls_ctx* ctx) { if (!ctx) return NBLS_EINVAL
 EXPORT int nbls_pairing_batch_dev(nbls_ctx* ctx, size_t n, const void* d_g1, const void* d_g2, int with_final_exp, void* d_out, void* stream) {
   if (!ctx || (n && (!d_g1 || !d_g2 || !d_out))) return NBLS_EINVAL;
   if (n == 0) return NBLS_OK;
-  std::lock_guard<std::mutex> g(ctx->mu);
+  std::lock_guard<std::recursive_mutex> g(ctx->mu);
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  StreamOrder order_(ctx, s);
   int r;
-  if (!with_final_exp) return run(ctx, P_MILLER_BYTES, n, {B(0, d_g1, 96), B(1, d_g2, 192), B(2, d_out, 576)}, s);
-  if ((r = ensure_scratch(ctx, n))) return r;
-  if ((r = run(ctx, P_MILLER_FE, n, {B(0, d_g1, 96), B(1, d_g2, 192), B(3, ctx->F, F12), B(4, ctx->N, RAW)}, s))) return r;
+  // One program or two?  LINES + ACC execute 15 % fewer instructions per pairing (no idle lanes in the Fp12 steps, 20 instead of 37 lane-ops
+  // per bit in the point chain) but are two dependent chains of 316 + 173 steps where the fused program has 349: a launch that is only one
+  // wavefront per SIMD deep takes the time of its longest instruction stream, so small batches keep the fused program (4096 pairings: 1.43 ms
+  // against 0.72 + 0.94 ms; 65,536: 12.9 against 12.5 ms).  NBLS_FUSED_MILLER = 1 / 0 forces one or the other.
+  static const int fused_mode = getenv("NBLS_FUSED_MILLER") ? atoi(getenv("NBLS_FUSED_MILLER")) : -1;
+  const bool fused = fused_mode >= 0 ? fused_mode != 0 : n < SPLIT_MILLER_MIN;
+  if (fused) {
+    if (!with_final_exp) return run(ctx, P_MILLER_BYTES, n, {B(0, d_g1, 96), B(1, d_g2, 192), B(2, d_out, 576)}, s);
+    if ((r = ensure_scratch(ctx, n))) return r;
+    if ((r = run(ctx, P_MILLER_FE, n, {B(0, d_g1, 96), B(1, d_g2, 192), B(3, ctx->F, F12), B(4, ctx->N, RAW)}, s))) return r;
+    return final_exp_pipeline(ctx, n, ctx->F, d_out, s);
+  }
+  // calcPairingPrecomputes + millerLoop (math.ts:1331-1388) as two programs: line tables through HBM (LINE_BYTES per pair)
+  if ((r = ensure_lines(ctx, n))) return r;
+  if (with_final_exp && (r = ensure_scratch(ctx, n))) return r;
+  for (size_t o = 0; o < n; o += LINES_CHUNK) {
+    const size_t c = n - o < LINES_CHUNK ? n - o : LINES_CHUNK;
+    const uint8_t *g1 = (const uint8_t*)d_g1 + o * 96, *g2 = (const uint8_t*)d_g2 + o * 192;
+    if ((r = run(ctx, P_LINES_PQ, c, {B(0, g1, 96), B(1, g2, 192), B(3, ctx->L, LINE_BYTES)}, s))) return r;
+    if (!with_final_exp) r = run(ctx, P_ACC_BYTES, c, {B(3, ctx->L, LINE_BYTES), B(2, (uint8_t*)d_out + o * 576, 576)}, s);
+    else r = run(ctx, P_ACC_FE, c, {B(3, ctx->L, LINE_BYTES), B(5, ctx->F + o * F12, F12), B(4, ctx->N + o * RAW, RAW)}, s);
+    if (r) return r;
+  }
+  if (!with_final_exp) return NBLS_OK;
   return final_exp_pipeline(ctx, n, ctx->F, d_out, s);
 }
 
 EXPORT int nbls_pairing_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2, int with_final_exp, int validate, uint8_t* out, int8_t* status) {
+  std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);   // scratch and I/O staging buffers belong to this call until it returns
   if (!ctx || (n && (!g1 || !g2 || !out))) return NBLS_EINVAL;
   if (n == 0) return NBLS_OK;
   int r;
@@ -285,14 +337,14 @@ EXPORT int nbls_pairing_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1, const 
     if ((r = nbls_g1_validate_batch(ctx, n, g1, st1.data())) || (r = nbls_g2_validate_batch(ctx, n, g2, st2.data()))) return r;
   }
   {
-    std::lock_guard<std::mutex> g(ctx->mu);
+    std::lock_guard<std::recursive_mutex> g(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     if ((r = ensure_io(ctx, n))) return r;
     HIPCHK(hipMemcpyAsync(ctx->io_g1, g1, n * 96, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->io_g2, g2, n * 192, hipMemcpyHostToDevice, ctx->stream));
   }
   if ((r = nbls_pairing_batch_dev(ctx, n, ctx->io_g1, ctx->io_g2, with_final_exp, ctx->io_f12, ctx->stream))) return r;
-  std::lock_guard<std::mutex> g(ctx->mu);
+  std::lock_guard<std::recursive_mutex> g(ctx->mu);
   HIPCHK(hipMemcpyAsync(out, ctx->io_f12, n * 576, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (status) memset(status, 0, n);
@@ -305,9 +357,10 @@ EXPORT int nbls_pairing_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1, const 
 
 EXPORT int nbls_miller_product_dev(nbls_ctx* ctx, size_t n, const void* d_g1, const void* d_g2, int final_exp, void* d_out, void* stream) {
   if (!ctx || !d_out || (n && (!d_g1 || !d_g2))) return NBLS_EINVAL;
-  std::lock_guard<std::mutex> g(ctx->mu);
+  std::lock_guard<std::recursive_mutex> g(ctx->mu);
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  StreamOrder order_(ctx, s);
   int r;
   if ((r = ensure_scratch(ctx, n ? n : 1))) return r;
   uint8_t* res = ctx->F;
@@ -315,14 +368,27 @@ EXPORT int nbls_miller_product_dev(nbls_ctx* ctx, size_t n, const void* d_g1, co
   else {
     // pairs are taken two at a time with a shared accumulator (one Fp12 squaring per bit for both); an odd last pair runs alone
     const size_t n2 = n / 2, m = n2 + (n & 1);
-    if (n2 && (r = run(ctx, P_MILLER_RAW2, n2, {B(0, d_g1, 192), B(1, d_g2, 384), B(3, ctx->F, F12)}, s))) return r;
-    if ((n & 1) && (r = run(ctx, P_MILLER_RAW, 1, {B(0, (const uint8_t*)d_g1 + (n - 1) * 96, 96), B(1, (const uint8_t*)d_g2 + (n - 1) * 192, 192), B(3, ctx->F + n2 * F12, F12)}, s))) return r;
+    static const int fused_mode = getenv("NBLS_FUSED_MILLER") ? atoi(getenv("NBLS_FUSED_MILLER")) : -1;
+    const bool fused = fused_mode >= 0 ? fused_mode != 0 : n < SPLIT_MILLER_MIN;
+    if (fused) {
+      if (n2 && (r = run(ctx, P_MILLER_RAW2, n2, {B(0, d_g1, 192), B(1, d_g2, 384), B(3, ctx->F, F12)}, s))) return r;
+      if ((n & 1) && (r = run(ctx, P_MILLER_RAW, 1, {B(0, (const uint8_t*)d_g1 + (n - 1) * 96, 96), B(1, (const uint8_t*)d_g2 + (n - 1) * 192, 192), B(3, ctx->F + n2 * F12, F12)}, s))) return r;
+    } else {
+      if ((r = ensure_lines(ctx, n))) return r;
+      for (size_t o = 0; o < n; o += LINES_CHUNK) {   // LINES_CHUNK is even: a chunk boundary never splits a pair of pairs
+        const size_t c = n - o < LINES_CHUNK ? n - o : LINES_CHUNK, c2 = c / 2;
+        if ((r = run(ctx, P_LINES_PQ, c, {B(0, (const uint8_t*)d_g1 + o * 96, 96), B(1, (const uint8_t*)d_g2 + o * 192, 192), B(3, ctx->L, LINE_BYTES)}, s))) return r;
+        if (c2 && (r = run(ctx, P_ACC2_RAW, c2, {B(3, ctx->L, 2 * LINE_BYTES), B(5, ctx->F + (o / 2) * F12, F12)}, s))) return r;
+        if ((c & 1) && (r = run(ctx, P_ACC_RAW, 1, {B(3, ctx->L + (c - 1) * LINE_BYTES, LINE_BYTES), B(5, ctx->F + (o / 2 + c2) * F12, F12)}, s))) return r;
+      }
+    }
     if ((r = reduce_product(ctx, m, &res, s))) return r;
   }
   return finish_single(ctx, res, final_exp, d_out, s);
 }
 
 EXPORT int nbls_miller_product(nbls_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2, int final_exp, int validate, uint8_t* out, int8_t* status) {
+  std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);   // scratch and I/O staging buffers belong to this call until it returns
   if (!ctx || !out || (n && (!g1 || !g2))) return NBLS_EINVAL;
   int r;
   if (validate && n) {
@@ -332,7 +398,7 @@ EXPORT int nbls_miller_product(nbls_ctx* ctx, size_t n, const uint8_t* g1, const
     if (bad) { memset(out, 0, 576); return NBLS_EDECODE; }
   }
   {
-    std::lock_guard<std::mutex> g(ctx->mu);
+    std::lock_guard<std::recursive_mutex> g(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     if ((r = ensure_io(ctx, n ? n : 1))) return r;
     if (n) {
@@ -341,7 +407,7 @@ EXPORT int nbls_miller_product(nbls_ctx* ctx, size_t n, const uint8_t* g1, const
     }
   }
   if ((r = nbls_miller_product_dev(ctx, n, ctx->io_g1, ctx->io_g2, final_exp, ctx->io_f12, ctx->stream))) return r;
-  std::lock_guard<std::mutex> g(ctx->mu);
+  std::lock_guard<std::recursive_mutex> g(ctx->mu);
   HIPCHK(hipMemcpyAsync(out, ctx->io_f12, 576, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (status) memset(status, 0, n);
@@ -351,9 +417,10 @@ EXPORT int nbls_miller_product(nbls_ctx* ctx, size_t n, const uint8_t* g1, const
 EXPORT int nbls_final_exp_batch_dev(nbls_ctx* ctx, size_t n, const void* d_in, void* d_out, void* stream) {
   if (!ctx || (n && (!d_in || !d_out))) return NBLS_EINVAL;
   if (n == 0) return NBLS_OK;
-  std::lock_guard<std::mutex> g(ctx->mu);
+  std::lock_guard<std::recursive_mutex> g(ctx->mu);
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  StreamOrder order_(ctx, s);
   int r;
   if ((r = ensure_scratch(ctx, n))) return r;
   if ((r = run(ctx, P_NORM_BYTES, n, {B(2, d_in, 576), B(3, ctx->F, F12), B(4, ctx->N, RAW)}, s))) return r;
@@ -361,18 +428,19 @@ EXPORT int nbls_final_exp_batch_dev(nbls_ctx* ctx, size_t n, const void* d_in, v
 }
 
 EXPORT int nbls_final_exp_batch(nbls_ctx* ctx, size_t n, const uint8_t* in, uint8_t* out) {
+  std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);   // scratch and I/O staging buffers belong to this call until it returns
   if (!ctx || (n && (!in || !out))) return NBLS_EINVAL;
   if (n == 0) return NBLS_OK;
   int r;
   {
-    std::lock_guard<std::mutex> g(ctx->mu);
+    std::lock_guard<std::recursive_mutex> g(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     if ((r = ensure_io(ctx, 2 * n))) return r;
     HIPCHK(hipMemcpyAsync(ctx->io_f12, in, n * 576, hipMemcpyHostToDevice, ctx->stream));
   }
   uint8_t* d_out = ctx->io_f12 + n * 576;
   if ((r = nbls_final_exp_batch_dev(ctx, n, ctx->io_f12, d_out, ctx->stream))) return r;
-  std::lock_guard<std::mutex> g(ctx->mu);
+  std::lock_guard<std::recursive_mutex> g(ctx->mu);
   HIPCHK(hipMemcpyAsync(out, d_out, n * 576, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return NBLS_OK;
@@ -381,9 +449,10 @@ EXPORT int nbls_final_exp_batch(nbls_ctx* ctx, size_t n, const uint8_t* in, uint
 // n Fp12 wire elements on the device -> their product, optionally final-exponentiated (multi-GPU: partials of all ranks)
 EXPORT int nbls_fp12_product_final_dev(nbls_ctx* ctx, size_t n, const void* d_in, int final_exp, void* d_out, void* stream) {
   if (!ctx || !d_out || (n && !d_in)) return NBLS_EINVAL;
-  std::lock_guard<std::mutex> g(ctx->mu);
+  std::lock_guard<std::recursive_mutex> g(ctx->mu);
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  StreamOrder order_(ctx, s);
   int r;
   if ((r = ensure_scratch(ctx, n ? n : 1))) return r;
   uint8_t* res = ctx->F;
@@ -399,7 +468,7 @@ EXPORT int nbls_fp12_product_final_dev(nbls_ctx* ctx, size_t n, const void* d_in
 // Placement study: runs the EXPX program on n scratch items and returns, per workgroup, three words: HW_ID | XCC_ID << 32 of its wavefront, start and end tick (s_memtime).
 EXPORT int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks) {
   if (!ctx || !n || !out_blocks) return NBLS_EINVAL;
-  std::lock_guard<std::mutex> g(ctx->mu); HIPCHK(hipSetDevice(ctx->device));
+  std::lock_guard<std::recursive_mutex> g(ctx->mu); HIPCHK(hipSetDevice(ctx->device));
   int r = ensure_scratch(ctx, n); if (r) return r;
   if ((r = ensure_io(ctx, n))) return r;
   const ProgId pid = getenv("NBLS_PROBE_MILLER") ? P_MILLER_FE : P_EXPX;   // NBLS_PROBE_MILLER: probe the (4x longer) Miller program instead
@@ -432,13 +501,13 @@ EXPORT int nbls_program_stats(nbls_ctx* ctx, int prog, uint32_t* o) {
 // launch counts per program (index P_COUNT = the inversion kernel).  ms/counts must hold P_COUNT+1 entries.
 EXPORT int nbls_timing_enable(nbls_ctx* ctx, int on) {
   if (!ctx) return NBLS_EINVAL;
-  std::lock_guard<std::mutex> g(ctx->mu);
+  std::lock_guard<std::recursive_mutex> g(ctx->mu);
   for (auto& t : ctx->tev) { hipEventDestroy(t.second.first); hipEventDestroy(t.second.second); }
   ctx->tev.clear(); ctx->timing = on != 0; return NBLS_OK;
 }
 EXPORT int nbls_timing_read(nbls_ctx* ctx, float* ms, uint32_t* counts) {
   if (!ctx || !ms || !counts) return NBLS_EINVAL;
-  std::lock_guard<std::mutex> g(ctx->mu);
+  std::lock_guard<std::recursive_mutex> g(ctx->mu);
   HIPCHK(hipSetDevice(ctx->device));
   for (int i = 0; i <= P_COUNT; i++) { ms[i] = 0; counts[i] = 0; }
   for (auto& t : ctx->tev) {
@@ -506,7 +575,99 @@ struct HostIO {   // staging buffers on the device for one call
   ~HostIO() { for (void* p : bufs) hipFree(p); }
   void* alloc(size_t n) { void* p = nullptr; if (hipMalloc(&p, n ? n : 1) != hipSuccess) return nullptr; bufs.push_back(p); return p; }
 };
-#define LOCKED(ctx) std::lock_guard<std::mutex> g_((ctx)->mu); HIPCHK(hipSetDevice((ctx)->device)); hipStream_t s = (ctx)->stream
+#define LOCKED(ctx) std::lock_guard<std::recursive_mutex> g_((ctx)->mu); HIPCHK(hipSetDevice((ctx)->device)); hipStream_t s = (ctx)->stream
+
+// ---- prepared G2 points: PointG2.pairingPrecomputes() (index.ts:703-711) and PointG1.millerLoop (index.ts:452-454) -----------------
+// d_tables: n line tables of NBLS_LINE_TABLE_BYTES each, device-resident, in the engine's raw limb format
+EXPORT int nbls_g2_prepare_dev(nbls_ctx* ctx, size_t n, const void* d_g2, void* d_tables, void* stream) {
+  if (!ctx || (n && (!d_g2 || !d_tables))) return NBLS_EINVAL;
+  if (n == 0) return NBLS_OK;
+  std::lock_guard<std::recursive_mutex> g(ctx->mu);
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  StreamOrder order_(ctx, s);
+  return run(ctx, P_LINES_Q, n, {B(1, d_g2, 192), B(3, d_tables, LINE_BYTES)}, s);
+}
+// raw tables <-> the reference's value: 68 x [Fp2, Fp2, Fp2] as Fp2.toBytes (NBLS_LINE_WIRE_BYTES per point)
+EXPORT int nbls_lines_to_wire_dev(nbls_ctx* ctx, size_t n, const void* d_tables, void* d_wire, void* stream) {
+  if (!ctx || (n && (!d_tables || !d_wire))) return NBLS_EINVAL;
+  if (n == 0) return NBLS_OK;
+  std::lock_guard<std::recursive_mutex> g(ctx->mu);
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  return run(ctx, P_LINES_BYTES, n * N_LINES, {B(3, d_tables, 6 * RAW), B(2, d_wire, 288)}, s);
+}
+EXPORT int nbls_lines_from_wire_dev(nbls_ctx* ctx, size_t n, const void* d_wire, void* d_tables, void* stream) {
+  if (!ctx || (n && (!d_tables || !d_wire))) return NBLS_EINVAL;
+  if (n == 0) return NBLS_OK;
+  std::lock_guard<std::recursive_mutex> g(ctx->mu);
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  return run(ctx, P_LINES_FROM_BYTES, n * N_LINES, {B(2, d_wire, 288), B(3, d_tables, 6 * RAW)}, s);
+}
+// millerLoop(table_i, P_i) for n items (table_stride = NBLS_LINE_TABLE_BYTES) or millerLoop(table, P_i) with ONE table for every item
+// (table_stride = 0): raw Fp12 values in ctx->F
+static int acc_prepared(nbls_ctx* ctx, size_t n, const void* d_g1, const void* d_tables, size_t table_stride, hipStream_t s) {
+  if (table_stride != 0 && table_stride != LINE_BYTES) return NBLS_EINVAL;
+  int r = ensure_scratch(ctx, n); if (r) return r;
+  return run(ctx, P_ACC_Q, n, {B(0, d_g1, 96), B(3, d_tables, table_stride), B(5, ctx->F, F12)}, s);
+}
+EXPORT int nbls_pairing_prepared_dev(nbls_ctx* ctx, size_t n, const void* d_g1, const void* d_tables, size_t table_stride, int with_final_exp, void* d_out, void* stream) {
+  if (!ctx || (n && (!d_g1 || !d_tables || !d_out))) return NBLS_EINVAL;
+  if (n == 0) return NBLS_OK;
+  std::lock_guard<std::recursive_mutex> g(ctx->mu);
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  StreamOrder order_(ctx, s);
+  int r = acc_prepared(ctx, n, d_g1, d_tables, table_stride, s); if (r) return r;
+  if (!with_final_exp) return run(ctx, P_RAW_TO_BYTES, n, {B(3, ctx->F, F12), B(2, d_out, 576)}, s);
+  if ((r = run(ctx, P_NORM_RAW, n, {B(3, ctx->F, F12), B(4, ctx->N, RAW)}, s))) return r;
+  return final_exp_pipeline(ctx, n, ctx->F, d_out, s);
+}
+EXPORT int nbls_miller_product_prepared_dev(nbls_ctx* ctx, size_t n, const void* d_g1, const void* d_tables, size_t table_stride, int final_exp, void* d_out, void* stream) {
+  if (!ctx || !d_out || (n && (!d_g1 || !d_tables))) return NBLS_EINVAL;
+  std::lock_guard<std::recursive_mutex> g(ctx->mu);
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  StreamOrder order_(ctx, s);
+  int r;
+  uint8_t* res = ctx->F;
+  if (n == 0) { if ((r = ensure_scratch(ctx, 1))) return r; HIPCHK(hipMemcpyAsync(ctx->F, ctx->one12, F12, hipMemcpyDeviceToDevice, s)); }
+  else {
+    if ((r = acc_prepared(ctx, n, d_g1, d_tables, table_stride, s))) return r;
+    if ((r = reduce_product(ctx, n, &res, s))) return r;
+  }
+  return finish_single(ctx, res, final_exp, d_out, s);
+}
+// host buffers: affine G2 points -> tables in wire form (what PointG2.pairingPrecomputes() returns)
+EXPORT int nbls_g2_prepare(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, uint8_t* out_wire) {
+  if (!ctx || (n && (!g2_aff || !out_wire))) return NBLS_EINVAL; if (!n) return NBLS_OK;
+  LOCKED(ctx); HostIO io{ctx}; void *d = io.alloc(n * 192), *t = io.alloc(n * LINE_BYTES), *w = io.alloc(n * (size_t)N_LINES * 288); if (!d || !t || !w) return NBLS_EHIP;
+  HIPCHK(hipMemcpyAsync(d, g2_aff, n * 192, hipMemcpyHostToDevice, s));
+  int r;
+  if ((r = nbls_g2_prepare_dev(ctx, n, d, t, s)) || (r = nbls_lines_to_wire_dev(ctx, n, t, w, s))) return r;
+  HIPCHK(hipMemcpyAsync(out_wire, w, n * (size_t)N_LINES * 288, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); return NBLS_OK;
+}
+// host buffers: n G1 points against n_tables (1 or n) tables in wire form; product != 0: one Fp12 (the product of the Miller values), else n
+EXPORT int nbls_pairing_prepared(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, const uint8_t* tables_wire, size_t n_tables, int with_final_exp, int product, uint8_t* out_fp12) {
+  if (!ctx || !out_fp12 || (n && (!g1_aff || !tables_wire)) || (n && n_tables != 1 && n_tables != n)) return NBLS_EINVAL;
+  if (!n && !product) return NBLS_OK;
+  LOCKED(ctx); HostIO io{ctx};
+  const size_t wire = (size_t)N_LINES * 288, nout = product ? 1 : n;
+  void *d = io.alloc(n * 96), *w = io.alloc(n_tables * wire), *t = io.alloc(n_tables * LINE_BYTES), *o = io.alloc(nout * 576); if (!d || !w || !t || !o) return NBLS_EHIP;
+  int r;
+  if (n) {
+    HIPCHK(hipMemcpyAsync(d, g1_aff, n * 96, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(w, tables_wire, n_tables * wire, hipMemcpyHostToDevice, s));
+    if ((r = nbls_lines_from_wire_dev(ctx, n_tables, w, t, s))) return r;
+  }
+  const size_t stride = n_tables == 1 && n > 1 ? 0 : LINE_BYTES;
+  r = product ? nbls_miller_product_prepared_dev(ctx, n, d, t, stride, with_final_exp, o, s) : nbls_pairing_prepared_dev(ctx, n, d, t, stride, with_final_exp, o, s);
+  if (r) return r;
+  HIPCHK(hipMemcpyAsync(out_fp12, o, nout * 576, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); return NBLS_OK;
+}
+EXPORT int nbls_program_count(void) { return (int)P_COUNT; }
+EXPORT const char* nbls_program_name(int prog) { return prog >= 0 && prog < P_COUNT ? get_program((ProgId)prog).name.c_str() : nullptr; }
 
 EXPORT int nbls_g1_validate_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, int8_t* status) {
   if (!ctx || (n && (!g1_aff || !status))) return NBLS_EINVAL; if (!n) return NBLS_OK;
@@ -770,13 +931,16 @@ EXPORT int nbls_g2_msm(nbls_ctx* ctx, size_t n, const uint8_t* pts192, const uin
 // in device memory; enqueued on `stream` (NULL = the context's stream) except for one 4-byte read-back in the middle
 EXPORT int nbls_msm_dev(nbls_ctx* ctx, int g2, size_t n, const void* d_pts, const void* d_scalars32, unsigned nbits, void* d_out, void* d_status, void* stream) {
   if (!ctx || !d_out || !d_status || (n && (!d_pts || !d_scalars32))) return NBLS_EINVAL;
-  std::lock_guard<std::mutex> g_(ctx->mu); HIPCHK(hipSetDevice(ctx->device));
-  return dev_msm(ctx, g2 != 0, n, d_pts, d_scalars32, nbits, d_out, d_status, stream ? (hipStream_t)stream : ctx->stream);
+  std::lock_guard<std::recursive_mutex> g_(ctx->mu); HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  StreamOrder order_(ctx, s);
+  return dev_msm(ctx, g2 != 0, n, d_pts, d_scalars32, nbits, d_out, d_status, s);
 }
 
 // sign(message_i, key_i) (index.ts:744-752): hashToCurve -> multiply by the key -> affine signature point (the caller
 // compresses, PointG2.toSignature index.ts:586-602).  status: 0 ok, 5 key is 0 mod r.
 EXPORT int nbls_sign_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len, const uint8_t* keys32, uint8_t* out192, int8_t* status) {
+  std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);   // scratch and I/O staging buffers belong to this call until it returns
   if (!ctx || (n && (!offsets || !out192 || !dst || !keys32))) return NBLS_EINVAL; if (!n) return NBLS_OK;
   LOCKED(ctx); HostIO io{ctx}; void *h = io.alloc(n * 192), *dk = io.alloc(n * 32), *o = io.alloc(n * 192), *st = io.alloc(n);
   if (!h || !dk || !o || !st) return NBLS_EHIP;
@@ -798,6 +962,7 @@ EXPORT int nbls_sign_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const u
 //   inside the try block, index.ts:716, 818-820).
 EXPORT int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_sig96, const void* d_uniform, const void* d_pk48, int* ok, int8_t* pk_status, void* stream);
 EXPORT int nbls_verify_batch(nbls_ctx* ctx, size_t n, const uint8_t* sig96, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48, const uint8_t* dst, size_t dst_len, int* ok) {
+  std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);   // scratch and I/O staging buffers belong to this call until it returns
   if (!ctx || !ok || !n || !sig96 || !offsets || !pk48 || !dst) return NBLS_EINVAL;
   void *d_sig, *d_uni, *d_pk;
   {
@@ -818,8 +983,9 @@ EXPORT int nbls_verify_batch(nbls_ctx* ctx, size_t n, const uint8_t* sig96, cons
 static int verify_stage(nbls_ctx* ctx, size_t n, const void* d_sig96, const void* d_uniform, const void* d_pk48, std::vector<int8_t>& st, void* stream) {
   const size_t np = n + (d_sig96 ? 1 : 0);
   st.assign(np, 0);
-  std::lock_guard<std::mutex> g_(ctx->mu); HIPCHK(hipSetDevice(ctx->device));
+  std::lock_guard<std::recursive_mutex> g_(ctx->mu); HIPCHK(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  StreamOrder order_(ctx, s);
   uint8_t *G1, *G2, *ST, *O; int r;
   if ((r = need(ctx, 10, (n + 1) * (96 + 192) + (n + 1) + 576 + 64, &G1))) return r;
   G2 = G1 + (n + 1) * 96; O = G2 + (n + 1) * 192; ST = O + 576;
@@ -864,6 +1030,7 @@ static int verify_stage(nbls_ctx* ctx, size_t n, const void* d_sig96, const void
   return NBLS_OK;
 }
 EXPORT int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_sig96, const void* d_uniform, const void* d_pk48, int* ok, int8_t* pk_status, void* stream) {
+  std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);   // scratch and I/O staging buffers belong to this call until it returns
   if (!ctx || !ok || !n || !d_sig96 || !d_uniform || !d_pk48) return NBLS_EINVAL;
   std::vector<int8_t> st;
   uint8_t out[576];
@@ -875,7 +1042,7 @@ EXPORT int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_s
     uint8_t* base = ctx->sb[10];
     r = nbls_miller_product_dev(ctx, n + 1, base, base + (n + 1) * 96, 1, base + (n + 1) * 288, stream);
     if (r) return r;
-    std::lock_guard<std::mutex> g_(ctx->mu);
+    std::lock_guard<std::recursive_mutex> g_(ctx->mu);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     HIPCHK(hipMemcpyAsync(out, base + (n + 1) * 288, 576, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -889,6 +1056,7 @@ EXPORT int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_s
 // as 576 wire bytes in device memory.  The ranks exchange their partials (one all-gather) and finish with
 // nbls_fp12_product_final_dev.  *zero_flag = 1 when a zero point was met (verifyBatch then answers false; d_out is not written).
 EXPORT int nbls_verify_batch_partial_dev(nbls_ctx* ctx, size_t n, const void* d_sig96, const void* d_uniform, const void* d_pk48, void* d_out_fp12, int* zero_flag, int8_t* pk_status, void* stream) {
+  std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);   // scratch and I/O staging buffers belong to this call until it returns
   if (!ctx || !zero_flag || !n || !d_uniform || !d_pk48 || !d_out_fp12) return NBLS_EINVAL;
   std::vector<int8_t> st;
   int r = verify_stage(ctx, n, d_sig96, d_uniform, d_pk48, st, stream); if (r) return r;

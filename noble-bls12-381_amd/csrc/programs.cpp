@@ -89,6 +89,72 @@ static SFp12 trace_miller_shared(const std::vector<SFp>& Px, const std::vector<S
   return conj(f);
 }
 
+
+// ---------------------------------------------------------------- Miller loop in two programs (math.ts:1331-1388)
+// LINES: the point chain R <- 2R (+ Q) of calcPairingPrecomputes with the reference's polynomials (so that every line coefficient is the
+// reference's field element and pairing(P, Q, false) stays bit-exact), regrouped for the lane-op model: the state is (Rx, Ry, D = 2 Rz), on
+// which a doubling is two levels of ten lane-ops around one level of sums --
+//   level 1: t0 = Ry^2, t2 = 3 xi D^2 (= 3 b Rz^2, multiplier 3 and one doubled operand), t4 = Ry D (= (Ry + Rz)^2 - Rz^2 - Ry^2), c1 = 3 Rx^2, Rx Ry
+//   sums:    A = (t0 - 3 t2) / 2, B = (t0 + 3 t2) / 2, t3 = 3 t2, c0 = t2 - t0, c2 = -t4
+//   level 2: Rx' = A (Rx Ry), Ry' = B^2 - t2 t3, D' = 2 t0 t4 (= 2 Rz'), and with P known c1 Px, c2 Py
+// -- 20 lane-ops per bit where the fused trace of round 1 spent 37.  Entry j of a table: c0.c0 c0.c1 c1.c0 c1.c1 c2.c0 c2.c1 (raw elements).
+struct LineSink { int buf; int base; const SFp* Px; const SFp* Py; };
+static void emit_line(const LineSink& o, int j, const SFp2& c0, const SFp2& c1, const SFp2& c2) {
+  const int off = o.base + 48 * 6 * j;
+  SFp2 e1 = c1, e2 = c2;
+  if (o.Px) { e1 = mul_fp(c1, *o.Px); e2 = mul_fp(c2, *o.Py); }   // E[1].multiply(Px), E[2].multiply(Py), math.ts:1379
+  outputw(c0.c0, o.buf, off); outputw(c0.c1, o.buf, off + 48);
+  outputw(e1.c0, o.buf, off + 96); outputw(e1.c1, o.buf, off + 144);
+  outputw(e2.c0, o.buf, off + 192); outputw(e2.c1, o.buf, off + 240);
+}
+static void trace_lines(const SFp2& Qx, const SFp2& Qy, const LineSink& out) {
+  SFp2 Rx = Qx, Ry = Qy, D = mat(scale(fp2_one(), 2));
+  int j = 0;
+  for (int i = 62; i >= 0; i--) {
+    // doubling step, math.ts:1339-1351
+    SFp2 t0 = mat(sqr(Ry)), t2 = mat(scale(mulnr(sqr(D)), 3)), t4 = mat(mul(Ry, D)), c1 = mat(scale(sqr(Rx), 3)), rxry = mat(mul(Rx, Ry));
+    SFp2 t3 = mat(scale(t2, 3));
+    SFp2 A = halve(t0 - scale(t2, 3)), Bh = halve(t0 + scale(t2, 3));
+    emit_line(out, j++, mat(t2 - t0), c1, mat(-t4));
+    SFp2 nRx = mat(mul(A, rxry)), nRy = mat(sqr(Bh) - mul(t2, t3)), nD = mat(scale(mul(t0, t4), 2));
+    Rx = nRx; Ry = nRy; D = nD;
+    if ((NBLS_X >> i) & 1) {
+      // addition step, math.ts:1353-1367, on Rz = D / 2
+      SFp2 Rz = halve(D);
+      SFp2 a0 = mat(Ry - mul(Qy, Rz)), a1 = mat(Rx - mul(Qx, Rz));
+      emit_line(out, j++, mat(mul(a0, Qx) - mul(a1, Qy)), mat(-a0), a1);
+      SFp2 a2 = mat(sqr(a1)), a3 = mat(mul(a2, a1)), a4 = mat(mul(a2, Rx));
+      SFp2 a5 = mat(a3 - scale(a4, 2) + mul(sqr(a0), Rz));
+      nRx = mat(mul(a1, a5)); nRy = mat(mul(a4 - a5, a0) - mul(a3, Ry));
+      SFp2 nRz = mat(mul(Rz, a3));
+      Rx = nRx; Ry = nRy; D = mat(scale(nRz, 2));
+    }
+  }
+}
+static SFp2 load_line_coef(int buf, int off) { return {inputw(buf, off), inputw(buf, off + 48)}; }
+// ACC: millerLoop (math.ts:1373-1388) over m line tables per item with ONE accumulator: f <- (f * prod_t line_t)^2 per bit.  m = 1 is the
+// reference's loop; for m > 1 the product of the m Miller values is the same field element ((prod a_t)^2 = prod a_t^2), so Miller products
+// (verify / verifyBatch, index.ts:756-821) stay bit-exact while m - 1 of the m Fp12 squarings per bit are saved.  With Px / Py given the
+// tables hold prepared lines (calcPairingPrecomputes output) and the G1 coordinates are folded in here.
+static SFp12 trace_acc(int m, int buf, const std::vector<SFp>* Px = nullptr, const std::vector<SFp>* Py = nullptr) {
+  SFp12 f = fp12_one();
+  int j = 0;
+  auto step = [&](int jj) {
+    for (int t = 0; t < m; t++) {
+      const int off = 48 * LINE_ELEMS * t + 48 * 6 * jj;
+      SFp2 c0 = load_line_coef(buf, off), c1 = load_line_coef(buf, off + 96), c2 = load_line_coef(buf, off + 192);
+      if (Px) { c1 = mat(mul_fp(c1, (*Px)[t])); c2 = mat(mul_fp(c2, (*Py)[t])); }
+      f = mat(mul_by_014(f, c0, c1, c2));
+    }
+  };
+  for (int i = 62; i >= 0; i--) {
+    step(j++);
+    if ((NBLS_X >> i) & 1) step(j++);
+    if (i != 0) f = mat(sqr(f));
+  }
+  return conj(f);
+}
+
 // ---------------------------------------------------------------- Fp12 inversion split around the one Fp inversion
 // Fp12.invert (math.ts:793-797) -> Fp6.invert (672-680) -> Fp2.invert (522-526) -> Fp.invert.  Everything except
 // the Fp inversion is recomputed on both sides of the inversion kernel (cheap: ~90 Fp products).
@@ -145,7 +211,10 @@ static const int MILLER_W = env_int("NBLS_MILLER_W", 16);
 // 65,536 keys); the G2 ladder at 8 lanes instead of 16: +9 % steps, twice the items (5.9 -> 4.5 ms at 8192 signatures).  The other
 // G2 programs stay at 8: at 4 lanes their LDS footprint (50 KB per wavefront) leaves less than one wavefront per SIMD.
 static const int G1_W = env_int("NBLS_G1_W", 4), G2_W = env_int("NBLS_G2_W", 8), G2MUL_W = env_int("NBLS_G2MUL_W", 8), G1MUL_W = env_int("NBLS_G1MUL_W", 4);
-static const int EXPX_W = env_int("NBLS_EXPX_W", 12);   // an Fp12 op has exactly 12 lane-ops: 5 items per wave, no idle lane (+5..9 % over 16 lanes once >= 2 waves share a SIMD)
+static const int EXPX_W = env_int("NBLS_EXPX_W", 12);
+// the two Miller programs: ten lane-ops per level of the point chain (6 items per wavefront); an Fp12 op has 12 lane-ops (5 items, no idle lane).
+// ACC_WINDOW keeps the line loads about one and a half iterations ahead of their use (they would otherwise all be hoisted to the front and pin 408 slots)
+static const int LINES_W = env_int("NBLS_LINES_W", 10), ACC_W = env_int("NBLS_ACC_W", 12), ACC_WINDOW = env_int("NBLS_ACC_WINDOW", 330);   // an Fp12 op has exactly 12 lane-ops: 5 items per wave, no idle lane (+5..9 % over 16 lanes once >= 2 waves share a SIMD)
 
 static Program build(ProgId id) {
   Builder B;
@@ -408,6 +477,45 @@ static Program build(ProgId id) {
       else r = pt_add(pt_dbl_n(ld(3, 0), MSM_WINDOW_BITS), ld(4, 0));
       outputw(r.x.c0, 5, 0); outputw(r.x.c1, 5, 48); outputw(r.y.c0, 5, 96); outputw(r.y.c1, 5, 144); outputw(r.z.c0, 5, 192); outputw(r.z.c1, 5, 240);
       return B.compile(id == P_G2_ADD_AB ? "g2_add_ab" : id == P_G2_HORNER ? "g2_horner" : "g2_shiftadd", 8);
+    }
+    case P_LINES_PQ: {
+      SFp Px, Py; SFp2 Qx, Qy; load_points(Px, Py, Qx, Qy);
+      LineSink o{3, 0, &Px, &Py};
+      B.light_max = MAX_DOT_PRODUCTS;   // the ten lane-ops of a level (1..3 products) belong in ONE step
+      B.neg_cap = 7.0; B.store_batch = 6;   // t2 = 3 xi D^2 is bounded by 6.2 p: subtracting it as it is saves a contraction level per bit
+      trace_lines(Qx, Qy, o);
+      return B.compile("lines_pq", LINES_W);
+    }
+    case P_LINES_Q: {
+      SFp2 Qx = input_fp2(1, 0), Qy = input_fp2(1, 96);
+      LineSink o{3, 0, nullptr, nullptr};
+      B.light_max = MAX_DOT_PRODUCTS; B.neg_cap = 7.0; B.store_batch = 6;
+      trace_lines(Qx, Qy, o);
+      return B.compile("lines_q", LINES_W);
+    }
+    case P_LINES_BYTES: {   // one ITEM per line triple (launched over 68 n items): 6 raw elements (buf 3) -> c0 || c1 || c2 as Fp2.toBytes (buf 2)
+      for (int e = 0; e < 6; e++) output(inputw(3, 48 * e), 2, 48 * e);
+      return B.compile("lines_bytes", 6);
+    }
+    case P_LINES_FROM_BYTES: {   // the inverse: 288 wire bytes (buf 2) -> 6 raw elements (buf 3)
+      for (int e = 0; e < 6; e++) outputw(input(2, 48 * e), 3, 48 * e);
+      return B.compile("lines_from_bytes", 6);
+    }
+    case P_ACC_BYTES: { B.sched_window = ACC_WINDOW; output_fp12(trace_acc(1, 3), 2, 0); return B.compile("acc_bytes", ACC_W); }
+    case P_ACC_RAW: { B.sched_window = ACC_WINDOW; outputw_fp12(trace_acc(1, 3), 5, 0); return B.compile("acc_raw", ACC_W); }
+    case P_ACC_FE: {
+      B.sched_window = ACC_WINDOW;
+      SFp12 f = mat(trace_acc(1, 3));
+      outputw_fp12(f, 5, 0);
+      outputw(inv_chain(f).n, 4, 0);
+      return B.compile("acc_fe", ACC_W);
+    }
+    case P_ACC2_RAW: { B.sched_window = ACC_WINDOW; outputw_fp12(trace_acc(2, 3), 5, 0); return B.compile("acc2_raw", ACC_W); }
+    case P_ACC_Q: {
+      B.sched_window = ACC_WINDOW;
+      std::vector<SFp> Px{input(0, 0)}, Py{input(0, 48)};
+      outputw_fp12(trace_acc(1, 3, &Px, &Py), 5, 0);
+      return B.compile("acc_q", ACC_W);
     }
     default: break;
   }

@@ -41,8 +41,22 @@ enum ProgId {
   P_G1_SHIFTADD, P_G2_SHIFTADD,   // 2^12 * acc (buf 3) + S (buf 4) -> buf 5
   P_G1_MSM_PREP,                  // affine P (buf 0) -> P, [z^2]P = -phi(P) = (beta x, -y) as projective points (buf 3): scalars split in base z^2
   P_G2_MSM_PREP,                  // affine Q (buf 1) -> Q, [|z|]Q = -psi(Q), [z^2]Q = psi^2(Q), [|z|^3]Q = -psi^3(Q) (buf 3): scalars split in base |z|
+  // Miller loop in two programs (round 2), the reference's own decomposition (calcPairingPrecomputes math.ts:1331-1371 + millerLoop 1373-1388):
+  // the point chain of Q (little parallelism: many items per wavefront) writes its 68 line triples to HBM, the Fp12 accumulation (12 lanes
+  // per item, no idle lane) reads them back.  A line table is NBLS_LINE_BYTES = 68 * 6 raw elements per point.
+  P_LINES_PQ,          // G1 (buf 0), G2 (buf 1) -> lines (buf 3) with the G1 coordinates folded in: (c0, c1 * Px, c2 * Py)
+  P_LINES_Q,           // G2 (buf 1) -> lines (buf 3) as calcPairingPrecomputes returns them (prepared Q: PointG2.pairingPrecomputes, index.ts:703-711)
+  P_LINES_BYTES,       // one line triple per item: 6 raw elements (buf 3) -> c0 || c1 || c2 as 3 x 96 wire bytes (buf 2); a table is 68 items
+  P_LINES_FROM_BYTES,  // the inverse (a caller hands a table back in wire form)
+  P_ACC_BYTES,         // folded lines (buf 3) -> conj-Miller value as wire bytes (buf 2)             [pairing(P, Q, false)]
+  P_ACC_RAW,           // folded lines (buf 3) -> F (buf 5)
+  P_ACC_FE,            // folded lines (buf 3) -> F (buf 5), N = norm to invert (buf 4)
+  P_ACC2_RAW,          // two folded line tables per item (buf 3) -> F (buf 5): one shared accumulator, one Fp12 squaring per bit for both
+  P_ACC_Q,             // prepared lines (buf 3) + G1 (buf 0) -> F (buf 5)                           [PointG1.millerLoop, index.ts:452-454]
   P_COUNT
 };
+static const int N_LINES = 68;                 // 63 doubling steps + 5 addition steps (bits of |x|)
+static const int LINE_ELEMS = 6 * N_LINES;     // raw field elements per line table
 static const int MSM_WINDOW_BITS = 12;
 const Program& get_program(ProgId id);
 void print_stats(const Program& p);

@@ -9,7 +9,6 @@
 namespace nbls {
 
 static const double P_OVER_R = 1.0 / 1234.0;   // p / 2^392 = 0.00079..., rounded up
-static const double NEG_CAP = 6.0;              // negated linear terms above this bound are contracted first (their bound is paid as a +k p offset)
 static const int MAX_OFFS = 15;                 // DOT: 4-bit multiple of p baked into the accumulator
 static const double OUT_CAP = 10.0;             // results above this bound get their post-added terms folded into the dot product
 static const double OP_CAP = 24.0;              // product operands above this bound are contracted first (keeps bounds from compounding)
@@ -111,7 +110,7 @@ static int emit_dot(Builder* B, std::vector<DotProduct> prods, int mult, std::ve
     auto cap = [&](int& a) { if (a >= 0 && B->atom_bound(a) > OP_CAP && !B->nodes[a].raw) a = B->contract(a); };
     cap(p.a.s0); cap(p.a.s1); cap(p.b.s0); cap(p.b.s1);
   }
-  for (auto& t : lin) if (B->atom_bound(t.first) > (t.second < 0 ? NEG_CAP : OP_CAP)) t.first = B->contract(t.first);
+  for (auto& t : lin) if (B->atom_bound(t.first) > (t.second < 0 ? B->neg_cap : OP_CAP)) t.first = B->contract(t.first);
   Node n; n.kind = K_DOT; n.mult = mult; n.halve = halve_it;
   // value bounds: REDC(T) lies in (T/R, T/R + p); products that may be negative are compensated by offs * p
   double Vpos = 0, Vneg = 0, Lpos = 0, Lneg = 0;
@@ -150,7 +149,7 @@ static int emit_dot(Builder* B, std::vector<DotProduct> prods, int mult, std::ve
   return B->add_node(n);
 }
 static int emit_lin(Builder* B, std::vector<std::pair<int, int>> terms, bool halve_it) {
-  for (auto& t : terms) if (B->atom_bound(t.first) > (t.second < 0 ? NEG_CAP : OP_CAP)) t.first = B->contract(t.first);
+  for (auto& t : terms) if (B->atom_bound(t.first) > (t.second < 0 ? B->neg_cap : OP_CAP)) t.first = B->contract(t.first);
   // negative terms are limb-wise subtractions; a constant k p keeps the value non-negative
   auto finish = [&](std::vector<std::pair<int, int>>& ts) {
     double neg = 0; for (auto& t : ts) if (t.second < 0) neg += B->atom_bound(t.first);
@@ -223,7 +222,7 @@ int materialize(const SFp& x, bool halve_it) {
   if (!dps.empty() && !lin.empty()) {
     // If the post-added terms would make the result large, fold them into the accumulator as products with small
     // constants (x * (c/m)): the Montgomery reduction then contracts everything to about m p.
-    double T = mult * 3.0; for (auto& t : lin) T += std::min(B->atom_bound(t.first), t.second < 0 ? NEG_CAP : OP_CAP);
+    double T = mult * 3.0; for (auto& t : lin) T += std::min(B->atom_bound(t.first), t.second < 0 ? B->neg_cap : OP_CAP);
     if (T > OUT_CAP) {
       std::map<int, int> net; for (auto& t : lin) net[t.first] += t.second;
       for (auto& kv : net) if (kv.second) { Operand a; a.s0 = kv.first; Operand c; c.s0 = B->frac_const(kv.second, mult); dps.push_back({a, c, false}); }
@@ -294,7 +293,7 @@ Program Builder::compile(const std::string& name, int W) {
   }
   // 4. list scheduling.  Ready queues per (kind, p0).
   // DOT lane-ops are bucketed by weight class so that a step's lanes do similar amounts of work (step time = max k)
-  auto dot_class = [&](const Node& n) { size_t k = n.prods.size(); return k <= 2 ? 0 : 1; };
+  auto dot_class = [&](const Node& n) { size_t k = n.prods.size(); return (int)k <= light_max ? 0 : 1; };
   auto qkey = [&](const Node& n) { return (int)n.kind * 256 + ((n.kind == K_CMP || n.kind == K_FLAG || n.kind == K_LOAD || n.kind == K_STORE) ? n.p0 : n.kind == K_DOT ? dot_class(n) : 0); };
   auto cmp = [&](int a, int b) { return nodes[a].height < nodes[b].height || (nodes[a].height == nodes[b].height && a > b); };
   typedef std::priority_queue<int, std::vector<int>, decltype(cmp)> PQ;
@@ -323,7 +322,14 @@ Program Builder::compile(const std::string& name, int W) {
     // class that holds the most urgent (highest critical path) ready lane-op
     std::vector<int> cand[2];
     for (int c = 1; c >= 0; c--) { auto itq = ready.find(DOTKEY + c); if (itq != ready.end()) take(itq->second, cand[c]); }
-    if ((int)cand[1].size() >= W) key = DOTKEY + 1;
+    // results that only wait to be written out keep their slots alive: a batch of ready stores goes first
+    if (store_batch > 0) {
+      int nst = 0, kst = -1;
+      for (auto& kv : ready) if (kv.first / 256 == K_STOREW || kv.first / 256 == K_STORE) { int c = 0; PQ q = kv.second; while (!q.empty() && c < W) { q.pop(); c++; } if (c > nst) { nst = c; kst = kv.first; } }
+      if (nst >= std::min(store_batch, W)) key = kst;
+    }
+    if (key >= 0) {}
+    else if ((int)cand[1].size() >= W) key = DOTKEY + 1;
     else if ((int)cand[0].size() >= W) key = DOTKEY;
     if (key < 0) {
       static const int order[] = {K_LOAD, K_LOADW, K_BIT, K_BITAND, K_LIN, K_ISZ, K_FLAG, K_CMP, K_CANON, K_SEL, K_STOREW, K_STORE, K_STATUS};
@@ -446,14 +452,13 @@ Program Builder::compile(const std::string& name, int W) {
   P.slots = nslots;
   P.nconst = (u32)const_words.size() / SLOT_WORDS;
   // LDS layout: every instance region holds the constants (replicated, so that an operand address is base + offset whatever it
-  // names) followed by the slots.  Slot stride 80 bytes makes the 16-byte reads of 16 lanes that name 16 different slots conflict-free
-  // (bank group (5 k + c) mod 16; with 64 bytes only 4 of the 16 groups are ever hit by the same chunk c); it is used when the LDS
-  // footprint still allows 12 wavefronts per CU (3 per SIMD, the VGPR limit), else 64.
+  // names) followed by the slots.  Slot stride: 64 bytes.  An 80-byte stride spreads the 16-byte reads of lanes that name different
+  // slots over all 16 bank groups (64 bytes: 4 of 16) and removes most bank-conflict cycles, but measured slower on the Miller
+  // programs (1.98 vs 1.43 ms at 4096 pairings, 14.4 vs 13.0 ms at 65,536) and equal on EXPX: the kernel is bound by VALU issue, not by
+  // LDS cycles.  NBLS_SLOT_BYTES=80 selects it for experiments.
   {
     const char* e = getenv("NBLS_SLOT_BYTES");
-    u32 sb = e && *e ? (u32)atoi(e) : 0;
-    if (sb != 64 && sb != 80) sb = (u64)P.G * (P.nconst + P.slots) * 80 <= 163840 / 12 ? 80 : 64;
-    P.slot_bytes = sb;
+    P.slot_bytes = e && atoi(e) == 80 ? 80 : 64;
   }
   assert(P.inst_bytes() < 65536);
   // 6. emit
@@ -535,6 +540,7 @@ Program Builder::compile(const std::string& name, int W) {
       }
       P.descs.insert(P.descs.end(), w.begin(), w.end());
     }
+    if (getenv("NBLS_DUMP_SEQ")) fprintf(stderr, "%s step %zu kind=%d lanes=%d p0=%d p1=%d\n", name.c_str(), s, st.kind, st.nlanes, st.p0, st.p1);
     P.steps.push_back(st);
   }
   P.consts = const_words;

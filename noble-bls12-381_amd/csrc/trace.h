@@ -85,6 +85,9 @@ struct Builder {
   int zero_atom = -1, one_atom = -1, r2_atom = -1, rawone_atom = -1;
   int TMAX = 12;         // soft cap on the size of a lazy form
   int max_dot = MAX_DOT_PRODUCTS;   // products per lane-op: a lower cap splits heavy lane-ops (first chunk, then the rest + the first as a post-added term) so that the few heaviest lanes do not set the length of a step
+  int light_max = 2;     // lane-ops with at most this many products form the "light" class of the scheduler (they ride in the free lanes of heavy steps; MAX_DOT_PRODUCTS = one class)
+  double neg_cap = 6.0;  // negated linear terms above this bound are contracted first (their bound is paid as a +k p offset)
+  int store_batch = 0;   // > 0: a store step is issued as soon as this many stores are ready (programs that stream results out: the values do not linger in LDS)
   int sched_window = 0;  // scheduler look-ahead limit in critical-path units (0 = unlimited), see compile()
   static Builder*& cur() { static thread_local Builder* b = nullptr; return b; }
   Builder();

@@ -8,9 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-PROGRAMS = ['miller_bytes', 'miller_raw', 'miller_fe', 'norm_raw', 'norm_bytes', 'fe_easy', 'expx', 'fe_mid1', 'fe_mid2', 'fe_final', 'fp12_mul2', 'raw_to_bytes',
-            'g1_validate', 'g2_validate', 'g1_dec_a', 'g1_dec_b', 'g2_dec_a', 'g2_dec_b', 'h2c_a', 'h2c_b',
-            'g1_to_proj', 'g1_add2', 'g1_norm', 'g1_to_affine', 'g2_to_proj', 'g2_add2', 'g2_norm', 'g2_to_affine', 't_swu', 't_iso', 't_clear', 'h2c_c', 'miller_raw2', 'g1_compress', 'g2_compress', 'h2c1_a', 'enc1_a', 'h2c1_b', 'enc1_b', 'g1_clear', 'enc2_a', 'enc2_b', 'g1_mul', 'g2_mul', 'g1_add_ab', 'g2_add_ab', 'g1_horner', 'g2_horner', 'g1_shiftadd', 'g2_shiftadd', 'g1_msm_prep', 'g2_msm_prep']
+PROGRAMS = []   # names of the step programs in the library's numbering (filled by load_library from nbls_program_name)
 DST_DEFAULT = b'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_'   # htfDefaults.DST, reference index.ts:64
 
 
@@ -62,6 +60,17 @@ def load_library():
     lib.nbls_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, sz, C.POINTER(i32)]
     lib.nbls_verify_batch_dev_inputs.argtypes = [vp, sz, vp, vp, vp, C.POINTER(i32), vp, vp]
     lib.nbls_verify_batch_partial_dev.argtypes = [vp, sz, vp, vp, vp, vp, C.POINTER(i32), vp, vp]
+    lib.nbls_g2_prepare.argtypes = [vp, sz, vp, vp]
+    lib.nbls_g2_prepare_dev.argtypes = [vp, sz, vp, vp, vp]
+    lib.nbls_lines_to_wire_dev.argtypes = [vp, sz, vp, vp, vp]
+    lib.nbls_lines_from_wire_dev.argtypes = [vp, sz, vp, vp, vp]
+    lib.nbls_pairing_prepared_dev.argtypes = [vp, sz, vp, vp, sz, i32, vp, vp]
+    lib.nbls_miller_product_prepared_dev.argtypes = [vp, sz, vp, vp, sz, i32, vp, vp]
+    lib.nbls_pairing_prepared.argtypes = [vp, sz, vp, vp, sz, i32, i32, vp]
+    lib.nbls_program_name.restype = C.c_char_p
+    lib.nbls_program_name.argtypes = [i32]
+    if not PROGRAMS:
+        PROGRAMS.extend(lib.nbls_program_name(k).decode() for k in range(lib.nbls_program_count()))
     lib.nbls_timing_enable.argtypes = [vp, i32]
     lib.nbls_timing_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     return lib
@@ -109,6 +118,34 @@ class Engine:
         st = C.create_string_buffer(max(n, 1))
         self._chk(self.lib.nbls_miller_product(self.h, n, g1_aff, g2_aff, int(final_exp), int(validate), out, st))
         return out.raw, st.raw[:n]
+
+    # ---- prepared G2 points (PointG2.pairingPrecomputes index.ts:703-711, PointG1.millerLoop index.ts:452-454)
+    LINE_TABLE_BYTES = 26112
+    LINE_WIRE_BYTES = 19584
+
+    def g2_prepare(self, g2_aff):
+        """n affine G2 points -> n line tables in wire form (68 x [Fp2, Fp2, Fp2] as Fp2.toBytes, 19,584 B each)"""
+        n = len(g2_aff) // 192
+        out = C.create_string_buffer(max(self.LINE_WIRE_BYTES * n, 1))
+        self._chk(self.lib.nbls_g2_prepare(self.h, n, g2_aff, out))
+        return out.raw[:self.LINE_WIRE_BYTES * n]
+
+    def pairing_prepared(self, g1_aff, tables_wire, with_final_exp=True, product=False):
+        """n G1 points against n (or 1) prepared tables: n pairings, or with product=True the one product of their Miller values"""
+        n = len(g1_aff) // 96
+        nt = len(tables_wire) // self.LINE_WIRE_BYTES
+        out = C.create_string_buffer(576 * (1 if product else max(n, 1)))
+        self._chk(self.lib.nbls_pairing_prepared(self.h, n, g1_aff, tables_wire, nt, int(with_final_exp), int(product), out))
+        return out.raw[:576 * (1 if product else n)]
+
+    def g2_prepare_dev(self, n, d_g2, d_tables, stream=None):
+        self._chk(self.lib.nbls_g2_prepare_dev(self.h, n, d_g2, d_tables, stream))
+
+    def pairing_prepared_dev(self, n, d_g1, d_tables, d_out, with_final_exp=True, shared_table=False, stream=None):
+        self._chk(self.lib.nbls_pairing_prepared_dev(self.h, n, d_g1, d_tables, 0 if shared_table else self.LINE_TABLE_BYTES, int(with_final_exp), d_out, stream))
+
+    def miller_product_prepared_dev(self, n, d_g1, d_tables, d_out, final_exp=True, shared_table=False, stream=None):
+        self._chk(self.lib.nbls_miller_product_prepared_dev(self.h, n, d_g1, d_tables, 0 if shared_table else self.LINE_TABLE_BYTES, int(final_exp), d_out, stream))
 
     def final_exp_batch(self, fp12s):
         n = len(fp12s) // 576

@@ -256,3 +256,71 @@ def test_g1_hash_and_encode_programs(sim, oracle, golden, testdata):
     uni = b''.join(oracle.expand_message_xmd(hx(v['msg']), v['dst'].encode(), 128) for v in vs)
     out = vmsim_py.hash_to_g1(sim, uni, 2)
     assert [out[96 * i:96 * i + 96] for i in range(len(vs))] == [hx(v['g1_hash']) for v in vs]
+
+
+LINE_BYTES = 68 * 6 * vmsim_py.RAW
+
+
+def _lines(sim, g1, g2, n, folded=True):
+    L = C.create_string_buffer(LINE_BYTES * n)
+    bufs = {1: (C.create_string_buffer(g2, len(g2)), 192), 3: (L, LINE_BYTES)}
+    if folded:
+        bufs[0] = (C.create_string_buffer(g1, len(g1)), 96)
+    vmsim_py.run(sim, 'LINES_PQ' if folded else 'LINES_Q', n, bufs)
+    return L
+
+
+def test_line_tables(sim, golden):
+    """LINES_Q + LINES_BYTES == calcPairingPrecomputes (math.ts:1331-1371): the 68 line triples of the reference, bit for bit
+    (7 points: LINES runs 6 items per wave)"""
+    import hashlib
+    n = 7
+    g1, g2 = _points(golden, n)
+    L = _lines(sim, g1, g2, n, folded=False)
+    out = C.create_string_buffer(19584 * n)
+    vmsim_py.run(sim, 'LINES_BYTES', 68 * n, {3: (L, 6 * vmsim_py.RAW), 2: (out, 288)})
+    for i, v in enumerate(golden['pairs'][:n]):
+        t = out.raw[19584 * i:19584 * (i + 1)]
+        assert t[:288] == hx(v['ell_first']) and t[-288:] == hx(v['ell_last']), i
+        assert hashlib.sha256(t).hexdigest() == v['ell_sha256'], i
+    # wire form back to raw: the round trip reproduces the table
+    L2 = C.create_string_buffer(LINE_BYTES * n)
+    vmsim_py.run(sim, 'LINES_FROM_BYTES', 68 * n, {2: (out, 288), 3: (L2, 6 * vmsim_py.RAW)})
+    out2 = C.create_string_buffer(19584 * n)
+    vmsim_py.run(sim, 'LINES_BYTES', 68 * n, {3: (L2, 6 * vmsim_py.RAW), 2: (out2, 288)})
+    assert out2.raw == out.raw
+
+
+def test_split_miller(sim, oracle, golden):
+    """LINES_PQ + ACC_* == millerLoop / pairing of the reference (11 pairs: ACC runs 5 items per wave)"""
+    n = 11
+    g1, g2 = _points(golden, n)
+    L = _lines(sim, g1, g2, n)
+    out = C.create_string_buffer(576 * n)
+    vmsim_py.run(sim, 'ACC_BYTES', n, {3: (L, LINE_BYTES), 2: (out, 576)})
+    for i in range(n):
+        assert out.raw[576 * i:576 * (i + 1)] == hx(golden['pairs'][i]['miller']), i
+    F = C.create_string_buffer(vmsim_py.F12 * n); N = C.create_string_buffer(vmsim_py.RAW * n)
+    vmsim_py.run(sim, 'ACC_FE', n, {3: (L, LINE_BYTES), 5: (F, vmsim_py.F12), 4: (N, vmsim_py.RAW)})
+    vmsim_py.final_exp(sim, n, F, N, out)
+    for i in range(n):
+        assert out.raw[576 * i:576 * (i + 1)] == hx(golden['pairs'][i]['pairing']), i
+    # two tables per item, shared accumulator == product of the separate Miller loops (index.ts:756-767, 810-817)
+    m = n // 2
+    F2 = C.create_string_buffer(vmsim_py.F12 * m)
+    vmsim_py.run(sim, 'ACC2_RAW', m, {3: (L, 2 * LINE_BYTES), 5: (F2, vmsim_py.F12)})
+    vmsim_py.run(sim, 'RAW_TO_BYTES', m, {3: (F2, vmsim_py.F12), 2: (out, 576)})
+    for i in range(m):
+        assert out.raw[576 * i:576 * i + 576] == oracle.miller_product(g1[192 * i:192 * i + 192], g2[384 * i:384 * i + 384], final_exp=False), i
+    # prepared lines (not folded) + G1: PointG1.millerLoop(Q) with Q.pairingPrecomputes() (index.ts:452-454, 703-711); one table shared by
+    # every item (stride 0) pairs every P with the same Q
+    LQ = _lines(sim, g1, g2, n, folded=False)
+    FQ = C.create_string_buffer(vmsim_py.F12 * n)
+    vmsim_py.run(sim, 'ACC_Q', n, {0: (C.create_string_buffer(g1, len(g1)), 96), 3: (LQ, LINE_BYTES), 5: (FQ, vmsim_py.F12)})
+    vmsim_py.run(sim, 'RAW_TO_BYTES', n, {3: (FQ, vmsim_py.F12), 2: (out, 576)})
+    for i in range(n):
+        assert out.raw[576 * i:576 * (i + 1)] == hx(golden['pairs'][i]['miller']), i
+    vmsim_py.run(sim, 'ACC_Q', n, {0: (C.create_string_buffer(g1, len(g1)), 96), 3: (LQ, 0), 5: (FQ, vmsim_py.F12)})
+    vmsim_py.run(sim, 'RAW_TO_BYTES', n, {3: (FQ, vmsim_py.F12), 2: (out, 576)})
+    for i in range(n):
+        assert out.raw[576 * i:576 * (i + 1)] == oracle.miller_loop(g1[96 * i:96 * i + 96], g2[:192]), i
