@@ -158,6 +158,10 @@ int nbls_device_synchronize(nbls_ctx* ctx);
 int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks);
 /* Per-kernel HIP-event timing (benchmark roofline leg): ms[i]/counts[i] for program i, last entry = inversion kernel. */
 #define NBLS_N_PROGRAMS 96
+/* Tuning knobs of a context (defaults are the measured optimum; tests use them to force a code path).
+ * NBLS_TUNE_SPLIT_MILLER_MIN: number of pairs from which the Miller loop runs as two programs (line tables through HBM) instead of one. */
+#define NBLS_TUNE_SPLIT_MILLER_MIN 1
+int nbls_set_tuning(nbls_ctx* ctx, int key, long long value);
 int nbls_program_count(void);                 /* number of step programs; timing slot nbls_program_count() = the inversion kernel */
 const char* nbls_program_name(int prog);
 int nbls_timing_enable(nbls_ctx* ctx, int on);

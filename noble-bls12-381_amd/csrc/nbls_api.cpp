@@ -63,6 +63,7 @@ struct nbls_ctx {
   hipStream_t side2 = nullptr; hipEvent_t ev_join2 = nullptr;   // verifyBatch: key decoding runs beside message hashing (their exponentiation kernels are latency-bound and leave issue slots free)
   uint8_t* ident_g1 = nullptr; uint8_t* ident_g2 = nullptr;   // projective identity (0 : 1 : 0), raw
   size_t cap_F = 0, cap_io = 0;
+  size_t split_min = SPLIT_MILLER_MIN;   // nbls_set_tuning(NBLS_TUNE_SPLIT_MILLER_MIN)
   uint8_t* L = nullptr; size_t cap_L = 0;   // line tables of the Miller loop (LINE_BYTES each), at most LINES_CHUNK of them
   // the scratch above is shared by every call on this context: a call that uses another stream than its predecessor waits for it (StreamOrder)
   hipStream_t last_stream = nullptr; hipEvent_t ev_last = nullptr; bool ev_last_set = false;
@@ -304,7 +305,7 @@ EXPORT int nbls_pairing_batch_dev(nbls_ctx* ctx, size_t n, const void* d_g1, con
   // wavefront per SIMD deep takes the time of its longest instruction stream, so small batches keep the fused program (4096 pairings: 1.43 ms
   // against 0.72 + 0.94 ms; 65,536: 12.9 against 12.5 ms).  NBLS_FUSED_MILLER = 1 / 0 forces one or the other.
   static const int fused_mode = getenv("NBLS_FUSED_MILLER") ? atoi(getenv("NBLS_FUSED_MILLER")) : -1;
-  const bool fused = fused_mode >= 0 ? fused_mode != 0 : n < SPLIT_MILLER_MIN;
+  const bool fused = fused_mode >= 0 ? fused_mode != 0 : n < ctx->split_min;
   if (fused) {
     if (!with_final_exp) return run(ctx, P_MILLER_BYTES, n, {B(0, d_g1, 96), B(1, d_g2, 192), B(2, d_out, 576)}, s);
     if ((r = ensure_scratch(ctx, n))) return r;
@@ -369,7 +370,7 @@ EXPORT int nbls_miller_product_dev(nbls_ctx* ctx, size_t n, const void* d_g1, co
     // pairs are taken two at a time with a shared accumulator (one Fp12 squaring per bit for both); an odd last pair runs alone
     const size_t n2 = n / 2, m = n2 + (n & 1);
     static const int fused_mode = getenv("NBLS_FUSED_MILLER") ? atoi(getenv("NBLS_FUSED_MILLER")) : -1;
-    const bool fused = fused_mode >= 0 ? fused_mode != 0 : n < SPLIT_MILLER_MIN;
+    const bool fused = fused_mode >= 0 ? fused_mode != 0 : n < ctx->split_min;
     if (fused) {
       if (n2 && (r = run(ctx, P_MILLER_RAW2, n2, {B(0, d_g1, 192), B(1, d_g2, 384), B(3, ctx->F, F12)}, s))) return r;
       if ((n & 1) && (r = run(ctx, P_MILLER_RAW, 1, {B(0, (const uint8_t*)d_g1 + (n - 1) * 96, 96), B(1, (const uint8_t*)d_g2 + (n - 1) * 192, 192), B(3, ctx->F + n2 * F12, F12)}, s))) return r;
@@ -665,6 +666,14 @@ EXPORT int nbls_pairing_prepared(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff,
   r = product ? nbls_miller_product_prepared_dev(ctx, n, d, t, stride, with_final_exp, o, s) : nbls_pairing_prepared_dev(ctx, n, d, t, stride, with_final_exp, o, s);
   if (r) return r;
   HIPCHK(hipMemcpyAsync(out_fp12, o, nout * 576, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); return NBLS_OK;
+}
+EXPORT int nbls_set_tuning(nbls_ctx* ctx, int key, long long value) {
+  if (!ctx) return NBLS_EINVAL;
+  std::lock_guard<std::recursive_mutex> g(ctx->mu);
+  switch (key) {
+    case NBLS_TUNE_SPLIT_MILLER_MIN: if (value < 0) return NBLS_EINVAL; ctx->split_min = (size_t)value; return NBLS_OK;
+    default: return NBLS_EINVAL;
+  }
 }
 EXPORT int nbls_program_count(void) { return (int)P_COUNT; }
 EXPORT const char* nbls_program_name(int prog) { return prog >= 0 && prog < P_COUNT ? get_program((ProgId)prog).name.c_str() : nullptr; }

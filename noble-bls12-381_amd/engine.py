@@ -67,6 +67,7 @@ def load_library():
     lib.nbls_pairing_prepared_dev.argtypes = [vp, sz, vp, vp, sz, i32, vp, vp]
     lib.nbls_miller_product_prepared_dev.argtypes = [vp, sz, vp, vp, sz, i32, vp, vp]
     lib.nbls_pairing_prepared.argtypes = [vp, sz, vp, vp, sz, i32, i32, vp]
+    lib.nbls_set_tuning.argtypes = [vp, i32, C.c_longlong]
     lib.nbls_program_name.restype = C.c_char_p
     lib.nbls_program_name.argtypes = [i32]
     if not PROGRAMS:
@@ -302,6 +303,10 @@ class Engine:
 
     def fp12_product_final_dev(self, n, d_in, d_out, final_exp=True, stream=None):
         self._chk(self.lib.nbls_fp12_product_final_dev(self.h, n, d_in, int(final_exp), d_out, stream))
+
+    def set_split_miller_min(self, n):
+        """pairs from which the Miller loop runs as LINES + ACC (0: always, a huge value: never)"""
+        self._chk(self.lib.nbls_set_tuning(self.h, 1, n))
 
     def synchronize(self):
         self._chk(self.lib.nbls_device_synchronize(self.h))
