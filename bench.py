@@ -57,8 +57,8 @@ def synth_points(oracle, n, seed=0x6e626c73):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=512, help='timed steps (default: about one second of GPU time)')
+    ap.add_argument('--warmup', type=int, default=16)
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--inflight', type=int, default=5, help='batches kept in flight on separate HIP streams during the timed steps (1 = strictly one batch at a time)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -66,6 +66,7 @@ def main():
     ap.add_argument('--verify-sharded', action='store_true', help='run the multi-GPU form of the verifyBatch leg (parallel.verify_batch_sharded) even on one rank')
     ap.add_argument('--msm-points', type=int, default=65536, help='points in the multi-scalar multiplication leg (SURVEY 8(f).3); 0 disables')
     ap.add_argument('--sign-batch', type=int, default=8192, help='signatures produced in the sign leg (SURVEY 8(f).1); 0 disables')
+    ap.add_argument('--large-batch', type=int, default=65536, help='pairings of the saturated single-call leg (roofline at a launch that fills every SIMD three wavefronts deep); 0 disables')
     ap.add_argument('--product-terms', type=int, default=262144, help='terms of the sharded multi-pairing product leg (BASELINE configs[4]); 0 disables')
     args = ap.parse_args()
 
@@ -133,11 +134,12 @@ def main():
         dt = float(t.item())
     # strictly serial figure (one batch at a time on one stream) = per-batch latency, this rank
     torch.cuda.synchronize()
+    serial_steps = max(8, min(args.steps, 320))
     s0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(serial_steps):
         step1()
     torch.cuda.synchronize()
-    dt_serial = time.perf_counter() - s0
+    dt_serial = (time.perf_counter() - s0) * args.steps / serial_steps     # scaled to args.steps (the figures below divide by it)
     step = step1
     total = n * args.steps * world
     value = total / dt
@@ -244,9 +246,10 @@ def main():
         tm = eng.timing_read()
         eng.timing_enable(False)
         per_step = {k: v[0] / reps for k, v in tm.items()}          # ms per bench step, summed over that program's launches
-        ms_miller = per_step['miller_fe']
+        MILLER_PROGS = ('miller_fe', 'lines_pq', 'acc_fe')          # one program below 16,384 pairings per call, LINES + ACC from there on
+        ms_miller = sum(v for k, v in per_step.items() if k in MILLER_PROGS)
         ms_inv = per_step['fp_inv']
-        ms_hard = sum(v for k, v in per_step.items() if k not in ('miller_fe', 'fp_inv'))
+        ms_hard = sum(v for k, v in per_step.items() if k not in MILLER_PROGS + ('fp_inv',))
         mads = n * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL
         vm_ms = ms_miller + ms_hard
         achieved = mads / (vm_ms * 1e-3) / 1e12
@@ -267,7 +270,7 @@ def main():
             'traffic': traffic,
             'valu_issue_busy': valu_busy,    # SQ_INSTS_VALU x 4 clocks / (kernel time x 2.4 GHz x 1024 SIMDs) from the PMC pass in profiles/ (same batch size, one batch at a time)
             'frac_at_value': round(value / world * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL / 1e12 / PEAK_TMAD, 4),
-            'frac_note': 'achieved/frac: the kernels of one batch running alone (HIP-event durations); frac_at_value: the same work at the rate of `value` (batches overlapping on %d streams)' % D,
+            'frac_note': 'achieved/frac: the kernels of ONE %d-pairing call running alone (sum of the HIP-event durations of its nbls_vm_kernel launches; profiles/ holds the rocprofv3 kernel trace of the same command); frac_at_value: the same algorithmic work at the rate of `value` (%d calls overlapping on %d streams; profiles/ holds a kernel trace taken with the same --inflight)' % (n, D, D),
             'kernel_ms': {k: round(v, 4) for k, v in per_step.items()},
             'miller_frac': round(n * FPMUL_MILLER * MAD_PER_FPMUL / (ms_miller * 1e-3) / 1e12 / PEAK_TMAD, 4),
             'final_exp_frac': round(n * FPMUL_FINALEXP * MAD_PER_FPMUL / (ms_hard * 1e-3) / 1e12 / PEAK_TMAD, 4),
@@ -279,11 +282,37 @@ def main():
         for _ in range(3):
             eng.pairing_batch(G1, G2, True, False)
         roof['host_call_pairings_per_s'] = round(3 * n / (time.perf_counter() - h0), 2)
+        # the same pipeline as ONE call of --large-batch pairings: every SIMD holds three wavefronts (the VGPR limit), the issue slots are saturated
+        if args.large_batch > 0:
+            nl = args.large_batch
+            GL1, GL2 = (G1 * (nl // n + 1))[:96 * nl], (G2 * (nl // n + 1))[:192 * nl]
+            dl1 = torch.frombuffer(bytearray(GL1), dtype=torch.uint8).cuda(); dl2 = torch.frombuffer(bytearray(GL2), dtype=torch.uint8).cuda()
+            dlo = torch.empty(576 * nl, dtype=torch.uint8, device='cuda')
+            for _ in range(2):
+                eng.pairing_batch_dev(nl, dl1.data_ptr(), dl2.data_ptr(), dlo.data_ptr(), True, stream)
+            torch.cuda.synchronize()
+            assert bytes(dlo[:576 * 8].cpu().numpy().tobytes()) == ref and bytes(dlo[576 * n:576 * (n + 8)].cpu().numpy().tobytes()) == ref, 'large-batch parity check failed'
+            lreps = max(3, int(1.0 / (nl / 2.0e6)))      # about one second
+            l0 = time.perf_counter()
+            for _ in range(lreps):
+                eng.pairing_batch_dev(nl, dl1.data_ptr(), dl2.data_ptr(), dlo.data_ptr(), True, stream)
+            torch.cuda.synchronize()
+            ldt = (time.perf_counter() - l0) / lreps
+            eng.timing_enable(True)
+            eng.pairing_batch_dev(nl, dl1.data_ptr(), dl2.data_ptr(), dlo.data_ptr(), True, stream); torch.cuda.synchronize()
+            ltm = eng.timing_read(); eng.timing_enable(False)
+            l_vm = sum(v[0] for k, v in ltm.items() if k != 'fp_inv')
+            roof['large_batch'] = {'pairings': nl, 'pairings_per_s': round(nl / ldt, 2), 'ms_per_call': round(ldt * 1e3, 3),
+                                   'achieved': round(nl * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL / (l_vm * 1e-3) / 1e12, 4),
+                                   'frac': round(nl * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL / (l_vm * 1e-3) / 1e12 / PEAK_TMAD, 4),
+                                   'kernel_ms': {k: round(v[0], 4) for k, v in ltm.items()},
+                                   'note': 'one call, one stream; achieved/frac from the HIP-event durations of its nbls_vm_kernel launches (Miller loop as LINES + ACC at this size)'}
+            del dl1, dl2, dlo
         if world == 1 and not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
-            threads = min(cores, 64)
-            sample = 4096 if threads >= 16 else 512
-            g1s, g2s = G1[:96 * sample], G2[:192 * sample]
+            threads = min(cores, 256)
+            sample = 16384 if threads >= 128 else 4096 if threads >= 16 else 512
+            g1s, g2s = (G1 * (sample // n + 1))[:96 * sample], (G2 * (sample // n + 1))[:192 * sample]
             oracle.pairing_batch(g1s[:96 * threads], g2s[:192 * threads], True, False, threads=threads)   # warm
             c0 = time.perf_counter()
             oracle.pairing_batch(g1s, g2s, True, False, threads=threads)
@@ -293,12 +322,13 @@ def main():
             cdt1 = time.perf_counter() - c1
             cpu = {'value': round(sample / cdt, 2), 'unit': 'pairings/s', 'cores': threads, 'kind': 'port',
                    'sample': '%d pairings of the same workload on %d host threads (oracle/ C restatement); 1 thread: %.1f pairings/s' % (sample, threads, 64 / cdt1),
-                   'host_cpu_count': cores}
+                   'host_cpu_count': cores,
+                   'reference_figure': {'value': 38.6, 'unit': 'pairings/s per core', 'source': 'BASELINE.md section 2: the reference itself (noble-bls12-381 v1.4.0, TypeScript / bigint) under Node 12 in the build container; it does not travel to the GPU box, so the port above is what is timed here'}}
         vbatch = None
         if world == 1 and args.verify_batch > 0:
             nv = args.verify_batch
             cores = os.cpu_count() or 1
-            th = min(cores, 128)
+            th = min(cores, 256)
             sks = [(int.from_bytes(hashlib.sha256(b'nbls-bench-sk' + i.to_bytes(4, 'big')).digest(), 'big') % (2 ** 254) + 1).to_bytes(32, 'big') for i in range(nv)]
             msgs = [hashlib.sha256(b'msg' + i.to_bytes(4, 'big')).digest() for i in range(nv)]
             pks, sig = oracle.aggregate_sign(msgs, sks, threads=th)
@@ -333,7 +363,11 @@ def main():
             c0 = time.perf_counter()
             okc = oracle.verify_batch_mt(sig_s, msgs[:ns], pks[:ns], threads=min(th, 64))
             cdt = time.perf_counter() - c0
+            FPMUL_VERIFY = 13294 + 12452 + 610       # SURVEY.md 8(d), per signature: validity + Miller loop + product term; hash-to-G2; key decompression
+            v_ach = nv * FPMUL_VERIFY * MAD_PER_FPMUL / vdt_dev / 1e12
             vbatch = {'metric': 'verifyBatch sigs/sec', 'n_signatures': nv, 'value': round(nv / vdt_dev, 2), 'unit': 'sigs/s',
+                      'roofline': {'bound': 'valu-int32-mad', 'achieved': round(v_ach, 4), 'peak': round(PEAK_TMAD, 3), 'unit': 'TMAD32/s', 'frac': round(v_ach / PEAK_TMAD, 4),
+                                   'note': 'algorithmic work per signature %d Fp multiplications x %d MAD32 (SURVEY 8(d)) over the wall time of the call (all kernels of all three streams)' % (FPMUL_VERIFY, MAD_PER_FPMUL)},
                       'note': 'distinct 32-byte messages, 48-byte keys, one 96-byte aggregate signature; decompress + hash-to-G2 + %d Miller loops + 1 final exp on the GPU; inputs (incl. expand_message_xmd output) resident in HBM' % (nv + 1),
                       'ms': round(vdt_dev * 1e3, 3), 'host_call_sigs_per_s': round(nv / vdt, 2), 'host_call_ms': round(vdt * 1e3, 3),
                       'single_verify_ms': round(single_ms, 3), 'host_call_note': 'full nbls_verify_batch from host buffers: PCIe copies of messages, keys and signature included; SHA-256 expand_message_xmd runs on the device',
@@ -415,7 +449,13 @@ def main():
             'dtype': 'int64', 'dtype_detail': 'signed 64-bit column accumulators over 14 x 28-bit limbs (v_mad_i64_i32), 381-bit Fp in Montgomery form R = 2^392; results bit-exact', 'data': 'synthetic',
             'config': {'workload': 'batch of %d independent BLS12-381 pairings per GPU (Miller loop + final exponentiation, inputs pre-validated, bit-exact vs reference), inputs/outputs resident in HBM' % n,
                        'batch_per_gpu': n, 'sharding': 'independent batches per rank, no collective', 'batches_in_flight': D},
-            'single_stream': {'pairings_per_s': round(n * args.steps / dt_serial, 2), 'ms_per_batch': round(dt_serial / args.steps * 1e3, 4), 'note': 'one batch at a time on one stream (this rank): the latency of a 4096-pairing call'},
+            'in_flight': {'pairings_per_s': round(value, 2), 'batches_in_flight': D, 'ms_per_batch_amortised': round(dt / args.steps * 1e3, 4), 'timed_s': round(dt, 3),
+                          'roofline_frac': round(value / world * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL / 1e12 / PEAK_TMAD, 4),
+                          'note': '`value`: %d independent calls of %d pairings overlapping on %d streams / engine contexts per GPU' % (D, n, D)},
+            'single_call': {'pairings_per_s': round(n * args.steps / dt_serial, 2), 'ms_per_batch': round(dt_serial / args.steps * 1e3, 4), 'roofline_frac': roof['frac'] if roof else None,
+                            'note': 'one %d-pairing call at a time on one stream (this rank): the latency of a call; its roofline is the top-level `roofline` object' % n},
+            'single_stream': {'pairings_per_s': round(n * args.steps / dt_serial, 2), 'ms_per_batch': round(dt_serial / args.steps * 1e3, 4), 'note': 'alias of single_call (round-1 name)'},
+            'rccl_ranks': world if world > 1 else None,
             'roofline': roof, 'cpu_baseline': cpu, 'product': product, 'verify_batch': vbatch if vbatch is not None else vshard, 'verify_batch_sharded': vshard if vbatch is not None else None, 'sign': sleg, 'aggregate': aleg, 'msm': mleg,
         }
         print(json.dumps(line))

@@ -91,6 +91,24 @@ int nbls_g2_validate_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, int8_
 int nbls_g1_decompress_batch(nbls_ctx* ctx, size_t n, const uint8_t* in48, uint8_t* out96, int8_t* status);
 int nbls_g2_decompress_batch(nbls_ctx* ctx, size_t n, const uint8_t* in96, uint8_t* out192, int8_t* status);
 
+/* Every wire form of the reference's point codecs, in bulk.  `len` = bytes per encoded point.
+ *   nbls_g1_from_hex_batch        PointG1.fromHex (index.ts:298-327): len 48 compressed | 96 uncompressed (x || y, infinity flag 0x40)
+ *   nbls_g2_from_hex_batch        PointG2.fromHex (index.ts:532-579): len 96 compressed -- flag rules, root chosen by the S bit, NO subgroup
+ *                                 check, exactly as the reference -- | 192 uncompressed (x.c1 || x.c0 || y.c1 || y.c0, infinity flag 0x40)
+ *   nbls_g2_from_signature_batch  PointG2.fromSignature (index.ts:500-530): len 96, or 192 (z1 and z2 read as 96-byte integers)
+ * Output: canonical affine wire bytes.  status: 0 ok, 1 zero point, 2 not on curve, 3 not in the prime-order subgroup, 4 no square root,
+ * 6 invalid encoding flag (first byte & 0xe0 in {0x20, 0x60, 0xe0}), 7 infinity flag with other bits set, 8 compression bit clear on 96 bytes.
+ *   nbls_g*_to_hex_batch          PointG1.toHex / PointG2.toHex (index.ts:359-381, 603-631) of valid points: compressed != 0 -> 48 / 96 bytes,
+ *                                 else 96 / 192 bytes (G2 in c1 || c0 order); zero (may be NULL) marks zero points.
+ *   nbls_g*_clear_cofactor_batch  PointG1.clearCofactor (index.ts:401-405), PointG2.clearCofactor (index.ts:659-672) for points on the curve. */
+int nbls_g1_from_hex_batch(nbls_ctx* ctx, size_t n, const uint8_t* in, size_t len, uint8_t* out96, int8_t* status);
+int nbls_g2_from_hex_batch(nbls_ctx* ctx, size_t n, const uint8_t* in, size_t len, uint8_t* out192, int8_t* status);
+int nbls_g2_from_signature_batch(nbls_ctx* ctx, size_t n, const uint8_t* in, size_t len, uint8_t* out192, int8_t* status);
+int nbls_g1_to_hex_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, const int8_t* zero, int compressed, uint8_t* out);
+int nbls_g2_to_hex_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, const int8_t* zero, int compressed, uint8_t* out);
+int nbls_g1_clear_cofactor_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, uint8_t* out96, int8_t* status);
+int nbls_g2_clear_cofactor_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, uint8_t* out192, int8_t* status);
+
 /* PointG2.hashToCurve(msg, {DST}) for n messages (index.ts:481-490): msgs are concatenated, message i = msgs[offsets[i] ..
  * offsets[i+1]); SHA-256 expand_message_xmd (index.ts:207-231) and everything after it run on the GPU. */
 int nbls_hash_to_g2_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len, uint8_t* out192);
@@ -150,6 +168,30 @@ int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_sig96, c
  * *zero_flag = 1: a zero point was met (verifyBatch answers false, d_out_fp12 not written).  NBLS_EDECODE as nbls_verify_batch. */
 int nbls_verify_batch_partial_dev(nbls_ctx* ctx, size_t n, const void* d_sig96 /* or NULL */, const void* d_uniform256, const void* d_pk48,
                                   void* d_out_fp12, int* zero_flag, int8_t* pk_status /* n, may be NULL */, void* stream);
+
+/* The same as one device's share of a product that is spread over several GPUs, from HOST inputs: *d_partial points at 576 wire bytes on
+ * the context's device (owned by the context, valid until its next *_partial call), ready for hipMemcpyPeer / a collective; the call
+ * returns when the partial is complete.  An empty shard (n = 0, product only) yields the unit element. */
+int nbls_miller_product_partial(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, const uint8_t* g2_aff, int validate, void** d_partial, int8_t* status);
+int nbls_verify_batch_partial(nbls_ctx* ctx, size_t n, const uint8_t* sig96 /* or NULL */, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
+                              const uint8_t* dst, size_t dst_len, void** d_partial, int* zero_flag, int8_t* pk_status /* n, may be NULL */);
+int nbls_context_device(nbls_ctx* ctx);
+
+/* Several GPUs of one node behind one handle (one context, host thread and stream per device; contiguous shards).  n_devices = 0 takes every
+ * visible device; device_ids = NULL means 0 .. n_devices-1.  Independent pairings need no exchange; the product paths reduce every shard
+ * to a 576-byte Fp12 partial, gather the partials on the first device with hipMemcpyPeer (xGMI) and run ONE shared final exponentiation
+ * there.  Same arguments, results and error behaviour as the single-device calls of the same name. */
+typedef struct nbls_multi nbls_multi;
+int nbls_init_multi(int n_devices, const int* device_ids, nbls_multi** out);
+void nbls_destroy_multi(nbls_multi* m);
+int nbls_multi_device_count(const nbls_multi* m);
+nbls_ctx* nbls_multi_context(nbls_multi* m, int i);
+int nbls_multi_pairing_batch(nbls_multi* m, size_t n, const uint8_t* g1_aff, const uint8_t* g2_aff, int with_final_exp, int validate,
+                             uint8_t* out_fp12, int8_t* status);
+int nbls_multi_miller_product(nbls_multi* m, size_t n, const uint8_t* g1_aff, const uint8_t* g2_aff, int final_exp, int validate,
+                              uint8_t* out_fp12, int8_t* status);
+int nbls_multi_verify_batch(nbls_multi* m, size_t n, const uint8_t* sig96, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
+                            const uint8_t* dst, size_t dst_len, int* ok);
 
 /* Introspection for the benchmark / tests. */
 int nbls_program_stats(nbls_ctx* ctx, int prog, uint32_t* out8);   /* steps, mul_steps, lin_steps, mul_ops, lin_ops, lin_terms, slots, lds_bytes */

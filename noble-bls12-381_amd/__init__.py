@@ -6,5 +6,5 @@ raises if the library or a GPU is missing.
 
 The package directory name contains '-', so load it with importlib.import_module('noble-bls12-381_amd').
 """
-from .engine import Engine, NblsError, lib_path, load_library, PROGRAMS  # noqa: F401
+from .engine import Engine, MultiEngine, NblsError, lib_path, load_library, PROGRAMS  # noqa: F401
 from .pipeline import PairingPipeline  # noqa: F401

@@ -56,9 +56,20 @@ static inline void g1_decompress_B(int in_buf, int x_buf, int rhs_buf, int cand_
 }
 
 // ---------------------------------------------------------------- PointG2.fromSignature, 96-byte compressed (index.ts:500-530)
-static inline void g2_decompress_A(int in_buf, int x_buf, int rhs_buf) {
-  SFp z1 = input_raw(in_buf, 0), z2 = input_raw(in_buf, 48);
-  SFp2 x = {to_mont(z2), to_mont(bit_and(z1, raw_const(NBLS_MASK381_RAW)))};   // x = Fp2(z2, z1 mod 2^381)
+// sig192: the 192-byte branch of fromSignature (index.ts:500-515) reads z1 and z2 as 96-byte big-endian integers: x.c1 = z1 mod 2^381 (the low
+// 381 bits: the second 48 bytes) and x.c0 = z2 mod p (a 768-bit value, reduced by the Fp constructor)
+static inline void g2_decompress_A(int in_buf, int x_buf, int rhs_buf, bool sig192 = false) {
+  Builder* B = Builder::cur();
+  SFp z1 = input_raw(in_buf, sig192 ? 48 : 0);
+  SFp x0;
+  if (!sig192) x0 = to_mont(input_raw(in_buf, 48));
+  else {   // (hi 2^384 + lo) R = REDC(hi * (2^384 R^2) + lo * R^2)
+    Operand t; t.s0 = materialize(input_raw(in_buf, 96)); Operand r3; r3.s0 = B->const_atom(NBLS_TOP384);
+    Operand l; l.s0 = materialize(input_raw(in_buf, 144)); Operand r2; r2.s0 = B->r2_atom;
+    SFp f; f.f = form_add({{PROD_BASE + B->product(t, r3), 1}}, {{PROD_BASE + B->product(l, r2), 1}}, 1);
+    x0 = SFp(materialize(f));
+  }
+  SFp2 x = {x0, to_mont(bit_and(z1, raw_const(NBLS_MASK381_RAW)))};   // x = Fp2(z2, z1 mod 2^381)
   outputw(x.c0, x_buf, 0); outputw(x.c1, x_buf, 48);
   SFp2 rhs = mul(mat(sqr(x)), x) + fp2_b();
   outputw(rhs.c0, rhs_buf, 0); outputw(rhs.c1, rhs_buf, 48);
@@ -76,22 +87,64 @@ static inline SFp2 fp2_sqrt_finish(const SFp2& a, const SFp2& cand, SFp& found) 
   SFp choose1 = f_or(cmp_gt(im1, im2), f_and(is_zero(x1.c1), cmp_gt(re1, re2)));     // im1 > im2 || (im1 == im2 && re1 > re2)
   return select2(choose1, x1, x2);
 }
-static inline void g2_decompress_B(int in_buf, int x_buf, int rhs_buf, int cand_buf, int out_buf, int status_buf) {
-  SFp z1 = input_raw(in_buf, 0);
+// mode 0: PointG2.fromSignature, 96 bytes (index.ts:500-530); 1: its 192-byte branch (flags in the second 48 bytes);
+// 2: PointG2.fromHex on 96 compressed bytes (index.ts:532-562): flag rules first, the root by the S bit, NO subgroup check.
+//    Fp2.sqrt returns the root with the larger imaginary part (real part on ties), whose Y_bit is 1, so "bitS && Y_bit ? y : -y" keeps
+//    that root when S is set and takes the other one when it is clear.
+//    status: 6 invalid encoding flag (0x20, 0x60, 0xe0), 8 compression bit clear, 7 infinity bit with other bits set, 1 zero point, 4 no square root
+static inline void g2_decompress_B(int in_buf, int x_buf, int rhs_buf, int cand_buf, int out_buf, int status_buf, int mode = 0) {
+  SFp z1 = input_raw(in_buf, mode == 1 ? 48 : 0);
   SFp inf = bit_flag(z1, 382), aflag = bit_flag(z1, 381);
   SFp2 x = {inputw(x_buf, 0), inputw(x_buf, 48)}, rhs = {inputw(rhs_buf, 0), inputw(rhs_buf, 48)}, cand = {inputw(cand_buf, 0), inputw(cand_buf, 48)};
   SFp found; SFp2 y = fp2_sqrt_finish(rhs, cand, found);
+  SFp not_inf = f_not(inf);
+  SFp2 zero = fp2_zero();
+  if (mode == 2) {
+    SFp cbit = bit_flag(z1, 383);
+    SFp enc_ok = f_or(f_not(aflag), f_and(cbit, not_inf));                      // S set requires C set and I clear
+    SFp rest = f_or(cmp_gt(bit_and(z1, raw_const(NBLS_MASK381_RAW)), SFp()), cmp_gt(input_raw(in_buf, 48), SFp()));   // any bit besides the flags
+    SFp inf_ok = f_not(f_and(inf, rest));
+    SFp2 ysel = select2(aflag, y, mat(-y));
+    status_out({{enc_ok, 6}, {cbit, 8}, {inf_ok, 7}, {not_inf, 1}, {found, 4}}, status_buf);
+    SFp good = f_and(f_and(f_and(enc_ok, cbit), not_inf), found);
+    output_fp2(select2(good, x, zero), out_buf, 0);
+    output_fp2(select2(good, ysel, zero), out_buf, 96);
+    return;
+  }
   SFp y1nz = f_not(is_zero(y.c1));
   SFp big1 = gt_half(std_canon(y.c1)), big0 = gt_half(std_canon(y.c0));
   SFp neg = f_or(f_and(y1nz, f_xor(big1, aflag)), f_and(f_not(y1nz), f_xor(big0, aflag)));   // isGreater || isZero (index.ts:524-526)
   SFp2 ysel = select2(neg, mat(-y), y);
   SFp oc, sg; g2_validity_flags(x, ysel, oc, sg);
-  SFp not_inf = f_not(inf);
   status_out({{not_inf, 1}, {found, 4}, {sg, 3}}, status_buf);
   SFp good = f_and(f_and(not_inf, found), sg);
-  SFp2 zero = fp2_zero();
   output_fp2(select2(good, x, zero), out_buf, 0);
   output_fp2(select2(good, ysel, zero), out_buf, 96);
+}
+// ---------------------------------------------------------------- uncompressed forms (index.ts:317-321, 563-575): coordinates as big-endian
+// integers (reduced by the Fp constructor), infinity flag = bit 6 of the first byte, then assertValidity; G2 in the order x.c1 x.c0 y.c1 y.c0
+static inline void g1_from_raw(int in_buf, int out_buf, int status_buf) {
+  SFp zx = input_raw(in_buf, 0);
+  SFp not_inf = f_not(bit_flag(zx, 382));
+  SFp x = to_mont(zx), y = input(in_buf, 48), oc, sg;
+  g1_validity_flags(x, y, oc, sg);
+  status_out({{not_inf, 1}, {oc, 2}, {sg, 3}}, status_buf);
+  SFp good = f_and(f_and(not_inf, oc), sg);
+  output(select(good, x, SFp()), out_buf, 0); output(select(good, y, SFp()), out_buf, 48);
+}
+static inline void g2_from_raw(int in_buf, int out_buf, int status_buf) {
+  SFp zx1 = input_raw(in_buf, 0);
+  SFp not_inf = f_not(bit_flag(zx1, 382));
+  SFp2 x = {input(in_buf, 48), to_mont(zx1)}, y = {input(in_buf, 144), input(in_buf, 96)};
+  SFp oc, sg; g2_validity_flags(x, y, oc, sg);
+  status_out({{not_inf, 1}, {oc, 2}, {sg, 3}}, status_buf);
+  SFp good = f_and(f_and(not_inf, oc), sg);
+  SFp2 zero = fp2_zero();
+  output_fp2(select2(good, x, zero), out_buf, 0); output_fp2(select2(good, y, zero), out_buf, 96);
+}
+// affine wire order (c0 || c1) <-> the order of PointG2.toHex(false) (c1 || c0), index.ts:622-629: its own inverse
+static inline void g2_swap_halves(int in_buf, int out_buf) {
+  for (int k = 0; k < 2; k++) { output_raw(input_raw(in_buf, 96 * k + 48), out_buf, 96 * k); output_raw(input_raw(in_buf, 96 * k), out_buf, 96 * k + 48); }
 }
 
 // ---------------------------------------------------------------- hash_to_field tail + SWU + isogeny + cofactor (index.ts:256-263, 481-490)

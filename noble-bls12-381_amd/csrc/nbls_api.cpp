@@ -64,6 +64,7 @@ struct nbls_ctx {
   uint8_t* ident_g1 = nullptr; uint8_t* ident_g2 = nullptr;   // projective identity (0 : 1 : 0), raw
   size_t cap_F = 0, cap_io = 0;
   size_t split_min = SPLIT_MILLER_MIN;   // nbls_set_tuning(NBLS_TUNE_SPLIT_MILLER_MIN)
+  uint8_t* partial = nullptr;   // 576 bytes: the Fp12 partial of the *_partial entry points (multi-GPU reductions)
   uint8_t* L = nullptr; size_t cap_L = 0;   // line tables of the Miller loop (LINE_BYTES each), at most LINES_CHUNK of them
   // the scratch above is shared by every call on this context: a call that uses another stream than its predecessor waits for it (StreamOrder)
   hipStream_t last_stream = nullptr; hipEvent_t ev_last = nullptr; bool ev_last_set = false;
@@ -266,7 +267,7 @@ EXPORT void nbls_destroy(nbls_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   for (auto& d : ctx->prog) { if (d.steps) hipFree(d.steps); if (d.descs) hipFree(d.descs); if (d.consts) hipFree(d.consts); }
-  for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->gen_g1, ctx->side_scratch, ctx->L}) if (p) hipFree(p);
+  for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->gen_g1, ctx->side_scratch, ctx->L, ctx->partial}) if (p) hipFree(p);
   for (uint8_t* p : ctx->T) if (p) hipFree(p);
   for (uint8_t* p : ctx->sb) if (p) hipFree(p);
   for (uint8_t* p : ctx->nib) if (p) hipFree(p);
@@ -531,13 +532,15 @@ static int dev_validate(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, voi
 // PointG1.fromHex (48 B) / PointG2.fromSignature (96 B): compressed -> affine wire bytes + status
 // slot0 / pow_slot: scratch-pool slots used (three from slot0, one for the exponentiation table), so that two chains can run on
 // different streams at the same time
-static int dev_decompress(nbls_ctx* ctx, bool g2, size_t n, const void* d_in, void* d_out, void* d_status, hipStream_t s, int slot0 = 0, int pow_slot = 11) {
-  const size_t e = g2 ? 96 : 48, q = g2 ? 2 * RAW : RAW;
+// mode (G2 only): 0 fromSignature 96 B, 1 fromSignature 192 B, 2 fromHex 96 B (no subgroup check, flag rules)
+static int dev_decompress(nbls_ctx* ctx, bool g2, size_t n, const void* d_in, void* d_out, void* d_status, hipStream_t s, int slot0 = 0, int pow_slot = 11, int mode = 0) {
+  const size_t e = g2 ? (mode == 1 ? 192 : 96) : 48, q = g2 ? 2 * RAW : RAW;
   uint8_t *X, *R, *Cd, *pw; int r;
   if ((r = need(ctx, slot0, n * q, &X)) || (r = need(ctx, slot0 + 1, n * q, &R)) || (r = need(ctx, slot0 + 2, n * q, &Cd)) || (r = need(ctx, pow_slot, n * 16 * (g2 ? 2 : 1) * RAW, &pw))) return r;
-  if ((r = run(ctx, g2 ? P_G2_DEC_A : P_G1_DEC_A, n, {B(0, d_in, e), B(3, X, q), B(4, R, q)}, s))) return r;
+  const ProgId pa = !g2 ? P_G1_DEC_A : mode == 1 ? P_G2_DEC_A192 : P_G2_DEC_A, pb = !g2 ? P_G1_DEC_B : mode == 1 ? P_G2_DEC_B192 : mode == 2 ? P_G2_DEC_B_HEX : P_G2_DEC_B;
+  if ((r = run(ctx, pa, n, {B(0, d_in, e), B(3, X, q), B(4, R, q)}, s))) return r;
   if ((r = run_pow(ctx, g2 ? 1 : 0, n, R, Cd, s, pw))) return r;
-  return run(ctx, g2 ? P_G2_DEC_B : P_G1_DEC_B, n, {B(0, d_in, e), B(3, X, q), B(4, R, q), B(5, Cd, q), B(6, d_out, 2 * e), B(7, d_status, 1)}, s);
+  return run(ctx, pb, n, {B(0, d_in, e), B(3, X, q), B(4, R, q), B(5, Cd, q), B(6, d_out, g2 ? 192 : 96), B(7, d_status, 1)}, s);
 }
 // 256 uniform bytes per message (expand_message_xmd output) -> hash point, affine wire bytes (PointG2.hashToCurve, index.ts:481-490)
 static int dev_hash_to_g2(nbls_ctx* ctx, size_t n, const void* d_uniform, void* d_out, hipStream_t s) {
@@ -667,6 +670,7 @@ EXPORT int nbls_pairing_prepared(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff,
   if (r) return r;
   HIPCHK(hipMemcpyAsync(out_fp12, o, nout * 576, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); return NBLS_OK;
 }
+
 EXPORT int nbls_set_tuning(nbls_ctx* ctx, int key, long long value) {
   if (!ctx) return NBLS_EINVAL;
   std::lock_guard<std::recursive_mutex> g(ctx->mu);
@@ -798,6 +802,67 @@ static int compress_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* aff, u
 }
 EXPORT int nbls_g1_compress_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, uint8_t* out48) { return compress_host(ctx, false, n, g1_aff, out48); }
 EXPORT int nbls_g2_compress_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, uint8_t* out96) { return compress_host(ctx, true, n, g2_aff, out96); }
+
+// ---- every wire form of the reference's point codecs, in bulk --------------------------------------------------------------
+// PointG1.fromHex (index.ts:298-327): 48 compressed or 96 uncompressed bytes per point; PointG2.fromHex (index.ts:532-579): 96 compressed
+// (flag rules, no subgroup check) or 192 uncompressed bytes; PointG2.fromSignature (index.ts:500-530): 96 or 192 bytes.
+static int decode_host(nbls_ctx* ctx, int kind /* 0 g1.fromHex, 1 g2.fromHex, 2 g2.fromSignature */, size_t n, const uint8_t* in, size_t len, uint8_t* out, int8_t* status) {
+  if (!ctx || (n && (!in || !out || !status))) return NBLS_EINVAL;
+  const bool g2 = kind != 0;
+  const size_t a = g2 ? 192 : 96;
+  if (len != a && len != a / 2) return NBLS_EINVAL;
+  if (!n) return NBLS_OK;
+  LOCKED(ctx); HostIO io{ctx}; void *d = io.alloc(n * len), *o = io.alloc(n * a), *st = io.alloc(n); if (!d || !o || !st) return NBLS_EHIP;
+  HIPCHK(hipMemcpyAsync(d, in, n * len, hipMemcpyHostToDevice, s));
+  int r;
+  if (kind == 0) r = len == 48 ? dev_decompress(ctx, false, n, d, o, st, s) : run(ctx, P_G1_FROM_RAW, n, {B(0, d, 96), B(6, o, 96), B(7, st, 1)}, s);
+  else if (kind == 1) r = len == 96 ? dev_decompress(ctx, true, n, d, o, st, s, 0, 11, 2) : run(ctx, P_G2_FROM_RAW, n, {B(0, d, 192), B(6, o, 192), B(7, st, 1)}, s);
+  else r = dev_decompress(ctx, true, n, d, o, st, s, 0, 11, len == 192 ? 1 : 0);
+  if (r) return r;
+  HIPCHK(hipMemcpyAsync(out, o, n * a, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(status, st, n, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+  return NBLS_OK;
+}
+EXPORT int nbls_g1_from_hex_batch(nbls_ctx* ctx, size_t n, const uint8_t* in, size_t len, uint8_t* out96, int8_t* status) { return decode_host(ctx, 0, n, in, len, out96, status); }
+EXPORT int nbls_g2_from_hex_batch(nbls_ctx* ctx, size_t n, const uint8_t* in, size_t len, uint8_t* out192, int8_t* status) { return decode_host(ctx, 1, n, in, len, out192, status); }
+EXPORT int nbls_g2_from_signature_batch(nbls_ctx* ctx, size_t n, const uint8_t* in, size_t len, uint8_t* out192, int8_t* status) { return decode_host(ctx, 2, n, in, len, out192, status); }
+// PointG1.toHex / PointG2.toHex (index.ts:359-381, 603-631) for n valid affine points; zero[i] != 0 marks the zero point (its affine bytes are
+// ignored): compressed 0xc0 00.., uncompressed 0x40 00..
+static int encode_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* aff, const int8_t* zero, int compressed, uint8_t* out) {
+  if (!ctx || (n && (!aff || !out))) return NBLS_EINVAL; if (!n) return NBLS_OK;
+  const size_t a = g2 ? 192 : 96, c = compressed ? a / 2 : a;
+  int r;
+  if (compressed) { if ((r = compress_host(ctx, g2, n, aff, out))) return r; }
+  else if (!g2) memcpy(out, aff, n * a);
+  else {
+    LOCKED(ctx); HostIO io{ctx}; void *d = io.alloc(n * a), *o = io.alloc(n * a); if (!d || !o) return NBLS_EHIP;
+    HIPCHK(hipMemcpyAsync(d, aff, n * a, hipMemcpyHostToDevice, s));
+    if ((r = run(ctx, P_G2_SWAP, n, {B(0, d, a), B(2, o, a)}, s))) return r;
+    HIPCHK(hipMemcpyAsync(out, o, n * a, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+  }
+  if (zero) for (size_t i = 0; i < n; i++) if (zero[i]) { memset(out + i * c, 0, c); out[i * c] = compressed ? 0xc0 : 0x40; }
+  return NBLS_OK;
+}
+EXPORT int nbls_g1_to_hex_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, const int8_t* zero, int compressed, uint8_t* out) { return encode_host(ctx, false, n, g1_aff, zero, compressed, out); }
+EXPORT int nbls_g2_to_hex_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, const int8_t* zero, int compressed, uint8_t* out) { return encode_host(ctx, true, n, g2_aff, zero, compressed, out); }
+// PointG1.clearCofactor (index.ts:401-405) / PointG2.clearCofactor (index.ts:659-672) for n affine points ON THE CURVE (any subgroup):
+// status 1 = the result is the zero point
+static int clear_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* aff, uint8_t* out, int8_t* status) {
+  if (!ctx || (n && (!aff || !out || !status))) return NBLS_EINVAL; if (!n) return NBLS_OK;
+  const size_t a = g2 ? 192 : 96, p = g2 ? 6 * RAW : 3 * RAW;
+  LOCKED(ctx); HostIO io{ctx};
+  void *d = io.alloc(n * a), *P = io.alloc(n * p), *Q = io.alloc(n * p), *N = io.alloc(n * RAW), *NI = io.alloc(n * RAW), *o = io.alloc(n * a), *st = io.alloc(n);
+  if (!d || !P || !Q || !N || !NI || !o || !st) return NBLS_EHIP;
+  HIPCHK(hipMemcpyAsync(d, aff, n * a, hipMemcpyHostToDevice, s));
+  int r;
+  if ((r = run(ctx, g2 ? P_G2_TO_PROJ : P_G1_TO_PROJ, n, {B(g2 ? 1 : 0, d, a), B(3, P, p)}, s))) return r;
+  if ((r = run(ctx, g2 ? P_H2C_C : P_G1_CLEAR, n, {B(3, P, p), B(6, Q, p), B(7, N, RAW)}, s))) return r;
+  if ((r = run_inv_buf(ctx, n, N, NI, s))) return r;
+  if ((r = run(ctx, g2 ? P_G2_TO_AFFINE : P_G1_TO_AFFINE, n, {B(3, Q, p), B(4, NI, RAW), B(2, o, a), B(7, st, 1)}, s))) return r;
+  HIPCHK(hipMemcpyAsync(out, o, n * a, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(status, st, n, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+  return NBLS_OK;
+}
+EXPORT int nbls_g1_clear_cofactor_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, uint8_t* out96, int8_t* status) { return clear_host(ctx, false, n, g1_aff, out96, status); }
+EXPORT int nbls_g2_clear_cofactor_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, uint8_t* out192, int8_t* status) { return clear_host(ctx, true, n, g2_aff, out192, status); }
 
 // [k_i]P_i for per-item 256-bit big-endian scalars (pt_stride 0 = one point for all items): ladder -> inversion -> affine
 static int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, size_t pt_stride, const void* d_scalars, void* d_out, void* d_status, hipStream_t s) {
@@ -1078,3 +1143,53 @@ EXPORT int nbls_verify_batch_partial_dev(nbls_ctx* ctx, size_t n, const void* d_
   // the pairs sit at stride n + 1 inside the scratch block whether or not the signature pair is present
   return nbls_miller_product_dev(ctx, np, base, base + (n + 1) * 96, 0, d_out_fp12, stream);
 }
+
+// ---- one device's share of a product that is spread over several GPUs, from HOST inputs: the partial stays on this context's device
+// (*d_partial: 576 wire bytes in a buffer owned by the context, valid until the next *_partial call) so that the caller can move it to the
+// reducing device with hipMemcpyPeer (nbls_multi.cpp) or hand it to a collective.  The call returns when the partial is complete.
+static int partial_buffer(nbls_ctx* ctx) {
+  if (!ctx->partial) HIPCHK(hipMalloc(&ctx->partial, 576));
+  return NBLS_OK;
+}
+EXPORT int nbls_miller_product_partial(nbls_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2, int validate, void** d_partial, int8_t* status) {
+  std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);
+  if (!ctx || !d_partial || (n && (!g1 || !g2))) return NBLS_EINVAL;
+  int r;
+  if (status) memset(status, 0, n);
+  if (validate && n) {
+    std::vector<int8_t> st1(n), st2(n);
+    if ((r = nbls_g1_validate_batch(ctx, n, g1, st1.data())) || (r = nbls_g2_validate_batch(ctx, n, g2, st2.data()))) return r;
+    bool bad = false;
+    for (size_t i = 0; i < n; i++) { int8_t c = st1[i] ? st1[i] : (st2[i] ? (int8_t)(10 + st2[i]) : 0); if (status) status[i] = c; bad |= c != 0; }
+    if (bad) return NBLS_EDECODE;
+  }
+  LOCKED(ctx);
+  if ((r = partial_buffer(ctx))) return r;
+  if (n) {
+    if ((r = ensure_io(ctx, n))) return r;
+    HIPCHK(hipMemcpyAsync(ctx->io_g1, g1, n * 96, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->io_g2, g2, n * 192, hipMemcpyHostToDevice, s));
+  }
+  if ((r = nbls_miller_product_dev(ctx, n, ctx->io_g1, ctx->io_g2, 0, ctx->partial, s))) return r;
+  HIPCHK(hipStreamSynchronize(s));
+  *d_partial = ctx->partial;
+  return NBLS_OK;
+}
+EXPORT int nbls_verify_batch_partial(nbls_ctx* ctx, size_t n, const uint8_t* sig96 /* or NULL */, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
+                                     const uint8_t* dst, size_t dst_len, void** d_partial, int* zero_flag, int8_t* pk_status) {
+  std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);
+  if (!ctx || !d_partial || !zero_flag || !n || !offsets || !pk48 || !dst) return NBLS_EINVAL;
+  LOCKED(ctx);
+  uint8_t *b, *c; int r;
+  if ((r = partial_buffer(ctx))) return r;
+  if ((r = dev_expand(ctx, n, msgs, offsets, dst, dst_len, &b, s))) return r;
+  if ((r = need(ctx, 9, n * 48 + 96, &c))) return r;
+  HIPCHK(hipMemcpyAsync(c, pk48, n * 48, hipMemcpyHostToDevice, s));
+  if (sig96) HIPCHK(hipMemcpyAsync(c + n * 48, sig96, 96, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if ((r = nbls_verify_batch_partial_dev(ctx, n, sig96 ? c + n * 48 : nullptr, b, c, ctx->partial, zero_flag, pk_status, nullptr))) return r;
+  HIPCHK(hipStreamSynchronize(s));
+  *d_partial = ctx->partial;
+  return NBLS_OK;
+}
+EXPORT int nbls_context_device(nbls_ctx* ctx) { return ctx ? ctx->device : -1; }

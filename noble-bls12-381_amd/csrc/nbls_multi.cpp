@@ -1,0 +1,130 @@
+// nbls_multi.cpp -- several GPUs of one node behind ONE handle: a context per device, one host thread and one
+// stream per device for the duration of a call, contiguous shards.
+//   * independent pairings: no exchange at all, results land in disjoint slices of the caller's buffer;
+//   * Miller product / verifyBatch: every device reduces its shard to ONE Fp12 partial (576 bytes, no final exponentiation), the partials
+//     are copied device-to-device (hipMemcpyPeer over xGMI) into the first device's gather buffer, which multiplies them and runs the one
+//     shared final exponentiation.  The exchange is 576 bytes per device -- pure latency -- so no collective library is involved.
+// This layer uses only the public single-device ABI (include/nbls.h) plus HIP for the peer copies.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include "nbls.h"
+
+#define EXPORT extern "C" __attribute__((visibility("default")))
+
+struct nbls_multi {
+  std::vector<nbls_ctx*> ctx;
+  std::vector<int> dev;
+  uint8_t* gather = nullptr;   // on dev[0]: one 576-byte partial per device, then 576 bytes of result
+};
+
+EXPORT void nbls_destroy_multi(nbls_multi* m) {
+  if (!m) return;
+  if (m->gather && !m->dev.empty()) { hipSetDevice(m->dev[0]); hipFree(m->gather); }
+  for (nbls_ctx* c : m->ctx) nbls_destroy(c);
+  delete m;
+}
+
+EXPORT int nbls_init_multi(int n_devices, const int* device_ids, nbls_multi** out) {
+  if (!out || n_devices < 0) return NBLS_EINVAL;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return NBLS_ENOGPU;
+  if (n_devices == 0) n_devices = count;   // 0 = every visible device
+  if (n_devices > count && !device_ids) return NBLS_EINVAL;
+  nbls_multi* m = new nbls_multi();
+  for (int i = 0; i < n_devices; i++) {
+    const int d = device_ids ? device_ids[i] : i;
+    nbls_ctx* c = nullptr;
+    int r = nbls_init(d, &c);
+    if (r) { nbls_destroy_multi(m); return r; }
+    m->ctx.push_back(c); m->dev.push_back(d);
+  }
+  if (hipSetDevice(m->dev[0]) != hipSuccess || hipMalloc(&m->gather, 576 * (m->dev.size() + 1)) != hipSuccess) { nbls_destroy_multi(m); return NBLS_EHIP; }
+  // peer access lets hipMemcpyPeer go straight over xGMI; without it the copy is staged, which is still correct
+  for (size_t i = 1; i < m->dev.size(); i++) { int can = 0; if (hipDeviceCanAccessPeer(&can, m->dev[0], m->dev[i]) == hipSuccess && can) { hipSetDevice(m->dev[0]); hipDeviceEnablePeerAccess(m->dev[i], 0); } }
+  (void)hipGetLastError();
+  *out = m;
+  return NBLS_OK;
+}
+EXPORT int nbls_multi_device_count(const nbls_multi* m) { return m ? (int)m->ctx.size() : 0; }
+EXPORT nbls_ctx* nbls_multi_context(nbls_multi* m, int i) { return m && i >= 0 && i < (int)m->ctx.size() ? m->ctx[i] : nullptr; }
+
+// contiguous shards [lo, hi) of n items over the devices (the first n % G devices take one item more)
+static void shard(size_t n, size_t G, size_t g, size_t* lo, size_t* hi) { const size_t q = n / G, r = n % G; *lo = g * q + (g < r ? g : r); *hi = *lo + q + (g < r ? 1 : 0); }
+
+template <class F> static int on_every_device(nbls_multi* m, F f) {
+  const size_t G = m->ctx.size();
+  std::vector<int> rc(G, 0);
+  std::vector<std::thread> th;
+  for (size_t g = 1; g < G; g++) th.emplace_back([&, g] { rc[g] = f(g); });
+  rc[0] = f(0);
+  for (auto& t : th) t.join();
+  for (size_t g = 0; g < G; g++) if (rc[g] && rc[g] != NBLS_EDECODE) return rc[g];
+  for (size_t g = 0; g < G; g++) if (rc[g]) return rc[g];
+  return NBLS_OK;
+}
+
+// pairing(P_i, Q_i) for n independent pairs, sharded over the devices (BASELINE configs[3]) -- reference index.ts:715-722
+EXPORT int nbls_multi_pairing_batch(nbls_multi* m, size_t n, const uint8_t* g1, const uint8_t* g2, int with_final_exp, int validate, uint8_t* out, int8_t* status) {
+  if (!m || m->ctx.empty() || (n && (!g1 || !g2 || !out))) return NBLS_EINVAL;
+  const size_t G = m->ctx.size();
+  return on_every_device(m, [&](size_t g) {
+    size_t lo, hi; shard(n, G, g, &lo, &hi);
+    if (hi == lo) return (int)NBLS_OK;
+    return nbls_pairing_batch(m->ctx[g], hi - lo, g1 + lo * 96, g2 + lo * 192, with_final_exp, validate, out + lo * 576, status ? status + lo : nullptr);
+  });
+}
+
+// gather the devices' partials on the first device, multiply, one shared final exponentiation, result to the host
+static int finish(nbls_multi* m, const std::vector<void*>& part, int final_exp, uint8_t* out) {
+  const size_t G = m->ctx.size();
+  if (hipSetDevice(m->dev[0]) != hipSuccess) return NBLS_EHIP;
+  for (size_t g = 0; g < G; g++) {
+    hipError_t e = g == 0 ? hipMemcpy(m->gather, part[0], 576, hipMemcpyDeviceToDevice) : hipMemcpyPeer(m->gather + 576 * g, m->dev[0], part[g], m->dev[g], 576);
+    if (e != hipSuccess) return NBLS_EHIP;
+  }
+  uint8_t* res = m->gather + 576 * G;
+  int r = nbls_fp12_product_final_dev(m->ctx[0], G, m->gather, final_exp, res, nullptr);
+  if (r) return r;
+  if (nbls_device_synchronize(m->ctx[0])) return NBLS_EHIP;
+  return hipMemcpy(out, res, 576, hipMemcpyDeviceToHost) == hipSuccess ? NBLS_OK : NBLS_EHIP;
+}
+
+// prod_i millerLoop(P_i, Q_i) with ONE shared final exponentiation (BASELINE configs[4]) -- the core of verify / verifyBatch, index.ts:763-766, 811-816
+EXPORT int nbls_multi_miller_product(nbls_multi* m, size_t n, const uint8_t* g1, const uint8_t* g2, int final_exp, int validate, uint8_t* out, int8_t* status) {
+  if (!m || m->ctx.empty() || !out || (n && (!g1 || !g2))) return NBLS_EINVAL;
+  const size_t G = m->ctx.size();
+  std::vector<void*> part(G, nullptr);
+  int r = on_every_device(m, [&](size_t g) {
+    size_t lo, hi; shard(n, G, g, &lo, &hi);   // an empty shard contributes the unit element
+    return nbls_miller_product_partial(m->ctx[g], hi - lo, g1 + lo * 96, g2 + lo * 192, validate, &part[g], status ? status + lo : nullptr);
+  });
+  if (r) return r;
+  return finish(m, part, final_exp, out);
+}
+
+// verifyBatch(signature, messages, publicKeys) with every message distinct (BASELINE configs[2] over several GPUs) -- reference index.ts:792-821.
+// Every device decodes the keys and hashes the messages of its shard; the first one also decodes the signature and adds millerLoop(-G, S).
+EXPORT int nbls_multi_verify_batch(nbls_multi* m, size_t n, const uint8_t* sig96, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
+                                   const uint8_t* dst, size_t dst_len, int* ok) {
+  if (!m || m->ctx.empty() || !ok || !n || !sig96 || !offsets || !pk48 || !dst) return NBLS_EINVAL;
+  size_t G = m->ctx.size();
+  if (G > n) G = n;   // fewer signatures than devices: the surplus devices stay idle
+  std::vector<void*> part(G, nullptr);
+  std::vector<int> zero(G, 0);
+  nbls_multi sub; sub.ctx.assign(m->ctx.begin(), m->ctx.begin() + G); sub.dev.assign(m->dev.begin(), m->dev.begin() + G); sub.gather = m->gather;
+  int r = on_every_device(&sub, [&](size_t g) {
+    size_t lo, hi; shard(n, G, g, &lo, &hi);
+    return nbls_verify_batch_partial(m->ctx[g], hi - lo, g == 0 ? sig96 : nullptr, msgs, offsets + lo, pk48 + lo * 48, dst, dst_len, &part[g], &zero[g], nullptr);
+  });
+  if (r) { sub.ctx.clear(); sub.gather = nullptr; return r; }
+  for (int z : zero) if (z) { *ok = 0; sub.ctx.clear(); sub.gather = nullptr; return NBLS_OK; }   // a zero point: pairing() throws, verifyBatch answers false
+  uint8_t e[576];
+  r = finish(&sub, part, 1, e);
+  sub.ctx.clear(); sub.gather = nullptr;
+  if (r) return r;
+  bool one = e[47] == 1; for (int i = 0; i < 576 && one; i++) if (i != 47 && e[i]) one = false;   // exp.equals(Fp12.ONE)
+  *ok = one ? 1 : 0;
+  return NBLS_OK;
+}

@@ -478,6 +478,12 @@ static Program build(ProgId id) {
       outputw(r.x.c0, 5, 0); outputw(r.x.c1, 5, 48); outputw(r.y.c0, 5, 96); outputw(r.y.c1, 5, 144); outputw(r.z.c0, 5, 192); outputw(r.z.c1, 5, 240);
       return B.compile(id == P_G2_ADD_AB ? "g2_add_ab" : id == P_G2_HORNER ? "g2_horner" : "g2_shiftadd", 8);
     }
+    case P_G2_DEC_A192: g2_decompress_A(0, 3, 4, true); return B.compile("g2_dec_a192", 4);
+    case P_G2_DEC_B192: g2_decompress_B(0, 3, 4, 5, 6, 7, 1); return B.compile("g2_dec_b192", G2_W);
+    case P_G2_DEC_B_HEX: g2_decompress_B(0, 3, 4, 5, 6, 7, 2); return B.compile("g2_dec_b_hex", G2_W);
+    case P_G1_FROM_RAW: g1_from_raw(0, 6, 7); return B.compile("g1_from_raw", G1_W);
+    case P_G2_FROM_RAW: g2_from_raw(0, 6, 7); return B.compile("g2_from_raw", G2_W);
+    case P_G2_SWAP: g2_swap_halves(0, 2); return B.compile("g2_swap", 4);
     case P_LINES_PQ: {
       SFp Px, Py; SFp2 Qx, Qy; load_points(Px, Py, Qx, Qy);
       LineSink o{3, 0, &Px, &Py};

@@ -53,6 +53,11 @@ enum ProgId {
   P_ACC_FE,            // folded lines (buf 3) -> F (buf 5), N = norm to invert (buf 4)
   P_ACC2_RAW,          // two folded line tables per item (buf 3) -> F (buf 5): one shared accumulator, one Fp12 squaring per bit for both
   P_ACC_Q,             // prepared lines (buf 3) + G1 (buf 0) -> F (buf 5)                           [PointG1.millerLoop, index.ts:452-454]
+  // wire-format completeness (round 2): the remaining decoders of the reference and the uncompressed G2 byte order
+  P_G2_DEC_A192, P_G2_DEC_B192,   // PointG2.fromSignature on 192 bytes (index.ts:500-530 with half = 96)
+  P_G2_DEC_B_HEX,                 // PointG2.fromHex on 96 compressed bytes (index.ts:532-562): flag rules, root by the S bit, no subgroup check
+  P_G1_FROM_RAW, P_G2_FROM_RAW,   // uncompressed 96 / 192 bytes (buf 0) -> canonical affine wire bytes (buf 6), status (buf 7)   (index.ts:317-321, 563-575)
+  P_G2_SWAP,                      // x.c0 x.c1 y.c0 y.c1 <-> x.c1 x.c0 y.c1 y.c0 (buf 0 -> buf 2)   (PointG2.toHex(false), index.ts:622-629)
   P_COUNT
 };
 static const int N_LINES = 68;                 // 63 doubling steps + 5 addition steps (bits of |x|)

@@ -68,6 +68,18 @@ def load_library():
     lib.nbls_miller_product_prepared_dev.argtypes = [vp, sz, vp, vp, sz, i32, vp, vp]
     lib.nbls_pairing_prepared.argtypes = [vp, sz, vp, vp, sz, i32, i32, vp]
     lib.nbls_set_tuning.argtypes = [vp, i32, C.c_longlong]
+    for nm in ('nbls_g1_from_hex_batch', 'nbls_g2_from_hex_batch', 'nbls_g2_from_signature_batch'):
+        getattr(lib, nm).argtypes = [vp, sz, vp, sz, vp, vp]
+    lib.nbls_g1_to_hex_batch.argtypes = [vp, sz, vp, vp, i32, vp]
+    lib.nbls_g2_to_hex_batch.argtypes = [vp, sz, vp, vp, i32, vp]
+    lib.nbls_g1_clear_cofactor_batch.argtypes = [vp, sz, vp, vp, vp]
+    lib.nbls_g2_clear_cofactor_batch.argtypes = [vp, sz, vp, vp, vp]
+    lib.nbls_init_multi.argtypes = [i32, C.POINTER(i32), C.POINTER(vp)]
+    lib.nbls_destroy_multi.argtypes = [vp]
+    lib.nbls_multi_device_count.argtypes = [vp]
+    lib.nbls_multi_pairing_batch.argtypes = [vp, sz, vp, vp, i32, i32, vp, vp]
+    lib.nbls_multi_miller_product.argtypes = [vp, sz, vp, vp, i32, i32, vp, vp]
+    lib.nbls_multi_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, sz, C.POINTER(i32)]
     lib.nbls_program_name.restype = C.c_char_p
     lib.nbls_program_name.argtypes = [i32]
     if not PROGRAMS:
@@ -168,6 +180,32 @@ class Engine:
         st = C.create_string_buffer(max(n, 1))
         self._chk((self.lib.nbls_g2_decompress_batch if g2 else self.lib.nbls_g1_decompress_batch)(self.h, n, comp, out, st))
         return out.raw[:2 * e * n], list(st.raw[:n])
+
+    # ---- every wire form of the point codecs (include/nbls.h): kind 'g1' / 'g2' = fromHex, 'sig' = PointG2.fromSignature
+    def decode_points(self, kind, blob, length):
+        """-> (canonical affine wire bytes, status list); length = bytes per encoded point"""
+        n = len(blob) // length
+        a = 96 if kind == 'g1' else 192
+        out = C.create_string_buffer(max(a * n, 1)); st = C.create_string_buffer(max(n, 1))
+        f = {'g1': self.lib.nbls_g1_from_hex_batch, 'g2': self.lib.nbls_g2_from_hex_batch, 'sig': self.lib.nbls_g2_from_signature_batch}[kind]
+        self._chk(f(self.h, n, blob, length, out, st))
+        return out.raw[:a * n], list(st.raw[:n])
+
+    def encode_points(self, aff, g2=False, compressed=True, zero=None):
+        a = 192 if g2 else 96
+        n = len(aff) // a
+        c = a // 2 if compressed else a
+        out = C.create_string_buffer(max(c * n, 1))
+        z = bytes(zero) if zero is not None else None
+        self._chk((self.lib.nbls_g2_to_hex_batch if g2 else self.lib.nbls_g1_to_hex_batch)(self.h, n, aff, z, int(compressed), out))
+        return out.raw[:c * n]
+
+    def clear_cofactor(self, aff, g2=False):
+        a = 192 if g2 else 96
+        n = len(aff) // a
+        out = C.create_string_buffer(max(a * n, 1)); st = C.create_string_buffer(max(n, 1))
+        self._chk((self.lib.nbls_g2_clear_cofactor_batch if g2 else self.lib.nbls_g1_clear_cofactor_batch)(self.h, n, aff, out, st))
+        return out.raw[:a * n], list(st.raw[:n])
 
     @staticmethod
     def _pack(msgs):
@@ -331,3 +369,55 @@ class Engine:
         self._chk(self.lib.nbls_timing_read(self.h, ms, cnt))
         names = PROGRAMS + ['fp_inv']
         return {names[i]: (ms[i], cnt[i]) for i in range(n) if cnt[i]}
+
+
+class MultiEngine:
+    """Several GPUs of one node behind one handle (include/nbls.h nbls_init_multi): contiguous shards, one host thread and stream per
+    device, 576-byte Fp12 partials gathered on the first device by hipMemcpyPeer.  devices=None takes every visible device; a device id
+    may be listed more than once (several contexts on one GPU: the tests exercise the sharded paths on a one-GPU box that way)."""
+
+    def __init__(self, devices=None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        if devices is None:
+            r = self.lib.nbls_init_multi(0, None, C.byref(h))
+        else:
+            ids = (C.c_int * len(devices))(*devices)
+            r = self.lib.nbls_init_multi(len(devices), ids, C.byref(h))
+        if r != 0:
+            raise NblsError('nbls_init_multi failed: %s (code %d)' % (self.lib.nbls_strerror(r).decode(), r))
+        self.h = h
+        self.n_devices = self.lib.nbls_multi_device_count(h)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.nbls_destroy_multi(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, r):
+        if r != 0:
+            raise NblsError('%s (code %d)' % (self.lib.nbls_strerror(r).decode(), r))
+
+    def pairing_batch(self, g1_aff, g2_aff, with_final_exp=True, validate=False):
+        n = len(g1_aff) // 96
+        out = C.create_string_buffer(max(576 * n, 1)); st = C.create_string_buffer(max(n, 1))
+        self._chk(self.lib.nbls_multi_pairing_batch(self.h, n, g1_aff, g2_aff, int(with_final_exp), int(validate), out, st))
+        return out.raw[:576 * n], st.raw[:n]
+
+    def miller_product(self, g1_aff, g2_aff, final_exp=True, validate=False):
+        n = len(g1_aff) // 96
+        out = C.create_string_buffer(576); st = C.create_string_buffer(max(n, 1))
+        self._chk(self.lib.nbls_multi_miller_product(self.h, n, g1_aff, g2_aff, int(final_exp), int(validate), out, st))
+        return out.raw, st.raw[:n]
+
+    def verify_batch(self, sig96, msgs, pks48, dst=DST_DEFAULT):
+        blob, offs = Engine._pack(msgs)
+        ok = C.c_int(0)
+        self._chk(self.lib.nbls_multi_verify_batch(self.h, len(msgs), sig96, blob, offs, b''.join(pks48), dst, len(dst), C.byref(ok)))
+        return bool(ok.value)

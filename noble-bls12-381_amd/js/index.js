@@ -32,7 +32,15 @@ const CURVE = {
 };
 const htfDefaults = { DST: 'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_' };      // reference index.ts:60-81
 let inited = false;
-function ensureInit() { if (!inited) { native.init(Number(process.env.NBLS_DEVICE || 0)); inited = true; } }
+// NBLS_DEVICES = "0,1,2,3" (or "all") opens every listed GPU behind one handle: pairing batches, Miller products and verifyBatch then shard
+// over them inside the library (nbls_multi_*, include/nbls.h); NBLS_DEVICE = n selects a single GPU (default 0).
+function ensureInit() {
+  if (inited) return;
+  const list = process.env.NBLS_DEVICES;
+  if (list) native.initMulti(list === 'all' ? null : Int32Array.from(list.split(',').map(Number)));
+  else native.init(Number(process.env.NBLS_DEVICE || 0));
+  inited = true;
+}
 
 // ---- byte helpers (reference math.ts:158-212)
 function hexToBytes(hex) {
@@ -86,8 +94,17 @@ class PointG1 {
   toAffineBatch(points) { return points.map((p) => p.toAffine()); }
   normalizeZ(points) { return points; }
   toString() { return this.zero ? 'Point<Zero>' : `Point<x=${this.x}, y=${this.y}>`; }
-  millerLoop(Q) { return pairing(this, Q, false); }                                        // index.ts:395-397 (line precomputation happens on the GPU)
-  clearCofactor() { return this.zero ? this : this.multiply(CURVE.x).add(this); }         // [x]P + P with x = |z| (index.ts:401-405)
+  // index.ts:452-454: millerLoop(P.pairingPrecomputes(), this.toAffine()); a Q whose table is already memoised is paired through the prepared path
+  millerLoop(Q) {
+    if (Q._lineTable && !this.zero) { ensureInit(); return Fp12.fromBytes(native.pairingPrepared(this.aff, Q._lineTable, false, false)); }
+    return pairing(this, Q, false);
+  }
+  clearCofactor() {                                                                       // [x]P + P with x = |z| (index.ts:401-405), for any point of the curve
+    if (this.zero) return this;
+    ensureInit();
+    const { out, status } = native.clearCofactor(false, this.aff);
+    return status[0] === 1 ? PointG1.ZERO : new PointG1(out);
+  }
   calcMultiplyPrecomputes() {} clearMultiplyPrecomputes() {}                               // window tables of the reference's host ladder: nothing to cache here
   static get ZERO() { return new PointG1(new Uint8Array(96), true); }
   static get BASE() {
@@ -115,8 +132,10 @@ class PointG1 {
       if (status[0]) throw new Error(G1_STATUS[status[0]]);
       return new PointG1(out);
     } else if (bytes.length === 96) {
-      if ((bytes[0] & (1 << 6)) !== 0) return PointG1.ZERO;
-      const p = new PointG1(bytes); p.assertValidity(); return p;
+      const { out, status } = native.decodePoints(0, bytes, 96);      // infinity flag, coordinates reduced by the Fp constructor, assertValidity (index.ts:317-325)
+      if (status[0] === 1) return PointG1.ZERO;
+      if (status[0]) throw new Error(G1_STATUS[status[0]]);
+      return new PointG1(out);
     }
     throw new Error('Invalid point G1, expected 48/96 bytes');
   }
@@ -201,8 +220,28 @@ class PointG2 {
   toAffineBatch(points) { return points.map((p) => p.toAffine()); }
   normalizeZ(points) { return points; }
   toString() { return this.zero ? 'Point<Zero>' : `Point<x=${this.x}, y=${this.y}>`; }
-  clearPairingPrecomputes() {} calcMultiplyPrecomputes() {} clearMultiplyPrecomputes() {}      // caches of the reference's host path
-  pairingPrecomputes() { throw new Error('pairingPrecomputes: the line coefficients are computed inside the Miller-loop kernel and never leave the GPU'); }
+  calcMultiplyPrecomputes() {} clearMultiplyPrecomputes() {}      // caches of the reference's host path
+  // reference index.ts:659-672 (clear_cofactor_bls12381_g2: [x^2 - x - 1]P + [x - 1]psi(P) + psi^2(2P)), for any point of the curve
+  clearCofactor() {
+    if (this.zero) return this;
+    ensureInit();
+    const { out, status } = native.clearCofactor(true, this.aff);
+    return status[0] === 1 ? PointG2.ZERO : new PointG2(out);
+  }
+  // reference index.ts:695-711: the 68 line triples of calcPairingPrecomputes (math.ts:1331-1371), memoised on the point.  Computed on the GPU
+  // (nbls_g2_prepare); the wire form is kept beside the Fp2 view so that PointG1.millerLoop can hand the table straight back to the engine.
+  clearPairingPrecomputes() { this._PPRECOMPUTES = undefined; this._lineTable = undefined; }
+  pairingPrecomputes() {
+    if (this._PPRECOMPUTES) return this._PPRECOMPUTES;
+    if (this.zero) throw new Error('No pairings at point of Infinity');
+    ensureInit();
+    const t = native.g2Prepare(this.aff);
+    this._lineTable = t;
+    const ell = [];
+    for (let j = 0; j < 68; j++) ell.push([0, 1, 2].map((k) => Fp2.fromBytes(t.subarray(288 * j + 96 * k, 288 * j + 96 * k + 96))));
+    this._PPRECOMPUTES = ell;
+    return ell;
+  }
   static get ZERO() { return new PointG2(new Uint8Array(192), true); }
   static get BASE() {
     return new PointG2(hexToBytes('024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8' +
@@ -223,27 +262,29 @@ class PointG2 {
     const dst = stringToBytes((options && options.DST) || htfDefaults.DST);
     return new PointG2(native.hashToCurve(2, msg, Uint32Array.from([0, msg.length]), dst));
   }
-  // reference index.ts:500-530
+  // reference index.ts:500-530: 96 bytes, or 192 bytes read as two 96-byte integers z1 || z2
   static fromSignature(hex) {
     hex = ensureBytes(hex); ensureInit();
     const half = hex.length / 2;
     if (half !== 48 && half !== 96) throw new Error('Invalid compressed signature length, must be 96 or 192');
-    if (half === 96) return PointG2.fromHex(hex);
-    const { out, status } = native.g2Decompress(hex);
+    const { out, status } = native.decodePoints(2, hex, hex.length);
     if (status[0] === 1) return PointG2.ZERO;
     if (status[0]) throw new Error(G2_STATUS[status[0]]);
     return new PointG2(out);
   }
-  // uncompressed 192-byte form x.c1 || x.c0 || y.c1 || y.c0 (reference index.ts:563-579)
+  // reference index.ts:532-579: 96 compressed bytes (flag rules, the root named by the S bit, NO subgroup check) or 192 uncompressed bytes
+  // x.c1 || x.c0 || y.c1 || y.c0 with the infinity flag 0x40, followed by assertValidity
   static fromHex(bytes) {
     bytes = ensureBytes(bytes);
-    if (bytes.length === 192 && !(bytes[0] & 0x80)) {
-      if ((bytes[0] & (1 << 6)) !== 0) return PointG2.ZERO;
-      const p = new PointG2(concat(bytes.subarray(48, 96), bytes.subarray(0, 48), bytes.subarray(144, 192), bytes.subarray(96, 144)));
-      p.assertValidity(); return p;
-    }
-    if (bytes.length === 96) return PointG2.fromSignature(bytes);
-    throw new Error('Invalid point G2, expected 96/192 bytes');
+    const m_byte = bytes[0] & 0xe0;
+    if (m_byte === 0x20 || m_byte === 0x60 || m_byte === 0xe0) throw new Error('Invalid encoding flag: ' + m_byte);
+    const bitC = m_byte & 0x80;
+    if (!((bytes.length === 96 && bitC) || (bytes.length === 192 && !bitC))) throw new Error('Invalid point G2, expected 96/192 bytes');
+    ensureInit();
+    const { out, status } = native.decodePoints(1, bytes, bytes.length);
+    if (status[0] === 1) return PointG2.ZERO;
+    if (status[0]) throw new Error(bytes.length === 96 ? 'Invalid compressed G2 point' : G2_STATUS[status[0]]);
+    return new PointG2(out);
   }
   assertValidity() {
     if (this.zero) return this;

@@ -21,6 +21,12 @@ def golden():
 
 
 @pytest.fixture(scope='session')
+def golden2():
+    import goldenio
+    return goldenio.load('ref_vectors2.json.gz')
+
+
+@pytest.fixture(scope='session')
 def testdata():
     import goldenio
     return goldenio.load('ref_testdata.json.gz')

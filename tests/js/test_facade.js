@@ -4,7 +4,7 @@
 const fs = require('fs'), zlib = require('zlib'), path = require('path'), assert = require('assert');
 const bls = require(path.join(__dirname, '..', '..', 'noble-bls12-381_amd', 'js', 'index.js'));
 const load = (f) => JSON.parse(zlib.gunzipSync(fs.readFileSync(path.join(__dirname, '..', 'golden', f))).toString());
-const gold = load('ref_vectors.json.gz'), td = load('ref_testdata.json.gz');
+const gold = load('ref_vectors.json.gz'), td = load('ref_testdata.json.gz'), gold2 = load('ref_vectors2.json.gz');
 const hex = bls.utils.bytesToHex, un = bls.utils.hexToBytes;
 
 (async () => {
@@ -135,6 +135,37 @@ const hex = bls.utils.bytesToHex, un = bls.utils.hexToBytes;
     assert.strictEqual(bls.utils.randomPrivateKey().length, 32);
     assert.strictEqual(bls.utils.mod(-1n, 5n), 4n);
     assert.strictEqual(hex(await bls.utils.sha256(bls.utils.stringToBytes('abc'))), 'ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad');
+  }
+  // round 2: every wire form with the reference's own error messages (vectors of tools/gen_golden2.mjs), public clearCofactor, prepared tables
+  {
+    const { PointG1, PointG2 } = bls;
+    const check = (fn, v, affOf) => {
+      if (v.result === 'ok') assert.strictEqual(hex(affOf(fn(v.hex))), v.aff);
+      else if (v.result === 'zero') assert.ok(fn(v.hex).isZero());
+      else assert.throws(() => fn(v.hex), (e) => e.message === v.result, v.result + ' for ' + v.hex.slice(0, 16));
+    };
+    for (const v of gold2.g2_fromhex96) check((h) => PointG2.fromHex(h), v, (p) => p.aff);
+    for (const v of gold2.g2_fromsig192) check((h) => PointG2.fromSignature(h), v, (p) => p.aff);
+    for (const v of gold2.g1_raw96) check((h) => PointG1.fromHex(h), v, (p) => p.aff);
+    for (const v of gold2.g2_raw192) check((h) => PointG2.fromHex(h), v, (p) => p.aff);
+    for (const v of gold2.g1_raw96.filter((x) => x.compressed)) { const p = PointG1.fromHex(v.hex); assert.strictEqual(p.toHex(false), v.hex); assert.strictEqual(p.toHex(true), v.compressed); }
+    for (const v of gold2.g2_raw192.filter((x) => x.compressed)) { const p = PointG2.fromHex(v.hex); assert.strictEqual(p.toHex(false), v.hex); assert.strictEqual(p.toHex(true), v.compressed); }
+    for (const v of gold2.g2_clear_cofactor) assert.strictEqual(hex(new PointG2(un(v.aff)).clearCofactor().aff), v.out);
+    for (const v of gold2.g1_clear_cofactor) assert.strictEqual(hex(new PointG1(un(v.aff)).clearCofactor().aff), v.out);
+    // PointG2.pairingPrecomputes (index.ts:703-711): 68 triples, first / last equal to the reference's; millerLoop over the memoised table
+    const crypto = require('crypto');
+    for (const v of gold.pairs.slice(0, 3)) {
+      const Q = new PointG2(un(v.g2)), P = new PointG1(un(v.g1));
+      const ell = Q.pairingPrecomputes();
+      assert.strictEqual(ell.length, 68);
+      const bytes = Buffer.concat(ell.map((t) => Buffer.concat(t.map((c) => Buffer.from(c.toBytes())))));
+      assert.strictEqual(bytes.slice(0, 288).toString('hex'), v.ell_first);
+      assert.strictEqual(crypto.createHash('sha256').update(bytes).digest('hex'), v.ell_sha256);
+      assert.strictEqual(Q.pairingPrecomputes(), ell);                                   // memoised
+      assert.strictEqual(hex(P.millerLoop(Q).toBytes()), v.miller);                      // prepared path
+      Q.clearPairingPrecomputes();
+      assert.strictEqual(hex(P.millerLoop(Q).toBytes()), v.miller);                      // plain path
+    }
   }
   // aggregate + verifyBatch
   const vb = gold.verify_batch;

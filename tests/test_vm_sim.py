@@ -324,3 +324,30 @@ def test_split_miller(sim, oracle, golden):
     vmsim_py.run(sim, 'RAW_TO_BYTES', n, {3: (FQ, vmsim_py.F12), 2: (out, 576)})
     for i in range(n):
         assert out.raw[576 * i:576 * (i + 1)] == oracle.miller_loop(g1[96 * i:96 * i + 96], g2[:192]), i
+
+
+def test_wire_decoders(sim, golden2):
+    """the round-2 codec programs on the reference-generated vectors (tools/gen_golden2.mjs): G2 fromHex(96), fromSignature(192), uncompressed forms, byte-order swap"""
+    def status_ok(result, st):
+        want = {'ok': {0}, 'zero': {1}, 'Failed to find a square root': {4}, 'Invalid compressed G2 point': {4, 7}}.get(result)
+        if want is None:
+            want = {2} if 'not on curve' in result else {3} if 'subgroup' in result else {6} if 'encoding flag' in result else {8}
+        return st in want
+    for key, kind, ln in (('g2_fromhex96', 'hex', 96), ('g2_fromsig192', 'sig192', 192)):
+        vs = golden2[key]
+        out, st = vmsim_py.g2_decompress(sim, b''.join(hx(v['hex']) for v in vs), mode=kind)
+        for i, v in enumerate(vs):
+            assert status_ok(v['result'], st[i]), (key, i, v['result'], st[i])
+            assert out[192 * i:192 * (i + 1)] == (hx(v['aff']) if v['result'] == 'ok' else bytes(192)), (key, i)
+    for key, prog, a in (('g1_raw96', 'G1_FROM_RAW', 96), ('g2_raw192', 'G2_FROM_RAW', 192)):
+        vs = golden2[key]
+        n = len(vs)
+        inb = vmsim_py.buf(b''.join(hx(v['hex']) for v in vs)); out = vmsim_py.buf(a * n); st = vmsim_py.buf(n)
+        vmsim_py.run(sim, prog, n, {0: (inb, a), 6: (out, a), 7: (st, 1)})
+        for i, v in enumerate(vs):
+            assert status_ok(v['result'], st.raw[i]), (key, i, v['result'], st.raw[i])
+            assert out.raw[a * i:a * (i + 1)] == (hx(v['aff']) if v['result'] == 'ok' else bytes(a)), (key, i)
+    vs = [v for v in golden2['g2_raw192'] if v['result'] == 'ok' and v['compressed']]      # Q.toHex(false) of valid points (canonical coordinates)
+    inb = vmsim_py.buf(b''.join(hx(v['aff']) for v in vs)); out = vmsim_py.buf(192 * len(vs))
+    vmsim_py.run(sim, 'G2_SWAP', len(vs), {0: (inb, 192), 2: (out, 192)})
+    assert out.raw == b''.join(hx(v['hex']) for v in vs)
