@@ -76,10 +76,22 @@ struct nbls_ctx {
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->last_hip = (int)e_; return NBLS_EHIP; } } while (0)
 
+// Checked mode (make debug builds it in with -DNBLS_CHECKED; NBLS_CHECKED=1 switches it on in any build): every program is verified statically
+// before its first upload (verify_program: all LDS offsets, descriptor reads and buffer indices the kernel will ever use) and every launch
+// checks its buffers against the extents the program touches.  A violation is reported on stderr and the call fails with NBLS_EINVAL.
+static bool checked_mode() {
+#if defined(NBLS_CHECKED)
+  return true;
+#else
+  static const bool on = getenv("NBLS_CHECKED") && atoi(getenv("NBLS_CHECKED")) != 0;
+  return on;
+#endif
+}
 static int upload(nbls_ctx* ctx, ProgId id) {
   DevProgram& d = ctx->prog[id];
   if (d.p) return NBLS_OK;
   const Program& p = get_program(id);
+  if (checked_mode()) { const std::string e = verify_program(p); if (!e.empty()) { fprintf(stderr, "nbls (checked): %s\n", e.c_str()); return NBLS_EINVAL; } }
   HIPCHK(hipMalloc(&d.steps, p.steps.size() * sizeof(Step)));
   HIPCHK(hipMalloc(&d.descs, p.descs.size() * 4 + 64));
   HIPCHK(hipMalloc(&d.consts, p.consts.size() * 4));
@@ -97,6 +109,16 @@ static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pa
   ka.steps = d.steps; ka.descs = d.descs; ka.consts = d.consts;
   ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slot_bytes = d.p->slot_bytes; ka.inst_bytes = d.p->inst_bytes(); ka.n_items = (u32)n; ka.n_items_dev = n_dev; ka.item_index = item_index;
   for (auto& b : bufs) { ka.bufs[b.first].ptr = (uint8_t*)b.second.first; ka.bufs[b.first].stride = b.second.second; }
+  if (checked_mode()) {
+    for (int k = 0; k < MAX_BUFS; k++) {
+      const u32 ext = d.p->buf_extent[k];
+      if (!ext) continue;
+      if (!ka.bufs[k].ptr || (ka.bufs[k].stride != 0 && ka.bufs[k].stride < ext)) {
+        fprintf(stderr, "nbls (checked): %s: buffer %d: %s (stride %llu, the program touches %u bytes per item)\n", d.p->name.c_str(), k, ka.bufs[k].ptr ? "stride too small" : "not bound", (unsigned long long)ka.bufs[k].stride, ext);
+        return NBLS_EINVAL;
+      }
+    }
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s); }
   int e = nbls_vm_launch(&ka, d.p->lds_bytes(), s);

@@ -525,15 +525,17 @@ Program Builder::compile(const std::string& name, int W) {
           put_lin(1);
           P.n_lin_terms += (u32)n.lin.size();
           break;
-        case K_LOAD: case K_LOADW: w[0] = op(c) | ((u32)n.buf << 16); w[1] = (u32)n.off; break;
-        case K_STORE: case K_STOREW: w[0] = op(n.a0) | ((u32)n.buf << 16); w[1] = (u32)n.off; break;
+        case K_LOAD: case K_LOADW: w[0] = op(c) | ((u32)n.buf << 16); w[1] = (u32)n.off;
+          P.buf_extent[n.buf] = std::max(P.buf_extent[n.buf], (u32)n.off + (n.kind == K_LOADW ? (u32)RAW_FP_BYTES : (n.p0 ? (u32)n.p0 : 48u))); break;
+        case K_STORE: case K_STOREW: w[0] = op(n.a0) | ((u32)n.buf << 16); w[1] = (u32)n.off;
+          P.buf_extent[n.buf] = std::max(P.buf_extent[n.buf], (u32)n.off + (n.kind == K_STOREW ? (u32)RAW_FP_BYTES : 48u)); break;
         case K_ISZ: case K_CANON: w[0] = op(c) | (op(n.a0) << 16); break;
         case K_SEL: w[0] = op(c) | (op(n.b0) << 16); w[1] = op(n.a0) | (op(n.a1) << 16); break;
         case K_CMP: case K_FLAG: case K_BITAND: w[0] = op(c); w[1] = op(n.a0) | (op(n.a1) << 16); break;
         case K_BIT: w[0] = op(c) | (op(n.a0) << 16); w[1] = (u32)n.off; break;
         case K_STATUS:
           assert(n.stat.size() <= 7);
-          w[0] = (u32)n.stat.size() | ((u32)n.buf << 16);
+          w[0] = (u32)n.stat.size() | ((u32)n.buf << 16); P.buf_extent[n.buf] = std::max(P.buf_extent[n.buf], 1u);
           for (size_t k = 0; k < n.stat.size(); k++) w[1 + k] = op(n.stat[k].first) | ((u32)n.stat[k].second << 16);
           break;
         default: assert(0);
@@ -545,6 +547,72 @@ Program Builder::compile(const std::string& name, int W) {
   }
   P.consts = const_words;
   return P;
+}
+
+std::string verify_program(const Program& p) {
+  char msg[256];
+  const u32 ib = p.inst_bytes(), cbytes = p.nconst * p.slot_bytes;
+  auto bad = [&](size_t s, unsigned lane, const char* what, u32 v) { snprintf(msg, sizeof msg, "%s: step %zu lane %u: %s (0x%x)", p.name.c_str(), s, lane, what, v); return std::string(msg); };
+  if (p.slot_bytes != 64 && p.slot_bytes != 80) return p.name + ": slot stride";
+  if ((u64)p.G * ib > 160 * 1024) return p.name + ": LDS image exceeds 160 KB";
+  if (p.W * p.G > 64 || p.W == 0) return p.name + ": lanes";
+  if (p.consts.size() != (size_t)p.nconst * RAW_WORDS) return p.name + ": constant table size";
+  for (size_t s = 0; s < p.steps.size(); s++) {
+    const Step& st = p.steps[s];
+    if (st.nlanes == 0 || st.nlanes > p.W) return bad(s, 0, "active lanes", st.nlanes);
+    if (st.stride % 4 || st.stride < 4) return bad(s, 0, "descriptor stride", st.stride);
+    if ((u64)st.desc_off + (u64)st.nlanes * st.stride > p.descs.size() || st.desc_off % 4) return bad(s, 0, "descriptors outside the program", st.desc_off);
+    for (unsigned l = 0; l < st.nlanes; l++) {
+      const u32* d = p.descs.data() + st.desc_off + l * st.stride;
+      auto src = [&](u32 f) { f &= 0xffffu; return (f & 15u) == 0 && f + 56 <= ib; };                    // a readable slot (constants included)
+      auto dst = [&](u32 f) { f &= 0xffffu; return (f & 15u) == 0 && f >= cbytes && f + 56 <= ib; };    // a writable slot (never a constant)
+      auto term = [&](u32 f, bool signs) { return (f & (signs ? 14u : 15u)) == 0 && (f & ~1u) + 56 <= ib; };   // product term: 32-bit offset, bit 0 = sign in mode 3
+      switch (st.kind) {
+        case K_DOT: {
+          if (st.p0 > MAX_DOT_PRODUCTS || st.stride != (u32)(DOT_HDR_WORDS + DOT_ROUND_WORDS * st.p0)) return bad(s, l, "product rounds / stride", st.p0);
+          if (!dst(d[0])) return bad(s, l, "destination", d[0]);
+          const u32 nadd = st.lin & 7, nsub = (st.lin >> 4) & 7;
+          if (nadd > MAX_DOT_LINEAR || nsub > MAX_DOT_LINEAR || (st.lin & ~0x77u)) return bad(s, l, "post-added term counts", st.lin);
+          for (u32 t = 0; t < nadd + nsub; t++) { const u32 f = (d[4 + t / 2] >> (16 * (t & 1))) & 0xffffu; if (!src(f)) return bad(s, l, "post-added term", f); }
+          const u32 mult = (d[0] >> 16) & 7; if (mult < 1 || mult > 4) return bad(s, l, "multiplier", mult);
+          if (mult > 1 && !(st.p1 & DOTF_MULT)) return bad(s, l, "multiplier without the step flag", mult);
+          if ((d[0] & (1u << 19)) && !(st.p1 & DOTF_HALVE)) return bad(s, l, "halving without the step flag", d[0]);
+          if (((d[0] >> 20) & 0xf) && !(st.p1 & DOTF_OFFS)) return bad(s, l, "offset without the step flag", d[0]);
+          for (u32 r = 0; r < st.p0; r++) {
+            const u32* rd = d + DOT_HDR_WORDS + DOT_ROUND_WORDS * r;
+            const u32 sh = ((r < 4 ? st.shape[0] : st.shape[1]) >> (8 * (r & 3))) & 0xff;
+            for (int o = 0; o < 2; o++) {
+              const u32 mode = (sh >> (3 * o)) & 3, f0 = rd[2 * o], f1 = rd[2 * o + 1];
+              if (!term(f0, mode == 3)) return bad(s, l, "first term of an operand", f0);
+              if (mode == 0 ? f1 != 0 : !term(f1, mode == 3)) return bad(s, l, "second term of an operand", f1);
+            }
+            if (sh & 0xc0) return bad(s, l, "round shape", sh);
+          }
+          break;
+        }
+        case K_LIN: {
+          if (!dst(d[0])) return bad(s, l, "destination", d[0]);
+          const u32 nt = (u32)st.p0 + st.p1;
+          if (st.p0 > MAX_LIN_TERMS || st.p1 > MAX_LIN_TERMS || 1 + (nt + 1) / 2 > st.stride) return bad(s, l, "term counts", nt);
+          for (u32 t = 0; t < nt; t++) { const u32 f = (d[1 + t / 2] >> (16 * (t & 1))) & 0xffffu; if (!src(f)) return bad(s, l, "term", f); }
+          break;
+        }
+        case K_LOAD: case K_LOADW: if (!dst(d[0]) || ((d[0] >> 16) & 0xffff) >= (u32)MAX_BUFS) return bad(s, l, "load", d[0]); if (st.kind == K_LOAD && (st.p0 % 4 || st.p0 > 48)) return bad(s, l, "load width", st.p0); break;
+        case K_STORE: case K_STOREW: if (!src(d[0]) || ((d[0] >> 16) & 0xffff) >= (u32)MAX_BUFS) return bad(s, l, "store", d[0]); break;
+        case K_ISZ: case K_CANON: if (!dst(d[0]) || !src(d[0] >> 16)) return bad(s, l, "unary", d[0]); break;
+        case K_BIT: if (!dst(d[0]) || !src(d[0] >> 16) || d[1] >= 392) return bad(s, l, "bit", d[1]); break;
+        case K_SEL: if (!dst(d[0]) || !src(d[0] >> 16) || !src(d[1]) || !src(d[1] >> 16)) return bad(s, l, "select", d[1]); break;
+        case K_CMP: case K_FLAG: case K_BITAND: if (!dst(d[0]) || !src(d[1]) || !src(d[1] >> 16)) return bad(s, l, "binary", d[1]); if (st.kind != K_BITAND && st.p0 > 3) return bad(s, l, "predicate", st.p0); break;
+        case K_STATUS: {
+          const u32 n = d[0] & 0xff; if (n > 7 || st.stride < 8 || ((d[0] >> 16) & 0xffff) >= (u32)MAX_BUFS) return bad(s, l, "status", d[0]);
+          for (u32 k = 0; k < n; k++) if (!src(d[1 + k])) return bad(s, l, "status flag", d[1 + k]);
+          break;
+        }
+        default: return bad(s, l, "step kind", st.kind);
+      }
+    }
+  }
+  return std::string();
 }
 
 }  // namespace nbls

@@ -36,6 +36,7 @@ struct Program {
   u32 n_dot_steps = 0, n_lin_steps = 0, n_other_steps = 0, n_dot_ops = 0, n_products = 0, n_prod_slots = 0, n_lin_ops = 0, n_lin_terms = 0, n_norm_operands = 0, n_neg_operands = 0, n_comb_operands = 0;
   u32 n_round_ops = 0, n_op_mode[4] = {0, 0, 0, 0}, n_op_norm = 0;   // product-round operands (two per round) by shape
   double est_valu = 0;       // cost-model estimate of VALU instructions per wave (see Builder::compile)
+  std::vector<u32> buf_extent = std::vector<u32>(MAX_BUFS, 0);   // per buffer index: bytes of one item the program touches (max offset + size); launch check in checked builds
   u32 inst_bytes() const { return (nconst + slots) * slot_bytes; }   // one instance region: constants (replicated per instance) + slots
   u32 lds_bytes() const { return G * inst_bytes(); }
 };
@@ -240,5 +241,11 @@ static inline void status_out(const std::vector<std::pair<SFp, int>>& checks, in
   for (auto& c : checks) n.stat.push_back({materialize(c.first), c.second});
   Builder::cur()->add_node(n);
 }
+
+// Static verifier of a compiled program (checked builds, NBLS_CHECKED=1, and the CPU test-suite): programs are straight-line with static
+// addresses, so EVERY LDS access, descriptor read and buffer offset the kernel will ever make can be checked on the host before the first launch:
+// offsets inside the instance region and 16-byte aligned, destinations outside the constant region, descriptors inside the program, round
+// shapes consistent with the lane descriptors, buffer indices valid.  Returns an empty string or the first violation.
+std::string verify_program(const Program& p);
 
 }  // namespace nbls

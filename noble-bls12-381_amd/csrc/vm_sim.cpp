@@ -86,5 +86,24 @@ __attribute__((visibility("default"))) void nbls_sim_fp_pow(unsigned n, const u3
     }
   }
 }
+// static verification of a compiled program (trace.h verify_program): 0 = clean, else the first violation in msg
+__attribute__((visibility("default"))) int nbls_sim_verify(int prog, char* msg, unsigned cap) {
+  if (prog < 0 || prog >= P_COUNT) return -1;
+  const std::string e = verify_program(get_program((ProgId)prog));
+  if (msg && cap) { snprintf(msg, cap, "%s", e.c_str()); }
+  return e.empty() ? 0 : 1;
+}
+// the verifier on a deliberately damaged copy of a program: descriptor word `word` (or, with step_field >= 0, a header field of step `word`) is
+// XOR-ed with `flip`; returns 1 and the violation when the damage is caught
+__attribute__((visibility("default"))) int nbls_sim_verify_damaged(int prog, unsigned word, unsigned flip, int step_field, char* msg, unsigned cap) {
+  if (prog < 0 || prog >= P_COUNT) return -1;
+  Program p = get_program((ProgId)prog);
+  if (step_field < 0) { if (word >= p.descs.size()) return -1; p.descs[word] ^= flip; }
+  else { if (word >= p.steps.size()) return -1; Step& st = p.steps[word]; if (step_field == 0) st.desc_off ^= flip; else if (step_field == 1) st.nlanes ^= (uint8_t)flip; else if (step_field == 2) st.p0 ^= (uint8_t)flip; else st.kind ^= (uint8_t)flip; }
+  const std::string e = verify_program(p);
+  if (msg && cap) snprintf(msg, cap, "%s", e.c_str());
+  return e.empty() ? 0 : 1;
+}
+__attribute__((visibility("default"))) int nbls_sim_program_count() { return (int)P_COUNT; }
 __attribute__((visibility("default"))) void nbls_sim_stats() { for (int i = 0; i < P_COUNT; i++) print_stats(get_program((ProgId)i)); }
 }
