@@ -64,6 +64,7 @@ struct nbls_ctx {
   uint8_t* ident_g1 = nullptr; uint8_t* ident_g2 = nullptr;   // projective identity (0 : 1 : 0), raw
   size_t cap_F = 0, cap_io = 0;
   size_t split_min = SPLIT_MILLER_MIN;   // nbls_set_tuning(NBLS_TUNE_SPLIT_MILLER_MIN)
+  u32* qp_table = nullptr;      // multiples of p for the weak reduction (vm_exec.h weak_reduce), device copy
   uint8_t* partial = nullptr;   // 576 bytes: the Fp12 partial of the *_partial entry points (multi-GPU reductions)
   uint8_t* L = nullptr; size_t cap_L = 0;   // line tables of the Miller loop (LINE_BYTES each), at most LINES_CHUNK of them
   // the scratch above is shared by every call on this context: a call that uses another stream than its predecessor waits for it (StreamOrder)
@@ -106,7 +107,7 @@ static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pa
   int r = upload(ctx, id); if (r) return r;
   const DevProgram& d = ctx->prog[id];
   KernelArgs ka; memset(&ka, 0, sizeof ka);
-  ka.steps = d.steps; ka.descs = d.descs; ka.consts = d.consts;
+  ka.steps = d.steps; ka.descs = d.descs; ka.consts = d.consts; ka.qp_table = ctx->qp_table;
   ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slot_bytes = d.p->slot_bytes; ka.inst_bytes = d.p->inst_bytes(); ka.n_items = (u32)n; ka.n_items_dev = n_dev; ka.item_index = item_index;
   for (auto& b : bufs) { ka.bufs[b.first].ptr = (uint8_t*)b.second.first; ka.bufs[b.first].stride = b.second.second; }
   if (checked_mode()) {
@@ -253,6 +254,7 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
   ctx->device = device_id;
   if (hipSetDevice(device_id) != hipSuccess) { delete ctx; return NBLS_ENOGPU; }
   if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return NBLS_EHIP; }
+  if (hipMalloc(&ctx->qp_table, (size_t)QP_TABLE_ENTRIES * RAW_WORDS * 4) != hipSuccess || hipMemcpy(ctx->qp_table, qp_table_words(), (size_t)QP_TABLE_ENTRIES * RAW_WORDS * 4, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   // Montgomery one as a raw Fp12 (pads odd-sized product reductions)
   u32 one[12 * SLOT_WORDS]; memset(one, 0, sizeof one); memcpy(one, NBLS_R1, NLIMBS * 4);
   if (hipMalloc(&ctx->one12, F12) != hipSuccess || hipMemcpy(ctx->one12, one, F12, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
@@ -293,6 +295,7 @@ EXPORT void nbls_destroy(nbls_ctx* ctx) {
   for (uint8_t* p : ctx->T) if (p) hipFree(p);
   for (uint8_t* p : ctx->sb) if (p) hipFree(p);
   for (uint8_t* p : ctx->nib) if (p) hipFree(p);
+  if (ctx->qp_table) hipFree(ctx->qp_table);
   for (uint8_t* p : {ctx->neg_g1, ctx->ident_g1, ctx->ident_g2}) if (p) hipFree(p);
   if (ctx->side) hipStreamDestroy(ctx->side);
   if (ctx->side2) hipStreamDestroy(ctx->side2);
@@ -501,7 +504,7 @@ EXPORT int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks) {
   const size_t blocks = (n + d.p->G - 1) / d.p->G;
   uint64_t* dbg = nullptr; HIPCHK(hipMalloc(&dbg, blocks * 40));
   KernelArgs ka; memset(&ka, 0, sizeof ka);
-  ka.steps = d.steps; ka.descs = d.descs; ka.consts = d.consts;
+  ka.steps = d.steps; ka.descs = d.descs; ka.consts = d.consts; ka.qp_table = ctx->qp_table;
   ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slot_bytes = d.p->slot_bytes; ka.inst_bytes = d.p->inst_bytes(); ka.n_items = (u32)n;
   ka.bufs[3].ptr = ctx->T[0]; ka.bufs[3].stride = F12; ka.bufs[5].ptr = ctx->T[1]; ka.bufs[5].stride = F12;
   if (pid == P_MILLER_FE) { ka.bufs[0].ptr = ctx->io_g1; ka.bufs[0].stride = 96; ka.bufs[1].ptr = ctx->io_g2; ka.bufs[1].stride = 192; ka.bufs[4].ptr = ctx->N; ka.bufs[4].stride = RAW; }

@@ -104,13 +104,25 @@ int Builder::contract(int atom) {
   int id = add_node(n); contract_cache[atom] = id; return id;
 }
 
+// Bring an atom's bound under `cap`: if the lane-op that produces it can still take a weak reduction (a table lookup and 14 subtractions at its
+// end) that is used -- retroactively, which only makes the bounds its earlier consumers assumed conservative -- else a contraction lane-op.
+int Builder::lower_bound(int atom, double cap) {
+  if (atom_bound(atom) <= cap) return atom;
+  Node& n = nodes[atom];
+  const double after = n.halve ? 3.02 / 2 + 0.5 : 3.02;
+  if (use_wred && !n.raw && !n.wred && after <= cap && n.bound < 100.0 &&
+      ((n.kind == K_DOT && n.mult + (int)n.lin.size() <= 7 && !n.prods.empty()) || n.kind == K_LIN)) { n.wred = true; n.bound = after; return atom; }
+  return contract(atom);
+}
+
 // Emit one DOT node for (prods, lin) -- caller guarantees the limits.
-static int emit_dot(Builder* B, std::vector<DotProduct> prods, int mult, std::vector<std::pair<int, int>> lin, bool halve_it) {
+static const double WRED_BOUND = 3.02, WRED_MAX_IN = 100.0;   // weak_reduce (vm_exec.h): output bound; largest input bound the table covers with margin
+static int emit_dot(Builder* B, std::vector<DotProduct> prods, int mult, std::vector<std::pair<int, int>> lin, bool halve_it, bool wred = false) {
   for (auto& p : prods) {
-    auto cap = [&](int& a) { if (a >= 0 && B->atom_bound(a) > OP_CAP && !B->nodes[a].raw) a = B->contract(a); };
+    auto cap = [&](int& a) { if (a >= 0 && B->atom_bound(a) > OP_CAP && !B->nodes[a].raw) a = B->lower_bound(a, OP_CAP); };
     cap(p.a.s0); cap(p.a.s1); cap(p.b.s0); cap(p.b.s1);
   }
-  for (auto& t : lin) if (B->atom_bound(t.first) > (t.second < 0 ? B->neg_cap : OP_CAP)) t.first = B->contract(t.first);
+  for (auto& t : lin) t.first = B->lower_bound(t.first, t.second < 0 ? B->neg_cap : OP_CAP);
   Node n; n.kind = K_DOT; n.mult = mult; n.halve = halve_it;
   // value bounds: REDC(T) lies in (T/R, T/R + p); products that may be negative are compensated by offs * p
   double Vpos = 0, Vneg = 0, Lpos = 0, Lneg = 0;
@@ -127,6 +139,7 @@ static int emit_dot(Builder* B, std::vector<DotProduct> prods, int mult, std::ve
   assert(offs <= MAX_OFFS);
   n.offs = offs;
   double T = mult * (Vpos * P_OVER_R + 1.0 + offs) + Lpos;
+  if (wred) { assert(T < WRED_MAX_IN && mult + (int)lin.size() <= 7); n.wred = true; T = WRED_BOUND; }
   if (halve_it) T = T / 2 + 0.5;
   assert(T < 1000.0);
   // limb budget of the signed column accumulators: sum of c_a * c_b <= 8, c = 2 for an un-normalised sum operand
@@ -149,7 +162,7 @@ static int emit_dot(Builder* B, std::vector<DotProduct> prods, int mult, std::ve
   return B->add_node(n);
 }
 static int emit_lin(Builder* B, std::vector<std::pair<int, int>> terms, bool halve_it) {
-  for (auto& t : terms) if (B->atom_bound(t.first) > (t.second < 0 ? B->neg_cap : OP_CAP)) t.first = B->contract(t.first);
+  for (auto& t : terms) t.first = B->lower_bound(t.first, t.second < 0 ? B->neg_cap : OP_CAP);
   // negative terms are limb-wise subtractions; a constant k p keeps the value non-negative
   auto finish = [&](std::vector<std::pair<int, int>>& ts) {
     double neg = 0; for (auto& t : ts) if (t.second < 0) neg += B->atom_bound(t.first);
@@ -219,11 +232,16 @@ int materialize(const SFp& x, bool halve_it) {
   for (auto& a : atoms) for (int k = 0; k < std::abs(a.second); k++) lin.push_back({a.first, a.second > 0 ? 1 : -1});
 
   int id;
+  bool want_wred = false;
   if (!dps.empty() && !lin.empty()) {
     // If the post-added terms would make the result large, fold them into the accumulator as products with small
     // constants (x * (c/m)): the Montgomery reduction then contracts everything to about m p.
     double T = mult * 3.0; for (auto& t : lin) T += std::min(B->atom_bound(t.first), t.second < 0 ? B->neg_cap : OP_CAP);
-    if (T > OUT_CAP) {
+    // ... or, cheaper, keep them as post-added terms and reduce weakly afterwards (a table lookup and 14 subtractions instead of a round of 196
+    // multiply-adds per term): possible while the un-reduced value stays inside the table and the limb sums inside 32 bits
+    double Tfull = mult * 3.0; for (auto& t : lin) Tfull += std::min(B->atom_bound(t.first), t.second < 0 ? B->neg_cap : OP_CAP) * (t.second < 0 ? 2 : 1);
+    if (T > OUT_CAP && B->use_wred && (int)lin.size() <= MAX_DOT_LINEAR && mult + (int)lin.size() <= 7 && Tfull < WRED_MAX_IN / 2 && (int)dps.size() <= B->max_dot) want_wred = true;
+    else if (T > OUT_CAP) {
       std::map<int, int> net; for (auto& t : lin) net[t.first] += t.second;
       for (auto& kv : net) if (kv.second) { Operand a; a.s0 = kv.first; Operand c; c.s0 = B->frac_const(kv.second, mult); dps.push_back({a, c, false}); }
       lin.clear();
@@ -241,7 +259,7 @@ int materialize(const SFp& x, bool halve_it) {
       if ((int)lin.size() >= MAX_DOT_LINEAR) { int l = emit_lin(B, lin, false); lin.clear(); lin.push_back({l, 1}); }
       lin.push_back({a, 1});
     }
-    id = emit_dot(B, dps, mult, lin, halve_it);
+    id = emit_dot(B, dps, mult, lin, halve_it, want_wred);
   }
   cse[x.f] = id;
   return id;
@@ -481,10 +499,11 @@ Program Builder::compile(const std::string& name, int W) {
     if (n0.kind == K_LIN) {
       assert(mp <= (size_t)MAX_LIN_TERMS && mn <= (size_t)MAX_LIN_TERMS);
       st.p0 = (uint8_t)mp; st.p1 = (uint8_t)mn; st.stride = mp + mn > 6 ? 8 : 4;
+      for (int c : L) if (nodes[c].wred) st.lin |= 1;
       P.n_lin_steps++; P.n_lin_ops += (u32)L.size();
     } else if (n0.kind == K_DOT) {
       size_t mk = step_shapes[s].size();
-      for (int c : L) { P.n_products += (u32)nodes[c].prods.size(); if (nodes[c].mult > 1) st.p1 |= DOTF_MULT; if (nodes[c].halve) st.p1 |= DOTF_HALVE; if (nodes[c].offs > 0) st.p1 |= DOTF_OFFS; }
+      for (int c : L) { P.n_products += (u32)nodes[c].prods.size(); if (nodes[c].mult > 1) st.p1 |= DOTF_MULT; if (nodes[c].halve) st.p1 |= DOTF_HALVE; if (nodes[c].offs > 0) st.p1 |= DOTF_OFFS; if (nodes[c].wred) st.p1 |= DOTF_WRED; }
       assert(mk <= (size_t)MAX_DOT_PRODUCTS && mp <= (size_t)MAX_DOT_LINEAR && mn <= (size_t)MAX_DOT_LINEAR);
       st.p0 = (uint8_t)mk; st.lin = (u32)mp | ((u32)mn << 4);
       for (size_t j = 0; j < mk; j++) {
@@ -546,7 +565,25 @@ Program Builder::compile(const std::string& name, int W) {
     P.steps.push_back(st);
   }
   P.consts = const_words;
+  if (getenv("NBLS_DUMP_CONTRACT")) { int nc = 0, nw = 0; for (auto& kv : contract_cache) if (nodes[kv.second].live) nc++; for (auto& n : nodes) if (n.live && n.wred) nw++; fprintf(stderr, "%s: %d live contraction lane-ops, %d weak reductions\n", name.c_str(), nc, nw); }
   return P;
+}
+
+const u32* qp_table_words() {
+  static std::vector<u32> tab;
+  static bool built = false;
+  if (!built) {
+    const u32 P[NLIMBS] = NBLS_P_INIT;
+    tab.assign((size_t)QP_TABLE_ENTRIES * RAW_WORDS, 0);
+    u32 acc[NLIMBS] = {0};
+    for (int q = 1; q < QP_TABLE_ENTRIES; q++) {
+      for (int j = 0; j < NLIMBS; j++) acc[j] += P[j];
+      carry_norm(acc);
+      memcpy(&tab[(size_t)q * RAW_WORDS], acc, NLIMBS * 4);
+    }
+    built = true;
+  }
+  return tab.data();
 }
 
 std::string verify_program(const Program& p) {

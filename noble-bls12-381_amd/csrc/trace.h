@@ -59,6 +59,7 @@ struct Node {
   uint8_t kind = 0;        // StepKind, or 0xff for constants
   uint8_t p0 = 0;
   bool halve = false;      // DOT/LIN: divide the reduced result by two (mod p)
+  bool wred = false;       // DOT/LIN: weak reduction after the post-added terms (result below 3.02 p whatever the terms' bounds)
   bool raw = false;        // K_LOAD result: any 384-bit integer (not < 2p)
   int a0 = -1, a1 = -1, b0 = -1;                           // generic sources (a0 = src, a1 = second src, b0 = flag)
   std::vector<DotProduct> prods; int mult = 1; int offs = 0;   // DOT: m * (REDC(sum of products) + offs * p) +- lin
@@ -88,6 +89,7 @@ struct Builder {
   int max_dot = MAX_DOT_PRODUCTS;   // products per lane-op: a lower cap splits heavy lane-ops (first chunk, then the rest + the first as a post-added term) so that the few heaviest lanes do not set the length of a step
   int light_max = 2;     // lane-ops with at most this many products form the "light" class of the scheduler (they ride in the free lanes of heavy steps; MAX_DOT_PRODUCTS = one class)
   double neg_cap = 6.0;  // negated linear terms above this bound are contracted first (their bound is paid as a +k p offset)
+  bool use_wred = getenv("NBLS_NO_WRED") == nullptr;   // large post-added terms: weak reduction (table of multiples of p) instead of folding them into the dot product
   int store_batch = 0;   // > 0: a store step is issued as soon as this many stores are ready (programs that stream results out: the values do not linger in LDS)
   int sched_window = 0;  // scheduler look-ahead limit in critical-path units (0 = unlimited), see compile()
   static Builder*& cur() { static thread_local Builder* b = nullptr; return b; }
@@ -119,6 +121,7 @@ struct Builder {
   double operand_bound(const Operand& o) const { return atom_bound(o.s0) + (o.s1 >= 0 ? atom_bound(o.s1) : 0.0); }
   int kp_atom(int k);                                // the constant k * p (normalised limbs), used to keep sums with negative terms non-negative
   int contract(int atom);                            // x -> x * R / R : same value mod p, bound ~1
+  int lower_bound(int atom, double cap);             // bound <= cap by a weak reduction at the producer where possible, else by contraction
   Program compile(const std::string& name, int W);
 };
 
@@ -217,7 +220,7 @@ static inline int raw_off(int off) { return off / 48 * RAW_FP_BYTES; }
 static inline SFp inputw(int buf, int off) { Node n; n.kind = K_LOADW; n.buf = buf; n.off = raw_off(off); n.bound = 8.0; return SFp(Builder::cur()->add_node(n)); }
 static inline void outputw(const SFp& x, int buf, int off) {
   Builder* B = Builder::cur(); Node n; n.kind = K_STOREW; n.a0 = materialize(x);
-  if (B->atom_bound(n.a0) > 8.0) n.a0 = B->contract(n.a0);     // scratch elements are reloaded with bound 8
+  n.a0 = B->lower_bound(n.a0, 8.0);     // scratch elements are reloaded with bound 8
   n.buf = buf; n.off = raw_off(off); n.live = true; B->add_node(n);
 }
 // flags (raw 0/1 integers in a slot)
@@ -247,5 +250,7 @@ static inline void status_out(const std::vector<std::pair<SFp, int>>& checks, in
 // offsets inside the instance region and 16-byte aligned, destinations outside the constant region, descriptors inside the program, round
 // shapes consistent with the lane descriptors, buffer indices valid.  Returns an empty string or the first violation.
 std::string verify_program(const Program& p);
+// q p for q = 0 .. QP_TABLE_ENTRIES-1 as normalised limbs, RAW_WORDS words per entry (weak_reduce, vm_exec.h); built once on the host
+const u32* qp_table_words();
 
 }  // namespace nbls

@@ -62,6 +62,8 @@ static const uint32_t SH_A_MODE = 0x03;     // 0 single slot, 1 x + y, 2 x - y, 
 static const uint32_t SH_A_NORM = 0x04;     // normalise the (sum) operand's limbs before multiplying
 static const uint32_t SH_B_SHIFT = 3;       // the same three bits for operand B
 static const uint32_t DOTF_MULT = 1, DOTF_HALVE = 2, DOTF_OFFS = 4;   // some lane of the step has m > 1 / halves its result / has offs > 0
+static const uint32_t DOTF_WRED = 8;     // weak reduction after the post-added terms: subtract q p with q estimated from the top limb (table lookup), result below 3.02 p
+static const int QP_TABLE_ENTRIES = 128; // q p for q = 0 .. 127, 16 words each (14 normalised limbs + padding)
 
 static const int MAX_LIN_TERMS = 7;    // signed limb-wise sums must stay inside (-2^31, 2^31): 7 x 2^28
 static const int NLIMBS = 14;
@@ -86,6 +88,7 @@ struct KernelArgs {
   const Step* steps;
   const uint32_t* descs;
   const uint32_t* consts;   // nconst * RAW_WORDS words
+  const uint32_t* qp_table; // QP_TABLE_ENTRIES * RAW_WORDS words: multiples of p for the weak reduction (DOTF_WRED)
   uint32_t nsteps, nconst;
   uint32_t W, G;            // lanes per instance, instances per wave (G * W <= 64)
   uint32_t slot_bytes;      // LDS slot stride of this program (64 or 80)

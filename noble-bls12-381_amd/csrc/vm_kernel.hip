@@ -92,9 +92,9 @@ template <bool FAIR> __device__ __forceinline__ void vm_kernel_body(const Kernel
           dot_round(acc, round_shape(st, r), cur.x, cur.y, cur.z, cur.w, lds, cx);
           cur = nx;
         }
-        dst = dot_finish(res, acc, st, d, lds, cx);
+        dst = dot_finish(res, acc, st, d, lds, cx, ka.qp_table);
       } else {
-        dst = exec_lane(st, d, lds, cx, ka.bufs, res);
+        dst = exec_lane(st, d, lds, cx, ka.bufs, res, ka.qp_table);
       }
       if (dst != 0xffffffffu) st14(lds, dst, res);
     }
@@ -169,7 +169,7 @@ extern "C" __global__ void __launch_bounds__(128) nbls_vm_kernel_split(KernelArg
 #pragma unroll
         for (int c = 0; c < 2 * NL; c++) acc[c] += xch[c * 64 + lane];
         u32 res[NL];
-        const u32 dst = dot_finish(res, acc, st, d, lds, cx);
+        const u32 dst = dot_finish(res, acc, st, d, lds, cx, ka.qp_table);
         st14(lds, dst, res);
       }
     } else if (active && wave == 0) {
@@ -179,8 +179,8 @@ extern "C" __global__ void __launch_bounds__(128) nbls_vm_kernel_split(KernelArg
         u64 acc[2 * NL];
         dot_init(acc, st, d[0]);
         for (u32 r = 0; r < st.p0; r++) { const uint4 cur = gr[r]; dot_round(acc, round_shape(st, r), cur.x, cur.y, cur.z, cur.w, lds, cx); }
-        dst = dot_finish(res, acc, st, d, lds, cx);
-      } else dst = exec_lane(st, d, lds, cx, ka.bufs, res);
+        dst = dot_finish(res, acc, st, d, lds, cx, ka.qp_table);
+      } else dst = exec_lane(st, d, lds, cx, ka.bufs, res, ka.qp_table);
       if (dst != 0xffffffffu) st14(lds, dst, res);
     }
     __syncthreads();

@@ -13,6 +13,7 @@
 using namespace nbls;
 
 static void sim_run(const Program& p, unsigned n_items, const IOBuf* bufs) {
+  const u32* qp_table = qp_table_words();
   const unsigned inst_bytes = p.inst_bytes();
   std::vector<V4> lds4((size_t)p.G * inst_bytes / 16 + 1);
   char* lds = (char*)lds4.data();
@@ -38,8 +39,8 @@ static void sim_run(const Program& p, unsigned n_items, const IOBuf* bufs) {
           u64 acc[2 * NL];
           dot_init(acc, st, dw[0]);
           for (u32 r = 0; r < st.p0; r++) { const u32* rd = gd + DOT_HDR_WORDS + DOT_ROUND_WORDS * r; dot_round(acc, round_shape(st, r), rd[0], rd[1], rd[2], rd[3], lds, cx); }
-          pd.dst = dot_finish(pd.v, acc, st, dw, lds, cx);
-        } else pd.dst = exec_lane(st, dw, lds, cx, bufs, pd.v);
+          pd.dst = dot_finish(pd.v, acc, st, dw, lds, cx, qp_table);
+        } else pd.dst = exec_lane(st, dw, lds, cx, bufs, pd.v, qp_table);
         if (pd.dst != 0xffffffffu) pend.push_back(pd);
       }
       for (auto& pd : pend) st14(lds, pd.dst, pd.v);
