@@ -264,6 +264,20 @@ static inline Pt<SFp> clear_cofactor_g1(const Pt<SFp>& P) { return pt_add(pt_mul
 static inline Pt<SFp2> psi_proj(const Pt<SFp2>& p) { return pt_mat<SFp2>({mul(conj(p.x), fp2_const(NBLS_PSI_X)), mul(conj(p.y), fp2_const(NBLS_PSI_Y)), conj(p.z)}); }
 static inline Pt<SFp2> psi2_proj(const Pt<SFp2>& p) { return pt_mat<SFp2>({mul_fp(p.x, fp_const(NBLS_PSI2_C1)), -p.y, p.z}); }
 // PointG2.clearCofactor (index.ts:659-672)
+// The same in two halves around the second multiplication by x, chained through HBM so that neither program keeps more than the ladder's base,
+// its running point and their temporaries live (26 slots instead of 38: twelve wavefronts per CU instead of six -- the one-program form ran at
+// 1.5 wavefronts per SIMD and half the issue rate).  clear_cofactor_g2(P) = S + (-[x]base) with
+//   t1 = -[x]P, base = t1 + psi(P), S = psi^2(2P) - psi(P) - t1 - P.
+static inline void clear_cofactor_g2_first(const Pt<SFp2>& P, Pt<SFp2>& base, Pt<SFp2>& S) {
+  Pt<SFp2> t1 = pt_neg(pt_mul_u64(P, NBLS_X));           // [-x]P
+  Pt<SFp2> t2 = psi_proj(P);
+  Pt<SFp2> t3 = pt_add(psi2_proj(pt_dbl(P)), pt_neg(t2));
+  base = pt_add(t1, t2);
+  S = pt_add(pt_add(t3, pt_neg(t1)), pt_neg(P));
+}
+static inline Pt<SFp2> clear_cofactor_g2_second(const Pt<SFp2>& base, const Pt<SFp2>& S) {
+  return pt_add(S, pt_neg(pt_mul_u64(base, NBLS_X)));
+}
 static inline Pt<SFp2> clear_cofactor_g2(const Pt<SFp2>& P) {
   Pt<SFp2> t1 = pt_neg(pt_mul_u64(P, NBLS_X));           // [-x]P
   Pt<SFp2> t2 = psi_proj(P);

@@ -108,7 +108,7 @@ static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pa
   const DevProgram& d = ctx->prog[id];
   KernelArgs ka; memset(&ka, 0, sizeof ka);
   ka.steps = d.steps; ka.descs = d.descs; ka.consts = d.consts; ka.qp_table = ctx->qp_table;
-  ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slot_bytes = d.p->slot_bytes; ka.inst_bytes = d.p->inst_bytes(); ka.n_items = (u32)n; ka.n_items_dev = n_dev; ka.item_index = item_index;
+  ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slot_bytes = d.p->slot_bytes; ka.inst_bytes = d.p->inst_bytes(); ka.shared_consts = d.p->shared_consts ? 1u : 0u; ka.n_items = (u32)n; ka.n_items_dev = n_dev; ka.item_index = item_index;
   for (auto& b : bufs) { ka.bufs[b.first].ptr = (uint8_t*)b.second.first; ka.bufs[b.first].stride = b.second.second; }
   if (checked_mode()) {
     for (int k = 0; k < MAX_BUFS; k++) {
@@ -505,7 +505,7 @@ EXPORT int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks) {
   uint64_t* dbg = nullptr; HIPCHK(hipMalloc(&dbg, blocks * 40));
   KernelArgs ka; memset(&ka, 0, sizeof ka);
   ka.steps = d.steps; ka.descs = d.descs; ka.consts = d.consts; ka.qp_table = ctx->qp_table;
-  ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slot_bytes = d.p->slot_bytes; ka.inst_bytes = d.p->inst_bytes(); ka.n_items = (u32)n;
+  ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slot_bytes = d.p->slot_bytes; ka.inst_bytes = d.p->inst_bytes(); ka.shared_consts = d.p->shared_consts ? 1u : 0u; ka.n_items = (u32)n;
   ka.bufs[3].ptr = ctx->T[0]; ka.bufs[3].stride = F12; ka.bufs[5].ptr = ctx->T[1]; ka.bufs[5].stride = F12;
   if (pid == P_MILLER_FE) { ka.bufs[0].ptr = ctx->io_g1; ka.bufs[0].stride = 96; ka.bufs[1].ptr = ctx->io_g2; ka.bufs[1].stride = 192; ka.bufs[4].ptr = ctx->N; ka.bufs[4].stride = RAW; }
   ka.hwid_out = dbg;
@@ -568,6 +568,12 @@ static int dev_decompress(nbls_ctx* ctx, bool g2, size_t n, const void* d_in, vo
   return run(ctx, pb, n, {B(0, d_in, e), B(3, X, q), B(4, R, q), B(5, Cd, q), B(6, d_out, g2 ? 192 : 96), B(7, d_status, 1)}, s);
 }
 // 256 uniform bytes per message (expand_message_xmd output) -> hash point, affine wire bytes (PointG2.hashToCurve, index.ts:481-490)
+// PointG2.clearCofactor (index.ts:659-672) on raw projective points: two programs around the second multiplication by x (programs.h P_H2C_C1 / C2).
+// in -> out (may alias in), norm of Z -> N; base and S are scratch of n * 6 raw elements each
+static int dev_clear_g2(nbls_ctx* ctx, size_t n, const void* in, uint8_t* base, uint8_t* S, void* out, void* N, hipStream_t s) {
+  int r = run(ctx, P_H2C_C1, n, {B(3, in, 6 * RAW), B(6, base, 6 * RAW), B(5, S, 6 * RAW)}, s); if (r) return r;
+  return run(ctx, P_H2C_C2, n, {B(3, base, 6 * RAW), B(4, S, 6 * RAW), B(6, out, 6 * RAW), B(7, N, RAW)}, s);
+}
 static int dev_hash_to_g2(nbls_ctx* ctx, size_t n, const void* d_uniform, void* d_out, hipStream_t s) {
   uint8_t *T, *E, *Pw, *Q, *N, *NI, *st; int r;
   if ((r = need(ctx, 0, n * 4 * RAW, &T)) || (r = need(ctx, 1, n * 6 * RAW, &E)) || (r = need(ctx, 2, n * 4 * RAW, &Pw)) || (r = need(ctx, 3, n * 6 * RAW, &Q)) ||
@@ -575,9 +581,10 @@ static int dev_hash_to_g2(nbls_ctx* ctx, size_t n, const void* d_uniform, void* 
   if ((r = run(ctx, P_H2C_A, n, {B(0, d_uniform, 256), B(3, T, 4 * RAW), B(4, E, 4 * RAW)}, s))) return r;
   if ((r = run_pow(ctx, 2, 2 * n, E, Pw, s))) return r;
   if ((r = run(ctx, P_H2C_B, n, {B(3, T, 4 * RAW), B(5, Pw, 4 * RAW), B(6, E, 6 * RAW)}, s))) return r;        // E is free again: reuse it for the E2 point
-  if ((r = run(ctx, P_H2C_C, n, {B(3, E, 6 * RAW), B(6, Q, 6 * RAW), B(7, N, RAW)}, s))) return r;
+  uint8_t* S; if ((r = need(ctx, 13, n * 6 * RAW, &S))) return r;
+  if ((r = dev_clear_g2(ctx, n, E, Q, S, E, N, s))) return r;
   if ((r = run_inv_buf(ctx, n, N, NI, s))) return r;
-  return run(ctx, P_G2_TO_AFFINE, n, {B(3, Q, 6 * RAW), B(4, NI, RAW), B(2, d_out, 192), B(7, st, 1)}, s);
+  return run(ctx, P_G2_TO_AFFINE, n, {B(3, E, 6 * RAW), B(4, NI, RAW), B(2, d_out, 192), B(7, st, 1)}, s);
 }
 // sum of n affine points (left fold of add == tree of complete additions): affine wire bytes + status (1 = sum is the zero point)
 static int dev_point_sum(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, void* d_out, void* d_status, hipStream_t s) {
@@ -798,9 +805,10 @@ static int dev_encode_to_g2(nbls_ctx* ctx, size_t n, const void* d_uniform, void
   if ((r = run(ctx, P_ENC2_A, n, {B(0, d_uniform, 128), B(3, T, 2 * RAW), B(4, E, 2 * RAW)}, s))) return r;
   if ((r = run_pow(ctx, 2, n, E, Pw, s))) return r;
   if ((r = run(ctx, P_ENC2_B, n, {B(3, T, 2 * RAW), B(5, Pw, 2 * RAW), B(6, E, 6 * RAW)}, s))) return r;
-  if ((r = run(ctx, P_H2C_C, n, {B(3, E, 6 * RAW), B(6, Q, 6 * RAW), B(7, N, RAW)}, s))) return r;
+  uint8_t* S; if ((r = need(ctx, 13, n * 6 * RAW, &S))) return r;
+  if ((r = dev_clear_g2(ctx, n, E, Q, S, E, N, s))) return r;
   if ((r = run_inv_buf(ctx, n, N, NI, s))) return r;
-  return run(ctx, P_G2_TO_AFFINE, n, {B(3, Q, 6 * RAW), B(4, NI, RAW), B(2, d_out, 192), B(7, st, 1)}, s);
+  return run(ctx, P_G2_TO_AFFINE, n, {B(3, E, 6 * RAW), B(4, NI, RAW), B(2, d_out, 192), B(7, st, 1)}, s);
 }
 // mode: 0 = PointG1.hashToCurve, 1 = PointG1.encodeToCurve, 2 = PointG2.encodeToCurve
 static int hash_curve_host(nbls_ctx* ctx, int mode, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len, uint8_t* out) {
@@ -880,7 +888,8 @@ static int clear_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* aff, uint
   HIPCHK(hipMemcpyAsync(d, aff, n * a, hipMemcpyHostToDevice, s));
   int r;
   if ((r = run(ctx, g2 ? P_G2_TO_PROJ : P_G1_TO_PROJ, n, {B(g2 ? 1 : 0, d, a), B(3, P, p)}, s))) return r;
-  if ((r = run(ctx, g2 ? P_H2C_C : P_G1_CLEAR, n, {B(3, P, p), B(6, Q, p), B(7, N, RAW)}, s))) return r;
+  if (g2) { void* S2 = io.alloc(n * p); if (!S2) return NBLS_EHIP; if ((r = dev_clear_g2(ctx, n, P, (uint8_t*)Q, (uint8_t*)S2, Q, N, s))) return r; }
+  else if ((r = run(ctx, P_G1_CLEAR, n, {B(3, P, p), B(6, Q, p), B(7, N, RAW)}, s))) return r;
   if ((r = run_inv_buf(ctx, n, N, NI, s))) return r;
   if ((r = run(ctx, g2 ? P_G2_TO_AFFINE : P_G1_TO_AFFINE, n, {B(3, Q, p), B(4, NI, RAW), B(2, o, a), B(7, st, 1)}, s))) return r;
   HIPCHK(hipMemcpyAsync(out, o, n * a, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(status, st, n, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));

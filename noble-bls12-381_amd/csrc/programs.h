@@ -58,6 +58,8 @@ enum ProgId {
   P_G2_DEC_B_HEX,                 // PointG2.fromHex on 96 compressed bytes (index.ts:532-562): flag rules, root by the S bit, no subgroup check
   P_G1_FROM_RAW, P_G2_FROM_RAW,   // uncompressed 96 / 192 bytes (buf 0) -> canonical affine wire bytes (buf 6), status (buf 7)   (index.ts:317-321, 563-575)
   P_G2_SWAP,                      // x.c0 x.c1 y.c0 y.c1 <-> x.c1 x.c0 y.c1 y.c0 (buf 0 -> buf 2)   (PointG2.toHex(false), index.ts:622-629)
+  P_H2C_C1, P_H2C_C2,             // PointG2.clearCofactor (index.ts:659-672) in two halves around the second multiplication by x: projective P (3) -> base (6), S (5) ;
+                                  // base (3), S (4) -> projective result (6), norm of Z (7)
   P_COUNT
 };
 static const int N_LINES = 68;                 // 63 doubling steps + 5 addition steps (bits of |x|)

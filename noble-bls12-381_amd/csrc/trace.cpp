@@ -478,16 +478,20 @@ Program Builder::compile(const std::string& name, int W) {
     const char* e = getenv("NBLS_SLOT_BYTES");
     P.slot_bytes = e && atoi(e) == 80 ? 80 : 64;
   }
-  assert(P.inst_bytes() < 65536);
+  // constants: a copy per instance (operand address = base + offset) unless that costs real LDS: with 8 or 16 instances per wavefront the copies
+  // of a dozen constants are 5-10 KB and push the point programs from 8 to 6 wavefronts per CU; those keep one shared copy, marked by bit 1
+  P.shared_consts = getenv("NBLS_SHARED_CONSTS") ? atoi(getenv("NBLS_SHARED_CONSTS")) != 0 : P.G >= 8;
+  assert(P.lds_bytes() < 65536 * 2 && P.inst_bytes() < 32768);
   // 6. emit
-  auto op = [&](int atom) -> u32 {   // LDS byte offset inside the instance region
-    if (atom < 0) return 0;   // const slot 0 is zero
+  const u32 CONST_FLAG = P.shared_consts ? 2u : 0u;
+  auto op = [&](int atom) -> u32 {   // LDS byte offset: inside the instance region, or (shared constants) absolute with CONST_FLAG
+    if (atom < 0) return CONST_FLAG;   // const slot 0 is zero
     const Node& n = nodes[atom];
-    if (n.kind == 0xff) return (u32)n.const_idx * P.slot_bytes;
+    if (n.kind == 0xff) return (u32)n.const_idx * P.slot_bytes | CONST_FLAG;
     assert(n.slot >= 0);
-    return (P.nconst + (u32)n.slot) * P.slot_bytes;
+    return ((P.shared_consts ? 0u : P.nconst) + (u32)n.slot) * P.slot_bytes;
   };
-  auto put16 = [](std::vector<u32>& w, int first, int t, u32 v) { w[first + t / 2] |= (v & 0xffffu) << (16 * (t & 1)); };
+  const u32 ZERO_FIELD = op(-1);
   for (size_t s = 0; s < step_nodes.size(); s++) {
     const std::vector<int>& L = step_nodes[s];
     const Node& n0 = nodes[L[0]];
@@ -520,6 +524,12 @@ Program Builder::compile(const std::string& name, int W) {
     for (int c : L) {
       const Node& n = nodes[c];
       std::vector<u32> w(st.stride, 0);
+      if (ZERO_FIELD && (n.kind == K_DOT || n.kind == K_LIN)) {   // padding fields name the zero constant
+        const int first = n.kind == K_DOT ? 4 : 1, cnt = n.kind == K_DOT ? 8 : std::min<int>(14, 2 * ((int)st.stride - 1));
+        for (int t = 0; t < cnt; t++) w[first + t / 2] |= ZERO_FIELD << (16 * (t & 1));
+        if (n.kind == K_DOT) for (u32 r = 0; r < st.p0; r++) for (int q = 0; q < 4; q++) w[DOT_HDR_WORDS + DOT_ROUND_WORDS * r + q] = ZERO_FIELD;
+      }
+      auto put16 = [&](std::vector<u32>& ww, int first, int t, u32 v) { u32& x = ww[first + t / 2]; x = (x & ~(0xffffu << (16 * (t & 1)))) | ((v & 0xffffu) << (16 * (t & 1))); };
       auto put_lin = [&](int first) {   // added terms first, then subtracted ones, each group padded with the zero constant (offset 0)
         int ia = 0, is = 0;
         for (auto& t : n.lin) { if (t.second > 0) put16(w, first, ia++, op(t.first)); else put16(w, first, (int)mp + is++, op(t.first)); }
@@ -534,8 +544,8 @@ Program Builder::compile(const std::string& name, int W) {
             u32* r = &w[DOT_HDR_WORDS + DOT_ROUND_WORDS * i];
             const int sa = step_shapes[s][i].first, sb = step_shapes[s][i].second;
             const bool ma = (sa & 3) == 3 || (sa & 8), mb = (sb & 3) == 3 || (sb & 8);   // per-lane signs in bit 0 of the offsets
-            r[0] = op(p.a.s0) | ((ma && p.neg0_a) ? 1u : 0u); r[1] = p.a.s1 >= 0 ? (op(p.a.s1) | ((ma && p.a.n1) ? 1u : 0u)) : 0u;
-            r[2] = op(p.b.s0) | ((mb && p.neg0_b) ? 1u : 0u); r[3] = p.b.s1 >= 0 ? (op(p.b.s1) | ((mb && p.b.n1) ? 1u : 0u)) : 0u;
+            r[0] = op(p.a.s0) | ((ma && p.neg0_a) ? 1u : 0u); r[1] = p.a.s1 >= 0 ? (op(p.a.s1) | ((ma && p.a.n1) ? 1u : 0u)) : ((sa & 3) || (sa & 8) ? ZERO_FIELD : 0u);
+            r[2] = op(p.b.s0) | ((mb && p.neg0_b) ? 1u : 0u); r[3] = p.b.s1 >= 0 ? (op(p.b.s1) | ((mb && p.b.n1) ? 1u : 0u)) : ((sb & 3) || (sb & 8) ? ZERO_FIELD : 0u);
             P.n_norm_operands += p.norm_a + p.norm_b; P.n_comb_operands += (p.a.s1 >= 0) + (p.b.s1 >= 0);
           }
           break;
@@ -589,11 +599,19 @@ const u32* qp_table_words() {
 std::string verify_program(const Program& p) {
   char msg[256];
   const u32 ib = p.inst_bytes(), cbytes = p.nconst * p.slot_bytes;
+  const bool sh = p.shared_consts;
   auto bad = [&](size_t s, unsigned lane, const char* what, u32 v) { snprintf(msg, sizeof msg, "%s: step %zu lane %u: %s (0x%x)", p.name.c_str(), s, lane, what, v); return std::string(msg); };
   if (p.slot_bytes != 64 && p.slot_bytes != 80) return p.name + ": slot stride";
-  if ((u64)p.G * ib > 160 * 1024) return p.name + ": LDS image exceeds 160 KB";
+  if ((u64)p.lds_bytes() > 160 * 1024) return p.name + ": LDS image exceeds 160 KB";
   if (p.W * p.G > 64 || p.W == 0) return p.name + ": lanes";
   if (p.consts.size() != (size_t)p.nconst * RAW_WORDS) return p.name + ": constant table size";
+  // an operand offset: replicated constants -> anything inside the instance region; shared -> bit 1 marks an absolute constant offset
+  auto inside = [&](u32 f, u32 flagmask) {
+    if (f & flagmask) return false;
+    const u32 o = f & ~15u;
+    if (sh && (f & 2u)) return o + 56 <= cbytes;
+    return o + 56 <= ib;
+  };
   for (size_t s = 0; s < p.steps.size(); s++) {
     const Step& st = p.steps[s];
     if (st.nlanes == 0 || st.nlanes > p.W) return bad(s, 0, "active lanes", st.nlanes);
@@ -601,9 +619,9 @@ std::string verify_program(const Program& p) {
     if ((u64)st.desc_off + (u64)st.nlanes * st.stride > p.descs.size() || st.desc_off % 4) return bad(s, 0, "descriptors outside the program", st.desc_off);
     for (unsigned l = 0; l < st.nlanes; l++) {
       const u32* d = p.descs.data() + st.desc_off + l * st.stride;
-      auto src = [&](u32 f) { f &= 0xffffu; return (f & 15u) == 0 && f + 56 <= ib; };                    // a readable slot (constants included)
-      auto dst = [&](u32 f) { f &= 0xffffu; return (f & 15u) == 0 && f >= cbytes && f + 56 <= ib; };    // a writable slot (never a constant)
-      auto term = [&](u32 f, bool signs) { return (f & (signs ? 14u : 15u)) == 0 && (f & ~1u) + 56 <= ib; };   // product term: 32-bit offset, bit 0 = sign in mode 3
+      auto src = [&](u32 f) { return inside(f & 0xffffu, sh ? 13u : 15u); };                                  // a readable slot (constants included)
+      auto dst = [&](u32 f) { f &= 0xffffu; return (f & 15u) == 0 && (sh || f >= cbytes) && f + 56 <= ib; };  // a writable slot (never a constant)
+      auto term = [&](u32 f, bool signs) { return inside(f, (sh ? 13u : 15u) & (signs ? ~1u : ~0u)); };       // product term: 32-bit offset, bit 0 = sign in mode 3
       switch (st.kind) {
         case K_DOT: {
           if (st.p0 > MAX_DOT_PRODUCTS || st.stride != (u32)(DOT_HDR_WORDS + DOT_ROUND_WORDS * st.p0)) return bad(s, l, "product rounds / stride", st.p0);
@@ -621,7 +639,7 @@ std::string verify_program(const Program& p) {
             for (int o = 0; o < 2; o++) {
               const u32 mode = (sh >> (3 * o)) & 3, f0 = rd[2 * o], f1 = rd[2 * o + 1];
               if (!term(f0, mode == 3)) return bad(s, l, "first term of an operand", f0);
-              if (mode == 0 ? f1 != 0 : !term(f1, mode == 3)) return bad(s, l, "second term of an operand", f1);
+              if (mode == 0 ? (f1 & ~2u) != 0 : !term(f1, mode == 3)) return bad(s, l, "second term of an operand", f1);
             }
             if (sh & 0xc0) return bad(s, l, "round shape", sh);
           }

@@ -37,8 +37,10 @@ struct Program {
   u32 n_round_ops = 0, n_op_mode[4] = {0, 0, 0, 0}, n_op_norm = 0;   // product-round operands (two per round) by shape
   double est_valu = 0;       // cost-model estimate of VALU instructions per wave (see Builder::compile)
   std::vector<u32> buf_extent = std::vector<u32>(MAX_BUFS, 0);   // per buffer index: bytes of one item the program touches (max offset + size); launch check in checked builds
-  u32 inst_bytes() const { return (nconst + slots) * slot_bytes; }   // one instance region: constants (replicated per instance) + slots
-  u32 lds_bytes() const { return G * inst_bytes(); }
+  bool shared_consts = false;   // one shared copy of the constants instead of one per instance (chosen by compile() for G >= 8)
+  u32 inst_bytes() const { return (shared_consts ? slots : nconst + slots) * slot_bytes; }   // one instance region: [constants +] slots
+  u32 inst_base(u32 g) const { return (shared_consts ? nconst * slot_bytes : 0) + g * inst_bytes(); }
+  u32 lds_bytes() const { return inst_base(G); }
 };
 
 // operand of a pending product: s0 (never negated after canonicalisation) and optional s1 with sign

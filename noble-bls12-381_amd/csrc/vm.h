@@ -18,7 +18,8 @@
 //     ever tests a flag of its own inside the product loop.
 //   * PER-LANE data in the descriptors: LDS byte offsets (relative to the lane's instance region) of the slots to read
 //     and write.  The program's constants are replicated at the start of every instance region, so an operand address
-//     is one addition; the slot stride is a property of the program (80 bytes = conflict-free 16-byte reads when the
+//     is one addition (programs with eight or more instances per wavefront keep a single shared copy instead, at three more instructions
+//     per operand, because replication would cost them occupancy); the slot stride is a property of the program (80 bytes = conflict-free 16-byte reads when the
 //     LDS budget allows it, 64 otherwise), not of the kernel.
 #pragma once
 #include <stdint.h>
@@ -92,9 +93,10 @@ struct KernelArgs {
   uint32_t nsteps, nconst;
   uint32_t W, G;            // lanes per instance, instances per wave (G * W <= 64)
   uint32_t slot_bytes;      // LDS slot stride of this program (64 or 80)
-  uint32_t inst_bytes;      // LDS bytes per instance region: (nconst + slots) * slot_bytes
+  uint32_t inst_bytes;      // LDS bytes per instance region: (nconst + slots) * slot_bytes, or slots * slot_bytes with shared constants
   uint32_t n_items;
-  uint32_t pad_;
+  uint32_t shared_consts;   // 0: constants replicated at the start of every instance region; 1: one copy at the start of the LDS image, the instance
+                            //    regions behind it, constant operands marked by bit 1 of their offset (programs with 8 or more instances per wavefront)
   IOBuf bufs[MAX_BUFS];
   const uint32_t* item_index;    // optional (NULL): buffers are addressed with item_index[item] instead of item (gathered operands, results scattered back in place)
   const uint32_t* n_items_dev;   // optional (NULL): the item count lives in device memory (min with n_items, which then only sizes the launch)

@@ -68,26 +68,39 @@ NBLS_HD void st14(LDSP lds, u32 addr, const u32* x) {
 template <typename LDSP>
 NBLS_HD u32 ld1(LDSP lds, u32 addr) { return *(const u32*)(lds + addr); }
 
+struct LaneCtx {
+  u32 inst;       // byte offset of the instance region
+  u32 item;       // global work-item index
+  bool live;      // item < n_items (dead instances compute on zeros but never touch global memory)
+  bool shared;    // uniform: the program keeps ONE copy of its constants at the start of the LDS image (offsets with bit 1 set are absolute)
+};
+// LDS byte address of an operand field.  Replicated constants (the pairing programs): base + offset.  Shared constants (programs that run 8 or 16
+// instances per wavefront, where replication would cost occupancy): bit 1 of the offset marks a constant, addressed absolutely.
+NBLS_HD u32 term_addr(u32 f, const LaneCtx& cx) {
+  if (cx.shared) return ((f & 2u) ? 0u : cx.inst) + (f & ~15u);
+  return cx.inst + f;
+}
+
 // operand of a DOT product round, as signed limbs: x, x + y or x - y (f0, f1: byte offsets inside the instance region), optionally
 // normalised.  `shape` (3 bits: mode, normalise) is uniform for the wavefront, so these are scalar branches; a lane that has no second
 // term where another lane has one points f1 at the zero constant.  Mode 3: the signs of both terms are per lane (bit 0 of f0 / f1).
 template <typename LDSP>
-NBLS_HD void dot_operand(u32* A, u32 f0, u32 f1, u32 shape, LDSP lds, u32 inst) {
+NBLS_HD void dot_operand(u32* A, u32 f0, u32 f1, u32 shape, LDSP lds, const LaneCtx& cx) {
   const u32 mode = shape & 3;
-  if (mode != 3) ld14(A, lds, inst + f0);
+  if (mode != 3) ld14(A, lds, term_addr(f0, cx));
   if (mode) {
     u32 X[NL];
     if (mode == 1) {
-      ld14(X, lds, inst + f1);
+      ld14(X, lds, term_addr(f1, cx));
 #pragma unroll
       for (int i = 0; i < NL; i++) A[i] += X[i];
     } else if (mode == 2) {
-      ld14(X, lds, inst + f1);
+      ld14(X, lds, term_addr(f1, cx));
 #pragma unroll
       for (int i = 0; i < NL; i++) A[i] -= X[i];
     } else {   // per-lane signs on both terms (bit 0 of the offsets): +-x +- y
-      ld14(A, lds, inst + (f0 & ~1u));
-      ld14(X, lds, inst + (f1 & ~1u));
+      ld14(A, lds, term_addr(f0 & ~1u, cx));
+      ld14(X, lds, term_addr(f1 & ~1u, cx));
       const u32 m0 = 0u - (f0 & 1u), m1 = 0u - (f1 & 1u), c = (f0 & 1u) + (f1 & 1u);
 #pragma unroll
       for (int i = 0; i < NL; i++) A[i] = (A[i] ^ m0) + (X[i] ^ m1) + c;
@@ -206,12 +219,7 @@ NBLS_HD void halve28(u32* r) {
 // address (or 0xffffffff when the step has no LDS destination); the caller commits the limbs afterwards, so that
 // every read of a step precedes every write of that step (in-order LDS within a wavefront; explicit two-phase loop in
 // the simulator).
-struct LaneCtx {
-  u32 inst;       // byte offset of the instance region
-  u32 item;       // global work-item index
-  bool live;      // item < n_items (dead instances compute on zeros but never touch global memory)
-};
-NBLS_HD u32 slot_addr(u32 field, u32 inst) { return inst + (field & 0xffffu); }
+NBLS_HD u32 slot_addr(u32 field, const LaneCtx& cx) { return term_addr(field & 0xffffu, cx); }
 // 16-bit offset number t of a packed list that starts at word `first` of the descriptor
 NBLS_HD u32 field16(const u32* d, int first, int t) { return (d[first + t / 2] >> (16 * (t & 1))) & 0xffffu; }
 
@@ -229,8 +237,8 @@ NBLS_HD u32 round_shape(const Step& st, u32 r) { return ((r < 4 ? st.shape[0] : 
 template <typename LDSP>
 NBLS_HD void dot_round(u64* acc, u32 shape, u32 a0, u32 a1, u32 b0, u32 b1, LDSP lds, const LaneCtx& cx) {
   u32 A[NL], B[NL];
-  dot_operand(A, a0, a1, shape & 7, lds, cx.inst);
-  dot_operand(B, b0, b1, (shape >> SH_B_SHIFT) & 7, lds, cx.inst);
+  dot_operand(A, a0, a1, shape & 7, lds, cx);
+  dot_operand(B, b0, b1, (shape >> SH_B_SHIFT) & 7, lds, cx);
   mac28(acc, A, B);
 }
 template <typename LDSP>
@@ -252,7 +260,7 @@ NBLS_HD u32 dot_finish(u32* res, u64* acc, const Step& st, const u32* d /* the 8
   for (int t = 0; t < MAX_DOT_LINEAR; t++) {
     if (t < nadd) {   // uniform
       u32 X[NL];
-      ld14(X, lds, slot_addr(field16(d, 4, t), cx.inst));
+      ld14(X, lds, slot_addr(field16(d, 4, t), cx));
 #pragma unroll
       for (int i = 0; i < NL; i++) r[i] += X[i];
     }
@@ -261,7 +269,7 @@ NBLS_HD u32 dot_finish(u32* res, u64* acc, const Step& st, const u32* d /* the 8
   for (int t = 0; t < 2 * MAX_DOT_LINEAR; t++) {
     if (t >= nadd && t < nadd + nsub) {   // uniform
       u32 X[NL];
-      ld14(X, lds, slot_addr(field16(d, 4, t), cx.inst));
+      ld14(X, lds, slot_addr(field16(d, 4, t), cx));
 #pragma unroll
       for (int i = 0; i < NL; i++) r[i] -= X[i];
     }
@@ -271,7 +279,7 @@ NBLS_HD u32 dot_finish(u32* res, u64* acc, const Step& st, const u32* d /* the 8
   if (st.p1 & DOTF_HALVE) { if (w0 & (1u << 19)) halve28(r); }
 #pragma unroll
   for (int i = 0; i < NL; i++) res[i] = r[i];
-  return slot_addr(w0, cx.inst);
+  return slot_addr(w0, cx);
 }
 
 // every step kind except K_DOT
@@ -288,7 +296,7 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words *
       for (int t = 0; t < 2 * MAX_LIN_TERMS; t++) {
         if (t < nadd + nsub) {   // uniform
           u32 X[NL];
-          ld14(X, lds, slot_addr(field16(d, 1, t), cx.inst));
+          ld14(X, lds, slot_addr(field16(d, 1, t), cx));
           if (t < nadd) {
 #pragma unroll
             for (int i = 0; i < NL; i++) r[i] += X[i];
@@ -303,7 +311,7 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words *
       if (w0 & (1u << 16)) halve28(r);
 #pragma unroll
       for (int i = 0; i < NL; i++) res[i] = r[i];
-      return slot_addr(w0, cx.inst);
+      return slot_addr(w0, cx);
     }
     case K_LOAD: {
       u32 w0 = d[0], off = d[1];
@@ -314,7 +322,7 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words *
 #pragma unroll
       for (int i = 0; i < 12; i++) w[i] = (cx.live && i < nw) ? bswap32(src[nw - 1 - i]) : 0u;
       words_to_limbs(res, w);
-      return slot_addr(w0, cx.inst);
+      return slot_addr(w0, cx);
     }
     case K_LOADW: {
       u32 w0 = d[0], off = d[1];
@@ -322,12 +330,12 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words *
       const u32* src = (const u32*)(b.ptr + (u64)cx.item * b.stride + off);
 #pragma unroll
       for (int i = 0; i < NL; i++) res[i] = cx.live ? src[i] : 0u;
-      return slot_addr(w0, cx.inst);
+      return slot_addr(w0, cx);
     }
     case K_STORE: {
       u32 w0 = d[0], off = d[1];
       u32 X[NL], w[12];
-      ld14(X, lds, slot_addr(w0, cx.inst));
+      ld14(X, lds, slot_addr(w0, cx));
       if (st.p0 == 0) csub_p(X);     // p0 = 1: raw 384-bit integer (compressed encodings carry flag bits above bit 380)
       limbs_to_words(w, X);
       if (cx.live) {
@@ -341,7 +349,7 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words *
     case K_STOREW: {
       u32 w0 = d[0], off = d[1];
       u32 X[NL];
-      ld14(X, lds, slot_addr(w0, cx.inst));
+      ld14(X, lds, slot_addr(w0, cx));
       if (cx.live) {
         const IOBuf& b = bufs[(w0 >> 16) & 7];
         u32* dst = (u32*)(b.ptr + (u64)cx.item * b.stride + off);
@@ -354,38 +362,38 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words *
     case K_ISZ: {
       u32 w0 = d[0];
       u32 X[NL];
-      ld14(X, lds, slot_addr(w0 >> 16, cx.inst));
+      ld14(X, lds, slot_addr(w0 >> 16, cx));
       bool z = is_zero_mod_p(X);
 #pragma unroll
       for (int i = 0; i < NL; i++) res[i] = 0;
       res[0] = z ? 1u : 0u;
-      return slot_addr(w0, cx.inst);
+      return slot_addr(w0, cx);
     }
     case K_SEL: {
       u32 w0 = d[0], w1 = d[1];
       // both sources are read and merged with a mask: the LDS access pattern does not depend on the flag (the flag
       // can be a secret scalar bit in the sign / getPublicKey ladders)
-      const u32 m = 0u - (ld1(lds, slot_addr(w0 >> 16, cx.inst)) != 0 ? 1u : 0u);
+      const u32 m = 0u - (ld1(lds, slot_addr(w0 >> 16, cx)) != 0 ? 1u : 0u);
       u32 Xa[NL], Xb[NL];
-      ld14(Xa, lds, slot_addr(w1, cx.inst));
-      ld14(Xb, lds, slot_addr(w1 >> 16, cx.inst));
+      ld14(Xa, lds, slot_addr(w1, cx));
+      ld14(Xb, lds, slot_addr(w1 >> 16, cx));
 #pragma unroll
       for (int i = 0; i < NL; i++) res[i] = (Xa[i] & m) | (Xb[i] & ~m);
-      return slot_addr(w0, cx.inst);
+      return slot_addr(w0, cx);
     }
     case K_CANON: {
       u32 w0 = d[0];
-      ld14(res, lds, slot_addr(w0 >> 16, cx.inst));
+      ld14(res, lds, slot_addr(w0 >> 16, cx));
       csub_p(res);
-      return slot_addr(w0, cx.inst);
+      return slot_addr(w0, cx);
     }
     case K_CMP: {
       u32 w0 = d[0], w1 = d[1];
       u32 X[NL], Y[NL];
-      ld14(X, lds, slot_addr(w1, cx.inst));
+      ld14(X, lds, slot_addr(w1, cx));
       u32 f;
       if (st.p0 == 0) {   // X > Y  <=>  Y - X borrows (normalised limbs)
-        ld14(Y, lds, slot_addr(w1 >> 16, cx.inst));
+        ld14(Y, lds, slot_addr(w1 >> 16, cx));
         u32 br = 0;
 #pragma unroll
         for (int i = 0; i < NL; i++) { u32 t = Y[i] - X[i] - br; br = t >> 31; }
@@ -396,40 +404,40 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words *
 #pragma unroll
       for (int i = 0; i < NL; i++) res[i] = 0;
       res[0] = f;
-      return slot_addr(w0, cx.inst);
+      return slot_addr(w0, cx);
     }
     case K_BIT: {
       u32 w0 = d[0], bit = d[1];
-      u32 w = ld1(lds, slot_addr(w0 >> 16, cx.inst) + 4 * (bit / 28));
+      u32 w = ld1(lds, slot_addr(w0 >> 16, cx) + 4 * (bit / 28));
 #pragma unroll
       for (int i = 0; i < NL; i++) res[i] = 0;
       res[0] = (w >> (bit % 28)) & 1;
-      return slot_addr(w0, cx.inst);
+      return slot_addr(w0, cx);
     }
     case K_BITAND: {
       u32 w0 = d[0], w1 = d[1];
       u32 X[NL], Y[NL];
-      ld14(X, lds, slot_addr(w1, cx.inst));
-      ld14(Y, lds, slot_addr(w1 >> 16, cx.inst));
+      ld14(X, lds, slot_addr(w1, cx));
+      ld14(Y, lds, slot_addr(w1 >> 16, cx));
 #pragma unroll
       for (int i = 0; i < NL; i++) res[i] = X[i] & Y[i];
-      return slot_addr(w0, cx.inst);
+      return slot_addr(w0, cx);
     }
     case K_FLAG: {
       u32 w0 = d[0], w1 = d[1];
-      u32 a = ld1(lds, slot_addr(w1, cx.inst)) & 1, b = ld1(lds, slot_addr(w1 >> 16, cx.inst)) & 1;
+      u32 a = ld1(lds, slot_addr(w1, cx)) & 1, b = ld1(lds, slot_addr(w1 >> 16, cx)) & 1;
       u32 f = st.p0 == 0 ? (a & b) : st.p0 == 1 ? (a | b) : st.p0 == 2 ? (a ^ b) : (a & (b ^ 1));
 #pragma unroll
       for (int i = 0; i < NL; i++) res[i] = 0;
       res[0] = f;
-      return slot_addr(w0, cx.inst);
+      return slot_addr(w0, cx);
     }
     case K_STATUS: {
       u32 w0 = d[0];
       u32 n = w0 & 0xff, code = 0;
       for (int k = (int)n - 1; k >= 0; k--) {
         u32 e = d[1 + k];
-        if ((ld1(lds, slot_addr(e, cx.inst)) & 1) == 0) code = e >> 16;
+        if ((ld1(lds, slot_addr(e, cx)) & 1) == 0) code = e >> 16;
       }
       if (cx.live) { const IOBuf& b = bufs[(w0 >> 16) & 7]; ((int8_t*)b.ptr)[(u64)cx.item * b.stride] = (int8_t)code; }
       return 0xffffffffu;

@@ -19,16 +19,17 @@ __device__ __forceinline__ u32 kernel_prologue(const KernelArgs& ka, char* lds, 
   u32 n_items = ka.n_items;
   exit_now = false;
   if (ka.n_items_dev) { const u32 v = *ka.n_items_dev; n_items = v < n_items ? v : n_items; if (blockIdx.x * ka.G >= n_items) { exit_now = true; return 0; } }
-  // constants: replicated at the start of every instance region
-  const u32 per_inst = ka.nconst * NL;
-  for (u32 i = tid; i < ka.G * per_inst; i += nthreads) {
+  // constants: replicated at the start of every instance region, or one shared copy at the start of the LDS image
+  const u32 per_inst = ka.nconst * NL, copies = ka.shared_consts ? 1u : ka.G;
+  for (u32 i = tid; i < copies * per_inst; i += nthreads) {
     const u32 g = i / per_inst, r = i - g * per_inst, c = r / NL, l = r - c * NL;
     *(u32*)(lds + g * ka.inst_bytes + c * ka.slot_bytes + 4 * l) = ka.consts[c * RAW_WORDS + l];
   }
   const u32 W = ka.W;
   const u32 inst_id = lane / W;
   ls.lane_in = (inst_id < ka.G) ? (lane - inst_id * W) : 0xffffu;
-  ls.cx.inst = (inst_id < ka.G ? inst_id : 0) * ka.inst_bytes;
+  ls.cx.shared = ka.shared_consts != 0;
+  ls.cx.inst = (ka.shared_consts ? ka.nconst * ka.slot_bytes : 0u) + (inst_id < ka.G ? inst_id : 0) * ka.inst_bytes;
   ls.cx.item = blockIdx.x * ka.G + inst_id;
   ls.cx.live = inst_id < ka.G && ls.cx.item < n_items;
   if (ka.item_index && ls.cx.live) ls.cx.item = ka.item_index[ls.cx.item];
@@ -119,7 +120,7 @@ extern "C" __global__ void __launch_bounds__(128) nbls_vm_kernel_split(KernelArg
   if (exit_now) return;
   const u32 lane_in = ls.lane_in;
   const LaneCtx cx = ls.cx;
-  u64* xch = (u64*)(lds + ka.G * ka.inst_bytes);   // exchange area: 28 columns x 64 lanes, column-major (conflict-free)
+  u64* xch = (u64*)(lds + (ka.shared_consts ? ka.nconst * ka.slot_bytes : 0u) + ka.G * ka.inst_bytes);   // exchange area: 28 columns x 64 lanes, column-major (conflict-free)
   __syncthreads();
   const uint4* descs4 = (const uint4*)ka.descs;
   Step st = ka.steps[0];

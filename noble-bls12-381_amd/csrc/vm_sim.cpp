@@ -15,12 +15,12 @@ using namespace nbls;
 static void sim_run(const Program& p, unsigned n_items, const IOBuf* bufs) {
   const u32* qp_table = qp_table_words();
   const unsigned inst_bytes = p.inst_bytes();
-  std::vector<V4> lds4((size_t)p.G * inst_bytes / 16 + 1);
+  std::vector<V4> lds4((size_t)p.lds_bytes() / 16 + 1);
   char* lds = (char*)lds4.data();
   unsigned blocks = (n_items + p.G - 1) / p.G;
   for (unsigned blk = 0; blk < blocks; blk++) {
-    memset(lds, 0xde, (size_t)p.G * inst_bytes);
-    for (unsigned g = 0; g < p.G; g++) for (unsigned c = 0; c < p.nconst; c++) memcpy(lds + g * inst_bytes + c * p.slot_bytes, p.consts.data() + c * RAW_WORDS, NL * 4);
+    memset(lds, 0xde, (size_t)p.lds_bytes());
+    for (unsigned g = 0; g < (p.shared_consts ? 1u : p.G); g++) for (unsigned c = 0; c < p.nconst; c++) memcpy(lds + g * inst_bytes + c * p.slot_bytes, p.consts.data() + c * RAW_WORDS, NL * 4);
     for (size_t s = 0; s < p.steps.size(); s++) {
       const Step& st = p.steps[s];
       struct Pending { u32 dst; u32 v[NL]; };
@@ -30,7 +30,7 @@ static void sim_run(const Program& p, unsigned n_items, const IOBuf* bufs) {
         if (inst >= p.G) continue;
         unsigned lane_in = lane - inst * p.W;
         if (lane_in >= st.nlanes) continue;
-        LaneCtx cx; cx.inst = inst * inst_bytes; cx.item = blk * p.G + inst; cx.live = cx.item < n_items;
+        LaneCtx cx; cx.inst = p.inst_base(inst); cx.shared = p.shared_consts; cx.item = blk * p.G + inst; cx.live = cx.item < n_items;
         Pending pd;
         u32 dw[8] = {0};
         const u32* gd = p.descs.data() + st.desc_off + lane_in * st.stride;
