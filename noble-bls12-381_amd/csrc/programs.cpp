@@ -532,6 +532,7 @@ static Program build(ProgId id) {
       return B.compile("acc_fe", ACC_W);
     }
     case P_ACC2_RAW: { B.sched_window = ACC_WINDOW; outputw_fp12(trace_acc(2, 3), 5, 0); return B.compile("acc2_raw", ACC_W); }
+    case P_ACC4_RAW: { B.sched_window = ACC_WINDOW; outputw_fp12(trace_acc(4, 3), 5, 0); return B.compile("acc4_raw", ACC_W); }
     case P_ACC_Q: {
       B.sched_window = ACC_WINDOW;
       std::vector<SFp> Px{input(0, 0)}, Py{input(0, 48)};

@@ -60,6 +60,7 @@ enum ProgId {
   P_G2_SWAP,                      // x.c0 x.c1 y.c0 y.c1 <-> x.c1 x.c0 y.c1 y.c0 (buf 0 -> buf 2)   (PointG2.toHex(false), index.ts:622-629)
   P_H2C_C1, P_H2C_C2,             // PointG2.clearCofactor (index.ts:659-672) in two halves around the second multiplication by x: projective P (3) -> base (6), S (5) ;
                                   // base (3), S (4) -> projective result (6), norm of Z (7)
+  P_ACC4_RAW,                     // four folded line tables per item (buf 3) -> F (buf 5): one Fp12 squaring per bit for four Miller loops
   P_COUNT
 };
 static const int N_LINES = 68;                 // 63 doubling steps + 5 addition steps (bits of |x|)

@@ -312,6 +312,17 @@ def test_split_miller(sim, oracle, golden):
     vmsim_py.run(sim, 'RAW_TO_BYTES', m, {3: (F2, vmsim_py.F12), 2: (out, 576)})
     for i in range(m):
         assert out.raw[576 * i:576 * i + 576] == oracle.miller_product(g1[192 * i:192 * i + 192], g2[384 * i:384 * i + 384], final_exp=False), i
+    # four tables per item; the last group is filled up with unit tables (every line = 1), as nbls_miller_product_dev does
+    unit = b''.join(vmsim_py.raw_elem(1) + bytes(5 * vmsim_py.RAW) for _ in range(68))
+    assert len(unit) == LINE_BYTES
+    g = (n + 3) // 4
+    L4 = C.create_string_buffer(L.raw[:LINE_BYTES * n] + unit * (4 * g - n), LINE_BYTES * 4 * g)
+    F4 = C.create_string_buffer(vmsim_py.F12 * g)
+    vmsim_py.run(sim, 'ACC4_RAW', g, {3: (L4, 4 * LINE_BYTES), 5: (F4, vmsim_py.F12)})
+    vmsim_py.run(sim, 'RAW_TO_BYTES', g, {3: (F4, vmsim_py.F12), 2: (out, 576)})
+    for i in range(g):
+        k = min(4, n - 4 * i)
+        assert out.raw[576 * i:576 * i + 576] == oracle.miller_product(g1[384 * i:384 * i + 96 * k], g2[768 * i:768 * i + 192 * k], final_exp=False), i
     # prepared lines (not folded) + G1: PointG1.millerLoop(Q) with Q.pairingPrecomputes() (index.ts:452-454, 703-711); one table shared by
     # every item (stride 0) pairs every P with the same Q
     LQ = _lines(sim, g1, g2, n, folded=False)
