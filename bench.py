@@ -60,7 +60,7 @@ def main():
     ap.add_argument('--steps', type=int, default=512, help='timed steps (default: about one second of GPU time)')
     ap.add_argument('--warmup', type=int, default=16)
     ap.add_argument('--batch', type=int, default=BATCH)
-    ap.add_argument('--inflight', type=int, default=5, help='batches kept in flight on separate HIP streams during the timed steps (1 = strictly one batch at a time)')
+    ap.add_argument('--inflight', type=int, default=6, help='batches kept in flight on separate HIP streams during the timed steps (1 = strictly one batch at a time)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--verify-batch', type=int, default=65536, help='signatures in the verifyBatch leg (BASELINE configs[2]); 0 disables')
     ap.add_argument('--verify-sharded', action='store_true', help='run the multi-GPU form of the verifyBatch leg (parallel.verify_batch_sharded) even on one rank')
@@ -134,6 +134,7 @@ def main():
         dt = float(t.item())
     # strictly serial figure (one batch at a time on one stream) = per-batch latency, this rank
     torch.cuda.synchronize()
+    eng.set_split_miller_min(16384)     # the single-call legs use the library's default (latency-oriented) choice of Miller programs
     serial_steps = max(8, min(args.steps, 320))
     s0 = time.perf_counter()
     for _ in range(serial_steps):
@@ -313,15 +314,23 @@ def main():
             threads = min(cores, 256)
             sample = 16384 if threads >= 128 else 4096 if threads >= 16 else 512
             g1s, g2s = (G1 * (sample // n + 1))[:96 * sample], (G2 * (sample // n + 1))[:192 * sample]
-            oracle.pairing_batch(g1s[:96 * threads], g2s[:192 * threads], True, False, threads=threads)   # warm
-            c0 = time.perf_counter()
-            oracle.pairing_batch(g1s, g2s, True, False, threads=threads)
-            cdt = time.perf_counter() - c0
+            # every hardware thread, and -- because two threads of a core share its multiplier -- every other one: the better figure is reported
+            best = None
+            for th_ in sorted({threads, max(1, threads // 2)}, reverse=True):
+                oracle.pairing_batch(g1s[:96 * th_], g2s[:192 * th_], True, False, threads=th_)   # warm
+                c0 = time.perf_counter()
+                oracle.pairing_batch(g1s, g2s, True, False, threads=th_)
+                d_ = time.perf_counter() - c0
+                if best is None or d_ < best[0]:
+                    best = (d_, th_)
+            cdt, threads_used = best
+            all_threads = threads
+            threads = threads_used
             c1 = time.perf_counter()
             oracle.pairing_batch(g1s[:96 * 64], g2s[:192 * 64], True, False, threads=1)
             cdt1 = time.perf_counter() - c1
             cpu = {'value': round(sample / cdt, 2), 'unit': 'pairings/s', 'cores': threads, 'kind': 'port',
-                   'sample': '%d pairings of the same workload on %d host threads (oracle/ C restatement); 1 thread: %.1f pairings/s' % (sample, threads, 64 / cdt1),
+                   'sample': '%d pairings of the same workload on %d host threads (oracle/ C restatement; timed on %d and on %d threads, the faster is reported); 1 thread: %.1f pairings/s' % (sample, threads, all_threads, max(1, all_threads // 2), 64 / cdt1),
                    'host_cpu_count': cores,
                    'reference_figure': {'value': 38.6, 'unit': 'pairings/s per core', 'source': 'BASELINE.md section 2: the reference itself (noble-bls12-381 v1.4.0, TypeScript / bigint) under Node 12 in the build container; it does not travel to the GPU box, so the port above is what is timed here'}}
         vbatch = None

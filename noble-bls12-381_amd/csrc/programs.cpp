@@ -267,7 +267,10 @@ static Program build(ProgId id) {
       return B.compile("fe_easy", 16);
     }
     case P_EXPX: {
-      outputw_fp12(conj(cyclotomic_exp_x(inputw_fp12(3, 0))), 5, 0);
+      if (env_int("NBLS_EXPX_RELOAD", 1)) {
+        B.sched_window = env_int("NBLS_EXPX_WINDOW", 150);   // the reloads of the base are scheduled about one squaring ahead of the multiplication that needs them
+        outputw_fp12(conj(cyclotomic_exp_x(inputw_fp12(3, 0), [&]() { return inputw_fp12(3, 0); })), 5, 0);
+      } else outputw_fp12(conj(cyclotomic_exp_x(inputw_fp12(3, 0))), 5, 0);
       return B.compile("expx", EXPX_W);
     }
     case P_FE_MID1: {

@@ -103,8 +103,15 @@ template <bool FAIR> __device__ __forceinline__ void vm_kernel_body(const Kernel
   }
   if (ka.hwid_out && lane == 0) { ka.hwid_out[5 * blockIdx.x + 2] = __builtin_readcyclecounter(); ka.hwid_out[5 * blockIdx.x + 4] = wall_clock64(); }
 }
-extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel(KernelArgs ka) { vm_kernel_body<false>(ka); }
-extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel_fair(KernelArgs ka) { vm_kernel_body<true>(ka); }
+// NBLS_WAVES_PER_EU (build-time experiment, tools/exp_variants.sh): cap the VGPR budget so that N wavefronts fit a SIMD (4 -> 128 registers, a few
+// descriptor registers spill to scratch once per step)
+#if defined(NBLS_WAVES_PER_EU)
+#define NBLS_OCC __attribute__((amdgpu_waves_per_eu(NBLS_WAVES_PER_EU, NBLS_WAVES_PER_EU)))
+#else
+#define NBLS_OCC
+#endif
+extern "C" __global__ void __launch_bounds__(64) NBLS_OCC nbls_vm_kernel(KernelArgs ka) { vm_kernel_body<false>(ka); }
+extern "C" __global__ void __launch_bounds__(64) NBLS_OCC nbls_vm_kernel_fair(KernelArgs ka) { vm_kernel_body<true>(ka); }
 
 // Two-wave variant for small batches.  A lone wavefront per SIMD issues at ~1/2 of the VALU rate (tools/ubench/lone_wave.hip)
 // and a second wavefront on the same SIMD runs beside it, so when a launch has no more workgroups than the chip has CUs each
