@@ -256,8 +256,9 @@ def main():
         achieved = mads / (vm_ms * 1e-3) / 1e12
         # algorithmic HBM bytes per pairing: wire points in (288) and Fp12 out (576) + the raw scratch
         # elements (768 B per Fp12, 64 B per Fp) every phase program reads and writes:
-        # miller_fe W 832 | fp_inv R 64 W 64 | fe_easy R 832 W 768 | 4 x expx R 768 W 768 | fe_mid1/2 R 1536 W 768 | fe_final R 5376
-        hbm_bytes = n * (288 + 832 + 128 + 832 + 768 + 4 * 1536 + 2 * 2304 + 5376 + 576)
+        # miller_fe W 832 | fp_inv R 64 W 64 | fe_easy R 832 W 768 | 5 x expx R 768 W 768 | fe_mid1/2 R 1536 W 768 | fe_final R 5376
+        # (from 16,384 pairings per call the Miller loop runs as LINES + ACC and adds one 26,112-byte line table written and read per pairing)
+        hbm_bytes = n * (288 + 832 + 128 + 832 + 768 + 5 * 1536 + 2 * 2304 + 5376 + 576 + (2 * 26112 if n >= 16384 else 0))
         traffic = None; valu_busy = None
         try:   # HBM bytes measured with rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, see profiles/README.md), same batch size only
             with open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')) as fh:

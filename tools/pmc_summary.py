@@ -11,17 +11,18 @@ min_grid = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 CYCLE = ['lines_pq', 'acc_fe', 'fe_easy', 'expx', 'fe_mid1', 'expx', 'expx', 'expx', 'fe_mid2', 'expx', 'fe_final']
 if os.environ.get('NBLS_FUSED_MILLER'):
     CYCLE = ['miller_fe'] + CYCLE[2:]   # the one-program Miller loop of round 1 (A/B switch of the library)
+VM = ('nbls_vm_kernel', 'nbls_vm_kernel_fair', 'nbls_vm_kernel_split')   # the launcher picks an instantiation by launch shape (csrc/vm_kernel.hip)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for f in sorted(glob.glob(root + '/pmc*/**/*_counter_collection.csv', recursive=True)):
     # min_grid drops the small launches of bench.py's parity spot check (grid = 64 lanes x waves; the inversion kernel runs one lane per item)
-    rows = [r for r in csv.DictReader(open(f)) if 'nbls' in r['Kernel_Name'] and int(r['Grid_Size']) >= (min_grid if r['Kernel_Name'] == 'nbls_vm_kernel' else min_grid // 16)]
-    ids = sorted({int(r['Dispatch_Id']) for r in rows if r['Kernel_Name'] == 'nbls_vm_kernel'})
+    rows = [r for r in csv.DictReader(open(f)) if 'nbls' in r['Kernel_Name'] and int(r['Grid_Size']) >= (min_grid if r['Kernel_Name'] in VM else min_grid // 16)]
+    ids = sorted({int(r['Dispatch_Id']) for r in rows if r['Kernel_Name'] in VM})
     label = {d: CYCLE[i % len(CYCLE)] for i, d in enumerate(ids)}
     seen = set()
     for r in rows:
         d = int(r['Dispatch_Id'])
-        key = label[d] if r['Kernel_Name'] == 'nbls_vm_kernel' else 'fp_inv'
+        key = label[d] if r['Kernel_Name'] in VM else 'fp_inv'
         acc[key][r['Counter_Name']].append(float(r['Counter_Value']))
         if d not in seen:
             seen.add(d); dur[key].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
