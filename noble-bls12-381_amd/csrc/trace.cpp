@@ -434,6 +434,16 @@ Program Builder::compile(const std::string& name, int W) {
       placed.resize(pr.size());
       pr = placed;
     }
+    // canonical operand order of a round: A carries the larger shape (mode, then normalise), so that the kernel's specialised round bodies
+    // (vm_exec.h dot_round) cover the shape pairs that occur
+    {
+      auto rank = [](int u) { int mode = ((u & 8) || (u & 3) == 3) ? 3 : (u & 3); return mode * 2 + ((u >> 2) & 1); };
+      for (size_t j = 0; j < mk; j++) {
+        if (rank(ua[j]) >= rank(ub[j])) continue;
+        std::swap(ua[j], ub[j]);
+        for (int c : L) { auto& pr = nodes[c].prods; if (j < pr.size()) { DotProduct& q = pr[j]; std::swap(q.a, q.b); std::swap(q.norm_a, q.norm_b); std::swap(q.neg0_a, q.neg0_b); } }
+      }
+    }
     for (size_t j = 0; j < mk; j++) { step_shapes[si].push_back({ua[j], ub[j]}); P.n_round_ops += 2; P.n_op_mode[(ua[j] & 8) ? 3 : (ua[j] & 3)]++; P.n_op_mode[(ub[j] & 8) ? 3 : (ub[j] & 3)]++; P.n_op_norm += ((ua[j] >> 2) & 1) + ((ub[j] >> 2) & 1); }
     if (getenv("NBLS_DUMP_STEPS")) { fprintf(stderr, "%s dot step lanes=%zu k:", name.c_str(), L.size()); for (int c : L) fprintf(stderr, " %zu", nodes[c].prods.size()); fprintf(stderr, "\n"); }
     if (getenv("NBLS_DUMP_NODES")) for (int c : L) { fprintf(stderr, "  node %d m=%d lin=%zu:", c, nodes[c].mult, nodes[c].lin.size()); for (auto& q : nodes[c].prods) fprintf(stderr, " (%d%s%d)x(%d%s%d)", q.a.s0, q.a.s1 < 0 ? "" : (q.a.n1 ? "-" : "+"), q.a.s1 < 0 ? 0 : q.a.s1, q.b.s0, q.b.s1 < 0 ? "" : (q.b.n1 ? "-" : "+"), q.b.s1 < 0 ? 0 : q.b.s1); fprintf(stderr, "\n"); }
@@ -483,13 +493,13 @@ Program Builder::compile(const std::string& name, int W) {
   P.shared_consts = getenv("NBLS_SHARED_CONSTS") ? atoi(getenv("NBLS_SHARED_CONSTS")) != 0 : P.G >= 8;
   assert(P.lds_bytes() < 65536 * 2 && P.inst_bytes() < 32768);
   // 6. emit
-  const u32 CONST_FLAG = P.shared_consts ? 2u : 0u;
-  auto op = [&](int atom) -> u32 {   // LDS byte offset: inside the instance region, or (shared constants) absolute with CONST_FLAG
-    if (atom < 0) return CONST_FLAG;   // const slot 0 is zero
+  const u32 SLOT_FLAG = P.shared_consts ? 2u : 0u;
+  auto op = [&](int atom) -> u32 {   // LDS byte offset: inside the instance region (with SLOT_FLAG when the constants are shared), or an absolute constant offset
+    if (atom < 0) return 0u;   // const slot 0 is zero
     const Node& n = nodes[atom];
-    if (n.kind == 0xff) return (u32)n.const_idx * P.slot_bytes | CONST_FLAG;
+    if (n.kind == 0xff) return (u32)n.const_idx * P.slot_bytes;
     assert(n.slot >= 0);
-    return ((P.shared_consts ? 0u : P.nconst) + (u32)n.slot) * P.slot_bytes;
+    return ((P.shared_consts ? 0u : P.nconst) + (u32)n.slot) * P.slot_bytes | SLOT_FLAG;
   };
   const u32 ZERO_FIELD = op(-1);
   for (size_t s = 0; s < step_nodes.size(); s++) {
@@ -605,11 +615,12 @@ std::string verify_program(const Program& p) {
   if ((u64)p.lds_bytes() > 160 * 1024) return p.name + ": LDS image exceeds 160 KB";
   if (p.W * p.G > 64 || p.W == 0) return p.name + ": lanes";
   if (p.consts.size() != (size_t)p.nconst * RAW_WORDS) return p.name + ": constant table size";
-  // an operand offset: replicated constants -> anything inside the instance region; shared -> bit 1 marks an absolute constant offset
+  // an operand offset: replicated constants -> anything inside the instance region; shared -> bit 1 marks a slot of the instance region, without it
+  // the offset is that of a constant (absolute)
   auto inside = [&](u32 f, u32 flagmask) {
     if (f & flagmask) return false;
     const u32 o = f & ~15u;
-    if (sh && (f & 2u)) return o + 56 <= cbytes;
+    if (sh && !(f & 2u)) return o + 56 <= cbytes;
     return o + 56 <= ib;
   };
   for (size_t s = 0; s < p.steps.size(); s++) {
@@ -620,7 +631,7 @@ std::string verify_program(const Program& p) {
     for (unsigned l = 0; l < st.nlanes; l++) {
       const u32* d = p.descs.data() + st.desc_off + l * st.stride;
       auto src = [&](u32 f) { return inside(f & 0xffffu, sh ? 13u : 15u); };                                  // a readable slot (constants included)
-      auto dst = [&](u32 f) { f &= 0xffffu; return (f & 15u) == 0 && (sh || f >= cbytes) && f + 56 <= ib; };  // a writable slot (never a constant)
+      auto dst = [&](u32 f) { f &= 0xffffu; return (f & 15u) == (sh ? 2u : 0u) && (sh || f >= cbytes) && (f & ~15u) + 56 <= ib; };  // a writable slot (never a constant)
       auto term = [&](u32 f, bool signs) { return inside(f, (sh ? 13u : 15u) & (signs ? ~1u : ~0u)); };       // product term: 32-bit offset, bit 0 = sign in mode 3
       switch (st.kind) {
         case K_DOT: {

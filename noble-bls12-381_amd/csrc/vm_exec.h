@@ -69,15 +69,16 @@ template <typename LDSP>
 NBLS_HD u32 ld1(LDSP lds, u32 addr) { return *(const u32*)(lds + addr); }
 
 struct LaneCtx {
-  u32 inst;       // byte offset of the instance region
+  u32 inst;       // byte offset of the instance region (shared constants: minus 2, see term_addr)
   u32 item;       // global work-item index
   bool live;      // item < n_items (dead instances compute on zeros but never touch global memory)
-  bool shared;    // uniform: the program keeps ONE copy of its constants at the start of the LDS image (offsets with bit 1 set are absolute)
+  bool shared;    // uniform: the program keeps ONE copy of its constants at the start of the LDS image; a compile-time constant in the kernels
 };
-// LDS byte address of an operand field.  Replicated constants (the pairing programs): base + offset.  Shared constants (programs that run 8 or 16
-// instances per wavefront, where replication would cost occupancy): bit 1 of the offset marks a constant, addressed absolutely.
+// LDS byte address of an operand field.  Replicated constants (the pairing programs): base + offset, one addition.  Shared constants (programs
+// that run 8 or 16 instances per wavefront, where replication would cost occupancy): bit 1 of the offset marks a SLOT (relative to the instance
+// region), constants are absolute; with inst = base - 2 that is (inst AND sign-extended bit 1) + offset: v_bfe_i32, v_and, v_add.
 NBLS_HD u32 term_addr(u32 f, const LaneCtx& cx) {
-  if (cx.shared) return ((f & 2u) ? 0u : cx.inst) + (f & ~15u);
+  if (cx.shared) return (cx.inst & (u32)((i32)(f << 30) >> 31)) + f;
   return cx.inst + f;
 }
 
@@ -87,26 +88,28 @@ NBLS_HD u32 term_addr(u32 f, const LaneCtx& cx) {
 template <typename LDSP>
 NBLS_HD void dot_operand(u32* A, u32 f0, u32 f1, u32 shape, LDSP lds, const LaneCtx& cx) {
   const u32 mode = shape & 3;
-  if (mode != 3) ld14(A, lds, term_addr(f0, cx));
-  if (mode) {
-    u32 X[NL];
-    if (mode == 1) {
-      ld14(X, lds, term_addr(f1, cx));
+  // The optional normalisation sits inside every two-term branch (a single slot is normalised already): as a separate stage after the point
+  // where the modes merge, it cost ~15 register copies per operand (the compiler kept the operand in two places, one per successor).
+  const bool norm = (shape & 4) != 0;
+  u32 X[NL];
+  if (mode == 0) ld14(A, lds, term_addr(f0, cx));
+  else if (mode == 1) {
+    ld14(A, lds, term_addr(f0, cx)); ld14(X, lds, term_addr(f1, cx));
 #pragma unroll
-      for (int i = 0; i < NL; i++) A[i] += X[i];
-    } else if (mode == 2) {
-      ld14(X, lds, term_addr(f1, cx));
+    for (int i = 0; i < NL; i++) A[i] += X[i];
+    if (norm) carry_norm(A);
+  } else if (mode == 2) {
+    ld14(A, lds, term_addr(f0, cx)); ld14(X, lds, term_addr(f1, cx));
 #pragma unroll
-      for (int i = 0; i < NL; i++) A[i] -= X[i];
-    } else {   // per-lane signs on both terms (bit 0 of the offsets): +-x +- y
-      ld14(A, lds, term_addr(f0 & ~1u, cx));
-      ld14(X, lds, term_addr(f1 & ~1u, cx));
-      const u32 m0 = 0u - (f0 & 1u), m1 = 0u - (f1 & 1u), c = (f0 & 1u) + (f1 & 1u);
+    for (int i = 0; i < NL; i++) A[i] -= X[i];
+    if (norm) carry_norm(A);
+  } else {   // per-lane signs on both terms (bit 0 of the offsets): +-x +- y
+    ld14(A, lds, term_addr(f0 & ~1u, cx)); ld14(X, lds, term_addr(f1 & ~1u, cx));
+    const u32 m0 = 0u - (f0 & 1u), m1 = 0u - (f1 & 1u), c = (f0 & 1u) + (f1 & 1u);
 #pragma unroll
-      for (int i = 0; i < NL; i++) A[i] = (A[i] ^ m0) + (X[i] ^ m1) + c;
-    }
+    for (int i = 0; i < NL; i++) A[i] = (A[i] ^ m0) + (X[i] ^ m1) + c;
+    if (norm) carry_norm(A);
   }
-  if (shape & 4) carry_norm(A);
 }
 
 // acc[i+j] += a[j] * b[i] on signed limbs: 196 in-place v_mad_i64_i32, no carries

@@ -29,14 +29,14 @@ __device__ __forceinline__ u32 kernel_prologue(const KernelArgs& ka, char* lds, 
   const u32 inst_id = lane / W;
   ls.lane_in = (inst_id < ka.G) ? (lane - inst_id * W) : 0xffffu;
   ls.cx.shared = ka.shared_consts != 0;
-  ls.cx.inst = (ka.shared_consts ? ka.nconst * ka.slot_bytes : 0u) + (inst_id < ka.G ? inst_id : 0) * ka.inst_bytes;
+  ls.cx.inst = (ka.shared_consts ? ka.nconst * ka.slot_bytes - 2u : 0u) + (inst_id < ka.G ? inst_id : 0) * ka.inst_bytes;   // shared constants: base - 2 (term_addr)
   ls.cx.item = blockIdx.x * ka.G + inst_id;
   ls.cx.live = inst_id < ka.G && ls.cx.item < n_items;
   if (ka.item_index && ls.cx.live) ls.cx.item = ka.item_index[ls.cx.item];
   return n_items;
 }
 
-template <bool FAIR> __device__ __forceinline__ void vm_kernel_body(const KernelArgs& ka) {
+template <bool FAIR, bool SHARED> __device__ __forceinline__ void vm_kernel_body(const KernelArgs& ka) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds = smem;
   const u32 lane = threadIdx.x;
@@ -44,7 +44,8 @@ template <bool FAIR> __device__ __forceinline__ void vm_kernel_body(const Kernel
   kernel_prologue(ka, lds, lane, 64, lane, ls, exit_now);
   if (exit_now) return;
   const u32 lane_in = ls.lane_in;
-  const LaneCtx cx = ls.cx;
+  LaneCtx cxv = ls.cx; cxv.shared = SHARED;   // compile-time: the address arithmetic of every operand depends on it
+  const LaneCtx cx = cxv;
   if (ka.hwid_out && lane == 0) { ka.hwid_out[5 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); ka.hwid_out[5 * blockIdx.x + 1] = __builtin_readcyclecounter(); ka.hwid_out[5 * blockIdx.x + 3] = wall_clock64(); }   // HW_ID, XCC_ID, start tick (s_memtime), start time (s_memrealtime, 100 MHz): placement study
   __syncthreads();   // single wave: orders the constant fill before first use
   // Software-pipelined interpreter loop: the header of step s+2 (scalar), this lane's descriptor header and first product round of
@@ -105,13 +106,19 @@ template <bool FAIR> __device__ __forceinline__ void vm_kernel_body(const Kernel
 }
 // NBLS_WAVES_PER_EU (build-time experiment, tools/exp_variants.sh): cap the VGPR budget so that N wavefronts fit a SIMD (4 -> 128 registers, a few
 // descriptor registers spill to scratch once per step)
-#if defined(NBLS_WAVES_PER_EU)
+#if !defined(NBLS_WAVES_PER_EU)
+#define NBLS_WAVES_PER_EU 0
+#endif
+#if NBLS_WAVES_PER_EU > 0
 #define NBLS_OCC __attribute__((amdgpu_waves_per_eu(NBLS_WAVES_PER_EU, NBLS_WAVES_PER_EU)))
 #else
 #define NBLS_OCC
 #endif
-extern "C" __global__ void __launch_bounds__(64) NBLS_OCC nbls_vm_kernel(KernelArgs ka) { vm_kernel_body<false>(ka); }
-extern "C" __global__ void __launch_bounds__(64) NBLS_OCC nbls_vm_kernel_fair(KernelArgs ka) { vm_kernel_body<true>(ka); }
+// four instantiations: plain / fair (priority schedule), replicated / shared constants (_sc)
+extern "C" __global__ void __launch_bounds__(64) NBLS_OCC nbls_vm_kernel(KernelArgs ka) { vm_kernel_body<false, false>(ka); }
+extern "C" __global__ void __launch_bounds__(64) NBLS_OCC nbls_vm_kernel_fair(KernelArgs ka) { vm_kernel_body<true, false>(ka); }
+extern "C" __global__ void __launch_bounds__(64) NBLS_OCC nbls_vm_kernel_sc(KernelArgs ka) { vm_kernel_body<false, true>(ka); }
+extern "C" __global__ void __launch_bounds__(64) NBLS_OCC nbls_vm_kernel_fair_sc(KernelArgs ka) { vm_kernel_body<true, true>(ka); }
 
 // Two-wave variant for small batches.  A lone wavefront per SIMD issues at ~1/2 of the VALU rate (tools/ubench/lone_wave.hip)
 // and a second wavefront on the same SIMD runs beside it, so when a launch has no more workgroups than the chip has CUs each
@@ -213,6 +220,8 @@ extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, vo
     if (!attr_set[dev]) {
       hipFuncSetAttribute((const void*)nbls_vm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipFuncSetAttribute((const void*)nbls_vm_kernel_fair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute((const void*)nbls_vm_kernel_sc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute((const void*)nbls_vm_kernel_fair_sc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipFuncSetAttribute((const void*)nbls_vm_kernel_split, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set[dev] = true;
     }
@@ -227,8 +236,13 @@ extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, vo
   else {
     static const int fair_mode = getenv("NBLS_FAIR") ? atoi(getenv("NBLS_FAIR")) : -1;   // 0 never, 1 always, unset: launches of 2..4 wavefronts per SIMD
     const bool fair = fair_mode >= 0 ? fair_mode != 0 : (blocks > 1024 && blocks <= 4096);
-    if (fair) hipLaunchKernelGGL(nbls_vm_kernel_fair, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, *ka);
-    else hipLaunchKernelGGL(nbls_vm_kernel, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, *ka);
+    if (ka->shared_consts) {
+      if (fair) hipLaunchKernelGGL(nbls_vm_kernel_fair_sc, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, *ka);
+      else hipLaunchKernelGGL(nbls_vm_kernel_sc, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, *ka);
+    } else {
+      if (fair) hipLaunchKernelGGL(nbls_vm_kernel_fair, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, *ka);
+      else hipLaunchKernelGGL(nbls_vm_kernel, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, *ka);
+    }
   }
   return (int)hipGetLastError();
 }

@@ -30,7 +30,7 @@ static void sim_run(const Program& p, unsigned n_items, const IOBuf* bufs) {
         if (inst >= p.G) continue;
         unsigned lane_in = lane - inst * p.W;
         if (lane_in >= st.nlanes) continue;
-        LaneCtx cx; cx.inst = p.inst_base(inst); cx.shared = p.shared_consts; cx.item = blk * p.G + inst; cx.live = cx.item < n_items;
+        LaneCtx cx; cx.inst = p.inst_base(inst) - (p.shared_consts ? 2u : 0u); cx.shared = p.shared_consts; cx.item = blk * p.G + inst; cx.live = cx.item < n_items;
         Pending pd;
         u32 dw[8] = {0};
         const u32* gd = p.descs.data() + st.desc_off + lane_in * st.stride;
