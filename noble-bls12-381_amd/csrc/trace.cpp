@@ -511,6 +511,7 @@ Program Builder::compile(const std::string& name, int W) {
     size_t mp = 0, mn = 0;   // DOT / LIN: added and subtracted terms, max over the lanes
     if (n0.kind == K_LIN || n0.kind == K_DOT) for (int c : L) { size_t np = 0, nn = 0; for (auto& t : nodes[c].lin) (t.second < 0 ? nn : np)++; mp = std::max(mp, np); mn = std::max(mn, nn); }
     if (n0.kind == K_LIN) {
+      if (mp == 0) mp = 1;   // the kernel starts from the first added field (the zero constant when no lane adds anything)
       assert(mp <= (size_t)MAX_LIN_TERMS && mn <= (size_t)MAX_LIN_TERMS);
       st.p0 = (uint8_t)mp; st.p1 = (uint8_t)mn; st.stride = mp + mn > 6 ? 8 : 4;
       for (int c : L) if (nodes[c].wred) st.lin |= 1;
@@ -659,7 +660,7 @@ std::string verify_program(const Program& p) {
         case K_LIN: {
           if (!dst(d[0])) return bad(s, l, "destination", d[0]);
           const u32 nt = (u32)st.p0 + st.p1;
-          if (st.p0 > MAX_LIN_TERMS || st.p1 > MAX_LIN_TERMS || 1 + (nt + 1) / 2 > st.stride) return bad(s, l, "term counts", nt);
+          if (st.p0 < 1 || st.p0 > MAX_LIN_TERMS || st.p1 > MAX_LIN_TERMS || 1 + (nt + 1) / 2 > st.stride) return bad(s, l, "term counts", nt);
           for (u32 t = 0; t < nt; t++) { const u32 f = (d[1 + t / 2] >> (16 * (t & 1))) & 0xffffu; if (!src(f)) return bad(s, l, "term", f); }
           break;
         }

@@ -293,20 +293,25 @@ NBLS_HD u32 exec_lane(const Step& st, const u32* d /* first 8 descriptor words *
       const u32 w0 = d[0];
       const int nadd = st.p0, nsub = st.p1;
       u32 r[NL];
+      // the first field is always an added term (the host pads with the zero constant); added terms first, then the subtracted ones, as two
+      // separate runs of uniform branches: one run whose body chooses between adding and subtracting cost 14 register copies per term
+      ld14(r, lds, slot_addr(field16(d, 1, 0), cx));
 #pragma unroll
-      for (int i = 0; i < NL; i++) r[i] = 0;
-#pragma unroll
-      for (int t = 0; t < 2 * MAX_LIN_TERMS; t++) {
-        if (t < nadd + nsub) {   // uniform
+      for (int t = 1; t < MAX_LIN_TERMS; t++) {
+        if (t < nadd) {   // uniform
           u32 X[NL];
           ld14(X, lds, slot_addr(field16(d, 1, t), cx));
-          if (t < nadd) {
 #pragma unroll
-            for (int i = 0; i < NL; i++) r[i] += X[i];
-          } else {
+          for (int i = 0; i < NL; i++) r[i] += X[i];
+        }
+      }
 #pragma unroll
-            for (int i = 0; i < NL; i++) r[i] -= X[i];
-          }
+      for (int t = 1; t < 2 * MAX_LIN_TERMS; t++) {
+        if (t >= nadd && t < nadd + nsub) {   // uniform
+          u32 X[NL];
+          ld14(X, lds, slot_addr(field16(d, 1, t), cx));
+#pragma unroll
+          for (int i = 0; i < NL; i++) r[i] -= X[i];
         }
       }
       if (st.lin & 1) weak_reduce(r, qp_table);     // LIN steps carry the weak-reduction flag in the header's `lin` field

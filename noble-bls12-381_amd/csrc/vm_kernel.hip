@@ -53,12 +53,12 @@ template <bool FAIR, bool SHARED> __device__ __forceinline__ void vm_kernel_body
   const uint4* descs4 = (const uint4*)ka.descs;
   Step st = ka.steps[0];
   Step nst = ka.steps[ka.nsteps > 1 ? 1 : 0];
-  uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0, dr = d0;
-  if (lane_in < st.nlanes) {
-    const u32 o = (st.desc_off + lane_in * st.stride) >> 2;
-    d0 = descs4[o];
-    if (st.stride > 4) d1 = descs4[o + 1];
-    if (st.stride > 8) dr = descs4[o + 2];
+  // Every lane reads 12 descriptor words whatever the step's stride (the descriptor stream is padded by 8 words) and idle lanes read lane 0's:
+  // no conditional loads, no zero-filled registers (12 instructions per step).
+  uint4 d0, d1, dr;
+  {
+    const u32 o = (st.desc_off + (lane_in < st.nlanes ? lane_in : 0u) * st.stride) >> 2;
+    d0 = descs4[o]; d1 = descs4[o + 1]; dr = descs4[o + 2];
   }
   // Fairness between the wavefronts that share a SIMD: the issue arbiter prefers the oldest wavefront, which then runs at ~94 % of
   // its lone speed while a second one gets ~55 % and a third ~23 % (tools/placement.py), so the youngest finishes long after the
@@ -72,12 +72,10 @@ template <bool FAIR, bool SHARED> __device__ __forceinline__ void vm_kernel_body
     if (FAIR) { if (s == quarter) __builtin_amdgcn_s_setprio(2); else if (s == 3 * quarter) __builtin_amdgcn_s_setprio(1); }
     const u32 sn = (s + 2 < ka.nsteps) ? s + 2 : ka.nsteps - 1;
     const Step nnst = ka.steps[sn];
-    uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, nr = n0;
-    if (lane_in < nst.nlanes) {
-      const u32 o = (nst.desc_off + lane_in * nst.stride) >> 2;
-      n0 = descs4[o];
-      if (nst.stride > 4) n1 = descs4[o + 1];
-      if (nst.stride > 8) nr = descs4[o + 2];
+    uint4 n0, n1, nr;
+    {
+      const u32 o = (nst.desc_off + (lane_in < nst.nlanes ? lane_in : 0u) * nst.stride) >> 2;
+      n0 = descs4[o]; n1 = descs4[o + 1]; nr = descs4[o + 2];
     }
     if (lane_in < st.nlanes) {
       const u32 d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
