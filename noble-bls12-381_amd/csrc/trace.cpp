@@ -555,8 +555,10 @@ Program Builder::compile(const std::string& name, int W) {
             u32* r = &w[DOT_HDR_WORDS + DOT_ROUND_WORDS * i];
             const int sa = step_shapes[s][i].first, sb = step_shapes[s][i].second;
             const bool ma = (sa & 3) == 3 || (sa & 8), mb = (sb & 3) == 3 || (sb & 8);   // per-lane signs in bit 0 of the offsets
-            r[0] = op(p.a.s0) | ((ma && p.neg0_a) ? 1u : 0u); r[1] = p.a.s1 >= 0 ? (op(p.a.s1) | ((ma && p.a.n1) ? 1u : 0u)) : ((sa & 3) || (sa & 8) ? ZERO_FIELD : 0u);
-            r[2] = op(p.b.s0) | ((mb && p.neg0_b) ? 1u : 0u); r[3] = p.b.s1 >= 0 ? (op(p.b.s1) | ((mb && p.b.n1) ? 1u : 0u)) : ((sb & 3) || (sb & 8) ? ZERO_FIELD : 0u);
+            r[0] = op(p.a.s0); r[1] = p.a.s1 >= 0 ? op(p.a.s1) : ZERO_FIELD;
+            r[2] = op(p.b.s0); r[3] = p.b.s1 >= 0 ? op(p.b.s1) : ZERO_FIELD;
+            const u32 neg = ((ma && p.neg0_a) ? 1u : 0u) | ((ma && p.a.s1 >= 0 && p.a.n1) ? 2u : 0u) | ((mb && p.neg0_b) ? 4u : 0u) | ((mb && p.b.s1 >= 0 && p.b.n1) ? 8u : 0u);
+            w[1] |= neg << (4 * i);   // per-lane signs of the round's four terms (rounds of shape mode 3)
             P.n_norm_operands += p.norm_a + p.norm_b; P.n_comb_operands += (p.a.s1 >= 0) + (p.b.s1 >= 0);
           }
           break;
@@ -633,7 +635,7 @@ std::string verify_program(const Program& p) {
       const u32* d = p.descs.data() + st.desc_off + l * st.stride;
       auto src = [&](u32 f) { return inside(f & 0xffffu, sh ? 13u : 15u); };                                  // a readable slot (constants included)
       auto dst = [&](u32 f) { f &= 0xffffu; return (f & 15u) == (sh ? 2u : 0u) && (sh || f >= cbytes) && (f & ~15u) + 56 <= ib; };  // a writable slot (never a constant)
-      auto term = [&](u32 f, bool signs) { return inside(f, (sh ? 13u : 15u) & (signs ? ~1u : ~0u)); };       // product term: 32-bit offset, bit 0 = sign in mode 3
+      auto term = [&](u32 f) { return inside(f, sh ? 13u : 15u); };       // product term: 32-bit offset
       switch (st.kind) {
         case K_DOT: {
           if (st.p0 > MAX_DOT_PRODUCTS || st.stride != (u32)(DOT_HDR_WORDS + DOT_ROUND_WORDS * st.p0)) return bad(s, l, "product rounds / stride", st.p0);
@@ -645,13 +647,15 @@ std::string verify_program(const Program& p) {
           if (mult > 1 && !(st.p1 & DOTF_MULT)) return bad(s, l, "multiplier without the step flag", mult);
           if ((d[0] & (1u << 19)) && !(st.p1 & DOTF_HALVE)) return bad(s, l, "halving without the step flag", d[0]);
           if (((d[0] >> 20) & 0xf) && !(st.p1 & DOTF_OFFS)) return bad(s, l, "offset without the step flag", d[0]);
+          if (st.p0 < 8 && (d[1] >> (4 * st.p0))) return bad(s, l, "sign bits beyond the last round", d[1]);
           for (u32 r = 0; r < st.p0; r++) {
             const u32* rd = d + DOT_HDR_WORDS + DOT_ROUND_WORDS * r;
             const u32 sh = ((r < 4 ? st.shape[0] : st.shape[1]) >> (8 * (r & 3))) & 0xff;
             for (int o = 0; o < 2; o++) {
               const u32 mode = (sh >> (3 * o)) & 3, f0 = rd[2 * o], f1 = rd[2 * o + 1];
-              if (!term(f0, mode == 3)) return bad(s, l, "first term of an operand", f0);
-              if (mode == 0 ? (f1 & ~2u) != 0 : !term(f1, mode == 3)) return bad(s, l, "second term of an operand", f1);
+              if (!term(f0)) return bad(s, l, "first term of an operand", f0);
+              if (mode == 0 ? f1 != 0 : !term(f1)) return bad(s, l, "second term of an operand", f1);
+              if (mode != 3 && ((d[1] >> (4 * r + 2 * o)) & 3u)) return bad(s, l, "sign bits on an operand without per-lane signs", d[1]);
             }
             if (sh & 0xc0) return bad(s, l, "round shape", sh);
           }

@@ -74,8 +74,8 @@ static const int RAW_FP_BYTES = 64;
 static const int MAX_BUFS = 8;
 static const int MAX_DOT_PRODUCTS = 8;
 static const int MAX_DOT_LINEAR = 4;
-// Operand fields are LDS byte offsets relative to the instance region (multiples of 16, below 64 KB); bit 0 of a product term = negate (rounds of shape mode 3 only).
-// K_DOT lane descriptor (words):  w0 = dst | m << 16 | halve << 19 | offs << 20 ;  w1..w3 reserved ;
+// Operand fields are LDS byte offsets (multiples of 16, below 64 KB) relative to the instance region; with shared constants bit 1 marks a slot, an offset without it is an absolute constant offset.
+// K_DOT lane descriptor (words):  w0 = dst | m << 16 | halve << 19 | offs << 20 ;  w1 = per-lane term signs, 4 bits per round (a0, a1, b0, b1; mode 3) ;  w2, w3 reserved ;
 //                                 w4..w7 = eight 16-bit offsets of post-added terms (added ones first, then subtracted ones, each group zero-padded
 //                                          to the step's count) -- only read when the step has any ;
 //                                 then per product round 4 words: a0, a1, b0, b1 (32-bit offsets; a1 / b1 = 0 when the round's shape has no second term)

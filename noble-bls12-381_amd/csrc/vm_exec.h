@@ -82,30 +82,24 @@ NBLS_HD u32 term_addr(u32 f, const LaneCtx& cx) {
   return cx.inst + f;
 }
 
-// operand of a DOT product round, as signed limbs: x, x + y or x - y (f0, f1: byte offsets inside the instance region), optionally
-// normalised.  `shape` (3 bits: mode, normalise) is uniform for the wavefront, so these are scalar branches; a lane that has no second
-// term where another lane has one points f1 at the zero constant.  Mode 3: the signs of both terms are per lane (bit 0 of f0 / f1).
-template <typename LDSP>
-NBLS_HD void dot_operand(u32* A, u32 f0, u32 f1, u32 shape, LDSP lds, const LaneCtx& cx) {
+// Operand of a DOT product round, as signed limbs: x, x + y, x - y or (mode 3) +-x +- y with the signs per lane (`neg`: bit 0 first term, bit 1
+// second term), optionally normalised.  The terms are in registers already (dot_round loads all four of a round first); `shape` (3 bits: mode,
+// normalise) is uniform for the wavefront, so these are scalar branches; a lane that has no second term where another lane has one adds the zero
+// constant.  The normalisation sits inside every two-term branch (a single slot is normalised already): as a separate stage after the point
+// where the modes merge it cost ~15 register copies per operand (the compiler kept the operand in two places, one per successor).
+NBLS_HD void dot_combine(u32* A, const u32* X, u32 shape, u32 neg) {
   const u32 mode = shape & 3;
-  // The optional normalisation sits inside every two-term branch (a single slot is normalised already): as a separate stage after the point
-  // where the modes merge, it cost ~15 register copies per operand (the compiler kept the operand in two places, one per successor).
   const bool norm = (shape & 4) != 0;
-  u32 X[NL];
-  if (mode == 0) ld14(A, lds, term_addr(f0, cx));
-  else if (mode == 1) {
-    ld14(A, lds, term_addr(f0, cx)); ld14(X, lds, term_addr(f1, cx));
+  if (mode == 1) {
 #pragma unroll
     for (int i = 0; i < NL; i++) A[i] += X[i];
     if (norm) carry_norm(A);
   } else if (mode == 2) {
-    ld14(A, lds, term_addr(f0, cx)); ld14(X, lds, term_addr(f1, cx));
 #pragma unroll
     for (int i = 0; i < NL; i++) A[i] -= X[i];
     if (norm) carry_norm(A);
-  } else {   // per-lane signs on both terms (bit 0 of the offsets): +-x +- y
-    ld14(A, lds, term_addr(f0 & ~1u, cx)); ld14(X, lds, term_addr(f1 & ~1u, cx));
-    const u32 m0 = 0u - (f0 & 1u), m1 = 0u - (f1 & 1u), c = (f0 & 1u) + (f1 & 1u);
+  } else if (mode == 3) {
+    const u32 n0 = neg & 1u, n1 = (neg >> 1) & 1u, m0 = 0u - n0, m1 = 0u - n1, c = n0 + n1;
 #pragma unroll
     for (int i = 0; i < NL; i++) A[i] = (A[i] ^ m0) + (X[i] ^ m1) + c;
     if (norm) carry_norm(A);
@@ -237,13 +231,22 @@ NBLS_HD void dot_init(u64* acc, const Step& st, u32 w0) {
   }
 }
 NBLS_HD u32 round_shape(const Step& st, u32 r) { return ((r < 4 ? st.shape[0] : st.shape[1]) >> (8 * (r & 3))) & 0xffu; }
+// One product round: acc += A * B.  All four terms are requested before the first is used (one LDS round trip per round instead of two: -4 % for
+// a lone wavefront); `neg`: the four per-lane sign bits of the round (a0, a1, b0, b1), read in mode 3 only.
 template <typename LDSP>
-NBLS_HD void dot_round(u64* acc, u32 shape, u32 a0, u32 a1, u32 b0, u32 b1, LDSP lds, const LaneCtx& cx) {
-  u32 A[NL], B[NL];
-  dot_operand(A, a0, a1, shape & 7, lds, cx);
-  dot_operand(B, b0, b1, (shape >> SH_B_SHIFT) & 7, lds, cx);
+NBLS_HD void dot_round(u64* acc, u32 shape, u32 neg, u32 a0, u32 a1, u32 b0, u32 b1, LDSP lds, const LaneCtx& cx) {
+  const u32 sa = shape & 7, sb = (shape >> SH_B_SHIFT) & 7;
+  u32 A[NL], B[NL], X[NL], Y[NL];
+  ld14(A, lds, term_addr(a0, cx));
+  if (sa & 3) ld14(X, lds, term_addr(a1, cx));
+  ld14(B, lds, term_addr(b0, cx));
+  if (sb & 3) ld14(Y, lds, term_addr(b1, cx));
+  dot_combine(A, X, sa, neg & 3);
+  dot_combine(B, Y, sb, (neg >> 2) & 3);
   mac28(acc, A, B);
 }
+// sign bits of round r in word 1 of the lane descriptor
+NBLS_HD u32 round_signs(u32 w1, u32 r) { return (w1 >> (4 * r)) & 15u; }
 template <typename LDSP>
 NBLS_HD u32 dot_finish(u32* res, u64* acc, const Step& st, const u32* d /* the 8 header words */, LDSP lds, const LaneCtx& cx, const u32* __restrict__ qp_table) {
   const u32 w0 = d[0];

@@ -89,7 +89,7 @@ template <bool FAIR, bool SHARED> __device__ __forceinline__ void vm_kernel_body
         for (u32 r = 0; r < st.p0; r++) {   // uniform trip count; the next round's offsets are fetched ahead
           uint4 nx = cur;
           if (r + 1 < st.p0) nx = gr[r];
-          dot_round(acc, round_shape(st, r), cur.x, cur.y, cur.z, cur.w, lds, cx);
+          dot_round(acc, round_shape(st, r), round_signs(d[1], r), cur.x, cur.y, cur.z, cur.w, lds, cx);
           cur = nx;
         }
         dst = dot_finish(res, acc, st, d, lds, cx, ka.qp_table);
@@ -169,7 +169,7 @@ extern "C" __global__ void __launch_bounds__(128) nbls_vm_kernel_split(KernelArg
         for (u32 r = lo; r < hi; r++) {
           uint4 nx = cur;
           if (r + 1 < hi) nx = gr[r + 1];
-          dot_round(acc, round_shape(st, r), cur.x, cur.y, cur.z, cur.w, lds, cx);
+          dot_round(acc, round_shape(st, r), round_signs(d[1], r), cur.x, cur.y, cur.z, cur.w, lds, cx);
           cur = nx;
         }
         if (wave == 1) {
@@ -191,7 +191,7 @@ extern "C" __global__ void __launch_bounds__(128) nbls_vm_kernel_split(KernelArg
       if (st.kind == K_DOT) {
         u64 acc[2 * NL];
         dot_init(acc, st, d[0]);
-        for (u32 r = 0; r < st.p0; r++) { const uint4 cur = gr[r]; dot_round(acc, round_shape(st, r), cur.x, cur.y, cur.z, cur.w, lds, cx); }
+        for (u32 r = 0; r < st.p0; r++) { const uint4 cur = gr[r]; dot_round(acc, round_shape(st, r), round_signs(d[1], r), cur.x, cur.y, cur.z, cur.w, lds, cx); }
         dst = dot_finish(res, acc, st, d, lds, cx, ka.qp_table);
       } else dst = exec_lane(st, d, lds, cx, ka.bufs, res, ka.qp_table);
       if (dst != 0xffffffffu) st14(lds, dst, res);
@@ -224,12 +224,13 @@ extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, vo
       attr_set[dev] = true;
     }
   }
-  // NBLS_SPLIT: 0 = never, 1 = always, unset = for launches of at most 256 workgroups (one per CU): measured 18 % lower latency
-  // there, break-even at 512 workgroups, a loss beyond (two co-resident wavefronts per CU contend for LDS)
+  // NBLS_SPLIT=1 forces the two-wave kernel.  It was the default for launches of at most 256 workgroups in round 1 (18 % lower latency there);
+  // since the instruction-count cuts of round 2 the one-wave kernel is faster at every size (one pairing: 2.96 ms against 3.30 ms), so it is
+  // kept as an experiment (and exercised by the tests) only.
   static const int split_mode = getenv("NBLS_SPLIT") ? atoi(getenv("NBLS_SPLIT")) : -1;
   static const unsigned lds_floor = getenv("NBLS_LDS_FLOOR") ? (unsigned)atoi(getenv("NBLS_LDS_FLOOR")) : 0u;   // placement studies: caps workgroups per CU at 160 KB / floor
   if (lds_bytes < lds_floor) lds_bytes = lds_floor;
-  const bool split = split_mode == 1 || (split_mode < 0 && blocks <= 256);
+  const bool split = split_mode == 1;
   if (split) hipLaunchKernelGGL(nbls_vm_kernel_split, dim3(blocks), dim3(128), lds_bytes + 2 * NLIMBS * 64 * 8, (hipStream_t)stream, *ka);
   else {
     static const int fair_mode = getenv("NBLS_FAIR") ? atoi(getenv("NBLS_FAIR")) : -1;   // 0 never, 1 always, unset: launches of 2..4 wavefronts per SIMD

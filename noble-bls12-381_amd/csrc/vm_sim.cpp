@@ -38,7 +38,7 @@ static void sim_run(const Program& p, unsigned n_items, const IOBuf* bufs) {
         if (st.kind == K_DOT) {
           u64 acc[2 * NL];
           dot_init(acc, st, dw[0]);
-          for (u32 r = 0; r < st.p0; r++) { const u32* rd = gd + DOT_HDR_WORDS + DOT_ROUND_WORDS * r; dot_round(acc, round_shape(st, r), rd[0], rd[1], rd[2], rd[3], lds, cx); }
+          for (u32 r = 0; r < st.p0; r++) { const u32* rd = gd + DOT_HDR_WORDS + DOT_ROUND_WORDS * r; dot_round(acc, round_shape(st, r), round_signs(gd[1], r), rd[0], rd[1], rd[2], rd[3], lds, cx); }
           pd.dst = dot_finish(pd.v, acc, st, dw, lds, cx, qp_table);
         } else pd.dst = exec_lane(st, dw, lds, cx, bufs, pd.v, qp_table);
         if (pd.dst != 0xffffffffu) pend.push_back(pd);
