@@ -4,7 +4,7 @@
 One "step" = one pass of the hot path over one batch: pairing(P_i, Q_i) for a batch of 4096 independent, pre-validated
 point pairs per GPU (BASELINE.json configs[1]; Miller loop with on-the-fly line computation + final exponentiation),
 inputs and outputs resident in HBM, called through the C ABI (libnbls.so).  Consecutive steps are independent batches; they
-are submitted to `--inflight` engine contexts (default 5), each with its own HIP stream and scratch, so that they overlap
+are submitted to `--inflight` engine contexts (default 7), each with its own HIP stream and scratch, so that they overlap
 on the GPU the way a service keeps several requests in flight (a 4096-pairing call alone fills the chip one wavefront
 deep).  `value` is the throughput of the K timed steps; `single_stream` reports the strictly serial figure (= per-batch
 latency) next to it, and the roofline object is measured on one batch running alone.  Multi-GPU: one process per GPU,
@@ -60,7 +60,7 @@ def main():
     ap.add_argument('--steps', type=int, default=512, help='timed steps (default: about one second of GPU time)')
     ap.add_argument('--warmup', type=int, default=16)
     ap.add_argument('--batch', type=int, default=BATCH)
-    ap.add_argument('--inflight', type=int, default=6, help='batches kept in flight on separate HIP streams during the timed steps (1 = strictly one batch at a time)')
+    ap.add_argument('--inflight', type=int, default=7, help='batches kept in flight on separate HIP streams during the timed steps (1 = strictly one batch at a time)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--verify-batch', type=int, default=65536, help='signatures in the verifyBatch leg (BASELINE configs[2]); 0 disables')
     ap.add_argument('--verify-sharded', action='store_true', help='run the multi-GPU form of the verifyBatch leg (parallel.verify_batch_sharded) even on one rank')
@@ -257,8 +257,8 @@ def main():
         # algorithmic HBM bytes per pairing: wire points in (288) and Fp12 out (576) + the raw scratch
         # elements (768 B per Fp12, 64 B per Fp) every phase program reads and writes:
         # miller_fe W 832 | fp_inv R 64 W 64 | fe_easy R 832 W 768 | 5 x expx R 768 W 768 | fe_mid1/2 R 1536 W 768 | fe_final R 5376
-        # (from 16,384 pairings per call the Miller loop runs as LINES + ACC and adds one 26,112-byte line table written and read per pairing)
-        hbm_bytes = n * (288 + 832 + 128 + 832 + 768 + 5 * 1536 + 2 * 2304 + 5376 + 576 + (2 * 26112 if n >= 16384 else 0))
+        # (from 49,152 pairings per call -- SPLIT_MILLER_MIN in csrc/nbls_api.cpp -- the Miller loop runs as LINES + ACC and adds one 26,112-byte line table written and read per pairing)
+        hbm_bytes = n * (288 + 832 + 128 + 832 + 768 + 5 * 1536 + 2 * 2304 + 5376 + 576 + (2 * 26112 if n >= 49152 else 0))
         traffic = None; valu_busy = None
         try:   # HBM bytes measured with rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, see profiles/README.md), same batch size only
             with open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')) as fh:

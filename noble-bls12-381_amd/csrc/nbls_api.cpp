@@ -32,7 +32,7 @@ static_assert(P_COUNT <= NBLS_N_PROGRAMS, "nbls_timing_read's arrays (NBLS_N_PRO
 static const size_t RAW = RAW_FP_BYTES;     // one raw field element in HBM scratch (14 limbs + padding)
 static const size_t F12 = 12 * RAW;        // raw Fp12
 static const size_t LINE_BYTES = (size_t)LINE_ELEMS * RAW;   // one line table: 68 triples of Fp2 as raw elements (26,112 B)
-static const size_t SPLIT_MILLER_MIN = 16384;   // pairs from which the Miller loop runs as LINES + ACC (see nbls_pairing_batch_dev)
+static const size_t SPLIT_MILLER_MIN = 49152;   // pairs from which the Miller loop runs as LINES + ACC (see nbls_pairing_batch_dev)
 static const size_t LINES_CHUNK = 131072;   // pairs whose line tables are in HBM at a time (3.4 GB of the 288); larger batches run chunk by chunk on the same stream
 
 #define EXPORT extern "C" __attribute__((visibility("default")))
@@ -332,10 +332,11 @@ EXPORT int nbls_pairing_batch_dev(nbls_ctx* ctx, size_t n, const void* d_g1, con
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   StreamOrder order_(ctx, s);
   int r;
-  // One program or two?  LINES + ACC execute 15 % fewer instructions per pairing (no idle lanes in the Fp12 steps, 20 instead of 37 lane-ops
-  // per bit in the point chain) but are two dependent chains of 316 + 173 steps where the fused program has 349: a launch that is only one
-  // wavefront per SIMD deep takes the time of its longest instruction stream, so small batches keep the fused program (4096 pairings: 1.43 ms
-  // against 0.72 + 0.94 ms; 65,536: 12.9 against 12.5 ms).  NBLS_FUSED_MILLER = 1 / 0 forces one or the other.
+  // One program or two?  LINES + ACC execute ~12 % fewer instructions per pairing (no idle lanes in the Fp12 steps, 20 instead of 37 lane-ops
+  // per bit in the point chain) but are two dependent chains of 307 + 173 steps where the fused program has 349: a launch that is only a few
+  // wavefronts per SIMD deep takes the time of its longest instruction stream, so batches below 49,152 pairs keep the fused program (measured:
+  // 4096 pairs 1.22 ms against 1.39 ms, 32,768 10.3 against 10.4 ms, 65,536 12.2 against 11.5 ms, 131,072 23.6 against 21.9 ms); with several
+  // calls in flight the instruction count is what matters (pipeline.py sets the threshold to 0).  NBLS_FUSED_MILLER = 1 / 0 forces one or the other.
   static const int fused_mode = getenv("NBLS_FUSED_MILLER") ? atoi(getenv("NBLS_FUSED_MILLER")) : -1;
   const bool fused = fused_mode >= 0 ? fused_mode != 0 : n < ctx->split_min;
   if (fused) {

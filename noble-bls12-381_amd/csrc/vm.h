@@ -59,7 +59,7 @@ struct Step {
 static_assert(sizeof(Step) == 32, "Step header is read as eight dwords");
 
 // per-round operand shape (uniform for the wavefront): a lane whose operand has no second term adds / subtracts the zero constant
-static const uint32_t SH_A_MODE = 0x03;     // 0 single slot, 1 x + y, 2 x - y, 3 per-lane signs +-x +- y (bit 0 of each term's offset: negate)
+static const uint32_t SH_A_MODE = 0x03;     // 0 single slot, 1 x + y, 2 x - y, 3 per-lane signs +-x +- y (word 1 of the lane descriptor: 4 sign bits per round)
 static const uint32_t SH_A_NORM = 0x04;     // normalise the (sum) operand's limbs before multiplying
 static const uint32_t SH_B_SHIFT = 3;       // the same three bits for operand B
 static const uint32_t DOTF_MULT = 1, DOTF_HALVE = 2, DOTF_OFFS = 4;   // some lane of the step has m > 1 / halves its result / has offs > 0

@@ -3,8 +3,8 @@
 A call of 4096 pairings fills the chip exactly one wavefront deep (1024 workgroups on 1024 SIMDs), and a lone wavefront
 reaches well under half of a SIMD's issue rate, so one batch at a time leaves most of the machine
 idle.  Consecutive batches are independent, so a service keeps several of them in flight: the kernels of batch i+1 run
-beside those of batch i on other streams.  Per-batch latency is unchanged (about 4 ms at 4096); throughput at 4096-pairing
-batches rises from 1.0 M to 1.76 M pairings/s with five batches in flight (bench.py).  The HIP runtime multiplexes streams onto
+beside those of batch i on other streams.  Throughput at 4096-pairing batches rises from 1.3 M (one call at a time, 3.1 ms each) to 2.5 M pairings/s with seven batches in
+flight (bench.py; 2.15 M with four, 2.31 M with five, 2.42 M with six, 2.22 M with eight).  The HIP runtime multiplexes streams onto
 GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue serialise, so set GPU_MAX_HW_QUEUES=8 in the
 environment before the runtime initialises when more than three batches are kept in flight.
 """
@@ -12,7 +12,7 @@ from .engine import Engine
 
 
 class PairingPipeline:
-    def __init__(self, device_id=0, depth=5):
+    def __init__(self, device_id=0, depth=7):
         assert depth >= 1
         self.engines = [Engine(device_id) for _ in range(depth)]
         self.depth = depth
