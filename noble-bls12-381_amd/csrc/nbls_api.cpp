@@ -74,6 +74,7 @@ struct nbls_ctx {
   // optional per-kernel timing (HIP events on the launch stream); slot P_COUNT = inversion kernel
   bool timing = false;
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> tev;
+  std::vector<hipEvent_t> ev_pool;   // timing events are recycled (nbls_timing_read returns them here) instead of created per launch
 };
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->last_hip = (int)e_; return NBLS_EHIP; } } while (0)
@@ -104,6 +105,11 @@ static int upload(nbls_ctx* ctx, ProgId id) {
   return NBLS_OK;
 }
 
+static hipEvent_t timing_event(nbls_ctx* ctx) {
+  if (!ctx->ev_pool.empty()) { hipEvent_t e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr; hipEventCreate(&e); return e;
+}
+
 static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pair<int, std::pair<const void*, size_t>>> bufs, hipStream_t s, const uint32_t* n_dev = nullptr, const uint32_t* item_index = nullptr) {
   int r = upload(ctx, id); if (r) return r;
   const DevProgram& d = ctx->prog[id];
@@ -122,7 +128,7 @@ static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pa
     }
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (ctx->timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s); }
+  if (ctx->timing) { e0 = timing_event(ctx); e1 = timing_event(ctx); hipEventRecord(e0, s); }
   int e = nbls_vm_launch(&ka, d.p->lds_bytes(), s);
   if (ctx->timing) { hipEventRecord(e1, s); ctx->tev.push_back({(int)id, {e0, e1}}); }
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
@@ -130,7 +136,7 @@ static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pa
 }
 static int run_inv(nbls_ctx* ctx, size_t n, hipStream_t s) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (ctx->timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s); }
+  if (ctx->timing) { e0 = timing_event(ctx); e1 = timing_event(ctx); hipEventRecord(e0, s); }
   int e = nbls_fp_inv_launch((unsigned)n, ctx->N, ctx->NI, s);
   if (ctx->timing) { hipEventRecord(e1, s); ctx->tev.push_back({(int)P_COUNT, {e0, e1}}); }
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
@@ -306,6 +312,8 @@ EXPORT void nbls_destroy(nbls_ctx* ctx) {
   if (ctx->side) hipStreamDestroy(ctx->side);
   if (ctx->side2) hipStreamDestroy(ctx->side2);
   for (hipEvent_t e : {ctx->ev_fork, ctx->ev_join, ctx->ev_join2, ctx->ev_last}) if (e) hipEventDestroy(e);
+  for (auto& t : ctx->tev) { hipEventDestroy(t.second.first); hipEventDestroy(t.second.second); }
+  for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -541,7 +549,7 @@ EXPORT int nbls_program_stats(nbls_ctx* ctx, int prog, uint32_t* o) {
 EXPORT int nbls_timing_enable(nbls_ctx* ctx, int on) {
   if (!ctx) return NBLS_EINVAL;
   std::lock_guard<std::recursive_mutex> g(ctx->mu);
-  for (auto& t : ctx->tev) { hipEventDestroy(t.second.first); hipEventDestroy(t.second.second); }
+  for (auto& t : ctx->tev) { ctx->ev_pool.push_back(t.second.first); ctx->ev_pool.push_back(t.second.second); }
   ctx->tev.clear(); ctx->timing = on != 0; return NBLS_OK;
 }
 EXPORT int nbls_timing_read(nbls_ctx* ctx, float* ms, uint32_t* counts) {
@@ -553,7 +561,7 @@ EXPORT int nbls_timing_read(nbls_ctx* ctx, float* ms, uint32_t* counts) {
     HIPCHK(hipEventSynchronize(t.second.second));
     float m = 0; HIPCHK(hipEventElapsedTime(&m, t.second.first, t.second.second));
     ms[t.first] += m; counts[t.first]++;
-    hipEventDestroy(t.second.first); hipEventDestroy(t.second.second);
+    ctx->ev_pool.push_back(t.second.first); ctx->ev_pool.push_back(t.second.second);
   }
   ctx->tev.clear();
   return NBLS_OK;

@@ -584,7 +584,7 @@ Program Builder::compile(const std::string& name, int W) {
       }
       P.descs.insert(P.descs.end(), w.begin(), w.end());
     }
-    if (getenv("NBLS_DUMP_SEQ")) fprintf(stderr, "%s step %zu kind=%d lanes=%d p0=%d p1=%d\n", name.c_str(), s, st.kind, st.nlanes, st.p0, st.p1);
+    if (getenv("NBLS_DUMP_SEQ")) fprintf(stderr, "%s step %zu kind=%d lanes=%d p0=%d p1=%d lin=0x%x\n", name.c_str(), s, st.kind, st.nlanes, st.p0, st.p1, st.lin);
     P.steps.push_back(st);
   }
   P.consts = const_words;
