@@ -62,6 +62,7 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--inflight', type=int, default=7, help='batches kept in flight on separate HIP streams during the timed steps (1 = strictly one batch at a time)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-dist', action='store_true', help='run the torch.distributed / RCCL code paths (process group, barriers, all-gathers, sharded legs) even with one rank: the only way to execute them on a one-GPU box')
     ap.add_argument('--verify-batch', type=int, default=65536, help='signatures in the verifyBatch leg (BASELINE configs[2]); 0 disables')
     ap.add_argument('--verify-sharded', action='store_true', help='run the multi-GPU form of the verifyBatch leg (parallel.verify_batch_sharded) even on one rank')
     ap.add_argument('--msm-points', type=int, default=65536, help='points in the multi-scalar multiplication leg (SURVEY 8(f).3); 0 disables')
@@ -80,9 +81,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the engine has no CPU path)')
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist      # every collective below is gated on this
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if args.force_dist:
+            for k, v in (('MASTER_PORT', '29517'), ('RANK', '0'), ('WORLD_SIZE', '1'), ('NBLS_FORCE_COLLECTIVES', '1')): os.environ.setdefault(k, v)
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
     pkg = importlib.import_module('noble-bls12-381_amd')
@@ -118,23 +122,23 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # strictly serial figure (one batch at a time on one stream) = per-batch latency, this rank
     torch.cuda.synchronize()
-    eng.set_split_miller_min(16384)     # the single-call legs use the library's default (latency-oriented) choice of Miller programs
+    eng.set_split_miller_min(49152)     # the single-call legs use the library's default (latency-oriented) choice of Miller programs (SPLIT_MILLER_MIN in csrc/nbls_api.cpp)
     serial_steps = max(8, min(args.steps, 320))
     s0 = time.perf_counter()
     for _ in range(serial_steps):
@@ -168,7 +172,7 @@ def main():
         torch.cuda.synchronize()
         one = bytes(47) + b'\x01' + bytes(528)
         assert (m % 2 == 0) and bytes(res.cpu().numpy().tobytes()) == one, 'product parity check failed'
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         p0 = time.perf_counter()
@@ -176,10 +180,10 @@ def main():
         for _ in range(preps):
             res = par.miller_product_sharded(be, t1, t2)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         pdt = time.perf_counter() - p0
-        if world > 1:
+        if multi:
             t = torch.tensor([pdt], dtype=torch.float64, device='cuda')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             pdt = float(t.item())
@@ -191,7 +195,7 @@ def main():
     # (BASELINE configs[2] at 2 / 4 / 8 GPUs): every rank decodes + hashes its shard and reduces it to one Fp12 partial, ONE all-gather
     # of 576-byte partials, shared final exponentiation (parallel.verify_batch_sharded).  Setup (keys, signatures) also runs on the GPUs.
     vshard = None
-    if args.verify_batch > 0 and (world > 1 or args.verify_sharded):
+    if args.verify_batch > 0 and (multi or args.verify_sharded):
         par = importlib.import_module('noble-bls12-381_amd.parallel')
         nv = args.verify_batch
         lo, hi = par.shard_bounds(nv, world, rank)
@@ -201,13 +205,13 @@ def main():
         aff_l, _ = eng.sign_batch_affine(msgs_l, sks_l)
         psum, _ = eng.point_sum(aff_l, g2=True)                      # this rank's share of the aggregate signature (affine, 192 B)
         d_ps = torch.frombuffer(bytearray(psum), dtype=torch.uint8).cuda()
-        if world > 1:
+        if multi:
             allps = torch.empty(192 * world, dtype=torch.uint8, device='cuda')
             dist.all_gather_into_tensor(allps, d_ps)
-            total, _ = eng.point_sum(bytes(allps.cpu().numpy().tobytes()), g2=True)
+            agg_sig, _ = eng.point_sum(bytes(allps.cpu().numpy().tobytes()), g2=True)
         else:
-            total = psum
-        sig = eng.compress_g2(total)
+            agg_sig = psum
+        sig = eng.compress_g2(agg_sig)
         uni_l = b''.join(oracle.expand_message_xmd(m, oracle_py.DST_DEFAULT, 256) for m in msgs_l)
         d_sig = torch.frombuffer(bytearray(sig), dtype=torch.uint8).cuda()
         d_uni = torch.frombuffer(bytearray(uni_l), dtype=torch.uint8).cuda()
@@ -217,17 +221,17 @@ def main():
         if rank == 0 and lo == 0:      # spot check of the setup itself: the first key and signature share against the oracle
             assert pks_l[0] == oracle.get_public_key(sks_l[0])
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         s0 = time.perf_counter()
         sreps = 3
         for _ in range(sreps):
             par.verify_batch_sharded(be, d_sig, d_uni, d_pk)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         sdt_ = time.perf_counter() - s0
-        if world > 1:
+        if multi:
             t = torch.tensor([sdt_], dtype=torch.float64, device='cuda')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             sdt_ = float(t.item())
@@ -465,11 +469,11 @@ def main():
             'single_call': {'pairings_per_s': round(n * args.steps / dt_serial, 2), 'ms_per_batch': round(dt_serial / args.steps * 1e3, 4), 'roofline_frac': roof['frac'] if roof else None,
                             'note': 'one %d-pairing call at a time on one stream (this rank): the latency of a call; its roofline is the top-level `roofline` object' % n},
             'single_stream': {'pairings_per_s': round(n * args.steps / dt_serial, 2), 'ms_per_batch': round(dt_serial / args.steps * 1e3, 4), 'note': 'alias of single_call (round-1 name)'},
-            'rccl_ranks': world if world > 1 else None,
+            'rccl_ranks': world if multi else None,
             'roofline': roof, 'cpu_baseline': cpu, 'product': product, 'verify_batch': vbatch if vbatch is not None else vshard, 'verify_batch_sharded': vshard if vbatch is not None else None, 'sign': sleg, 'aggregate': aleg, 'msm': mleg,
         }
         print(json.dumps(line))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

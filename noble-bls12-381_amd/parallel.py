@@ -7,7 +7,18 @@
   product), and every rank finishes with the same product and one shared final exponentiation.  Fp12 multiplication is
   commutative and results are canonical, so the rank order cannot change a bit of the result.
 """
+import os
+
 import torch
+
+
+def _collective(group):
+    """True when the exchange step has to run: a process group with more than one rank -- or NBLS_FORCE_COLLECTIVES=1, which runs the RCCL calls even
+    with a single rank (tests/test_gpu_rccl.py: the only way to execute the nccl code path on a one-GPU box)"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get('NBLS_FORCE_COLLECTIVES') == '1'
 
 
 class EngineBackend:
@@ -47,7 +58,7 @@ def miller_product_sharded(backend, g1_local, g2_local, group=None, final_exp=Tr
     (identical on every rank)."""
     import torch.distributed as dist
     part = backend.local_product(g1_local, g2_local)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collective(group):
         w = dist.get_world_size(group)
         gathered = torch.empty(w * 576, dtype=torch.uint8, device=part.device)
         dist.all_gather_into_tensor(gathered, part, group=group)
@@ -66,7 +77,7 @@ def verify_batch_sharded(backend, sig96, msgs_local, pks_local, group=None):
     runs the shared final exponentiation and compares with ONE.  msgs_local is whatever the backend's verify_partial takes
     (EngineBackend: n x 256 expand_message_xmd bytes on the device)."""
     import torch.distributed as dist
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    multi = _collective(group)
     rank = dist.get_rank(group) if multi else 0
     err = None
     try:
