@@ -115,7 +115,7 @@ static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pa
   const DevProgram& d = ctx->prog[id];
   KernelArgs ka; memset(&ka, 0, sizeof ka);
   ka.steps = d.steps; ka.descs = d.descs; ka.consts = d.consts; ka.qp_table = ctx->qp_table;
-  ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slot_bytes = d.p->slot_bytes; ka.inst_bytes = d.p->inst_bytes(); ka.shared_consts = d.p->shared_consts ? 1u : 0u; ka.n_items = (u32)n; ka.n_items_dev = n_dev; ka.item_index = item_index;
+  ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slot_bytes = d.p->slot_bytes; ka.inst_bytes = d.p->inst_bytes(); ka.shared_consts = d.p->shared_consts ? 1u : 0u; ka.lsplit = d.p->lsplit; ka.n_items = (u32)n; ka.n_items_dev = n_dev; ka.item_index = item_index;
   for (auto& b : bufs) { ka.bufs[b.first].ptr = (uint8_t*)b.second.first; ka.bufs[b.first].stride = b.second.second; }
   if (checked_mode()) {
     for (int k = 0; k < MAX_BUFS; k++) {
@@ -218,6 +218,20 @@ typedef std::pair<int, std::pair<const void*, size_t>> BufArg;
 static inline BufArg B(int idx, const void* p, size_t stride) { return {idx, {p, stride}}; }
 
 // F (n raw Fp12) -> one element in F[0] (or F2[0]); returns pointer to the buffer holding the product
+// Launches of at most one wavefront per SIMD take the time of one wavefront's instruction stream, so up to LS_MAX items (one item per wavefront
+// on 1024 SIMDs) the lane-split variants run: the same formulas with every lane-op's products shared by four lanes (a third fewer instructions per
+// wavefront; csrc/vm_kernel.hip nbls_vm_kernel_ls4).  NBLS_LS_MAX overrides (0 = never).
+static size_t ls_max() { static const size_t v = getenv("NBLS_LS_MAX") ? (size_t)atol(getenv("NBLS_LS_MAX")) : 1024; return v; }
+static ProgId ls_variant(ProgId id, size_t n) {
+  if (n > ls_max()) return id;
+  switch (id) {
+    case P_MILLER_BYTES: return P_MILLER_BYTES_LS;
+    case P_MILLER_RAW: return P_MILLER_RAW_LS;
+    case P_MILLER_FE: return P_MILLER_FE_LS;
+    case P_EXPX: return P_EXPX_LS;
+    default: return id;
+  }
+}
 static int reduce_product(nbls_ctx* ctx, size_t n, uint8_t** result, hipStream_t s) {
   uint8_t *src = ctx->F, *dst = ctx->F2;
   size_t m = n;
@@ -235,13 +249,13 @@ static int final_exp_pipeline(nbls_ctx* ctx, size_t n, uint8_t* f_raw, void* d_o
   uint8_t** T = ctx->T;
   if ((r = run_inv(ctx, n, s))) return r;
   if ((r = run(ctx, P_FE_EASY, n, {B(3, f_raw, F12), B(4, ctx->NI, RAW), B(5, T[0], F12)}, s))) return r;
-  if ((r = run(ctx, P_EXPX, n, {B(3, T[0], F12), B(5, T[1], F12)}, s))) return r;                       // t2
+  if ((r = run(ctx, ls_variant(P_EXPX, n), n, {B(3, T[0], F12), B(5, T[1], F12)}, s))) return r;                       // t2
   if ((r = run(ctx, P_FE_MID1, n, {B(3, T[0], F12), B(5, T[1], F12), B(6, T[2], F12)}, s))) return r;   // t3
-  if ((r = run(ctx, P_EXPX, n, {B(3, T[2], F12), B(5, T[3], F12)}, s))) return r;                       // t4
-  if ((r = run(ctx, P_EXPX, n, {B(3, T[3], F12), B(5, T[4], F12)}, s))) return r;                       // t5
-  if ((r = run(ctx, P_EXPX, n, {B(3, T[4], F12), B(5, T[6], F12)}, s))) return r;                       // t6' (parked in T7's buffer)
+  if ((r = run(ctx, ls_variant(P_EXPX, n), n, {B(3, T[2], F12), B(5, T[3], F12)}, s))) return r;                       // t4
+  if ((r = run(ctx, ls_variant(P_EXPX, n), n, {B(3, T[3], F12), B(5, T[4], F12)}, s))) return r;                       // t5
+  if ((r = run(ctx, ls_variant(P_EXPX, n), n, {B(3, T[4], F12), B(5, T[6], F12)}, s))) return r;                       // t6' (parked in T7's buffer)
   if ((r = run(ctx, P_FE_MID2, n, {B(3, T[6], F12), B(5, T[1], F12), B(6, T[5], F12)}, s))) return r;   // t6
-  if ((r = run(ctx, P_EXPX, n, {B(3, T[5], F12), B(5, T[6], F12)}, s))) return r;                       // t7
+  if ((r = run(ctx, ls_variant(P_EXPX, n), n, {B(3, T[5], F12), B(5, T[6], F12)}, s))) return r;                       // t7
   return run(ctx, P_FE_FINAL, n, {B(0, T[0], F12), B(1, T[1], F12), B(2, T[2], F12), B(3, T[3], F12), B(4, T[4], F12), B(5, T[5], F12), B(6, T[6], F12), B(7, d_out, 576)}, s);
 }
 // one raw Fp12 -> final exponentiation (or plain encoding) -> wire bytes on device
@@ -348,9 +362,9 @@ EXPORT int nbls_pairing_batch_dev(nbls_ctx* ctx, size_t n, const void* d_g1, con
   static const int fused_mode = getenv("NBLS_FUSED_MILLER") ? atoi(getenv("NBLS_FUSED_MILLER")) : -1;
   const bool fused = fused_mode >= 0 ? fused_mode != 0 : n < ctx->split_min;
   if (fused) {
-    if (!with_final_exp) return run(ctx, P_MILLER_BYTES, n, {B(0, d_g1, 96), B(1, d_g2, 192), B(2, d_out, 576)}, s);
+    if (!with_final_exp) return run(ctx, ls_variant(P_MILLER_BYTES, n), n, {B(0, d_g1, 96), B(1, d_g2, 192), B(2, d_out, 576)}, s);
     if ((r = ensure_scratch(ctx, n))) return r;
-    if ((r = run(ctx, P_MILLER_FE, n, {B(0, d_g1, 96), B(1, d_g2, 192), B(3, ctx->F, F12), B(4, ctx->N, RAW)}, s))) return r;
+    if ((r = run(ctx, ls_variant(P_MILLER_FE, n), n, {B(0, d_g1, 96), B(1, d_g2, 192), B(3, ctx->F, F12), B(4, ctx->N, RAW)}, s))) return r;
     return final_exp_pipeline(ctx, n, ctx->F, d_out, s);
   }
   // calcPairingPrecomputes + millerLoop (math.ts:1331-1388) as two programs: line tables through HBM (LINE_BYTES per pair)
@@ -416,7 +430,7 @@ EXPORT int nbls_miller_product_dev(nbls_ctx* ctx, size_t n, const void* d_g1, co
       // up to one wavefront per SIMD (4 pairs per wavefront): the call takes the time of ONE wavefront's instruction stream whatever it computes, so every
       // pair gets an item of its own (420 k instructions) rather than sharing an accumulator with a second one (630 k): a single verify 6.1 -> 5.5 ms
       m = n;
-      if ((r = run(ctx, P_MILLER_RAW, n, {B(0, d_g1, 96), B(1, d_g2, 192), B(3, ctx->F, F12)}, s))) return r;
+      if ((r = run(ctx, ls_variant(P_MILLER_RAW, n), n, {B(0, d_g1, 96), B(1, d_g2, 192), B(3, ctx->F, F12)}, s))) return r;
     } else if (fused) {
       if (n2 && (r = run(ctx, P_MILLER_RAW2, n2, {B(0, d_g1, 192), B(1, d_g2, 384), B(3, ctx->F, F12)}, s))) return r;
       if ((n & 1) && (r = run(ctx, P_MILLER_RAW, 1, {B(0, (const uint8_t*)d_g1 + (n - 1) * 96, 96), B(1, (const uint8_t*)d_g2 + (n - 1) * 192, 192), B(3, ctx->F + n2 * F12, F12)}, s))) return r;
@@ -530,7 +544,7 @@ EXPORT int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks) {
   uint64_t* dbg = nullptr; HIPCHK(hipMalloc(&dbg, blocks * 40));
   KernelArgs ka; memset(&ka, 0, sizeof ka);
   ka.steps = d.steps; ka.descs = d.descs; ka.consts = d.consts; ka.qp_table = ctx->qp_table;
-  ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slot_bytes = d.p->slot_bytes; ka.inst_bytes = d.p->inst_bytes(); ka.shared_consts = d.p->shared_consts ? 1u : 0u; ka.n_items = (u32)n;
+  ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slot_bytes = d.p->slot_bytes; ka.inst_bytes = d.p->inst_bytes(); ka.shared_consts = d.p->shared_consts ? 1u : 0u; ka.lsplit = d.p->lsplit; ka.n_items = (u32)n;
   ka.bufs[3].ptr = ctx->T[0]; ka.bufs[3].stride = F12; ka.bufs[5].ptr = ctx->T[1]; ka.bufs[5].stride = F12;
   if (pid == P_MILLER_FE) { ka.bufs[0].ptr = ctx->io_g1; ka.bufs[0].stride = 96; ka.bufs[1].ptr = ctx->io_g2; ka.bufs[1].stride = 192; ka.bufs[4].ptr = ctx->N; ka.bufs[4].stride = RAW; }
   ka.hwid_out = dbg;

@@ -61,6 +61,9 @@ enum ProgId {
   P_H2C_C1, P_H2C_C2,             // PointG2.clearCofactor (index.ts:659-672) in two halves around the second multiplication by x: projective P (3) -> base (6), S (5) ;
                                   // base (3), S (4) -> projective result (6), norm of Z (7)
   P_ACC4_RAW,                     // four folded line tables per item (buf 3) -> F (buf 5): one Fp12 squaring per bit for four Miller loops
+  // lane-split variants (Program::lsplit = 4: every K_DOT lane-op on four adjacent lanes, one item per wavefront) for launches of at most one wavefront
+  // per SIMD: the same formulas, a third fewer instructions per wavefront
+  P_MILLER_BYTES_LS, P_MILLER_RAW_LS, P_MILLER_FE_LS, P_EXPX_LS,
   P_COUNT
 };
 static const int N_LINES = 68;                 // 63 doubling steps + 5 addition steps (bits of |x|)

@@ -284,7 +284,9 @@ static void node_deps(const Node& n, std::vector<int>& d) {
 }
 
 Program Builder::compile(const std::string& name, int W) {
-  Program P; P.name = name; P.W = W; P.G = 64 / W;
+  const int S = lane_split;
+  assert(S >= 1 && W * S <= 64 && (S & (S - 1)) == 0);
+  Program P; P.name = name; P.lsplit = (u32)S; P.W = (u32)(W * S); P.G = 64 / (W * S);   // W stays the logical lane count below
   const int N = (int)nodes.size();
   std::vector<int> d;
   // 1. liveness from sinks
@@ -520,7 +522,13 @@ Program Builder::compile(const std::string& name, int W) {
       size_t mk = step_shapes[s].size();
       for (int c : L) { P.n_products += (u32)nodes[c].prods.size(); if (nodes[c].mult > 1) st.p1 |= DOTF_MULT; if (nodes[c].halve) st.p1 |= DOTF_HALVE; if (nodes[c].offs > 0) st.p1 |= DOTF_OFFS; if (nodes[c].wred) st.p1 |= DOTF_WRED; }
       assert(mk <= (size_t)MAX_DOT_PRODUCTS && mp <= (size_t)MAX_DOT_LINEAR && mn <= (size_t)MAX_DOT_LINEAR);
-      st.p0 = (uint8_t)mk; st.lin = (u32)mp | ((u32)mn << 4);
+      st.lin = (u32)mp | ((u32)mn << 4);
+      if (S > 1) {   // lane split: physical round r holds the products r * S .. r * S + S - 1 (one per sub-lane); its shape is the union of theirs
+        std::vector<std::pair<int, int>> u((mk + S - 1) / S, {0, 0});
+        for (size_t j = 0; j < mk; j++) { u[j / S].first |= step_shapes[s][j].first; u[j / S].second |= step_shapes[s][j].second; }
+        step_shapes[s] = u; mk = u.size();
+      }
+      st.p0 = (uint8_t)mk;
       for (size_t j = 0; j < mk; j++) {
         auto sh3 = [](int m) { return (u32)(((m & 8) ? 3 : (m & 3)) | (m & 4)); };
         const u32 sh = sh3(step_shapes[s][j].first) | (sh3(step_shapes[s][j].second) << SH_B_SHIFT);
@@ -532,7 +540,7 @@ Program Builder::compile(const std::string& name, int W) {
       st.p0 = n0.p0; P.n_other_steps++;
       if (n0.kind == K_STATUS) st.stride = 8;
     }
-    for (int c : L) {
+    for (int c : L) for (int sub = 0; sub < (n0.kind == K_DOT ? S : 1); sub++) {
       const Node& n = nodes[c];
       std::vector<u32> w(st.stride, 0);
       if (ZERO_FIELD && (n.kind == K_DOT || n.kind == K_LIN)) {   // padding fields name the zero constant
@@ -548,10 +556,11 @@ Program Builder::compile(const std::string& name, int W) {
       switch (n.kind) {
         case K_DOT:
           assert(n.prods.size() <= (size_t)MAX_DOT_PRODUCTS && n.lin.size() <= (size_t)MAX_DOT_LINEAR && n.mult >= 1 && n.mult <= 4);
-          w[0] = op(c) | ((u32)n.mult << 16) | (n.halve ? (1u << 19) : 0u) | ((u32)n.offs << 20);
+          w[0] = op(c) | ((u32)n.mult << 16) | (n.halve ? (1u << 19) : 0u) | ((u32)(sub == 0 ? n.offs : 0) << 20);   // the bias enters once: sub-lane 0
           put_lin(4);
-          for (size_t i = 0; i < n.prods.size(); i++) {
-            const DotProduct& p = n.prods[i];
+          for (size_t pi = (size_t)sub; pi < n.prods.size(); pi += (size_t)S) {
+            const DotProduct& p = n.prods[pi];
+            const size_t i = pi / (size_t)S;    // physical round of this sub-lane
             u32* r = &w[DOT_HDR_WORDS + DOT_ROUND_WORDS * i];
             const int sa = step_shapes[s][i].first, sb = step_shapes[s][i].second;
             const bool ma = (sa & 3) == 3 || (sa & 8), mb = (sb & 3) == 3 || (sb & 8);   // per-lane signs in bit 0 of the offsets
@@ -630,8 +639,10 @@ std::string verify_program(const Program& p) {
     const Step& st = p.steps[s];
     if (st.nlanes == 0 || st.nlanes > p.W) return bad(s, 0, "active lanes", st.nlanes);
     if (st.stride % 4 || st.stride < 4) return bad(s, 0, "descriptor stride", st.stride);
-    if ((u64)st.desc_off + (u64)st.nlanes * st.stride > p.descs.size() || st.desc_off % 4) return bad(s, 0, "descriptors outside the program", st.desc_off);
-    for (unsigned l = 0; l < st.nlanes; l++) {
+    const unsigned ndesc = st.kind == K_DOT ? st.nlanes * p.lsplit : st.nlanes;   // lane split: a K_DOT lane-op has one descriptor per sub-lane
+    if (st.nlanes * (st.kind == K_DOT ? p.lsplit : 1u) > p.W) return bad(s, 0, "active lanes", st.nlanes);
+    if ((u64)st.desc_off + (u64)ndesc * st.stride > p.descs.size() || st.desc_off % 4) return bad(s, 0, "descriptors outside the program", st.desc_off);
+    for (unsigned l = 0; l < ndesc; l++) {
       const u32* d = p.descs.data() + st.desc_off + l * st.stride;
       auto src = [&](u32 f) { return inside(f & 0xffffu, sh ? 13u : 15u); };                                  // a readable slot (constants included)
       auto dst = [&](u32 f) { f &= 0xffffu; return (f & 15u) == (sh ? 2u : 0u) && (sh || f >= cbytes) && (f & ~15u) + 56 <= ib; };  // a writable slot (never a constant)

@@ -37,6 +37,8 @@ struct Program {
   u32 n_round_ops = 0, n_op_mode[4] = {0, 0, 0, 0}, n_op_norm = 0;   // product-round operands (two per round) by shape
   double est_valu = 0;       // cost-model estimate of VALU instructions per wave (see Builder::compile)
   std::vector<u32> buf_extent = std::vector<u32>(MAX_BUFS, 0);   // per buffer index: bytes of one item the program touches (max offset + size); launch check in checked builds
+  u32 lsplit = 1;            // lane split: every K_DOT lane-op is spread over `lsplit` adjacent lanes, each accumulating a share of the products; the columns are summed
+                             // across them before the one reduction (latency variant for launches of at most one wavefront per SIMD).  W is the PHYSICAL lane count.
   bool shared_consts = false;   // one shared copy of the constants instead of one per instance (chosen by compile() for G >= 8)
   u32 inst_bytes() const { return (shared_consts ? slots : nconst + slots) * slot_bytes; }   // one instance region: [constants +] slots
   u32 inst_base(u32 g) const { return (shared_consts ? nconst * slot_bytes : 0) + g * inst_bytes(); }
@@ -93,6 +95,7 @@ struct Builder {
   double neg_cap = 6.0;  // negated linear terms above this bound are contracted first (their bound is paid as a +k p offset)
   bool use_wred = getenv("NBLS_NO_WRED") == nullptr;   // large post-added terms: weak reduction (table of multiples of p) instead of folding them into the dot product
   int store_batch = 0;   // > 0: a store step is issued as soon as this many stores are ready (programs that stream results out: the values do not linger in LDS)
+  int lane_split = 1;    // see Program::lsplit (compile(name, W) takes the LOGICAL lanes per item; the program runs on W * lane_split)
   int sched_window = 0;  // scheduler look-ahead limit in critical-path units (0 = unlimited), see compile()
   static Builder*& cur() { static thread_local Builder* b = nullptr; return b; }
   Builder();

@@ -95,6 +95,7 @@ struct KernelArgs {
   uint32_t slot_bytes;      // LDS slot stride of this program (64 or 80)
   uint32_t inst_bytes;      // LDS bytes per instance region: (nconst + slots) * slot_bytes, or slots * slot_bytes with shared constants
   uint32_t n_items;
+  uint32_t lsplit;          // 1, or 4: lane-split program (every K_DOT lane-op on four adjacent lanes; W counts physical lanes)
   uint32_t shared_consts;   // 0: constants replicated at the start of every instance region; 1: one copy at the start of the LDS image, the instance
                             //    regions behind it, constant operands marked by bit 1 of their offset (programs with 8 or more instances per wavefront)
   IOBuf bufs[MAX_BUFS];

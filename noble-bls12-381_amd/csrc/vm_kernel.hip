@@ -36,7 +36,21 @@ __device__ __forceinline__ u32 kernel_prologue(const KernelArgs& ka, char* lds, 
   return n_items;
 }
 
-template <bool FAIR, bool SHARED> __device__ __forceinline__ void vm_kernel_body(const KernelArgs& ka) {
+// Lane split (LS = 4): sum of the 28 column accumulators over the four adjacent lanes of a lane-op, result in the first of them.  Two DPP stages
+// (lane i += lane i + 1, then lane i += lane i + 2, inside rows of 16 lanes; groups of four never straddle a row).
+__device__ __forceinline__ u32 dpp_shl1(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xf, 0xf, true); }   // row_shl:1
+__device__ __forceinline__ u32 dpp_shl2(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x102, 0xf, 0xf, true); }   // row_shl:2
+__device__ __forceinline__ void acc_sum4(u64* acc) {
+#pragma unroll
+  for (int c = 0; c < 2 * NL - 1; c++) {
+    u64 v = acc[c];
+    v += ((u64)dpp_shl1((u32)(v >> 32)) << 32) | dpp_shl1((u32)v);
+    v += ((u64)dpp_shl2((u32)(v >> 32)) << 32) | dpp_shl2((u32)v);
+    acc[c] = v;
+  }
+}
+
+template <bool FAIR, bool SHARED, int LS = 1> __device__ __forceinline__ void vm_kernel_body(const KernelArgs& ka) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds = smem;
   const u32 lane = threadIdx.x;
@@ -55,9 +69,12 @@ template <bool FAIR, bool SHARED> __device__ __forceinline__ void vm_kernel_body
   Step nst = ka.steps[ka.nsteps > 1 ? 1 : 0];
   // Every lane reads 12 descriptor words whatever the step's stride (the descriptor stream is padded by 8 words) and idle lanes read lane 0's:
   // no conditional loads, no zero-filled registers (12 instructions per step).
+  // lane split: a K_DOT lane-op has one descriptor per sub-lane (index = the physical lane), every other kind one per logical lane, executed by sub-lane 0
+  const u32 lg = LS > 1 ? lane_in / (u32)LS : lane_in, sub = LS > 1 ? lane_in % (u32)LS : 0u;
+  auto desc_index = [&](const Step& x) { const u32 idx = (LS > 1 && x.kind == K_DOT) ? lane_in : lg, cnt = (LS > 1 && x.kind == K_DOT) ? (u32)x.nlanes * LS : (u32)x.nlanes; return idx < cnt ? idx : 0u; };
   uint4 d0, d1, dr;
   {
-    const u32 o = (st.desc_off + (lane_in < st.nlanes ? lane_in : 0u) * st.stride) >> 2;
+    const u32 o = (st.desc_off + desc_index(st) * st.stride) >> 2;
     d0 = descs4[o]; d1 = descs4[o + 1]; dr = descs4[o + 2];
   }
   // Fairness between the wavefronts that share a SIMD: the issue arbiter prefers the oldest wavefront, which then runs at ~94 % of
@@ -74,10 +91,10 @@ template <bool FAIR, bool SHARED> __device__ __forceinline__ void vm_kernel_body
     const Step nnst = ka.steps[sn];
     uint4 n0, n1, nr;
     {
-      const u32 o = (nst.desc_off + (lane_in < nst.nlanes ? lane_in : 0u) * nst.stride) >> 2;
+      const u32 o = (nst.desc_off + desc_index(nst) * nst.stride) >> 2;
       n0 = descs4[o]; n1 = descs4[o + 1]; nr = descs4[o + 2];
     }
-    if (lane_in < st.nlanes) {
+    if (lg < st.nlanes && (LS == 1 || st.kind == K_DOT || sub == 0)) {
       const u32 d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
       u32 res[NL];
       u32 dst;
@@ -92,7 +109,8 @@ template <bool FAIR, bool SHARED> __device__ __forceinline__ void vm_kernel_body
           dot_round(acc, round_shape(st, r), round_signs(d[1], r), cur.x, cur.y, cur.z, cur.w, lds, cx);
           cur = nx;
         }
-        dst = dot_finish(res, acc, st, d, lds, cx, ka.qp_table);
+        if (LS > 1) acc_sum4(acc);   // all sub-lanes of the lane-op are active here (lg < nlanes holds for the four of them alike)
+        dst = (LS == 1 || sub == 0) ? dot_finish(res, acc, st, d, lds, cx, ka.qp_table) : 0xffffffffu;
       } else {
         dst = exec_lane(st, d, lds, cx, ka.bufs, res, ka.qp_table);
       }
@@ -117,6 +135,8 @@ extern "C" __global__ void __launch_bounds__(64) NBLS_OCC nbls_vm_kernel(KernelA
 extern "C" __global__ void __launch_bounds__(64) NBLS_OCC nbls_vm_kernel_fair(KernelArgs ka) { vm_kernel_body<true, false>(ka); }
 extern "C" __global__ void __launch_bounds__(64) NBLS_OCC nbls_vm_kernel_sc(KernelArgs ka) { vm_kernel_body<false, true>(ka); }
 extern "C" __global__ void __launch_bounds__(64) NBLS_OCC nbls_vm_kernel_fair_sc(KernelArgs ka) { vm_kernel_body<true, true>(ka); }
+// latency variant: lane-split programs (Program::lsplit = 4), launches of at most one wavefront per SIMD
+extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel_ls4(KernelArgs ka) { vm_kernel_body<false, false, 4>(ka); }
 
 // Two-wave variant for small batches.  A lone wavefront per SIMD issues at ~1/2 of the VALU rate (tools/ubench/lone_wave.hip)
 // and a second wavefront on the same SIMD runs beside it, so when a launch has no more workgroups than the chip has CUs each
@@ -219,6 +239,7 @@ extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, vo
       hipFuncSetAttribute((const void*)nbls_vm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipFuncSetAttribute((const void*)nbls_vm_kernel_fair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipFuncSetAttribute((const void*)nbls_vm_kernel_sc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute((const void*)nbls_vm_kernel_ls4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipFuncSetAttribute((const void*)nbls_vm_kernel_fair_sc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipFuncSetAttribute((const void*)nbls_vm_kernel_split, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set[dev] = true;
@@ -231,7 +252,10 @@ extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, vo
   static const unsigned lds_floor = getenv("NBLS_LDS_FLOOR") ? (unsigned)atoi(getenv("NBLS_LDS_FLOOR")) : 0u;   // placement studies: caps workgroups per CU at 160 KB / floor
   if (lds_bytes < lds_floor) lds_bytes = lds_floor;
   const bool split = split_mode == 1;
-  if (split) hipLaunchKernelGGL(nbls_vm_kernel_split, dim3(blocks), dim3(128), lds_bytes + 2 * NLIMBS * 64 * 8, (hipStream_t)stream, *ka);
+  if (ka->lsplit == 4) {
+    if (ka->shared_consts) return -1;   // lane-split programs are compiled with replicated constants only
+    hipLaunchKernelGGL(nbls_vm_kernel_ls4, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, *ka);
+  } else if (split) hipLaunchKernelGGL(nbls_vm_kernel_split, dim3(blocks), dim3(128), lds_bytes + 2 * NLIMBS * 64 * 8, (hipStream_t)stream, *ka);
   else {
     static const int fair_mode = getenv("NBLS_FAIR") ? atoi(getenv("NBLS_FAIR")) : -1;   // 0 never, 1 always, unset: launches of 2..4 wavefronts per SIMD
     const bool fair = fair_mode >= 0 ? fair_mode != 0 : (blocks > 1024 && blocks <= 4096);

@@ -29,16 +29,26 @@ static void sim_run(const Program& p, unsigned n_items, const IOBuf* bufs) {
         unsigned inst = lane / p.W;
         if (inst >= p.G) continue;
         unsigned lane_in = lane - inst * p.W;
-        if (lane_in >= st.nlanes) continue;
+        // lane split: lane_in is the physical lane; a K_DOT lane-op is the sum of its sub-lanes' accumulators (computed when sub-lane 0 is visited),
+        // every other kind runs on sub-lane 0 with the descriptor of its logical lane
+        const unsigned S = p.lsplit, lg = lane_in / S, sub = lane_in % S;
+        if (lg >= st.nlanes || sub != 0) continue;
         LaneCtx cx; cx.inst = p.inst_base(inst) - (p.shared_consts ? 2u : 0u); cx.shared = p.shared_consts; cx.item = blk * p.G + inst; cx.live = cx.item < n_items;
         Pending pd;
         u32 dw[8] = {0};
-        const u32* gd = p.descs.data() + st.desc_off + lane_in * st.stride;
+        const u32* gd = p.descs.data() + st.desc_off + (st.kind == K_DOT ? lane_in : lg) * st.stride;
         memcpy(dw, gd, (st.stride < 8 ? st.stride : 8) * 4);
         if (st.kind == K_DOT) {
           u64 acc[2 * NL];
           dot_init(acc, st, dw[0]);
           for (u32 r = 0; r < st.p0; r++) { const u32* rd = gd + DOT_HDR_WORDS + DOT_ROUND_WORDS * r; dot_round(acc, round_shape(st, r), round_signs(gd[1], r), rd[0], rd[1], rd[2], rd[3], lds, cx); }
+          for (unsigned j = 1; j < S; j++) {   // the other sub-lanes: their own descriptors, their own (bias-free) accumulators
+            const u32* gj = gd + j * st.stride;
+            u64 aj[2 * NL];
+            dot_init(aj, st, gj[0]);
+            for (u32 r = 0; r < st.p0; r++) { const u32* rd = gj + DOT_HDR_WORDS + DOT_ROUND_WORDS * r; dot_round(aj, round_shape(st, r), round_signs(gj[1], r), rd[0], rd[1], rd[2], rd[3], lds, cx); }
+            for (int c = 0; c < 2 * NL; c++) acc[c] += aj[c];
+          }
           pd.dst = dot_finish(pd.v, acc, st, dw, lds, cx, qp_table);
         } else pd.dst = exec_lane(st, dw, lds, cx, bufs, pd.v, qp_table);
         if (pd.dst != 0xffffffffu) pend.push_back(pd);

@@ -362,3 +362,19 @@ def test_wire_decoders(sim, golden2):
     inb = vmsim_py.buf(b''.join(hx(v['aff']) for v in vs)); out = vmsim_py.buf(192 * len(vs))
     vmsim_py.run(sim, 'G2_SWAP', len(vs), {0: (inb, 192), 2: (out, 192)})
     assert out.raw == b''.join(hx(v['hex']) for v in vs)
+
+
+def test_lane_split_programs(sim, oracle, golden):
+    """The latency variants (every K_DOT lane-op spread over four adjacent lanes, one item per wavefront): same results as the golden pairs --
+    Miller value, and the whole pairing with the lane-split Miller and exponentiation programs."""
+    n = 3
+    g1, g2 = _points(golden, n)
+    out = C.create_string_buffer(576 * n)
+    vmsim_py.run(sim, 'MILLER_BYTES_LS', n, {0: (C.create_string_buffer(g1, len(g1)), 96), 1: (C.create_string_buffer(g2, len(g2)), 192), 2: (out, 576)})
+    for i in range(n):
+        assert out.raw[576 * i:576 * (i + 1)] == hx(golden['pairs'][i]['miller']), i
+    F = C.create_string_buffer(vmsim_py.F12 * n); N = C.create_string_buffer(vmsim_py.RAW * n)
+    vmsim_py.run(sim, 'MILLER_FE_LS', n, {0: (C.create_string_buffer(g1, len(g1)), 96), 1: (C.create_string_buffer(g2, len(g2)), 192), 3: (F, vmsim_py.F12), 4: (N, vmsim_py.RAW)})
+    vmsim_py.final_exp(sim, n, F, N, out, expx='EXPX_LS')
+    for i in range(n):
+        assert out.raw[576 * i:576 * (i + 1)] == hx(golden['pairs'][i]['pairing']), i
