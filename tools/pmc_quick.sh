@@ -3,7 +3,7 @@
 tag=${1:-q}; batch=${2:-65536}
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/prof_$tag; mkdir -p $out
-cmd="python bench.py --steps 3 --warmup 1 --batch $batch --no-cpu-baseline --verify-batch 0 --product-terms 0 --sign-batch 0 --msm-points 0 --inflight 1"
+cmd="python bench.py --steps 3 --warmup 1 --batch $batch --no-cpu-baseline --verify-batch 0 --product-terms 0 --sign-batch 0 --msm-points 0 --large-batch 0 --inflight 1"
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"; do
