@@ -486,13 +486,17 @@ Program Builder::compile(const std::string& name, int W) {
   // slots over all 16 bank groups (64 bytes: 4 of 16) and removes most bank-conflict cycles, but measured slower on the Miller
   // programs (1.98 vs 1.43 ms at 4096 pairings, 14.4 vs 13.0 ms at 65,536) and equal on EXPX: the kernel is bound by VALU issue, not by
   // LDS cycles.  NBLS_SLOT_BYTES=80 selects it for experiments.
-  {
-    const char* e = getenv("NBLS_SLOT_BYTES");
-    P.slot_bytes = e && atoi(e) == 80 ? 80 : 64;
-  }
+  P.slot_bytes = 64;
   // constants: a copy per instance (operand address = base + offset) unless that costs real LDS: with 8 or 16 instances per wavefront the copies
   // of a dozen constants are 5-10 KB and push the point programs from 8 to 6 wavefronts per CU; those keep one shared copy, marked by bit 1
   P.shared_consts = getenv("NBLS_SHARED_CONSTS") ? atoi(getenv("NBLS_SHARED_CONSTS")) != 0 : P.G >= 8;
+  {   // slot stride: 80 bytes where the larger image still leaves room for twelve workgroups per CU (three wavefronts per SIMD is what the register budget
+      // allows anyway); NBLS_SLOT_BYTES = 64 / 80 forces one or the other
+    const char* e = getenv("NBLS_SLOT_BYTES");
+    P.slot_bytes = 80;
+    const bool fits = P.lds_bytes() <= (160u * 1024u) / 12u;
+    P.slot_bytes = e ? (atoi(e) == 80 ? 80 : 64) : (fits ? 80 : 64);
+  }
   assert(P.lds_bytes() < 65536 * 2 && P.inst_bytes() < 32768);
   // 6. emit
   const u32 SLOT_FLAG = P.shared_consts ? 2u : 0u;
