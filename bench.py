@@ -251,7 +251,7 @@ def main():
         tm = eng.timing_read()
         eng.timing_enable(False)
         per_step = {k: v[0] / reps for k, v in tm.items()}          # ms per bench step, summed over that program's launches
-        MILLER_PROGS = ('miller_fe', 'lines_pq', 'acc_fe')          # one program below 16,384 pairings per call, LINES + ACC from there on
+        MILLER_PROGS = ('miller_fe', 'miller_fe_ls', 'lines_pq', 'acc_fe')   # one program below 49,152 pairings per call (its lane-split variant up to 1024), LINES + ACC from there on
         ms_miller = sum(v for k, v in per_step.items() if k in MILLER_PROGS)
         ms_inv = per_step['fp_inv']
         ms_hard = sum(v for k, v in per_step.items() if k not in MILLER_PROGS + ('fp_inv',))
