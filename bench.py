@@ -472,10 +472,15 @@ def main():
             'rccl_ranks': world if multi else None,
             'roofline': roof, 'cpu_baseline': cpu, 'product': product, 'verify_batch': vbatch if vbatch is not None else vshard, 'verify_batch_sharded': vshard if vbatch is not None else None, 'sign': sleg, 'aggregate': aleg, 'msm': mleg,
         }
-        print(json.dumps(line))
+        out_line = json.dumps(line)
+    else:
+        out_line = None
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    if out_line is not None:      # the ONE JSON line is the last thing on stdout (RCCL prints a version banner there on some builds)
+        sys.stdout.flush()
+        print(out_line, flush=True)
 
 
 if __name__ == '__main__':

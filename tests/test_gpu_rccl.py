@@ -61,5 +61,5 @@ def test_bench_distributed_branches_one_rank():
            '--product-terms', '256', '--sign-batch', '0', '--msm-points', '0', '--large-batch', '0', '--no-cpu-baseline']
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])      # RCCL prints its version banner on stdout too
     assert line['rccl_ranks'] == 1 and line['n_gpus'] == 1 and line['product']['result_is_one'] and line['verify_batch']['n_signatures'] == 64
