@@ -48,11 +48,31 @@ static napi_value result2(napi_env env, napi_value out, napi_value status) {
 #define ALLOCATED(v) if (!(v)) { napi_throw_error(env, NULL, "nbls: out of memory"); return NULL; }
 #define BYTES(i, d, l) uint8_t* d; size_t l; if (!get_bytes(env, argv[i], &d, &l)) { napi_throw_type_error(env, NULL, "expected Uint8Array"); return NULL; }
 
+/* Contexts for asynchronous calls in flight: verifyBatchAsync takes them round-robin, so that `await Promise.all([verifyBatch(..), verifyBatch(..), ..])`
+ * overlaps the calls on the GPU (three 65,536-signature calls in flight: 22 ms per call amortised against 27 ms one at a time, bench.py).  pool[0] = ctx;
+ * NBLS_CONTEXTS (default 1) or init(device, contexts) sets the size; the extra contexts are created on first use. */
+#define MAX_POOL 8
+static nbls_ctx* pool[MAX_POOL]; static int pool_size = 1, pool_dev = 0; static unsigned pool_next = 0;
+static void pool_clear(void) { for (int i = 1; i < MAX_POOL; i++) if (pool[i]) { p_nbls_destroy(pool[i]); pool[i] = NULL; } pool[0] = NULL; pool_next = 0; }
+static nbls_ctx* pool_take(void) {
+  if (pool_size <= 1 || !ctx) return ctx;
+  const int k = (int)(pool_next++ % (unsigned)pool_size);
+  if (k == 0) return ctx;
+  if (!pool[k] && p_nbls_init(pool_dev, &pool[k]) != 0) { pool[k] = NULL; return ctx; }
+  return pool[k];
+}
 static napi_value Init(napi_env env, napi_callback_info info) {
-  ARGS(1); int32_t dev = 0; napi_get_value_int32(env, argv[0], &dev);
+  size_t argc = 2; napi_value argv[2]; CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 1) { napi_throw_type_error(env, NULL, "missing arguments"); return NULL; }
+  int32_t dev = 0, nctx = 0; napi_get_value_int32(env, argv[0], &dev);
+  napi_valuetype t1 = napi_undefined; if (argc > 1) napi_typeof(env, argv[1], &t1);
+  if (t1 == napi_number) napi_get_value_int32(env, argv[1], &nctx);
+  else { const char* e = getenv("NBLS_CONTEXTS"); nctx = e ? atoi(e) : 1; }
   if (multi) { p_nbls_destroy_multi(multi); multi = NULL; ctx = NULL; }
+  pool_clear();
   if (ctx) { p_nbls_destroy(ctx); ctx = NULL; }
   int r = p_nbls_init(dev, &ctx); if (r) return throw_code(env, r);
+  pool[0] = ctx; pool_dev = dev; pool_size = nctx < 1 ? 1 : (nctx > MAX_POOL ? MAX_POOL : nctx);
   napi_value t; napi_get_boolean(env, true, &t); return t;
 }
 /* initMulti(Int32Array of device ids | null for every visible device) -> number of devices.  pairingBatch, millerProduct and verifyBatch(Async)
@@ -65,6 +85,7 @@ static napi_value InitMulti(napi_env env, napi_callback_info info) {
     n = (int)(l / 4); memcpy(ids, d, l);
   }
   if (multi) { p_nbls_destroy_multi(multi); multi = NULL; ctx = NULL; }
+  pool_clear(); pool_size = 1;   /* asynchronous calls run on the multi-device handle */
   if (ctx) { p_nbls_destroy(ctx); ctx = NULL; }
   int r = p_nbls_init_multi(n, n ? ids : NULL, &multi); if (r) return throw_code(env, r);
   ctx = p_nbls_multi_context(multi, 0);
@@ -196,10 +217,11 @@ static napi_value VerifyBatch(napi_env env, napi_callback_info info) {
 typedef struct {
   napi_async_work work; napi_deferred deferred; napi_ref refs[5];
   const uint8_t *sig, *msgs, *pks, *dst; const uint32_t* offs; size_t n, dst_len;
+  nbls_ctx* c;      /* the pool context this call runs on */
   int rc, ok;
 } verify_job;
 static void verify_execute(napi_env env, void* data) { verify_job* j = (verify_job*)data; (void)env;
-  j->rc = MULTI() ? p_nbls_multi_verify_batch(multi, j->n, j->sig, j->msgs, j->offs, j->pks, j->dst, j->dst_len, &j->ok) : p_nbls_verify_batch(ctx, j->n, j->sig, j->msgs, j->offs, j->pks, j->dst, j->dst_len, &j->ok); }
+  j->rc = MULTI() ? p_nbls_multi_verify_batch(multi, j->n, j->sig, j->msgs, j->offs, j->pks, j->dst, j->dst_len, &j->ok) : p_nbls_verify_batch(j->c, j->n, j->sig, j->msgs, j->offs, j->pks, j->dst, j->dst_len, &j->ok); }
 static void verify_complete(napi_env env, napi_status status, void* data) {
   verify_job* j = (verify_job*)data;
   for (int i = 0; i < 5; i++) napi_delete_reference(env, j->refs[i]);
@@ -216,7 +238,7 @@ static napi_value VerifyBatchAsync(napi_env env, napi_callback_info info) {
   ARGS(5); NEED_CTX(); BYTES(0, sig, ls); BYTES(1, msgs, lm); BYTES(2, offs, lo); BYTES(3, pks, lp); BYTES(4, dst, ld); (void)lm; (void)ls;
   COUNT_FROM_OFFSETS(n, lo); if (lp != n * 48) { napi_throw_range_error(env, NULL, "bad public key array length"); return NULL; }
   verify_job* j = (verify_job*)calloc(1, sizeof *j); if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
-  j->sig = sig; j->msgs = msgs; j->offs = (const uint32_t*)offs; j->pks = pks; j->dst = dst; j->dst_len = ld; j->n = n;
+  j->sig = sig; j->msgs = msgs; j->offs = (const uint32_t*)offs; j->pks = pks; j->dst = dst; j->dst_len = ld; j->n = n; j->c = pool_take();
   for (int i = 0; i < 5; i++) napi_create_reference(env, argv[i], 1, &j->refs[i]);
   napi_value promise, name; napi_create_promise(env, &j->deferred, &promise); napi_create_string_utf8(env, "nbls_verify_batch", NAPI_AUTO_LENGTH, &name);
   if (napi_create_async_work(env, NULL, name, verify_execute, verify_complete, j, &j->work) != napi_ok || napi_queue_async_work(env, j->work) != napi_ok) {

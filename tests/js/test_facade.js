@@ -181,5 +181,10 @@ const hex = bls.utils.bytesToHex, un = bls.utils.hexToBytes;
   assert.strictEqual(await bls.verifyBatch(bls.PointG2.fromSignature(vb.same_sig), vb.pks.map(() => same), vb.pks.map((k) => bls.PointG1.fromHex(k))), true);
   assert.strictEqual(await bls.verify(vb.same_sig, vb.same_msg, vb.agg_pk), true);
   await assert.rejects(() => bls.verifyBatch(vb.agg_sig, [], []), /Expected non-empty messages array/);
+  // calls in flight: with NBLS_CONTEXTS > 1 (tests/test_js_facade.py runs this file a second time with 3) concurrent verifyBatch promises run on
+  // separate engine contexts and overlap on the GPU; the answers are those of the sequential calls above
+  const many = await Promise.all([bls.verifyBatch(vb.agg_sig, vb.msgs, vb.pks), bls.verifyBatch(vb.agg_sig, m2, vb.pks), bls.verifyBatch(vb.agg_sig, vb.msgs, p2),
+    bls.verifyBatch(vb.agg_sig, vb.msgs, vb.pks), bls.verifyBatch(vb.agg_sig, vb.msgs, vb.pks), bls.verifyBatch(vb.agg_sig, m2, vb.pks)]);
+  assert.deepStrictEqual(many, [true, false, false, true, true, false]);
   console.log('JS facade ok');
 })().catch((e) => { console.error(e); process.exit(1); });

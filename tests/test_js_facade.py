@@ -38,3 +38,12 @@ def test_facade_on_gpu():
     _build()
     out = subprocess.run(['node', os.path.join(ROOT, 'tests', 'js', 'test_facade.js')], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and 'JS facade ok' in out.stdout, out.stdout + out.stderr
+
+
+@needs_node
+@pytest.mark.gpu
+def test_facade_on_gpu_with_a_context_pool():
+    """the same file with NBLS_CONTEXTS=3: asynchronous verifyBatch calls take engine contexts round-robin (js/nbls_napi.c), so concurrent promises overlap on the GPU"""
+    _build()
+    out = subprocess.run(['node', os.path.join(ROOT, 'tests', 'js', 'test_facade.js')], capture_output=True, text=True, timeout=300, env=dict(os.environ, NBLS_CONTEXTS='3'))
+    assert out.returncode == 0 and 'JS facade ok' in out.stdout, out.stdout + out.stderr
