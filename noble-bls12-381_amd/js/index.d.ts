@@ -107,7 +107,8 @@ export declare function pairingBatch(Ps: PointG1[] | Uint8Array /* n x 96 affine
 export declare function millerProduct(Ps: PointG1[] | Uint8Array, Qs: PointG2[] | Uint8Array, finalExponent?: boolean, validate?: boolean): { out: Uint8Array /* 576 */; status: Uint8Array };
 export declare function getPublicKeys(privateKeys: PrivateKey[]): Uint8Array[];
 export declare function signBatch(messages: Hex[], privateKeys: PrivateKey[]): Promise<Uint8Array[]>;
-export declare function init(deviceId?: number): void;
+/** contexts (1..8, default NBLS_CONTEXTS or 1): engine contexts that asynchronous verifyBatch calls take round-robin, so that concurrent promises overlap on the GPU */
+export declare function init(deviceId?: number, contexts?: number): void;
 
 export declare const utils: {
   hashToField(msg: Uint8Array, count: number, options?: { DST?: string; p?: bigint; m?: number; k?: number; expand?: boolean; hash?: (m: Uint8Array) => Promise<Uint8Array> }): Promise<bigint[][]>;

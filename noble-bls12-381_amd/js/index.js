@@ -518,4 +518,4 @@ const utils = {
 };
 
 module.exports = { CURVE, Fp, Fr, Fp2, Fp6, Fp12, PointG1, PointG2, pairing, pairingBatch, millerProduct, getPublicKey, getPublicKeys, sign, signBatch, verify, verifyBatch,
-  aggregatePublicKeys, aggregateSignatures, utils, init: (dev) => { native.init(dev || 0); inited = true; } };
+  aggregatePublicKeys, aggregateSignatures, utils, init: (dev, contexts) => { if (contexts === undefined) native.init(dev || 0); else native.init(dev || 0, contexts); inited = true; } };
