@@ -60,6 +60,9 @@ struct nbls_ctx {
   // side stream for the one-element chains of verifyBatch (signature decompression: a 758-bit Fp2 exponentiation on a single
   // lane is ~4 ms of pure latency) so that they overlap the batch-wide kernels instead of serialising with them
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; uint8_t* side_scratch = nullptr;
+  // large pairing batches run as two halves on two streams (nbls_pairing_batch_dev): item offset applied to every per-item buffer of a launch, second stream, events
+  size_t ioff = 0; hipStream_t half_stream = nullptr; hipEvent_t ev_half_fork = nullptr, ev_half_join = nullptr;
+  size_t halves_min = getenv("NBLS_HALVES_MIN") ? (atol(getenv("NBLS_HALVES_MIN")) > 0 ? (size_t)atol(getenv("NBLS_HALVES_MIN")) : (size_t)-1) : 32768;   // NBLS_HALVES_MIN=0: never (profiles of kernels running alone)
   hipStream_t side2 = nullptr; hipEvent_t ev_join2 = nullptr;   // verifyBatch: key decoding runs beside message hashing (their exponentiation kernels are latency-bound and leave issue slots free)
   uint8_t* ident_g1 = nullptr; uint8_t* ident_g2 = nullptr;   // projective identity (0 : 1 : 0), raw
   size_t cap_F = 0, cap_io = 0;
@@ -116,7 +119,7 @@ static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pa
   KernelArgs ka; memset(&ka, 0, sizeof ka);
   ka.steps = d.steps; ka.descs = d.descs; ka.consts = d.consts; ka.qp_table = ctx->qp_table;
   ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slot_bytes = d.p->slot_bytes; ka.inst_bytes = d.p->inst_bytes(); ka.shared_consts = d.p->shared_consts ? 1u : 0u; ka.lsplit = d.p->lsplit; ka.n_items = (u32)n; ka.n_items_dev = n_dev; ka.item_index = item_index;
-  for (auto& b : bufs) { ka.bufs[b.first].ptr = (uint8_t*)b.second.first; ka.bufs[b.first].stride = b.second.second; }
+  for (auto& b : bufs) { ka.bufs[b.first].ptr = (uint8_t*)b.second.first + ctx->ioff * b.second.second; ka.bufs[b.first].stride = b.second.second; }   // ioff: the second half of a split call
   if (checked_mode()) {
     for (int k = 0; k < MAX_BUFS; k++) {
       const u32 ext = d.p->buf_extent[k];
@@ -137,7 +140,7 @@ static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pa
 static int run_inv(nbls_ctx* ctx, size_t n, hipStream_t s) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->timing) { e0 = timing_event(ctx); e1 = timing_event(ctx); hipEventRecord(e0, s); }
-  int e = nbls_fp_inv_launch((unsigned)n, ctx->N, ctx->NI, s);
+  int e = nbls_fp_inv_launch((unsigned)n, ctx->N + ctx->ioff * RAW, ctx->NI + ctx->ioff * RAW, s);
   if (ctx->timing) { hipEventRecord(e1, s); ctx->tev.push_back({(int)P_COUNT, {e0, e1}}); }
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
   return NBLS_OK;
@@ -324,6 +327,8 @@ EXPORT void nbls_destroy(nbls_ctx* ctx) {
   if (ctx->qp_table) hipFree(ctx->qp_table);
   for (uint8_t* p : {ctx->neg_g1, ctx->ident_g1, ctx->ident_g2}) if (p) hipFree(p);
   if (ctx->side) hipStreamDestroy(ctx->side);
+  if (ctx->half_stream) hipStreamDestroy(ctx->half_stream);
+  for (hipEvent_t e : {ctx->ev_half_fork, ctx->ev_half_join}) if (e) hipEventDestroy(e);
   if (ctx->side2) hipStreamDestroy(ctx->side2);
   for (hipEvent_t e : {ctx->ev_fork, ctx->ev_join, ctx->ev_join2, ctx->ev_last}) if (e) hipEventDestroy(e);
   for (auto& t : ctx->tev) { hipEventDestroy(t.second.first); hipEventDestroy(t.second.second); }
@@ -346,6 +351,7 @@ EXPORT const char* nbls_strerror(int code) {
 EXPORT int nbls_last_hip_error(nbls_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
 EXPORT int nbls_device_synchronize(nbls_ctx* ctx) { if (!ctx) return NBLS_EINVAL; HIPCHK(hipSetDevice(ctx->device)); HIPCHK(hipDeviceSynchronize()); return NBLS_OK; }
 
+static int pairing_core(nbls_ctx* ctx, size_t n, const void* d_g1, const void* d_g2, int with_final_exp, void* d_out, hipStream_t s, bool two_programs);
 EXPORT int nbls_pairing_batch_dev(nbls_ctx* ctx, size_t n, const void* d_g1, const void* d_g2, int with_final_exp, void* d_out, void* stream) {
   if (!ctx || (n && (!d_g1 || !d_g2 || !d_out))) return NBLS_EINVAL;
   if (n == 0) return NBLS_OK;
@@ -353,6 +359,25 @@ EXPORT int nbls_pairing_batch_dev(nbls_ctx* ctx, size_t n, const void* d_g1, con
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   StreamOrder order_(ctx, s);
+  // A large batch runs as two halves on two streams: every launch of a dependent chain ends in a partly filled round of wavefronts (EXPX at 65,536 pairs: 4.65
+  // rounds of 2,816 resident wavefronts), and the tail of one half is filled by the other (65,536 pairs: 27.4 -> 25.9 ms).  Both halves use the caller's scratch
+  // through an item offset (ctx->ioff, applied by run() to every per-item buffer) and the two-program Miller loop (what counts with work in flight is the instruction count).
+  if (n >= ctx->halves_min && n <= LINES_CHUNK) {
+    int r;
+    if ((r = ensure_lines(ctx, n))) return r;
+    if (with_final_exp && (r = ensure_scratch(ctx, n))) return r;
+    if (!ctx->half_stream && (hipStreamCreateWithFlags(&ctx->half_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_half_fork, hipEventDisableTiming) != hipSuccess ||
+                              hipEventCreateWithFlags(&ctx->ev_half_join, hipEventDisableTiming) != hipSuccess)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+    const size_t h = (n / 2 + 63) & ~(size_t)63;
+    HIPCHK(hipEventRecord(ctx->ev_half_fork, s)); HIPCHK(hipStreamWaitEvent(ctx->half_stream, ctx->ev_half_fork, 0));
+    r = pairing_core(ctx, h, d_g1, d_g2, with_final_exp, d_out, s, true);
+    if (!r) { ctx->ioff = h; r = pairing_core(ctx, n - h, d_g1, d_g2, with_final_exp, d_out, ctx->half_stream, true); ctx->ioff = 0; }
+    HIPCHK(hipEventRecord(ctx->ev_half_join, ctx->half_stream)); HIPCHK(hipStreamWaitEvent(s, ctx->ev_half_join, 0));
+    return r;
+  }
+  return pairing_core(ctx, n, d_g1, d_g2, with_final_exp, d_out, s, false);
+}
+static int pairing_core(nbls_ctx* ctx, size_t n, const void* d_g1, const void* d_g2, int with_final_exp, void* d_out, hipStream_t s, bool two_programs) {
   int r;
   // One program or two?  LINES + ACC execute ~12 % fewer instructions per pairing (no idle lanes in the Fp12 steps, 20 instead of 37 lane-ops
   // per bit in the point chain) but are two dependent chains of 307 + 173 steps where the fused program has 349: a launch that is only a few
@@ -360,7 +385,7 @@ EXPORT int nbls_pairing_batch_dev(nbls_ctx* ctx, size_t n, const void* d_g1, con
   // 4096 pairs 1.22 ms against 1.39 ms, 32,768 10.3 against 10.4 ms, 65,536 12.2 against 11.5 ms, 131,072 23.6 against 21.9 ms); with several
   // calls in flight the instruction count is what matters (pipeline.py sets the threshold to 0).  NBLS_FUSED_MILLER = 1 / 0 forces one or the other.
   static const int fused_mode = getenv("NBLS_FUSED_MILLER") ? atoi(getenv("NBLS_FUSED_MILLER")) : -1;
-  const bool fused = fused_mode >= 0 ? fused_mode != 0 : n < ctx->split_min;
+  const bool fused = fused_mode >= 0 ? fused_mode != 0 : (!two_programs && n < ctx->split_min);
   if (fused) {
     if (!with_final_exp) return run(ctx, ls_variant(P_MILLER_BYTES, n), n, {B(0, d_g1, 96), B(1, d_g2, 192), B(2, d_out, 576)}, s);
     if ((r = ensure_scratch(ctx, n))) return r;
@@ -747,6 +772,7 @@ EXPORT int nbls_set_tuning(nbls_ctx* ctx, int key, long long value) {
   std::lock_guard<std::recursive_mutex> g(ctx->mu);
   switch (key) {
     case NBLS_TUNE_SPLIT_MILLER_MIN: if (value < 0) return NBLS_EINVAL; ctx->split_min = (size_t)value; return NBLS_OK;
+    case NBLS_TUNE_HALVES_MIN: if (value < 0) return NBLS_EINVAL; ctx->halves_min = value == 0 ? (size_t)-1 : (size_t)value; return NBLS_OK;
     default: return NBLS_EINVAL;
   }
 }

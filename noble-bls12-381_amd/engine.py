@@ -346,6 +346,10 @@ class Engine:
         """pairs from which the Miller loop runs as LINES + ACC (0: always, a huge value: never)"""
         self._chk(self.lib.nbls_set_tuning(self.h, 1, n))
 
+    def set_halves_min(self, n):
+        """pairs from which pairing_batch_dev runs a batch as two halves on two streams (default 32768; 0: never)"""
+        self._chk(self.lib.nbls_set_tuning(self.h, 2, n))
+
     def synchronize(self):
         self._chk(self.lib.nbls_device_synchronize(self.h))
 

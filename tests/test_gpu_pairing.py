@@ -201,3 +201,21 @@ def test_batches_in_flight(oracle):
     for r in range(rounds):
         ref, _ = oracle.pairing_batch(ins[r][0], ins[r][1], True, False, threads=16)
         assert bytes(outs[r].cpu().numpy().tobytes()) == ref, r
+
+
+def test_two_halves_execution(oracle, golden):
+    """nbls_pairing_batch_dev runs batches from 32,768 pairs as two halves on two streams sharing the caller's scratch through an item offset; forced here at a
+    size the oracle can check: same bytes as the one-stream execution, with and without the final exponentiation, odd and even sizes."""
+    pkg = importlib.import_module('noble-bls12-381_amd')
+    eng = pkg.Engine(0)
+    for n in (130, 517):
+        g1 = b''.join(hx(golden['pairs'][i % len(golden['pairs'])]['g1']) for i in range(n)); g2 = b''.join(hx(golden['pairs'][(7 * i + 3) % len(golden['pairs'])]['g2']) for i in range(n))
+        for fe in (True, False):
+            eng.set_halves_min(0)
+            ref, _ = eng.pairing_batch(g1, g2, fe, False)
+            eng.set_halves_min(64)
+            got, _ = eng.pairing_batch(g1, g2, fe, False)
+            assert got == ref
+            exp, _ = oracle.pairing_batch(g1, g2, fe, False, threads=16)
+            assert got == exp
+    eng.set_halves_min(32768)

@@ -2,6 +2,7 @@
 # Two PMC passes + one kernel trace over the pairing pipeline at one batch size (a lighter tools/profile_round.sh). Usage: tools/pmc_quick.sh <tag> [batch]
 tag=${1:-q}; batch=${2:-65536}
 export TMPDIR=/tmp
+export NBLS_HALVES_MIN=0
 out=$PWD/gpurun_out/prof_$tag; mkdir -p $out
 cmd="python bench.py --steps 3 --warmup 1 --batch $batch --no-cpu-baseline --verify-batch 0 --product-terms 0 --sign-batch 0 --msm-points 0 --large-batch 0 --inflight 1"
 i=0

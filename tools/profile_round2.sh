@@ -8,6 +8,7 @@
 #   5. per-kernel times of one verifyBatch of 65,536 signatures (tools/verify_breakdown.py)                     -> verify_breakdown.txt
 #   6. the JSON line of a default bench run                                                                    -> bench_default.json
 export TMPDIR=/tmp
+export NBLS_HALVES_MIN=0      # kernel traces and counters of kernels running alone: a large call is not split into two overlapping halves here
 out=$PWD/gpurun_out/prof_r2; mkdir -p $out
 common="--no-cpu-baseline --verify-batch 0 --product-terms 0 --sign-batch 0 --msm-points 0 --large-batch 0"
 stats() {   # <name> <bench args>
@@ -28,6 +29,7 @@ for b in 4096 65536; do
   done
   if [ $b = 4096 ]; then NBLS_FUSED_MILLER=1 python tools/pmc_summary.py $out/pmc_b$b 4096 > $out/pmc_b$b.csv; else python tools/pmc_summary.py $out/pmc_b$b 4096 > $out/pmc_b$b.csv; fi
 done
+unset NBLS_HALVES_MIN
 python tools/verify_breakdown.py > $out/verify_breakdown.txt 2>&1
 python tools/verify_breakdown.py 1 > $out/verify_breakdown_n1.txt 2>&1
 python bench.py > $out/bench_default.json 2> $out/bench_default.err
