@@ -467,9 +467,20 @@ EXPORT int nbls_miller_product_dev(nbls_ctx* ctx, size_t n, const void* d_g1, co
       m = 0;
       for (size_t o = 0; o < n; o += LINES_CHUNK) {   // LINES_CHUNK is a multiple of four: a chunk boundary never splits a group
         const size_t c = n - o < LINES_CHUNK ? n - o : LINES_CHUNK, c4 = (c + 3) / 4;
-        if ((r = run(ctx, P_LINES_PQ, c, {B(0, (const uint8_t*)d_g1 + o * 96, 96), B(1, (const uint8_t*)d_g2 + o * 192, 192), B(3, ctx->L, LINE_BYTES)}, s))) return r;
-        for (size_t k = c; k < 4 * c4; k++) HIPCHK(hipMemcpyAsync(ctx->L + k * LINE_BYTES, ctx->unit_lines, LINE_BYTES, hipMemcpyDeviceToDevice, s));
-        if ((r = run(ctx, P_ACC4_RAW, c4, {B(3, ctx->L, 4 * LINE_BYTES), B(5, ctx->F + m * F12, F12)}, s))) return r;
+        // a large chunk runs as two halves (whole groups of four) on two streams, like nbls_pairing_batch_dev: the tail of LINES / ACC4 of one half under the other
+        const size_t h = (c >= ctx->halves_min && ctx->ioff == 0) ? ((c / 2 + 3) & ~(size_t)3) : c;
+        if (h < c && !ctx->half_stream && (hipStreamCreateWithFlags(&ctx->half_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_half_fork, hipEventDisableTiming) != hipSuccess ||
+                                           hipEventCreateWithFlags(&ctx->ev_half_join, hipEventDisableTiming) != hipSuccess)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+        if (h < c) { HIPCHK(hipEventRecord(ctx->ev_half_fork, s)); HIPCHK(hipStreamWaitEvent(ctx->half_stream, ctx->ev_half_fork, 0)); }
+        for (size_t lo = 0; lo < c; lo += h) {
+          const size_t cc = lo ? c - lo : h, g4 = (cc + 3) / 4;      // two parts: [0, h) and everything behind it
+          hipStream_t sh = lo ? ctx->half_stream : s;
+          if ((r = run(ctx, P_LINES_PQ, cc, {B(0, (const uint8_t*)d_g1 + (o + lo) * 96, 96), B(1, (const uint8_t*)d_g2 + (o + lo) * 192, 192), B(3, ctx->L + lo * LINE_BYTES, LINE_BYTES)}, sh))) return r;
+          for (size_t k = cc; k < 4 * g4; k++) HIPCHK(hipMemcpyAsync(ctx->L + (lo + k) * LINE_BYTES, ctx->unit_lines, LINE_BYTES, hipMemcpyDeviceToDevice, sh));
+          if ((r = run(ctx, P_ACC4_RAW, g4, {B(3, ctx->L + lo * LINE_BYTES, 4 * LINE_BYTES), B(5, ctx->F + (m + lo / 4) * F12, F12)}, sh))) return r;
+          if (lo) break;
+        }
+        if (h < c) { HIPCHK(hipEventRecord(ctx->ev_half_join, ctx->half_stream)); HIPCHK(hipStreamWaitEvent(s, ctx->ev_half_join, 0)); }
         m += c4;
       }
     }
