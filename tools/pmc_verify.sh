@@ -10,7 +10,7 @@ for r in rows:
     d=int(r['Dispatch_Id']); by.setdefault(d,{'k':r['Kernel_Name'],'grid':r['Grid_Size'],'dur':int(r['End_Timestamp'])-int(r['Start_Timestamp'])})[r['Counter_Name']]=float(r['Counter_Value'])
 ids=sorted(by)
 # last verify call: print the last 45 dispatches
-for d in ids[-45:]:
+for d in ids[-70:]:
     x=by[d]; w=x.get('SQ_WAVES',1) or 1
     print(d,x['k'][:22],x['grid'],'%.3fms'%(x['dur']/1e6),'waves',int(w),'valu/w %.0f'%(x.get('SQ_INSTS_VALU',0)/w),'wavecyc/w %.0f'%(x.get('SQ_WAVE_CYCLES',0)/w),'wait/w %.0f'%(x.get('SQ_WAIT_ANY',0)/w),'vmrd/w %.0f'%(x.get('SQ_INSTS_VMEM_RD',0)/w),'vmwr/w %.0f'%(x.get('SQ_INSTS_VMEM_WR',0)/w))
 PY
