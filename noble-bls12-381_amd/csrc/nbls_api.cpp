@@ -195,7 +195,7 @@ static int need(nbls_ctx* ctx, int i, size_t bytes, uint8_t** out) {
 static int run_pow(nbls_ctx* ctx, int which, size_t n, const void* in, void* out, hipStream_t s, uint8_t* scratch = nullptr) {
   int is_fp2 = which == 1 || which == 2;
   if (!scratch) { int r = need(ctx, 11, n * 16 * (is_fp2 ? 2 : 1) * RAW, &scratch); if (r) return r; }
-  int e = nbls_fp_pow_launch((unsigned)n, in, out, ctx->nib[which], ctx->nnib[which], scratch, is_fp2, s);
+  int e = nbls_fp_pow_launch((unsigned)n, in, out, ctx->nib[which], ctx->nnib[which], scratch, which == 1 ? 8 : which == 2 ? 7 : 0, s);   // Fp2: a^((p^2+7)/16) = b^K a^8, a^((p^2-9)/16) = b^K a^7
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
   return NBLS_OK;
 }
@@ -293,9 +293,14 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
     for (int k = 0; k < 4; k++) {
       int nn = (bits[k] + 3) / 4; std::vector<uint8_t> nb(nn);
       for (int j = 0; j < nn; j++) { int lo = 4 * (nn - 1 - j); uint8_t d = 0; for (int b = 3; b >= 0; b--) { int bit = lo + b; d = (uint8_t)((d << 1) | (bit < bits[k] ? (exps[k][bit >> 6] >> (bit & 63)) & 1 : 0)); } nb[j] = d; }
-      // the two Fp2 exponents go through the Frobenius split e = c0 + c1 p (pow_kernels.hip): joint 2-bit digits from tools/gen_consts.py
-      if (k == 1) { nb.assign(NBLS_JOINT_P2_PLUS_7_DIV_16, NBLS_JOINT_P2_PLUS_7_DIV_16 + sizeof NBLS_JOINT_P2_PLUS_7_DIV_16); nn = (int)nb.size(); }
-      if (k == 2) { nb.assign(NBLS_JOINT_P2_MINUS_9_DIV_16, NBLS_JOINT_P2_MINUS_9_DIV_16 + sizeof NBLS_JOINT_P2_MINUS_9_DIV_16); nn = (int)nb.size(); }
+      // the two Fp2 exponents are (K p + 11 K + 8) and (K p + 11 K + 7) with K = (p - 11) / 16: the kernel raises conj(a) a^11 to K (pow_kernels.hip), so both get the nibbles of K
+      if (k == 1 || k == 2) {
+        uint64_t K[6]; for (int j = 0; j < 6; j++) K[j] = NBLS_EXP_P_MINUS_3_DIV_4[j];
+        K[0] -= 2;                                                        // (p - 3) / 4 - 2 = (p - 11) / 4 (no borrow: the low word ends in ...aaaa)
+        for (int j = 0; j < 6; j++) K[j] = (K[j] >> 2) | (j < 5 ? K[j + 1] << 62 : 0);   // / 4
+        const int kb = 377; nn = (kb + 3) / 4; nb.assign(nn, 0);
+        for (int j = 0; j < nn; j++) { int lo = 4 * (nn - 1 - j); uint8_t d = 0; for (int b = 3; b >= 0; b--) { int bit = lo + b; d = (uint8_t)((d << 1) | (bit < kb ? (K[bit >> 6] >> (bit & 63)) & 1 : 0)); } nb[j] = d; }
+      }
       ctx->nnib[k] = nn;
       if (hipMalloc(&ctx->nib[k], nn) != hipSuccess || hipMemcpy(ctx->nib[k], nb.data(), nn, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
     }

@@ -126,43 +126,53 @@ __device__ __forceinline__ void fp2_sqr_2l(u32* res, const u32* X, bool r) {
   carry_norm(o1); carry_norm(o2);
   mont_mul28(res, o1, o2);
 }
-extern "C" __global__ void __launch_bounds__(64) nbls_fp2_pow_kernel(unsigned n, const u32* __restrict__ in, u32* __restrict__ out, const unsigned char* __restrict__ digits, int nwin, u32* __restrict__ scratch) {
+// a^e in Fp2 for the two exponents of the square roots, e = (p^2 + 7) / 16 (decompression, math.ts:547-561) and (p^2 - 9) / 16 (SWU, math.ts:1196-1198).  With
+// p = 16 K + 11:   (p^2 + 7) / 16 = K p + 11 K + 8   and   (p^2 - 9) / 16 = K p + 11 K + 7,   and a^p = conj(a), so
+//        a^e = (conj(a) a^11)^K  a^tail ,   tail = 8 or 7:
+// ONE 377-bit exponent on the base b = conj(a) a^11 (4-bit fixed windows: 376 squarings, ~88 multiplications, a 14-multiplication table) and 9 more
+// multiplications / squarings for a^2 .. a^11 -- 377 squarings + ~112 multiplications where the joint 2-bit double exponentiation a^c0 conj(a)^c1 that this
+// replaces took 382 + ~193 (same field element: -17 % instructions).  digits = the nibbles of K, most significant first.
+// TWO LANES PER ELEMENT (see above).
+extern "C" __global__ void __launch_bounds__(64) nbls_fp2_pow_kernel(unsigned n, const u32* __restrict__ in, u32* __restrict__ out, const unsigned char* __restrict__ digits, int nwin, u32* __restrict__ scratch, int tail) {
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x, i = t >> 1;
   const bool r = t & 1;
   if (i >= n) return;                              // both lanes of a pair leave together
   const u32 BIAS[NL] = NBLS_BIAS16_28;
-  u32* tab = scratch + (size_t)t * 16 * 16;        // tab[j << 2 | i] = own component of a^i conj(a)^j
+  u32* tab = scratch + (size_t)t * 16 * 16;        // tab[d] = own component of b^d for d = 1 .. 15; tab[0] = a^tail
   u32 acc[NL], tt[NL];
-  // table: powers a^0..a^3 first (kept in the table, not in registers), then the three conjugate rows from them
   {
-    u32 p1[NL], pk[NL];
+    u32 a1[NL], a2[NL], a3[NL], a4[NL], a8[NL], x[NL];
 #pragma unroll
-    for (int k = 0; k < NL; k++) { p1[k] = in[32 * i + 16 * r + k]; acc[k] = r ? 0u : NBLS_R1[k]; tab[k] = acc[k]; tab[16 + k] = p1[k]; }
-    fp2_sqr_2l(pk, p1, r);
+    for (int k = 0; k < NL; k++) a1[k] = in[32 * i + 16 * r + k];
+    fp2_sqr_2l(a2, a1, r); fp2_mul_2l(a3, a2, a1, r); fp2_sqr_2l(a4, a2, r); fp2_sqr_2l(a8, a4, r);
+    if (tail == 7) fp2_mul_2l(x, a4, a3, r);       // a^7
+    else {
 #pragma unroll
-    for (int k = 0; k < NL; k++) tab[32 + k] = pk[k];
-    fp2_mul_2l(tt, pk, p1, r);
-#pragma unroll
-    for (int k = 0; k < NL; k++) tab[48 + k] = tt[k];
-  }
-  for (int jj = 1; jj < 4; jj++) {
-    u32 cj[NL];                                    // own component of conj(a^j) = conj(a)^j: (c0, 16p - c1)
-#pragma unroll
-    for (int k = 0; k < NL; k++) { const u32 v = tab[16 * jj + k]; cj[k] = r ? BIAS[k] - v : v; }
-    carry_norm(cj);
-#pragma unroll
-    for (int k = 0; k < NL; k++) tab[16 * (jj << 2) + k] = cj[k];
-    for (int ii = 1; ii < 4; ii++) {
-      u32 pi[NL];
-#pragma unroll
-      for (int k = 0; k < NL; k++) pi[k] = tab[16 * ii + k];
-      fp2_mul_2l(tt, pi, cj, r);
-#pragma unroll
-      for (int k = 0; k < NL; k++) tab[16 * ((jj << 2) | ii) + k] = tt[k];
+      for (int k = 0; k < NL; k++) x[k] = a8[k];   // a^8
     }
+#pragma unroll
+    for (int k = 0; k < NL; k++) tab[k] = x[k];
+    fp2_mul_2l(x, a8, a3, r);                      // a^11
+    u32 cj[NL];                                    // own component of conj(a): (c0, 16p - c1)
+#pragma unroll
+    for (int k = 0; k < NL; k++) cj[k] = r ? BIAS[k] - a1[k] : a1[k];
+    carry_norm(cj);
+    fp2_mul_2l(acc, cj, x, r);                     // b = conj(a) a^11
+#pragma unroll
+    for (int k = 0; k < NL; k++) tab[16 + k] = acc[k];
   }
+  for (int d = 2; d < 16; d++) {                   // b^d = b^(d-1) b
+    u32 prev[NL], b1[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) { prev[k] = tab[16 * (d - 1) + k]; b1[k] = tab[16 + k]; }
+    fp2_mul_2l(tt, prev, b1, r);
+#pragma unroll
+    for (int k = 0; k < NL; k++) tab[16 * d + k] = tt[k];
+  }
+#pragma unroll
+  for (int k = 0; k < NL; k++) acc[k] = r ? 0u : NBLS_R1[k];
   for (int w = 0; w < nwin; w++) {
-    if (w) { fp2_sqr_2l(tt, acc, r); fp2_sqr_2l(acc, tt, r); }
+    if (w) { fp2_sqr_2l(tt, acc, r); fp2_sqr_2l(acc, tt, r); fp2_sqr_2l(tt, acc, r); fp2_sqr_2l(acc, tt, r); }
     const unsigned d = digits[w];                   // uniform
     if (d) {
       u32 e[NL];
@@ -173,16 +183,22 @@ extern "C" __global__ void __launch_bounds__(64) nbls_fp2_pow_kernel(unsigned n,
       for (int k = 0; k < NL; k++) acc[k] = tt[k];
     }
   }
+  {
+    u32 e[NL];
 #pragma unroll
-  for (int k = 0; k < NL; k++) out[32 * i + 16 * r + k] = acc[k];
+    for (int k = 0; k < NL; k++) e[k] = tab[k];
+    fp2_mul_2l(tt, acc, e, r);                     // times a^tail
+  }
+#pragma unroll
+  for (int k = 0; k < NL; k++) out[32 * i + 16 * r + k] = tt[k];
   out[32 * i + 16 * r + 14] = 0; out[32 * i + 16 * r + 15] = 0;
 }
 
 }  // namespace nbls
 
-extern "C" int nbls_fp_pow_launch(unsigned n, const void* in, void* out, const void* nibbles, int nnib, void* scratch, int is_fp2, void* stream) {
+extern "C" int nbls_fp_pow_launch(unsigned n, const void* in, void* out, const void* nibbles, int nnib, void* scratch, int is_fp2, void* stream) {   // is_fp2: 0 Fp, 7 / 8: Fp2 with that tail (nbls_fp2_pow_kernel)
   if (n == 0) return 0;
-  if (is_fp2) hipLaunchKernelGGL(nbls::nbls_fp2_pow_kernel, dim3((2 * n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, (const nbls::u32*)in, (nbls::u32*)out, (const unsigned char*)nibbles, nnib, (nbls::u32*)scratch);
+  if (is_fp2) hipLaunchKernelGGL(nbls::nbls_fp2_pow_kernel, dim3((2 * n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, (const nbls::u32*)in, (nbls::u32*)out, (const unsigned char*)nibbles, nnib, (nbls::u32*)scratch, is_fp2);
   else hipLaunchKernelGGL(nbls::nbls_fp_pow_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, (const nbls::u32*)in, (nbls::u32*)out, (const unsigned char*)nibbles, nnib, (nbls::u32*)scratch);
   return (int)hipGetLastError();
 }
