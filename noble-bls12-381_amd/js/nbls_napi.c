@@ -49,7 +49,7 @@ static napi_value result2(napi_env env, napi_value out, napi_value status) {
 #define BYTES(i, d, l) uint8_t* d; size_t l; if (!get_bytes(env, argv[i], &d, &l)) { napi_throw_type_error(env, NULL, "expected Uint8Array"); return NULL; }
 
 /* Contexts for asynchronous calls in flight: verifyBatchAsync takes them round-robin, so that `await Promise.all([verifyBatch(..), verifyBatch(..), ..])`
- * overlaps the calls on the GPU (three 65,536-signature calls in flight: 22 ms per call amortised against 27 ms one at a time, bench.py).  pool[0] = ctx;
+ * overlaps the calls on the GPU (three 65,536-signature calls in flight: 21 ms per call amortised against 26 ms one at a time, bench.py).  pool[0] = ctx;
  * NBLS_CONTEXTS (default 1) or init(device, contexts) sets the size; the extra contexts are created on first use. */
 #define MAX_POOL 8
 static nbls_ctx* pool[MAX_POOL]; static int pool_size = 1, pool_dev = 0; static unsigned pool_next = 0;
