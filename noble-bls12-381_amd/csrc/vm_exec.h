@@ -220,9 +220,9 @@ NBLS_HD u32 slot_addr(u32 field, const LaneCtx& cx) { return term_addr(field & 0
 // 16-bit offset number t of a packed list that starts at word `first` of the descriptor
 NBLS_HD u32 field16(const u32* d, int first, int t) { return (d[first + t / 2] >> (16 * (t & 1))) & 0xffffu; }
 
-// K_DOT in three pieces so that the two-wave kernel (vm_kernel.hip, small batches) can split the product rounds of a step
-// between two wavefronts: dot_init loads the bias, dot_round accumulates one product of this lane into the 28 signed
-// columns, dot_finish reduces the columns and applies multiplier, post-added slots, normalisation and halving.
+// K_DOT in three pieces (the lane-split kernel sums the columns of four lanes between the second and the third): dot_init loads the bias,
+// dot_round accumulates one product of this lane into the 28 signed columns, dot_finish reduces the columns and applies multiplier,
+// post-added slots, normalisation and halving.
 NBLS_HD void dot_init(u64* acc, const Step& st, u32 w0) {
   if (st.p1 & DOTF_OFFS) acc_init(acc, (w0 >> 20) & 0xf);
   else {

@@ -138,89 +138,6 @@ extern "C" __global__ void __launch_bounds__(64) NBLS_OCC nbls_vm_kernel_fair_sc
 // latency variant: lane-split programs (Program::lsplit = 4), launches of at most one wavefront per SIMD
 extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel_ls4(KernelArgs ka) { vm_kernel_body<false, false, 4>(ka); }
 
-// Two-wave variant for small batches.  A lone wavefront per SIMD issues at ~1/2 of the VALU rate (tools/ubench/lone_wave.hip)
-// and a second wavefront on the same SIMD runs beside it, so when a launch has no more workgroups than the chip has CUs each
-// workgroup gets TWO wavefronts that share the work of every K_DOT step: wave 0 accumulates the first half of the product
-// rounds, wave 1 the second half; wave 1 hands its 28 column accumulators over through LDS, wave 0 adds them, reduces once and
-// finishes the lane-op.  Same instances, same slots, same results (integer sums in a different order).
-extern "C" __global__ void __launch_bounds__(128) nbls_vm_kernel_split(KernelArgs ka) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* lds = smem;
-  const u32 tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  LaneSetup ls; bool exit_now;
-  kernel_prologue(ka, lds, tid, 128, lane, ls, exit_now);
-  if (exit_now) return;
-  const u32 lane_in = ls.lane_in;
-  const LaneCtx cx = ls.cx;
-  u64* xch = (u64*)(lds + (ka.shared_consts ? ka.nconst * ka.slot_bytes : 0u) + ka.G * ka.inst_bytes);   // exchange area: 28 columns x 64 lanes, column-major (conflict-free)
-  __syncthreads();
-  const uint4* descs4 = (const uint4*)ka.descs;
-  Step st = ka.steps[0];
-  Step nst = ka.steps[ka.nsteps > 1 ? 1 : 0];
-  uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0;
-  if (lane_in < st.nlanes) {
-    const u32 o = (st.desc_off + lane_in * st.stride) >> 2;
-    d0 = descs4[o];
-    if (st.stride > 4) d1 = descs4[o + 1];
-  }
-  for (u32 s = 0; s < ka.nsteps; s++) {
-    const u32 sn = (s + 2 < ka.nsteps) ? s + 2 : ka.nsteps - 1;
-    const Step nnst = ka.steps[sn];
-    uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
-    if (lane_in < nst.nlanes) {
-      const u32 o = (nst.desc_off + lane_in * nst.stride) >> 2;
-      n0 = descs4[o];
-      if (nst.stride > 4) n1 = descs4[o + 1];
-    }
-    const bool active = lane_in < st.nlanes;
-    const u32 d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-    const uint4* gr = descs4 + ((st.desc_off + lane_in * st.stride) >> 2) + 2;   // descriptor of round 0
-    if (st.kind == K_DOT && st.p0 >= 2) {        // uniform: split the product rounds between the two waves
-      const u32 h = (st.p0 + 1) / 2;
-      u64 acc[2 * NL];
-      if (active) {
-        const u32 lo = wave == 0 ? 0 : h, hi = wave == 0 ? h : st.p0;
-        if (wave == 0) dot_init(acc, st, d[0]);
-        else {
-#pragma unroll
-          for (int c = 0; c < 2 * NL; c++) acc[c] = 0;
-        }
-        uint4 cur = gr[lo];
-        for (u32 r = lo; r < hi; r++) {
-          uint4 nx = cur;
-          if (r + 1 < hi) nx = gr[r + 1];
-          dot_round(acc, round_shape(st, r), round_signs(d[1], r), cur.x, cur.y, cur.z, cur.w, lds, cx);
-          cur = nx;
-        }
-        if (wave == 1) {
-#pragma unroll
-          for (int c = 0; c < 2 * NL; c++) xch[c * 64 + lane] = acc[c];
-        }
-      }
-      __syncthreads();
-      if (active && wave == 0) {
-#pragma unroll
-        for (int c = 0; c < 2 * NL; c++) acc[c] += xch[c * 64 + lane];
-        u32 res[NL];
-        const u32 dst = dot_finish(res, acc, st, d, lds, cx, ka.qp_table);
-        st14(lds, dst, res);
-      }
-    } else if (active && wave == 0) {
-      u32 res[NL];
-      u32 dst;
-      if (st.kind == K_DOT) {
-        u64 acc[2 * NL];
-        dot_init(acc, st, d[0]);
-        for (u32 r = 0; r < st.p0; r++) { const uint4 cur = gr[r]; dot_round(acc, round_shape(st, r), round_signs(d[1], r), cur.x, cur.y, cur.z, cur.w, lds, cx); }
-        dst = dot_finish(res, acc, st, d, lds, cx, ka.qp_table);
-      } else dst = exec_lane(st, d, lds, cx, ka.bufs, res, ka.qp_table);
-      if (dst != 0xffffffffu) st14(lds, dst, res);
-    }
-    __syncthreads();
-    st = nst; nst = nnst; d0 = n0; d1 = n1;
-  }
-}
-
 }  // namespace nbls
 
 // host-side launcher (C linkage, used by nbls_api.cpp)
@@ -241,22 +158,15 @@ extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, vo
       hipFuncSetAttribute((const void*)nbls_vm_kernel_sc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipFuncSetAttribute((const void*)nbls_vm_kernel_ls4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipFuncSetAttribute((const void*)nbls_vm_kernel_fair_sc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute((const void*)nbls_vm_kernel_split, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set[dev] = true;
     }
   }
-  // NBLS_SPLIT=1 forces the two-wave kernel.  It was the default for launches of at most 256 workgroups in round 1 (18 % lower latency there);
-  // since the instruction-count cuts of round 2 the one-wave kernel is faster at every size (one pairing: 2.96 ms against 3.30 ms), so it is
-  // kept as an experiment (and exercised by the tests) only.
-  static const int split_mode = getenv("NBLS_SPLIT") ? atoi(getenv("NBLS_SPLIT")) : -1;
   static const unsigned lds_floor = getenv("NBLS_LDS_FLOOR") ? (unsigned)atoi(getenv("NBLS_LDS_FLOOR")) : 0u;   // placement studies: caps workgroups per CU at 160 KB / floor
   if (lds_bytes < lds_floor) lds_bytes = lds_floor;
-  const bool split = split_mode == 1;
   if (ka->lsplit == 4) {
     if (ka->shared_consts) return -1;   // lane-split programs are compiled with replicated constants only
     hipLaunchKernelGGL(nbls_vm_kernel_ls4, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, *ka);
-  } else if (split) hipLaunchKernelGGL(nbls_vm_kernel_split, dim3(blocks), dim3(128), lds_bytes + 2 * NLIMBS * 64 * 8, (hipStream_t)stream, *ka);
-  else {
+  } else {
     static const int fair_mode = getenv("NBLS_FAIR") ? atoi(getenv("NBLS_FAIR")) : -1;   // 0 never, 1 always, unset: launches of 2..4 wavefronts per SIMD
     const bool fair = fair_mode >= 0 ? fair_mode != 0 : (blocks > 1024 && blocks <= 4096);
     if (ka->shared_consts) {

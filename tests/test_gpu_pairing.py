@@ -151,11 +151,11 @@ def test_batch_131072_properties(eng, oracle):
     assert prod == bytes(47) + b'\x01' + bytes(528)
 
 
-@pytest.mark.parametrize('split', ['0', '1'])
-def test_both_vm_kernels(split):
-    """nbls_vm_kernel (one wavefront per workgroup) and nbls_vm_kernel_split (two wavefronts sharing every K_DOT lane-op, chosen
-    automatically for launches of <= 256 workgroups) forced in turn over the whole pipeline: pairings at several batch sizes
-    against the oracle, a Miller product and a verifyBatch.  NBLS_SPLIT is read once per process, hence the subprocess."""
+@pytest.mark.parametrize('ls_max', ['0', '1024'])
+def test_plain_and_lane_split_programs(ls_max):
+    """Launches of at most 1024 items run the lane-split programs (nbls_vm_kernel_ls4: every K_DOT lane-op on four adjacent lanes, columns summed by DPP); NBLS_LS_MAX=0
+    keeps the plain programs for them.  Both in turn over the whole pipeline: pairings at several batch sizes against the oracle, a Miller product and a verifyBatch.
+    NBLS_LS_MAX is read once per process, hence the subprocess."""
     import subprocess, sys, textwrap
     code = textwrap.dedent('''
         import importlib, os, sys
@@ -165,17 +165,20 @@ def test_both_vm_kernels(split):
         pkg = importlib.import_module('noble-bls12-381_amd')
         eng, oracle, golden = pkg.Engine(0), oracle_py.load(), goldenio.load('ref_vectors.json.gz')
         pairs = golden['pairs']
-        for n in (1, 3, 37, 1500):
+        for n in (1, 3, 37, 1024, 1500):
             g1 = b''.join(hx(pairs[i %% len(pairs)]['g1']) for i in range(n)); g2 = b''.join(hx(pairs[(5 * i + 1) %% len(pairs)]['g2']) for i in range(n))
-            out, st = eng.pairing_batch(g1, g2, True, False)
-            ref, _ = oracle.pairing_batch(g1, g2, True, False, threads=16)
-            assert out == ref, n
+            for fe in (True, False):
+                out, st = eng.pairing_batch(g1, g2, fe, False)
+                ref, _ = oracle.pairing_batch(g1, g2, fe, False, threads=16)
+                assert out == ref, n
             assert eng.miller_product(g1, g2, True)[0] == oracle.miller_product(g1, g2, True), n
         vb = golden['verify_batch']
         assert eng.verify_batch(hx(vb['agg_sig']), [hx(m) for m in vb['msgs']], [hx(p) for p in vb['pks']]) is True
+        names = [eng.lib.nbls_program_name(i).decode() for i in range(eng.lib.nbls_program_count())]
+        assert 'expx_ls' in names
         print('ok')
     ''') % (ROOT, ROOT)
-    env = dict(os.environ, NBLS_SPLIT=split)
+    env = dict(os.environ, NBLS_LS_MAX=ls_max)
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where does the dispatcher put the single-wavefront workgroups of a launch?  Histogram of workgroups per SIMD / per CU for
-n work items (4 per workgroup).  Usage: [NBLS_LDS_FLOOR=bytes] [NBLS_SPLIT=0] tools/placement.py n"""
+n work items (4 per workgroup).  Usage: [NBLS_LDS_FLOOR=bytes] tools/placement.py n"""
 import collections, ctypes as C, importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

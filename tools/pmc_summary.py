@@ -11,7 +11,7 @@ min_grid = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 CYCLE = ['lines_pq', 'acc_fe', 'fe_easy', 'expx', 'fe_mid1', 'expx', 'expx', 'expx', 'fe_mid2', 'expx', 'fe_final']
 if os.environ.get('NBLS_FUSED_MILLER'):
     CYCLE = ['miller_fe'] + CYCLE[2:]   # the one-program Miller loop of round 1 (A/B switch of the library)
-VM = ('nbls_vm_kernel', 'nbls_vm_kernel_fair', 'nbls_vm_kernel_sc', 'nbls_vm_kernel_fair_sc', 'nbls_vm_kernel_ls4', 'nbls_vm_kernel_split')   # the launcher picks an instantiation by launch shape (csrc/vm_kernel.hip)
+VM = ('nbls_vm_kernel', 'nbls_vm_kernel_fair', 'nbls_vm_kernel_sc', 'nbls_vm_kernel_fair_sc', 'nbls_vm_kernel_ls4')   # the launcher picks an instantiation by launch shape (csrc/vm_kernel.hip)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for f in sorted(glob.glob(root + '/pmc*/**/*_counter_collection.csv', recursive=True)):
