@@ -321,7 +321,7 @@ def main():
             ldt_f = (time.perf_counter() - f0) / (LF * lreps)
             assert bytes(louts[-1][:576 * 8].cpu().numpy().tobytes()) == ref, 'large-batch in-flight parity check failed'
             del louts
-            # the call runs as two halves on two streams from 32,768 pairs (csrc/nbls_api.cpp): its kernels overlap, so achieved / frac are over the WALL time of the call
+            # the call runs as two halves on two streams from 8192 pairs (csrc/nbls_api.cpp): its kernels overlap, so achieved / frac are over the WALL time of the call
             roof['large_batch'] = {'pairings': nl, 'pairings_per_s': round(nl / ldt, 2), 'ms_per_call': round(ldt * 1e3, 3),
                                    'achieved': round(nl * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL / ldt / 1e12, 4),
                                    'frac': round(nl * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL / ldt / 1e12 / PEAK_TMAD, 4),

@@ -203,7 +203,7 @@ int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks);
 /* Tuning knobs of a context (defaults are the measured optimum; tests use them to force a code path).
  * NBLS_TUNE_SPLIT_MILLER_MIN: number of pairs from which the Miller loop runs as two programs (line tables through HBM) instead of one. */
 #define NBLS_TUNE_SPLIT_MILLER_MIN 1
-#define NBLS_TUNE_HALVES_MIN 2         /* pairs from which nbls_pairing_batch_dev runs a batch as two halves on two streams (default 32768; 0 = never) */
+#define NBLS_TUNE_HALVES_MIN 2         /* pairs from which nbls_pairing_batch_dev runs a batch as two halves on two streams (default 8192; 0 = never) */
 int nbls_set_tuning(nbls_ctx* ctx, int key, long long value);
 int nbls_program_count(void);                 /* number of step programs; timing slot nbls_program_count() = the inversion kernel */
 const char* nbls_program_name(int prog);

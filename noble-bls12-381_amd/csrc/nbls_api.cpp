@@ -62,7 +62,7 @@ struct nbls_ctx {
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; uint8_t* side_scratch = nullptr;
   // large pairing batches run as two halves on two streams (nbls_pairing_batch_dev): item offset applied to every per-item buffer of a launch, second stream, events
   size_t ioff = 0; hipStream_t half_stream = nullptr; hipEvent_t ev_half_fork = nullptr, ev_half_join = nullptr;
-  size_t halves_min = getenv("NBLS_HALVES_MIN") ? (atol(getenv("NBLS_HALVES_MIN")) > 0 ? (size_t)atol(getenv("NBLS_HALVES_MIN")) : (size_t)-1) : 32768;   // NBLS_HALVES_MIN=0: never (profiles of kernels running alone)
+  size_t halves_min = getenv("NBLS_HALVES_MIN") ? (atol(getenv("NBLS_HALVES_MIN")) > 0 ? (size_t)atol(getenv("NBLS_HALVES_MIN")) : (size_t)-1) : 8192;   // NBLS_HALVES_MIN=0: never (profiles of kernels running alone)
   hipStream_t side2 = nullptr; hipEvent_t ev_join2 = nullptr;   // verifyBatch: key decoding runs beside message hashing (their exponentiation kernels are latency-bound and leave issue slots free)
   uint8_t* ident_g1 = nullptr; uint8_t* ident_g2 = nullptr;   // projective identity (0 : 1 : 0), raw
   size_t cap_F = 0, cap_io = 0;
@@ -364,10 +364,13 @@ EXPORT int nbls_pairing_batch_dev(nbls_ctx* ctx, size_t n, const void* d_g1, con
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   StreamOrder order_(ctx, s);
-  // A large batch runs as two halves on two streams: every launch of a dependent chain ends in a partly filled round of wavefronts (EXPX at 65,536 pairs: 4.65
+  // A batch of 8192 pairs or more runs as two halves on two streams: every launch of a dependent chain ends in a partly filled round of wavefronts (EXPX at 65,536 pairs: 4.65
   // rounds of 2,816 resident wavefronts), and the tail of one half is filled by the other (65,536 pairs: 27.4 -> 25.9 ms).  Both halves use the caller's scratch
   // through an item offset (ctx->ioff, applied by run() to every per-item buffer) and the two-program Miller loop (what counts with work in flight is the instruction count).
-  if (n >= ctx->halves_min && n <= LINES_CHUNK) {
+  // (measured from 8192 pairs up: 8192 5.08 -> 4.69 ms, 16,384 8.53 -> 7.73, 24,576 11.96 -> 10.33, 32,768 14.96 -> 13.64, 65,536 27.5 -> 26.0; the exception is a batch that
+  // fills the chip exactly three wavefronts deep in ONE round with the fused program, 12,288 pairs: 6.04 ms against 6.39)
+  const bool one_full_round = n > 10752 && n <= 12288;
+  if (n >= ctx->halves_min && !one_full_round && n <= LINES_CHUNK) {
     int r;
     if ((r = ensure_lines(ctx, n))) return r;
     if (with_final_exp && (r = ensure_scratch(ctx, n))) return r;

@@ -221,4 +221,4 @@ def test_two_halves_execution(oracle, golden):
             assert got == ref
             exp, _ = oracle.pairing_batch(g1, g2, fe, False, threads=16)
             assert got == exp
-    eng.set_halves_min(32768)
+    eng.set_halves_min(8192)
