@@ -128,6 +128,15 @@ static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pa
         fprintf(stderr, "nbls (checked): %s: buffer %d: %s (stride %llu, the program touches %u bytes per item)\n", d.p->name.c_str(), k, ka.bufs[k].ptr ? "stride too small" : "not bound", (unsigned long long)ka.bufs[k].stride, ext);
         return NBLS_EINVAL;
       }
+      // the last item's bytes must lie inside the allocation the pointer belongs to (items reached through an index list are not bounded by n)
+      hipDeviceptr_t base = nullptr; size_t size = 0;
+      if (n && !item_index && hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ka.bufs[k].ptr) == hipSuccess) {
+        const size_t end = (size_t)((uint8_t*)ka.bufs[k].ptr - (uint8_t*)base) + (n - 1) * ka.bufs[k].stride + ext;
+        if (end > size) {
+          fprintf(stderr, "nbls (checked): %s: buffer %d: %zu items of stride %llu (+%u) end %zu bytes into an allocation of %zu\n", d.p->name.c_str(), k, n, (unsigned long long)ka.bufs[k].stride, ext, end, size);
+          return NBLS_EINVAL;
+        }
+      } else (void)hipGetLastError();
     }
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
