@@ -4,7 +4,7 @@
 One "step" = one pass of the hot path over one batch: pairing(P_i, Q_i) for a batch of 4096 independent, pre-validated
 point pairs per GPU (BASELINE.json configs[1]; Miller loop with on-the-fly line computation + final exponentiation),
 inputs and outputs resident in HBM, called through the C ABI (libnbls.so).  Consecutive steps are independent batches; they
-are submitted to `--inflight` engine contexts (default 7), each with its own HIP stream and scratch, so that they overlap
+are submitted to `--inflight` engine contexts (default 12), each with its own HIP stream and scratch, so that they overlap
 on the GPU the way a service keeps several requests in flight (a 4096-pairing call alone fills the chip one wavefront
 deep).  `value` is the throughput of the K timed steps; `single_stream` reports the strictly serial figure (= per-batch
 latency) next to it, and the roofline object is measured on one batch running alone.  Multi-GPU: one process per GPU,
@@ -60,7 +60,7 @@ def main():
     ap.add_argument('--steps', type=int, default=512, help='timed steps (default: about one second of GPU time)')
     ap.add_argument('--warmup', type=int, default=16)
     ap.add_argument('--batch', type=int, default=BATCH)
-    ap.add_argument('--inflight', type=int, default=7, help='batches kept in flight on separate HIP streams during the timed steps (1 = strictly one batch at a time)')
+    ap.add_argument('--inflight', type=int, default=12, help='batches kept in flight on separate HIP streams during the timed steps (1 = strictly one batch at a time)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-dist', action='store_true', help='run the torch.distributed / RCCL code paths (process group, barriers, all-gathers, sharded legs) even with one rank: the only way to execute them on a one-GPU box')
     ap.add_argument('--verify-batch', type=int, default=65536, help='signatures in the verifyBatch leg (BASELINE configs[2]); 0 disables')
@@ -74,7 +74,7 @@ def main():
 
     # the HIP runtime maps streams onto this many hardware queues (default 4): with fewer queues than batches in flight two
     # streams share a queue and their kernels serialise (must be set before the runtime initialises)
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

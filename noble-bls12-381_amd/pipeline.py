@@ -3,22 +3,22 @@
 A call of 4096 pairings fills the chip exactly one wavefront deep (1024 workgroups on 1024 SIMDs), and a lone wavefront
 reaches well under half of a SIMD's issue rate, so one batch at a time leaves most of the machine
 idle.  Consecutive batches are independent, so a service keeps several of them in flight: the kernels of batch i+1 run
-beside those of batch i on other streams.  Throughput at 4096-pairing batches rises from 1.3 M (one call at a time, 3.1 ms each) to 2.5 M pairings/s with seven batches in
-flight (bench.py; 2.15 M with four, 2.31 M with five, 2.42 M with six, 2.22 M with eight).  The HIP runtime multiplexes streams onto
-GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue serialise, so set GPU_MAX_HW_QUEUES=8 in the
-environment before the runtime initialises when more than three batches are kept in flight.
+beside those of batch i on other streams.  Throughput at 4096-pairing batches rises from 1.3 M (one call at a time, 3.1 ms each) to 2.5 M pairings/s with seven to twenty batches in
+flight (bench.py; 2.15 M with four, 2.31 M with five, 2.42 M with six, 2.47 M with seven, 2.52 M with ten or twelve, 2.55 M with fourteen).  The HIP runtime
+multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue serialise (eight batches on eight queues: 2.22 M, on
+sixteen queues: 2.50 M), so set GPU_MAX_HW_QUEUES=16 in the environment before the runtime initialises when more than three batches are kept in flight.
 """
 from .engine import Engine
 
 
 class PairingPipeline:
-    def __init__(self, device_id=0, depth=7):
+    def __init__(self, device_id=0, depth=12):
         assert depth >= 1
         self.engines = [Engine(device_id) for _ in range(depth)]
         self.depth = depth
         # With several batches in flight the SIMDs are shared by wavefronts of different calls, so what counts is the instruction count per
         # pairing, not the length of one call's longest instruction stream: the two-program Miller loop (15 % fewer instructions) is used
-        # whatever the batch size.  A single context keeps the library's latency-oriented default (one program below 16,384 pairs).
+        # whatever the batch size.  A single context keeps the library's latency-oriented default (one fused program below 8192 pairs).
         if depth > 1:
             for e in self.engines:
                 e.set_split_miller_min(0)

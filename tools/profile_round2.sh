@@ -2,7 +2,7 @@
 # Round-2 profile set (run on the GPU box through gpurun; about four minutes).  Everything lands in gpurun_out/prof_r2/ and the summaries that
 # are kept are copied to profiles/ by hand (tools/README.md).  Counters are collected in their own passes with --kernel-trace only.
 #   1. rocprofv3 --kernel-trace --stats of the default bench configuration, one 4096-pairing call at a time     -> kernel_stats_b4096.csv
-#   2. the same with seven calls in flight (the configuration of `value`)                                      -> kernel_stats_b4096_inflight7.csv
+#   2. the same with twelve calls in flight (the configuration of `value`)                                     -> kernel_stats_b4096_inflight12.csv
 #   3. the same for one 65,536-pairing call at a time                                                          -> kernel_stats_b65536.csv
 #   4. PMC passes at 4096 and 65,536 (tools/pmc_summary.py)                                                    -> pmc_b4096.csv, pmc_b65536.csv
 #   5. per-kernel times of one verifyBatch of 65,536 signatures (tools/verify_breakdown.py)                     -> verify_breakdown.txt
@@ -16,7 +16,7 @@ stats() {   # <name> <bench args>
   f=$(find $out/$1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/kernel_stats_$1.csv
 }
 stats b4096 "--steps 16 --warmup 2 --batch 4096 --inflight 1"
-stats b4096_inflight7 "--steps 112 --warmup 7 --batch 4096 --inflight 7"
+stats b4096_inflight12 "--steps 192 --warmup 12 --batch 4096 --inflight 12"
 stats b65536 "--steps 3 --warmup 1 --batch 65536 --inflight 1"
 for b in 4096 65536; do
   cmd="python bench.py --steps 3 --warmup 1 --batch $b --inflight 1 $common"
