@@ -207,7 +207,7 @@ def test_batches_in_flight(oracle):
 
 
 def test_two_halves_execution(oracle, golden):
-    """nbls_pairing_batch_dev runs batches from 32,768 pairs as two halves on two streams sharing the caller's scratch through an item offset; forced here at a
+    """nbls_pairing_batch_dev runs batches from 8192 pairs as two halves on two streams sharing the caller's scratch through an item offset; forced here at a
     size the oracle can check: same bytes as the one-stream execution, with and without the final exponentiation, odd and even sizes."""
     pkg = importlib.import_module('noble-bls12-381_amd')
     eng = pkg.Engine(0)
@@ -222,3 +222,18 @@ def test_two_halves_execution(oracle, golden):
             exp, _ = oracle.pairing_batch(g1, g2, fe, False, threads=16)
             assert got == exp
     eng.set_halves_min(8192)
+
+
+@pytest.mark.gpu
+def test_default_dispatch_thresholds(oracle, golden):
+    """Batch sizes either side of the library's default dispatch thresholds (two halves from 8192 pairs, except the one-full-round window 10,753 .. 12,288),
+    untouched tuning: every pairing byte-equal to the oracle, last item included."""
+    import os
+    pkg = importlib.import_module('noble-bls12-381_amd')
+    eng = pkg.Engine(0)
+    pairs = golden['pairs']
+    for n in (8191, 8192, 10753, 12289):
+        g1 = b''.join(hx(pairs[(3 * i + n) % len(pairs)]['g1']) for i in range(n)); g2 = b''.join(hx(pairs[(5 * i + 1) % len(pairs)]['g2']) for i in range(n))
+        got, _ = eng.pairing_batch(g1, g2, True, False)
+        exp, _ = oracle.pairing_batch(g1, g2, True, False, threads=os.cpu_count() or 16)
+        assert got == exp, n
