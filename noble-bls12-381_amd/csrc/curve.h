@@ -75,6 +75,19 @@ template <> inline Pt<SFp2> pt_dbl_n<SFp2>(const Pt<SFp2>& p, int n) {
     // n2 = -t2 = -3(1 + u) d^2: as POSITIVE terms of the sums a = t0 + 3 n2 and b' = -b = n2 - t0 it needs no bound contraction
     // (a subtracted term must stay below 6p, and this lane-op's result is bounded by ~6.1p)
     SFp2 t0 = mat(sqr(y)), t1 = mat(mul(y, d)), n2 = mat(-scale(mulnr(sqr(d)), 3)), xy = mat(mul(x, y));
+    static const bool two_squares = !getenv("NBLS_DBL_PLAIN");
+    if (two_squares) {
+      // y' = -a nb - 8 t0 n2 = t0^2 - 6 t0 n2 - 3 n2^2 = S^2 - 12 n2^2 with S = t0 - 3 n2: a difference of two Fp2 SQUARES costs two limb products per
+      // coefficient where the sum of two Fp2 products costs four -- the second level of a doubling is then ONE product round instead of two.  The
+      // factor 12 rides on sums: 12 (q0^2 - q1^2) = 4 (q0 + q1)(3 q0 - 3 q1), 24 q0 q1 = 8 q0 (3 q1) (x 4 = both single-slot operands doubled).
+      SFp2 a = mat(t0 + scale(n2, 3)), S = mat(t0 - scale(n2, 3));
+      SFp P = SFp(materialize(n2.c0 + n2.c1)), M3 = SFp(materialize(scale(n2.c0 - n2.c1, 3))), K = SFp(materialize(scale(n2.c1, 3)));
+      SFp2 nx = mat(scale(mul(a, xy), 2));
+      SFp2 ny = mat(SFp2{mul(S.c0 + S.c1, S.c0 - S.c1) - scale(mul(P, M3), 4), scale(mul(S.c0, S.c1), 2) - scale(mul(n2.c0, K), 8)});
+      SFp2 nd = mat(scale(mul(t0, t1), 8));
+      x = nx; y = ny; d = nd;
+      continue;
+    }
     SFp2 a = mat(t0 + scale(n2, 3)), nb = mat(n2 - t0), e = mat(scale(t0, 4));
     SFp2 nx = mat(scale(mul(a, xy), 2)), ny = mat(-mul(a, nb) - scale(mul(e, n2), 2)), nd = mat(scale(mul(e, t1), 2));
     x = nx; y = ny; d = nd;
