@@ -113,10 +113,22 @@ static void trace_lines(const SFp2& Qx, const SFp2& Qy, const LineSink& out) {
   for (int i = 62; i >= 0; i--) {
     // doubling step, math.ts:1339-1351
     SFp2 t0 = mat(sqr(Ry)), t2 = mat(scale(mulnr(sqr(D)), 3)), t4 = mat(mul(Ry, D)), c1 = mat(scale(sqr(Rx), 3)), rxry = mat(mul(Rx, Ry));
-    SFp2 t3 = mat(scale(t2, 3));
     SFp2 A = halve(t0 - scale(t2, 3)), Bh = halve(t0 + scale(t2, 3));
-    emit_line(out, j++, mat(t2 - t0), c1, mat(-t4));
-    SFp2 nRx = mat(mul(A, rxry)), nRy = mat(sqr(Bh) - mul(t2, t3)), nD = mat(scale(mul(t0, t4), 2));
+    SFp2 nRy;
+    static const bool two_squares = !getenv("NBLS_DBL_PLAIN");
+    if (out.Px && two_squares) {
+      // Ry' = B^2 - 3 t2^2 is a difference of two Fp2 squares: two limb products per coefficient (B^2: (b0 + b1)(b0 - b1), 2 b0 b1; 3 t2^2: (t0' + t1')(3 t0' - 3 t1'),
+      // 2 t0' (3 t1') with the factor 3 carried by sums) where B^2 - t2 t3 costs three, so the second level is one full product round.  The three sums take the lanes that
+      // -t4 occupied: with P known, c2 Py = -(t4 Py) negates inside the product (LINES_Q stores c2 itself and keeps the other form).
+      SFp Ps = SFp(materialize(t2.c0 + t2.c1)), M = SFp(materialize(scale(t2.c0 - t2.c1, 3))), K = SFp(materialize(scale(t2.c1, 3)));
+      emit_line(out, j++, mat(t2 - t0), c1, -t4);
+      nRy = mat(SFp2{mul(Bh.c0 + Bh.c1, Bh.c0 - Bh.c1) - mul(Ps, M), scale(mul(Bh.c0, Bh.c1), 2) - scale(mul(t2.c0, K), 2)});
+    } else {
+      SFp2 t3 = mat(scale(t2, 3));
+      emit_line(out, j++, mat(t2 - t0), c1, mat(-t4));
+      nRy = mat(sqr(Bh) - mul(t2, t3));
+    }
+    SFp2 nRx = mat(mul(A, rxry)), nD = mat(scale(mul(t0, t4), 2));
     Rx = nRx; Ry = nRy; D = nD;
     if ((NBLS_X >> i) & 1) {
       // addition step, math.ts:1353-1367, on Rz = D / 2
