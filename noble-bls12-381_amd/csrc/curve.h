@@ -68,6 +68,22 @@ template <> inline Pt<SFp> pt_dbl<SFp>(const Pt<SFp>& p) {
 // d is 2 * 8 t0 (y z) = 2 e t1 with e = 4 t0.  Entering costs one sum (d = z + z), leaving one (x, y doubled: (2x : 2y : d) is
 // the same projective point as (x : y : d / 2)).  A single doubling stays with pt_dbl.
 template <class F> static inline Pt<F> pt_dbl_n(const Pt<F>& p, int n) { Pt<F> r = p; for (int i = 0; i < n; i++) r = pt_dbl(r); return r; }
+// Over Fp the second level of a doubling has three results, x' (one product), y' = a b + 8 t0 t2 (two) and z' (one), on four lanes: the wavefront walks a
+// two-product round for the sake of one lane.  With y' = t0^2 + 6 t0 t2 - 3 t2^2 = S^2 - 12 t2^2 (S = t0 + 3 t2; 3 is a non-residue, so it stays two
+// products) the two squares go to two lanes, U = S^2 and V = 12 t2^2 = 3 (2 t2)(2 t2), and y' = U - V is never formed: every use of y in the next doubling
+// is a product operand (y^2, y z, x y), where a two-term form is a pre-addition.  Four lanes x one product in both levels; y is summed once, when the run ends.
+template <> inline Pt<SFp> pt_dbl_n<SFp>(const Pt<SFp>& p, int n) {
+  static const bool lazy_y = !getenv("NBLS_DBL_PLAIN");
+  if (n < 4 || !lazy_y) { Pt<SFp> r = p; for (int i = 0; i < n; i++) r = pt_dbl(r); return r; }   // short runs (the 3-bit windows of the ladders): the closing sum costs a step, measured slower
+  SFp x = p.x, y = p.y, z = p.z;
+  for (int i = 0; i < n; i++) {
+    SFp t0 = mat(sqr(y)), t1 = mat(mul(y, z)), t2 = mat(mul_b3(sqr(z))), xy = mat(mul(x, y));
+    SFp a = mat(t0 - scale(t2, 3)), S = mat(t0 + scale(t2, 3));
+    SFp nx = mat(scale(mul(a, xy), 2)), U = mat(sqr(S)), V = mat(scale(sqr(t2), 12)), nz = mat(scale(mul(t0, t1), 8));
+    x = nx; y = U - V; z = nz;
+  }
+  return {x, mat(y), z};
+}
 template <> inline Pt<SFp2> pt_dbl_n<SFp2>(const Pt<SFp2>& p, int n) {
   if (n < 2) return n ? pt_dbl(p) : p;
   SFp2 x = p.x, y = p.y, d = mat(scale(p.z, 2));
