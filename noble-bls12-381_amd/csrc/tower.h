@@ -74,6 +74,20 @@ static inline SFp12 mul(const SFp12& a, const SFp12& b) {         // math.ts:748
   SFp6 t1 = mat(mul(a.c0, b.c0)), t2 = mat(mul(a.c1, b.c1));
   SFp6 sa = mat(a.c0 + a.c1), sb = mat(b.c0 + b.c1);
   SFp6 v = mul(sa, sb);
+  // The middle product alone would be six lanes of six limb products (three rounds) beside six idle lanes: every coefficient is cut into two lane-ops of
+  // three products on all twelve lanes (a round and a half), and the halves meet in the sum that forms c1 anyway (v - t1 - t2 becomes vl + vh - t1 - t2).
+  static const bool split_mid = !getenv("NBLS_MUL12_PLAIN");
+  if (split_mid) {
+    // each half takes one of the subtracted terms as a post-subtraction of its lane-op (offset inside the accumulator), so the closing sum has two positive terms and needs no k p constant
+    auto halves = [](const SFp& x, const SFp& s1, const SFp& s2) {
+      const size_t h = (x.f.size() + 1) / 2;
+      SFp lo, hi;
+      lo.f.assign(x.f.begin(), x.f.begin() + h); hi.f.assign(x.f.begin() + h, x.f.end());
+      return SFp(materialize(lo - s1)) + SFp(materialize(hi - s2));
+    };
+    auto halves2 = [&](const SFp2& x, const SFp2& s1, const SFp2& s2) { return SFp2{halves(x.c0, s1.c0, s2.c0), halves(x.c1, s1.c1, s2.c1)}; };
+    return {t1 + mulnr(t2), {halves2(v.c0, t1.c0, t2.c0), halves2(v.c1, t1.c1, t2.c1), halves2(v.c2, t1.c2, t2.c2)}};
+  }
   return {t1 + mulnr(t2), v - (t1 + t2)};
 }
 // f * (o0 + o1 v + o4 v w): every output coefficient is 3 Fp2 products of f with the line  (= math.ts:768-777)

@@ -92,7 +92,7 @@ int Builder::kp_atom(int k) {
   assert(k >= 1 && k <= 64);
   u32 P[NLIMBS] = NBLS_P_INIT, acc[NLIMBS] = {0};
   for (int i = 0; i < k; i++) { for (int j = 0; j < NLIMBS; j++) acc[j] += P[j]; carry_norm(acc); }
-  int id = const_atom(acc); nodes[id].bound = k; return id;
+  int id = const_atom(acc); nodes[id].bound = k; if (getenv("NBLS_DUMP_KP")) fprintf(stderr, "kp %d\n", k); return id;
 }
 
 int Builder::contract(int atom) {
