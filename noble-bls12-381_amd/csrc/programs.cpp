@@ -278,7 +278,7 @@ static Program build(ProgId id) {
       InvChain c = inv_chain(f);
       SFp12 finv = mat(inv_finish(f, c, ninv));
       outputw_fp12(trace_fe_easy(f, finv), 5, 0);
-      return B.compile("fe_easy", 16);
+      return B.compile("fe_easy", env_int("NBLS_FE_EASY_W", 16));
     }
     case P_EXPX: case P_EXPX_LS: {
       if (env_int("NBLS_EXPX_RELOAD", 1)) {
@@ -290,17 +290,17 @@ static Program build(ProgId id) {
     case P_FE_MID1: {
       SFp12 a = inputw_fp12(3, 0), b = inputw_fp12(5, 0);
       outputw_fp12(mul(conj(mat(cyclotomic_sqr(a))), b), 6, 0);
-      return B.compile("fe_mid1", 16);
+      return B.compile("fe_mid1", env_int("NBLS_FE_MID_W", 12));
     }
     case P_FE_MID2: {
       SFp12 a = inputw_fp12(3, 0), b = inputw_fp12(5, 0);
       outputw_fp12(mul(a, mat(cyclotomic_sqr(b))), 6, 0);
-      return B.compile("fe_mid2", 16);
+      return B.compile("fe_mid2", env_int("NBLS_FE_MID_W", 12));
     }
     case P_FE_FINAL: {
       SFp12 t[7]; for (int i = 0; i < 7; i++) t[i] = inputw_fp12(i, 0);
       output_fp12(trace_fe_final(t[0], t[1], t[2], t[3], t[4], t[5], t[6]), 7, 0);
-      return B.compile("fe_final", 32);
+      return B.compile("fe_final", env_int("NBLS_FE_FINAL_W", 32));
     }
     case P_MUL2: {
       SFp12 a = inputw_fp12(3, 0), b = inputw_fp12(3, 576);
