@@ -378,3 +378,15 @@ def test_lane_split_programs(sim, oracle, golden):
     vmsim_py.final_exp(sim, n, F, N, out, expx='EXPX_LS')
     for i in range(n):
         assert out.raw[576 * i:576 * (i + 1)] == hx(golden['pairs'][i]['pairing']), i
+
+
+def test_plain_formula_switches():
+    """NBLS_DBL_PLAIN / NBLS_MUL12_PLAIN select the formulas that the difference-of-squares doublings and the split Fp12 middle product replaced (DESIGN.md
+    section 3.3; they exist for A/B timing).  Both must stay bit-exact: the tests that cover the point chains, the line tables and the Fp12 products run again
+    in a fresh process with the switches set (the switches are read once per process)."""
+    import os, subprocess, sys
+    env = dict(os.environ, NBLS_DBL_PLAIN='1', NBLS_MUL12_PLAIN='1')
+    sel = 'validity or hash_to_g2 or scalar_mul or full_pairing or split_miller or final_exp'
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-p', 'no:cacheprovider', os.path.abspath(__file__), '-k', sel], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'passed' in r.stdout
