@@ -70,7 +70,33 @@ def main():
     ap.add_argument('--sign-batch', type=int, default=8192, help='signatures produced in the sign leg (SURVEY 8(f).1); 0 disables')
     ap.add_argument('--large-batch', type=int, default=65536, help='pairings of the saturated single-call leg (roofline at a launch that fills every SIMD three wavefronts deep); 0 disables')
     ap.add_argument('--product-terms', type=int, default=262144, help='terms of the sharded multi-pairing product leg (BASELINE configs[4]); 0 disables')
+    ap.add_argument('--dry-launch', action='store_true', help='launch check without a GPU: the ranks of --gpus N rendezvous over gloo, all-reduce their ranks and rank 0 prints one JSON line (tests/test_bench_launch.py)')
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (one process per GPU under torch.distributed.run, the
+    # same command line the driver uses) and let rank 0 of that job print the JSON line.  Under torchrun (WORLD_SIZE set) this is skipped.
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]
+        env = dict(os.environ); env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1', '--master-port', str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+    if args.dry_launch:
+        import torch
+        import torch.distributed as dist
+        world = int(os.environ.get('WORLD_SIZE', '1')); rank = int(os.environ.get('RANK', '0'))
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29519'); os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+        dist.init_process_group(backend='gloo')
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({'dry_launch': True, 'n_gpus': world, 'gpus_flag': args.gpus, 'rank_sum': int(t.item()), 'backend': 'gloo'}), flush=True)
+        dist.destroy_process_group()
+        return
 
     # the HIP runtime maps streams onto this many hardware queues (default 4): with fewer queues than batches in flight two
     # streams share a queue and their kernels serialise (must be set before the runtime initialises)
@@ -153,92 +179,98 @@ def main():
     # ---- secondary leg (all N): 2^18-term multi-pairing product with shared final exponentiation, terms sharded over the
     # ranks, ONE all-gather of 576-byte Fp12 partials over RCCL (BASELINE configs[4])
     product = None
-    if args.product_terms > 0:
-        par = importlib.import_module('noble-bls12-381_amd.parallel')
-        lo, hi = par.shard_bounds(args.product_terms, world, rank)
-        m = hi - lo
-        # interleave (P, Q) and (-P, Q): the product is ONE by bilinearity, a size-independent parity check
-        P1, Q1 = synth_points(oracle, 64, seed=77)
-        negP = b''.join(oracle.un('g1_neg_aff', P1[96 * i:96 * i + 96], 96) for i in range(64))
-        pg1 = bytearray(); pg2 = bytearray()
-        for j in range(0, 128, 2):
-            i = j // 2
-            pg1 += P1[96 * i:96 * i + 96] + negP[96 * i:96 * i + 96]
-            pg2 += Q1[192 * i:192 * i + 192] * 2
-        reps_needed = (m + 127) // 128
-        t1 = torch.frombuffer(bytearray(bytes(pg1) * reps_needed)[:96 * m], dtype=torch.uint8).cuda()
-        t2 = torch.frombuffer(bytearray(bytes(pg2) * reps_needed)[:192 * m], dtype=torch.uint8).cuda()
-        be = par.EngineBackend(eng)
-        res = par.miller_product_sharded(be, t1, t2)
-        torch.cuda.synchronize()
-        one = bytes(47) + b'\x01' + bytes(528)
-        assert (m % 2 == 0) and bytes(res.cpu().numpy().tobytes()) == one, 'product parity check failed'
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
-        p0 = time.perf_counter()
-        preps = 3
-        for _ in range(preps):
+    try:   # a failing secondary leg must not cost the headline line (its error is reported in its place)
+        if args.product_terms > 0:
+            par = importlib.import_module('noble-bls12-381_amd.parallel')
+            lo, hi = par.shard_bounds(args.product_terms, world, rank)
+            m = hi - lo
+            # interleave (P, Q) and (-P, Q): the product is ONE by bilinearity, a size-independent parity check
+            P1, Q1 = synth_points(oracle, 64, seed=77)
+            negP = b''.join(oracle.un('g1_neg_aff', P1[96 * i:96 * i + 96], 96) for i in range(64))
+            pg1 = bytearray(); pg2 = bytearray()
+            for j in range(0, 128, 2):
+                i = j // 2
+                pg1 += P1[96 * i:96 * i + 96] + negP[96 * i:96 * i + 96]
+                pg2 += Q1[192 * i:192 * i + 192] * 2
+            reps_needed = (m + 127) // 128
+            t1 = torch.frombuffer(bytearray(bytes(pg1) * reps_needed)[:96 * m], dtype=torch.uint8).cuda()
+            t2 = torch.frombuffer(bytearray(bytes(pg2) * reps_needed)[:192 * m], dtype=torch.uint8).cuda()
+            be = par.EngineBackend(eng)
             res = par.miller_product_sharded(be, t1, t2)
-        torch.cuda.synchronize()
-        if multi:
-            dist.barrier()
-        pdt = time.perf_counter() - p0
-        if multi:
-            t = torch.tensor([pdt], dtype=torch.float64, device='cuda')
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            pdt = float(t.item())
-        product = {'metric': 'multi-pairing product terms/sec (shared final exponentiation)', 'value': round(args.product_terms * preps / pdt, 2), 'terms': args.product_terms,
-                   'ms_per_product': round(pdt / preps * 1e3, 3), 'exchange': 'all-gather of %d x 576 B Fp12 partials' % world if world > 1 else 'none (1 rank)', 'result_is_one': True}
-        del t1, t2
+            torch.cuda.synchronize()
+            one = bytes(47) + b'\x01' + bytes(528)
+            assert (m % 2 == 0) and bytes(res.cpu().numpy().tobytes()) == one, 'product parity check failed'
+            if multi:
+                dist.barrier()
+            torch.cuda.synchronize()
+            p0 = time.perf_counter()
+            preps = 3
+            for _ in range(preps):
+                res = par.miller_product_sharded(be, t1, t2)
+            torch.cuda.synchronize()
+            if multi:
+                dist.barrier()
+            pdt = time.perf_counter() - p0
+            if multi:
+                t = torch.tensor([pdt], dtype=torch.float64, device='cuda')
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                pdt = float(t.item())
+            product = {'metric': 'multi-pairing product terms/sec (shared final exponentiation)', 'value': round(args.product_terms * preps / pdt, 2), 'terms': args.product_terms,
+                       'ms_per_product': round(pdt / preps * 1e3, 3), 'exchange': 'all-gather of %d x 576 B Fp12 partials' % world if world > 1 else 'none (1 rank)', 'result_is_one': True}
+            del t1, t2
+    except Exception as e:   # noqa: BLE001
+        product = {'error': repr(e)}
 
     # ---- secondary leg (N > 1): verifyBatch of --verify-batch signatures with the (key, message) pairs sharded over the ranks
     # (BASELINE configs[2] at 2 / 4 / 8 GPUs): every rank decodes + hashes its shard and reduces it to one Fp12 partial, ONE all-gather
     # of 576-byte partials, shared final exponentiation (parallel.verify_batch_sharded).  Setup (keys, signatures) also runs on the GPUs.
     vshard = None
-    if args.verify_batch > 0 and (multi or args.verify_sharded):
-        par = importlib.import_module('noble-bls12-381_amd.parallel')
-        nv = args.verify_batch
-        lo, hi = par.shard_bounds(nv, world, rank)
-        sks_l = [(int.from_bytes(hashlib.sha256(b'nbls-bench-sk' + i.to_bytes(4, 'big')).digest(), 'big') % (2 ** 254) + 1).to_bytes(32, 'big') for i in range(lo, hi)]
-        msgs_l = [hashlib.sha256(b'msg' + i.to_bytes(4, 'big')).digest() for i in range(lo, hi)]
-        pks_l = eng.get_public_keys(sks_l)
-        aff_l, _ = eng.sign_batch_affine(msgs_l, sks_l)
-        psum, _ = eng.point_sum(aff_l, g2=True)                      # this rank's share of the aggregate signature (affine, 192 B)
-        d_ps = torch.frombuffer(bytearray(psum), dtype=torch.uint8).cuda()
-        if multi:
-            allps = torch.empty(192 * world, dtype=torch.uint8, device='cuda')
-            dist.all_gather_into_tensor(allps, d_ps)
-            agg_sig, _ = eng.point_sum(bytes(allps.cpu().numpy().tobytes()), g2=True)
-        else:
-            agg_sig = psum
-        sig = eng.compress_g2(agg_sig)
-        uni_l = b''.join(oracle.expand_message_xmd(m, oracle_py.DST_DEFAULT, 256) for m in msgs_l)
-        d_sig = torch.frombuffer(bytearray(sig), dtype=torch.uint8).cuda()
-        d_uni = torch.frombuffer(bytearray(uni_l), dtype=torch.uint8).cuda()
-        d_pk = torch.frombuffer(bytearray(b''.join(pks_l)), dtype=torch.uint8).cuda()
-        be = par.EngineBackend(eng)
-        assert par.verify_batch_sharded(be, d_sig, d_uni, d_pk) is True, 'sharded verifyBatch parity (true case) failed'
-        if rank == 0 and lo == 0:      # spot check of the setup itself: the first key and signature share against the oracle
-            assert pks_l[0] == oracle.get_public_key(sks_l[0])
-        torch.cuda.synchronize()
-        if multi:
-            dist.barrier()
-        s0 = time.perf_counter()
-        sreps = 3
-        for _ in range(sreps):
-            par.verify_batch_sharded(be, d_sig, d_uni, d_pk)
-        torch.cuda.synchronize()
-        if multi:
-            dist.barrier()
-        sdt_ = time.perf_counter() - s0
-        if multi:
-            t = torch.tensor([sdt_], dtype=torch.float64, device='cuda')
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            sdt_ = float(t.item())
-        vshard = {'metric': 'verifyBatch sigs/sec', 'n_signatures': nv, 'value': round(nv * sreps / sdt_, 2), 'unit': 'sigs/s', 'ms': round(sdt_ / sreps * 1e3, 3),
-                  'note': 'distinct 32-byte messages, 48-byte keys, one 96-byte aggregate signature; (key, message) pairs sharded over %d rank(s): decompress + hash-to-G2 + Miller product per rank, all-gather of 576 B Fp12 partials, shared final exponentiation; inputs (incl. expand_message_xmd output) resident in HBM' % world}
-        del d_uni, d_pk
+    try:   # a failing secondary leg must not cost the headline line (its error is reported in its place)
+        if args.verify_batch > 0 and (multi or args.verify_sharded):
+            par = importlib.import_module('noble-bls12-381_amd.parallel')
+            nv = args.verify_batch
+            lo, hi = par.shard_bounds(nv, world, rank)
+            sks_l = [(int.from_bytes(hashlib.sha256(b'nbls-bench-sk' + i.to_bytes(4, 'big')).digest(), 'big') % (2 ** 254) + 1).to_bytes(32, 'big') for i in range(lo, hi)]
+            msgs_l = [hashlib.sha256(b'msg' + i.to_bytes(4, 'big')).digest() for i in range(lo, hi)]
+            pks_l = eng.get_public_keys(sks_l)
+            aff_l, _ = eng.sign_batch_affine(msgs_l, sks_l)
+            psum, _ = eng.point_sum(aff_l, g2=True)                      # this rank's share of the aggregate signature (affine, 192 B)
+            d_ps = torch.frombuffer(bytearray(psum), dtype=torch.uint8).cuda()
+            if multi:
+                allps = torch.empty(192 * world, dtype=torch.uint8, device='cuda')
+                dist.all_gather_into_tensor(allps, d_ps)
+                agg_sig, _ = eng.point_sum(bytes(allps.cpu().numpy().tobytes()), g2=True)
+            else:
+                agg_sig = psum
+            sig = eng.compress_g2(agg_sig)
+            uni_l = b''.join(oracle.expand_message_xmd(m, oracle_py.DST_DEFAULT, 256) for m in msgs_l)
+            d_sig = torch.frombuffer(bytearray(sig), dtype=torch.uint8).cuda()
+            d_uni = torch.frombuffer(bytearray(uni_l), dtype=torch.uint8).cuda()
+            d_pk = torch.frombuffer(bytearray(b''.join(pks_l)), dtype=torch.uint8).cuda()
+            be = par.EngineBackend(eng)
+            assert par.verify_batch_sharded(be, d_sig, d_uni, d_pk) is True, 'sharded verifyBatch parity (true case) failed'
+            if rank == 0 and lo == 0:      # spot check of the setup itself: the first key and signature share against the oracle
+                assert pks_l[0] == oracle.get_public_key(sks_l[0])
+            torch.cuda.synchronize()
+            if multi:
+                dist.barrier()
+            s0 = time.perf_counter()
+            sreps = 3
+            for _ in range(sreps):
+                par.verify_batch_sharded(be, d_sig, d_uni, d_pk)
+            torch.cuda.synchronize()
+            if multi:
+                dist.barrier()
+            sdt_ = time.perf_counter() - s0
+            if multi:
+                t = torch.tensor([sdt_], dtype=torch.float64, device='cuda')
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                sdt_ = float(t.item())
+            vshard = {'metric': 'verifyBatch sigs/sec', 'n_signatures': nv, 'value': round(nv * sreps / sdt_, 2), 'unit': 'sigs/s', 'ms': round(sdt_ / sreps * 1e3, 3),
+                      'note': 'distinct 32-byte messages, 48-byte keys, one 96-byte aggregate signature; (key, message) pairs sharded over %d rank(s): decompress + hash-to-G2 + Miller product per rank, all-gather of 576 B Fp12 partials, shared final exponentiation; inputs (incl. expand_message_xmd output) resident in HBM' % world}
+            del d_uni, d_pk
+    except Exception as e:   # noqa: BLE001
+        vshard = {'error': repr(e)}
 
     # ---- roofline leg: per-kernel HIP-event durations of the same step (separate untimed passes)
     roof = None

@@ -133,12 +133,18 @@ static inline void g1_from_raw(int in_buf, int out_buf, int status_buf) {
   output(select(good, x, SFp()), out_buf, 0); output(select(good, y, SFp()), out_buf, 48);
 }
 static inline void g2_from_raw(int in_buf, int out_buf, int status_buf) {
+  // PointG2.fromHex applies its flag rules to 192-byte input as well (index.ts:534-537, 563): sign bit without the compression bit, or with
+  // the infinity bit, is 'Invalid encoding flag' (6); the compression bit on 192 bytes falls through to 'Invalid point G2, expected 96/192
+  // bytes' (8); only then the infinity bit (1).  So a coordinate x.c1 + k p whose VALUE reaches bit 381 is rejected, not reduced.
   SFp zx1 = input_raw(in_buf, 0);
-  SFp not_inf = f_not(bit_flag(zx1, 382));
+  SFp sbit = bit_flag(zx1, 381), ibit = bit_flag(zx1, 382), cbit = bit_flag(zx1, 383);
+  SFp enc_ok = f_or(f_not(sbit), f_and(cbit, f_not(ibit)));
+  SFp not_c = f_not(cbit);
+  SFp not_inf = f_not(ibit);
   SFp2 x = {input(in_buf, 48), to_mont(zx1)}, y = {input(in_buf, 144), input(in_buf, 96)};
   SFp oc, sg; g2_validity_flags(x, y, oc, sg);
-  status_out({{not_inf, 1}, {oc, 2}, {sg, 3}}, status_buf);
-  SFp good = f_and(f_and(not_inf, oc), sg);
+  status_out({{enc_ok, 6}, {not_c, 8}, {not_inf, 1}, {oc, 2}, {sg, 3}}, status_buf);
+  SFp good = f_and(f_and(f_and(enc_ok, not_c), f_and(not_inf, oc)), sg);
   SFp2 zero = fp2_zero();
   output_fp2(select2(good, x, zero), out_buf, 0); output_fp2(select2(good, y, zero), out_buf, 96);
 }

@@ -1271,11 +1271,15 @@ EXPORT int nbls_verify_batch_partial_dev(nbls_ctx* ctx, size_t n, const void* d_
   return nbls_miller_product_dev(ctx, np, base, base + (n + 1) * 96, 0, d_out_fp12, stream);
 }
 
-// ---- one device's share of a product that is spread over several GPUs, from HOST inputs: the partial stays on this context's device
-// (*d_partial: 576 wire bytes in a buffer owned by the context, valid until the next *_partial call) so that the caller can move it to the
-// reducing device with hipMemcpyPeer (nbls_multi.cpp) or hand it to a collective.  The call returns when the partial is complete.
-static int partial_buffer(nbls_ctx* ctx) {
+// ---- one device's share of a product that is spread over several GPUs, from HOST inputs: the partial stays on this context's device so that
+// the caller can move it to the reducing device with hipMemcpyPeer (nbls_multi.cpp) or hand it to a collective.  *d_partial is IN/OUT: a non-NULL
+// value names a caller-owned 576-byte buffer on this context's device that receives the partial (what nbls_multi.cpp passes: one buffer per call,
+// so that calls racing on one context cannot see each other's partials); NULL selects a buffer owned by the context, valid only until the
+// context's next *_partial call.  The call returns when the partial is complete.
+static int partial_buffer(nbls_ctx* ctx, void** d_partial, uint8_t** dst) {
+  if (*d_partial) { *dst = (uint8_t*)*d_partial; return NBLS_OK; }
   if (!ctx->partial) HIPCHK(hipMalloc(&ctx->partial, 576));
+  *dst = ctx->partial;
   return NBLS_OK;
 }
 EXPORT int nbls_miller_product_partial(nbls_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2, int validate, void** d_partial, int8_t* status) {
@@ -1291,15 +1295,16 @@ EXPORT int nbls_miller_product_partial(nbls_ctx* ctx, size_t n, const uint8_t* g
     if (bad) return NBLS_EDECODE;
   }
   LOCKED(ctx);
-  if ((r = partial_buffer(ctx))) return r;
+  uint8_t* part;
+  if ((r = partial_buffer(ctx, d_partial, &part))) return r;
   if (n) {
     if ((r = ensure_io(ctx, n))) return r;
     HIPCHK(hipMemcpyAsync(ctx->io_g1, g1, n * 96, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(ctx->io_g2, g2, n * 192, hipMemcpyHostToDevice, s));
   }
-  if ((r = nbls_miller_product_dev(ctx, n, ctx->io_g1, ctx->io_g2, 0, ctx->partial, s))) return r;
+  if ((r = nbls_miller_product_dev(ctx, n, ctx->io_g1, ctx->io_g2, 0, part, s))) return r;
   HIPCHK(hipStreamSynchronize(s));
-  *d_partial = ctx->partial;
+  *d_partial = part;
   return NBLS_OK;
 }
 EXPORT int nbls_verify_batch_partial(nbls_ctx* ctx, size_t n, const uint8_t* sig96 /* or NULL */, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
@@ -1307,16 +1312,16 @@ EXPORT int nbls_verify_batch_partial(nbls_ctx* ctx, size_t n, const uint8_t* sig
   std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);
   if (!ctx || !d_partial || !zero_flag || !n || !offsets || !pk48 || !dst) return NBLS_EINVAL;
   LOCKED(ctx);
-  uint8_t *b, *c; int r;
-  if ((r = partial_buffer(ctx))) return r;
+  uint8_t *b, *c, *part; int r;
+  if ((r = partial_buffer(ctx, d_partial, &part))) return r;
   if ((r = dev_expand(ctx, n, msgs, offsets, dst, dst_len, &b, s))) return r;
   if ((r = need(ctx, 9, n * 48 + 96, &c))) return r;
   HIPCHK(hipMemcpyAsync(c, pk48, n * 48, hipMemcpyHostToDevice, s));
   if (sig96) HIPCHK(hipMemcpyAsync(c + n * 48, sig96, 96, hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));
-  if ((r = nbls_verify_batch_partial_dev(ctx, n, sig96 ? c + n * 48 : nullptr, b, c, ctx->partial, zero_flag, pk_status, nullptr))) return r;
+  if ((r = nbls_verify_batch_partial_dev(ctx, n, sig96 ? c + n * 48 : nullptr, b, c, part, zero_flag, pk_status, nullptr))) return r;
   HIPCHK(hipStreamSynchronize(s));
-  *d_partial = ctx->partial;
+  *d_partial = part;
   return NBLS_OK;
 }
 EXPORT int nbls_context_device(nbls_ctx* ctx) { return ctx ? ctx->device : -1; }

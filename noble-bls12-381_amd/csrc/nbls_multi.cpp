@@ -7,21 +7,61 @@
 // This layer uses only the public single-device ABI (include/nbls.h) plus HIP for the peer copies.
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "nbls.h"
 
 #define EXPORT extern "C" __attribute__((visibility("default")))
 
+// Buffers of ONE product call in flight: a 576-byte partial on every device and, on dev[0], the gather area (one partial per device, then 576
+// bytes of result).  A call takes a free set (or allocates one) and returns it when it is done, so that calls racing on one handle -- the
+// N-API addon runs nbls_multi_verify_batch on libuv worker threads -- never see each other's partials: the contexts serialise the per-device
+// work themselves, and everything between a context's *_partial call and the end of finish() touches only the call's own set.
+struct CallBuffers {
+  std::vector<uint8_t*> part;   // part[g] on dev[g]
+  uint8_t* gather = nullptr;    // on dev[0]
+};
 struct nbls_multi {
   std::vector<nbls_ctx*> ctx;
   std::vector<int> dev;
-  uint8_t* gather = nullptr;   // on dev[0]: one 576-byte partial per device, then 576 bytes of result
+  std::mutex mu;                       // guards `free_sets` only
+  std::vector<CallBuffers*> free_sets;
+  std::vector<CallBuffers*> all_sets;
+};
+
+static void free_set(nbls_multi* m, CallBuffers* b) {
+  for (size_t g = 0; g < b->part.size(); g++) if (b->part[g]) { hipSetDevice(m->dev[g]); hipFree(b->part[g]); }
+  if (b->gather) { hipSetDevice(m->dev[0]); hipFree(b->gather); }
+  delete b;
+}
+static CallBuffers* take_set(nbls_multi* m) {
+  {
+    std::lock_guard<std::mutex> g(m->mu);
+    if (!m->free_sets.empty()) { CallBuffers* b = m->free_sets.back(); m->free_sets.pop_back(); return b; }
+  }
+  int prev = 0; hipGetDevice(&prev);
+  CallBuffers* b = new CallBuffers();
+  b->part.assign(m->dev.size(), nullptr);
+  bool ok = true;
+  for (size_t g = 0; g < m->dev.size() && ok; g++) ok = hipSetDevice(m->dev[g]) == hipSuccess && hipMalloc(&b->part[g], 576) == hipSuccess;
+  ok = ok && hipSetDevice(m->dev[0]) == hipSuccess && hipMalloc(&b->gather, 576 * (m->dev.size() + 1)) == hipSuccess;
+  hipSetDevice(prev);
+  if (!ok) { free_set(m, b); (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> g(m->mu);
+  m->all_sets.push_back(b);
+  return b;
+}
+static void give_set(nbls_multi* m, CallBuffers* b) { std::lock_guard<std::mutex> g(m->mu); m->free_sets.push_back(b); }
+struct SetLease {   // returns the set on every exit path
+  nbls_multi* m; CallBuffers* b;
+  explicit SetLease(nbls_multi* m_) : m(m_), b(take_set(m_)) {}
+  ~SetLease() { if (b) give_set(m, b); }
 };
 
 EXPORT void nbls_destroy_multi(nbls_multi* m) {
   if (!m) return;
-  if (m->gather && !m->dev.empty()) { hipSetDevice(m->dev[0]); hipFree(m->gather); }
+  for (CallBuffers* b : m->all_sets) free_set(m, b);
   for (nbls_ctx* c : m->ctx) nbls_destroy(c);
   delete m;
 }
@@ -40,7 +80,7 @@ EXPORT int nbls_init_multi(int n_devices, const int* device_ids, nbls_multi** ou
     if (r) { nbls_destroy_multi(m); return r; }
     m->ctx.push_back(c); m->dev.push_back(d);
   }
-  if (hipSetDevice(m->dev[0]) != hipSuccess || hipMalloc(&m->gather, 576 * (m->dev.size() + 1)) != hipSuccess) { nbls_destroy_multi(m); return NBLS_EHIP; }
+  { CallBuffers* b = take_set(m); if (!b) { nbls_destroy_multi(m); return NBLS_EHIP; } give_set(m, b); }   // the first call's buffers
   // peer access lets hipMemcpyPeer go straight over xGMI; without it the copy is staged, which is still correct
   for (size_t i = 1; i < m->dev.size(); i++) { int can = 0; if (hipDeviceCanAccessPeer(&can, m->dev[0], m->dev[i]) == hipSuccess && can) { hipSetDevice(m->dev[0]); hipDeviceEnablePeerAccess(m->dev[i], 0); } }
   (void)hipGetLastError();
@@ -53,8 +93,7 @@ EXPORT nbls_ctx* nbls_multi_context(nbls_multi* m, int i) { return m && i >= 0 &
 // contiguous shards [lo, hi) of n items over the devices (the first n % G devices take one item more)
 static void shard(size_t n, size_t G, size_t g, size_t* lo, size_t* hi) { const size_t q = n / G, r = n % G; *lo = g * q + (g < r ? g : r); *hi = *lo + q + (g < r ? 1 : 0); }
 
-template <class F> static int on_every_device(nbls_multi* m, F f) {
-  const size_t G = m->ctx.size();
+template <class F> static int on_every_device(size_t G, F f) {
   std::vector<int> rc(G, 0);
   std::vector<std::thread> th;
   for (size_t g = 1; g < G; g++) th.emplace_back([&, g] { rc[g] = f(g); });
@@ -69,23 +108,22 @@ template <class F> static int on_every_device(nbls_multi* m, F f) {
 EXPORT int nbls_multi_pairing_batch(nbls_multi* m, size_t n, const uint8_t* g1, const uint8_t* g2, int with_final_exp, int validate, uint8_t* out, int8_t* status) {
   if (!m || m->ctx.empty() || (n && (!g1 || !g2 || !out))) return NBLS_EINVAL;
   const size_t G = m->ctx.size();
-  return on_every_device(m, [&](size_t g) {
+  return on_every_device(G, [&](size_t g) {
     size_t lo, hi; shard(n, G, g, &lo, &hi);
     if (hi == lo) return (int)NBLS_OK;
     return nbls_pairing_batch(m->ctx[g], hi - lo, g1 + lo * 96, g2 + lo * 192, with_final_exp, validate, out + lo * 576, status ? status + lo : nullptr);
   });
 }
 
-// gather the devices' partials on the first device, multiply, one shared final exponentiation, result to the host
-static int finish(nbls_multi* m, const std::vector<void*>& part, int final_exp, uint8_t* out) {
-  const size_t G = m->ctx.size();
+// gather the partials of the first G devices on the first device (the call's own gather area), multiply, one shared final exponentiation, result to the host
+static int finish(nbls_multi* m, CallBuffers* b, size_t G, int final_exp, uint8_t* out) {
   if (hipSetDevice(m->dev[0]) != hipSuccess) return NBLS_EHIP;
   for (size_t g = 0; g < G; g++) {
-    hipError_t e = g == 0 ? hipMemcpy(m->gather, part[0], 576, hipMemcpyDeviceToDevice) : hipMemcpyPeer(m->gather + 576 * g, m->dev[0], part[g], m->dev[g], 576);
+    hipError_t e = g == 0 ? hipMemcpy(b->gather, b->part[0], 576, hipMemcpyDeviceToDevice) : hipMemcpyPeer(b->gather + 576 * g, m->dev[0], b->part[g], m->dev[g], 576);
     if (e != hipSuccess) return NBLS_EHIP;
   }
-  uint8_t* res = m->gather + 576 * G;
-  int r = nbls_fp12_product_final_dev(m->ctx[0], G, m->gather, final_exp, res, nullptr);
+  uint8_t* res = b->gather + 576 * m->dev.size();
+  int r = nbls_fp12_product_final_dev(m->ctx[0], G, b->gather, final_exp, res, nullptr);
   if (r) return r;
   if (nbls_device_synchronize(m->ctx[0])) return NBLS_EHIP;
   return hipMemcpy(out, res, 576, hipMemcpyDeviceToHost) == hipSuccess ? NBLS_OK : NBLS_EHIP;
@@ -95,13 +133,16 @@ static int finish(nbls_multi* m, const std::vector<void*>& part, int final_exp, 
 EXPORT int nbls_multi_miller_product(nbls_multi* m, size_t n, const uint8_t* g1, const uint8_t* g2, int final_exp, int validate, uint8_t* out, int8_t* status) {
   if (!m || m->ctx.empty() || !out || (n && (!g1 || !g2))) return NBLS_EINVAL;
   const size_t G = m->ctx.size();
-  std::vector<void*> part(G, nullptr);
-  int r = on_every_device(m, [&](size_t g) {
+  SetLease lease(m);
+  if (!lease.b) return NBLS_EHIP;
+  CallBuffers* b = lease.b;
+  int r = on_every_device(G, [&](size_t g) {
     size_t lo, hi; shard(n, G, g, &lo, &hi);   // an empty shard contributes the unit element
-    return nbls_miller_product_partial(m->ctx[g], hi - lo, g1 + lo * 96, g2 + lo * 192, validate, &part[g], status ? status + lo : nullptr);
+    void* p = b->part[g];
+    return nbls_miller_product_partial(m->ctx[g], hi - lo, g1 + lo * 96, g2 + lo * 192, validate, &p, status ? status + lo : nullptr);
   });
-  if (r) return r;
-  return finish(m, part, final_exp, out);
+  if (r) { if (r == NBLS_EDECODE) memset(out, 0, 576); return r; }   // as nbls_miller_product: a rejected input zeroes the output
+  return finish(m, b, G, final_exp, out);
 }
 
 // verifyBatch(signature, messages, publicKeys) with every message distinct (BASELINE configs[2] over several GPUs) -- reference index.ts:792-821.
@@ -111,18 +152,19 @@ EXPORT int nbls_multi_verify_batch(nbls_multi* m, size_t n, const uint8_t* sig96
   if (!m || m->ctx.empty() || !ok || !n || !sig96 || !offsets || !pk48 || !dst) return NBLS_EINVAL;
   size_t G = m->ctx.size();
   if (G > n) G = n;   // fewer signatures than devices: the surplus devices stay idle
-  std::vector<void*> part(G, nullptr);
+  SetLease lease(m);
+  if (!lease.b) return NBLS_EHIP;
+  CallBuffers* b = lease.b;
   std::vector<int> zero(G, 0);
-  nbls_multi sub; sub.ctx.assign(m->ctx.begin(), m->ctx.begin() + G); sub.dev.assign(m->dev.begin(), m->dev.begin() + G); sub.gather = m->gather;
-  int r = on_every_device(&sub, [&](size_t g) {
+  int r = on_every_device(G, [&](size_t g) {
     size_t lo, hi; shard(n, G, g, &lo, &hi);
-    return nbls_verify_batch_partial(m->ctx[g], hi - lo, g == 0 ? sig96 : nullptr, msgs, offsets + lo, pk48 + lo * 48, dst, dst_len, &part[g], &zero[g], nullptr);
+    void* p = b->part[g];
+    return nbls_verify_batch_partial(m->ctx[g], hi - lo, g == 0 ? sig96 : nullptr, msgs, offsets + lo, pk48 + lo * 48, dst, dst_len, &p, &zero[g], nullptr);
   });
-  if (r) { sub.ctx.clear(); sub.gather = nullptr; return r; }
-  for (int z : zero) if (z) { *ok = 0; sub.ctx.clear(); sub.gather = nullptr; return NBLS_OK; }   // a zero point: pairing() throws, verifyBatch answers false
+  if (r) return r;
+  for (int z : zero) if (z) { *ok = 0; return NBLS_OK; }   // a zero point: pairing() throws, verifyBatch answers false
   uint8_t e[576];
-  r = finish(&sub, part, 1, e);
-  sub.ctx.clear(); sub.gather = nullptr;
+  r = finish(m, b, G, 1, e);
   if (r) return r;
   bool one = e[47] == 1; for (int i = 0; i < 576 && one; i++) if (i != 47 && e[i]) one = false;   // exp.equals(Fp12.ONE)
   *ok = one ? 1 : 0;

@@ -220,6 +220,17 @@ class Fp12 {
   }
   static fromBytes(b) { if (b.length !== Fp12.BYTES_LEN) throw new Error(`fromBytes wrong length=${b.length}`); return new Fp12(Fp6.fromBytes(b.subarray(0, 288)), Fp6.fromBytes(b.subarray(288, 576))); }
   toBytes() { const o = new Uint8Array(576); o.set(this.c0.toBytes(), 0); o.set(this.c1.toBytes(), 288); return o; }
+  // kilic/bls12-381 (and zkcrypto) write the twelve 48-byte coefficients in the opposite order: highest tower coefficient first, c1 before c0 in
+  // every Fp2.  The reference's tests convert by reversing the 48-byte chunks (test/deterministic.test.ts:9-12, 41); this is that adaptor
+  // (SURVEY 8(f).4).  Accepts / returns 576 bytes; a 1152-character hex string is accepted too.
+  static fromKilicBytes(b) {
+    if (typeof b === 'string') { if (b.length !== 1152) throw new Error(`fromKilicBytes wrong length=${b.length / 2}`); const u = new Uint8Array(576); for (let i = 0; i < 576; i++) u[i] = Number.parseInt(b.slice(2 * i, 2 * i + 2), 16); b = u; }
+    if (b.length !== Fp12.BYTES_LEN) throw new Error(`fromKilicBytes wrong length=${b.length}`);
+    const o = new Uint8Array(576);
+    for (let k = 0; k < 12; k++) o.set(b.subarray(48 * (11 - k), 48 * (12 - k)), 48 * k);
+    return Fp12.fromBytes(o);
+  }
+  toKilicBytes() { const b = this.toBytes(), o = new Uint8Array(576); for (let k = 0; k < 12; k++) o.set(b.subarray(48 * (11 - k), 48 * (12 - k)), 48 * k); return o; }
 }
 Fp12.BYTES_LEN = 2 * Fp6.BYTES_LEN;
 Fp12.ZERO = new Fp12(Fp6.ZERO, Fp6.ZERO);

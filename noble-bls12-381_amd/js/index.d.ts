@@ -56,6 +56,8 @@ export declare class Fp12 implements Field<Fp12> {
   /** runs on the GPU (nbls_final_exp_batch) */
   finalExponentiate(): Fp12;
   static fromBytes(b: Uint8Array): Fp12; toBytes(): Uint8Array;
+  /** kilic / zkcrypto coefficient order (the twelve 48-byte words reversed; reference test/deterministic.test.ts:9-12, 41) */
+  static fromKilicBytes(b: Uint8Array | string): Fp12; toKilicBytes(): Uint8Array;
 }
 
 export declare class PointG1 {

@@ -27,6 +27,12 @@ def golden2():
 
 
 @pytest.fixture(scope='session')
+def golden3():
+    import goldenio
+    return goldenio.load('ref_vectors3.json.gz')
+
+
+@pytest.fixture(scope='session')
 def testdata():
     import goldenio
     return goldenio.load('ref_testdata.json.gz')

@@ -4,7 +4,7 @@
 const fs = require('fs'), zlib = require('zlib'), path = require('path'), assert = require('assert');
 const bls = require(path.join(__dirname, '..', '..', 'noble-bls12-381_amd', 'js', 'index.js'));
 const load = (f) => JSON.parse(zlib.gunzipSync(fs.readFileSync(path.join(__dirname, '..', 'golden', f))).toString());
-const gold = load('ref_vectors.json.gz'), td = load('ref_testdata.json.gz'), gold2 = load('ref_vectors2.json.gz');
+const gold = load('ref_vectors.json.gz'), td = load('ref_testdata.json.gz'), gold2 = load('ref_vectors2.json.gz'), gold3 = load('ref_vectors3.json.gz');
 const hex = bls.utils.bytesToHex, un = bls.utils.hexToBytes;
 
 (async () => {
@@ -166,6 +166,57 @@ const hex = bls.utils.bytesToHex, un = bls.utils.hexToBytes;
       Q.clearPairingPrecomputes();
       assert.strictEqual(hex(P.millerLoop(Q).toBytes()), v.miller);                      // plain path
     }
+  }
+  // round 3: (i) the reference's whole kilic vector set (test/deterministic.test.ts:34-46: e(i G1, i G2), i = 1..1000) in ONE pairingBatch call, compared in
+  // kilic's own byte order through Fp12.toKilicBytes / fromKilicBytes (:9-12, 41; SURVEY 8(f).4); (ii) the doubling known answers of test/point.test.ts:89-146,
+  // 270-346 -- projective inputs, a.double() against the reference's projective double, a.multiply(2n) and a.add(a); (iii) flag bits over uncompressed input
+  {
+    const { Fp, Fp2, Fp12, PointG1, PointG2 } = bls;
+    const N = td.pairing_iG1_iG2.length;
+    assert.strictEqual(N, 1000);
+    const ks = Array.from({ length: N }, (_, i) => BigInt(i + 1));
+    const g1s = [], g2s = [];
+    // i G1 / i G2 by repeated addition would be 2000 single-point calls; the batched scalar multiplication does it in two
+    const sc = ks.map((k) => un(k.toString(16).padStart(64, '0')));
+    const pk = bls.getPublicKeys(sc);                                                   // 48-byte compressed i G1
+    for (let i = 0; i < N; i++) g1s.push(PointG1.fromHex(pk[i]));
+    const h = bls.PointG2.BASE;
+    let acc = h;
+    for (let i = 0; i < N; i++) { g2s.push(acc); if (i + 1 < N) acc = (i % 50 === 49) ? h.multiply(BigInt(i + 2)) : acc.add(h); }   // additions, re-anchored on multiply every 50
+    const { out, status } = bls.pairingBatch(g1s, g2s, true, true);
+    assert.ok(status.every((x) => x === 0));
+    for (let i = 0; i < N; i++) {
+      const e = Fp12.fromBytes(out.subarray(576 * i, 576 * (i + 1)));
+      const kilic = td.pairing_iG1_iG2[i].match(/.{96}/g).reverse().join('');           // the file's own order (tools/gen_golden.py stores it reversed)
+      assert.strictEqual(hex(e.toKilicBytes()), kilic, 'kilic vector ' + (i + 1));
+      if (i < 8) assert.ok(Fp12.fromKilicBytes(kilic).equals(e) && Fp12.fromKilicBytes(un(kilic)).equals(e));
+    }
+    assert.strictEqual(hex(bls.pairing(PointG1.BASE, PointG2.BASE).toKilicBytes()), td.e_G1_G2.match(/.{96}/g).reverse().join(''));
+    assert.throws(() => Fp12.fromKilicBytes(new Uint8Array(575)), /wrong length/);
+    const f = (hx_) => new Fp(BigInt('0x' + hx_)), f2 = (a, b) => Fp2.fromBigTuple([BigInt('0x' + a), BigInt('0x' + b)]);
+    for (const v of td.point_double_kats.g1) {
+      const a = new PointG1(f(v.a[0]), f(v.a[1]), f(v.a[2])), want = new PointG1(f(v.double[0]), f(v.double[1]), f(v.double[2]));
+      const d = a.double(); d.assertValidity();
+      assert.ok(d.equals(want) && d.equals(a.multiply(2n)) && d.equals(a.add(a)));
+    }
+    for (const v of td.point_double_kats.g2) {
+      const a = new PointG2(f2(v.a[0], v.a[1]), f2(v.a[2], v.a[3]), f2(v.a[4], v.a[5])), want = new PointG2(f2(v.double[0], v.double[1]), f2(v.double[2], v.double[3]), f2(v.double[4], v.double[5]));
+      const d = a.double(); d.assertValidity();
+      assert.ok(d.equals(want) && d.equals(a.multiply(2n)) && d.equals(a.add(a)));
+    }
+    for (const k of td.wnaf_scalars) {                                                   // test/point.test.ts:347-372: multiply == multiplyUnsafe on the wNAF scalar list
+      const s_ = BigInt('0x' + k);
+      assert.ok(s_ > 0n && s_ < bls.CURVE.r);
+      assert.ok(PointG1.BASE.multiply(s_).equals(PointG1.BASE.multiplyUnsafe(s_)) && PointG1.BASE.multiply(s_).equals(PointG1.BASE.multiply(s_ - 1n).add(PointG1.BASE)));
+      assert.ok(PointG2.BASE.multiply(s_).equals(PointG2.BASE.multiplyUnsafe(s_)) && PointG2.BASE.multiply(s_).equals(PointG2.BASE.multiply(s_ - 1n).add(PointG2.BASE)));
+    }
+    const check3 = (fn, v) => {
+      if (v.result === 'ok') assert.strictEqual(hex(fn(v.hex).aff), v.aff);
+      else if (v.result === 'zero') assert.ok(fn(v.hex).isZero());
+      else assert.throws(() => fn(v.hex), (e) => e.message === v.result, v.result + ' for ' + v.hex.slice(0, 16));
+    };
+    for (const v of gold3.g1_raw96_flags) check3((h_) => PointG1.fromHex(h_), v);
+    for (const v of gold3.g2_raw192_flags) check3((h_) => PointG2.fromHex(h_), v);
   }
   // aggregate + verifyBatch
   const vb = gold.verify_batch;

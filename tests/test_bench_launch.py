@@ -1,0 +1,35 @@
+"""`python bench.py --gpus N` must produce an N-rank job by itself (round-2 verdict: the flag was parsed and ignored, so the driver's
+command line `python3 bench.py --gpus 8 ...` ran one rank).  Without a launcher around it bench.py re-executes itself under
+torch.distributed.run with N processes; --dry-launch replaces the GPU work by a gloo rendezvous + all-reduce so that the launch path runs
+on a CPU-only box."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout.decode()       # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_gpus_flag_spawns_ranks():
+    d = _run(['--gpus', '2', '--dry-launch'])
+    assert d == {'dry_launch': True, 'n_gpus': 2, 'gpus_flag': 2, 'rank_sum': 3, 'backend': 'gloo'}
+
+
+def test_gpus_flag_three_ranks():
+    d = _run(['--gpus', '3', '--dry-launch'])
+    assert d['n_gpus'] == 3 and d['rank_sum'] == 6
+
+
+def test_single_rank_needs_no_launcher():
+    d = _run(['--gpus', '1', '--dry-launch'])
+    assert d['n_gpus'] == 1 and d['rank_sum'] == 1

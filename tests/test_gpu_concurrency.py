@@ -43,3 +43,43 @@ def test_racing_calls_on_one_context(oracle):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+def test_racing_calls_on_one_multi_handle(oracle):
+    """Round-2 finding: nbls_multi_* shared ONE partial buffer per context and ONE gather buffer per handle, so that two product calls
+    racing on a handle (the N-API addon runs nbls_multi_verify_batch on libuv worker threads) could be finished with each other's
+    partials -- a forged batch answered with a valid batch's verdict.  Every call now owns its partial / gather buffers
+    (csrc/nbls_multi.cpp CallBuffers).  A valid and a forged verifyBatch, a Miller product with a known value and a pairing batch race
+    on ONE handle opened on device 0 twice, twelve times each, every answer checked."""
+    pkg = importlib.import_module('noble-bls12-381_amd')
+    m = pkg.MultiEngine([0, 0])
+    n = 129
+    sks = [(int.from_bytes(hashlib.sha256(b'mrace-sk' + bytes([i & 255, i >> 8])).digest(), 'big') % (2 ** 254) + 1).to_bytes(32, 'big') for i in range(n)]
+    msgs = [hashlib.sha256(b'mrace-msg' + bytes([i & 255, i >> 8])).digest() for i in range(n)]
+    pks, sig = oracle.aggregate_sign(msgs, sks, threads=16)
+    forged = list(msgs); forged[n - 2] = bytes(32)
+    g1 = b''.join(oracle.g1_mul(oracle.g1_generator(), k)[1] for k in range(1, 34))
+    g2 = b''.join(oracle.g2_mul(oracle.g2_generator(), k)[1] for k in range(1, 34))
+    ref_pair, _ = oracle.pairing_batch(g1, g2, True, False)
+    ref_prod = oracle.miller_product(g1, g2, final_exp=True)
+    errors = []
+
+    def run(name, fn, expect, reps):
+        try:
+            for k in range(reps):
+                got = fn()
+                if got != expect:
+                    errors.append((name, k))
+        except Exception as e:   # noqa: BLE001
+            errors.append((name, repr(e)))
+
+    ts = [threading.Thread(target=run, args=('valid', lambda: m.verify_batch(sig, msgs, pks), True, 12)),
+          threading.Thread(target=run, args=('forged', lambda: m.verify_batch(sig, forged, pks), False, 12)),
+          threading.Thread(target=run, args=('product', lambda: m.miller_product(g1, g2, True, False)[0], ref_prod, 12)),
+          threading.Thread(target=run, args=('pairing', lambda: m.pairing_batch(g1, g2, True, False)[0], ref_pair, 12))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    m.close()
+    assert not errors, errors

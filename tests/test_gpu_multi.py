@@ -72,6 +72,27 @@ def test_sharded_paths_on_one_gpu(pkg, eng, oracle, golden, devices):
     m.close()
 
 
+def test_config3_full_size_eight_contexts(pkg, eng, oracle):
+    """BASELINE configs[3] at its full size -- 2^20 independent pairings sharded eight ways -- in ONE nbls_multi_pairing_batch call.  On a
+    one-GPU box the eight shards are eight contexts on device 0 (2^17 pairs each, the per-GPU share); with eight GPUs they are the real
+    devices.  4096 distinct pairs x 256: the 4096 distinct results against the oracle, every repetition equal to the first (bit-exact,
+    wherever in whichever shard the pair sits)."""
+    G = torch.cuda.device_count()
+    m = pkg.MultiEngine(None if G >= 8 else [i % G for i in range(8)])
+    assert m.n_devices >= 8
+    base_n, reps = 4096, 256
+    P, Q = _points(eng, oracle, base_n, 20)
+    out = m.pairing_batch(P * reps, Q * reps, True, False)[0]
+    m.close()
+    assert len(out) == 576 * base_n * reps
+    first = out[:576 * base_n]
+    ref, _ = oracle.pairing_batch(P, Q, True, False, threads=64)
+    assert first == ref
+    mv = memoryview(out)
+    for r in range(1, reps):
+        assert mv[576 * base_n * r:576 * base_n * (r + 1)] == first, r
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two or more GPUs')
 def test_across_real_devices(pkg, eng, oracle):
     G = torch.cuda.device_count()

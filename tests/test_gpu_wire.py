@@ -79,6 +79,18 @@ def test_uncompressed_forms(eng, golden2):
             assert st[i] == (1 if zero[i] else 0) and back[a * i:a * (i + 1)] == (bytes(a) if zero[i] else hx(v['aff'])), (key, i)
 
 
+def test_uncompressed_flag_bits(eng, golden3):
+    """flag bits in the first byte of the uncompressed forms through the C ABI (nbls_g*_from_hex_batch, len 96 / 192): the reference's own outcomes
+    (tools/gen_golden3.mjs) -- PointG2.fromHex rejects 0x20 / 0x60 / 0xe0 ('Invalid encoding flag', status 6) and the compression bit (status 8) on 192
+    bytes, a coordinate x.c1 + k p reaching bit 381 included; PointG1.fromHex(96 B) only honours the infinity bit"""
+    for kind, key, a in (('g1', 'g1_raw96_flags', 96), ('g2', 'g2_raw192_flags', 192)):
+        vs = golden3[key]
+        out, st = eng.decode_points(kind, b''.join(hx(v['hex']) for v in vs), a)
+        for i, v in enumerate(vs):
+            assert {st[i]} == expected_status(v['result']), (kind, i, hex(v['flag']), v['result'], st[i])
+            assert out[a * i:a * (i + 1)] == (hx(v['aff']) if v['result'] == 'ok' else bytes(a)), (kind, i)
+
+
 def test_clear_cofactor(eng, golden2):
     for key, g2, a in (('g1_clear_cofactor', False, 96), ('g2_clear_cofactor', True, 192)):
         vs = golden2[key]

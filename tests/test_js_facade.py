@@ -47,3 +47,14 @@ def test_facade_on_gpu_with_a_context_pool():
     _build()
     out = subprocess.run(['node', os.path.join(ROOT, 'tests', 'js', 'test_facade.js')], capture_output=True, text=True, timeout=300, env=dict(os.environ, NBLS_CONTEXTS='3'))
     assert out.returncode == 0 and 'JS facade ok' in out.stdout, out.stdout + out.stderr
+
+
+@needs_node
+@pytest.mark.gpu
+def test_facade_on_gpu_with_a_multi_handle():
+    """the same file with NBLS_DEVICES=0,0: pairingBatch / millerProduct / verifyBatch(Async) go through nbls_multi_* on ONE handle (two contexts on device 0);
+    the Promise.all at the end races six verifyBatch calls -- valid and forged -- on that handle from libuv worker threads (round-2 finding: shared partial /
+    gather buffers; every call now owns its buffers, csrc/nbls_multi.cpp)"""
+    _build()
+    out = subprocess.run(['node', os.path.join(ROOT, 'tests', 'js', 'test_facade.js')], capture_output=True, text=True, timeout=600, env=dict(os.environ, NBLS_DEVICES='0,0'))
+    assert out.returncode == 0 and 'JS facade ok' in out.stdout, out.stdout + out.stderr

@@ -364,6 +364,25 @@ def test_wire_decoders(sim, golden2):
     assert out.raw == b''.join(hx(v['hex']) for v in vs)
 
 
+def test_uncompressed_flag_bits(sim, golden3):
+    """Round-2 advisor finding: PointG2.fromHex applies its flag rules to 192-byte input too (index.ts:534-537, 563) -- 0x20 / 0x60 / 0xe0 in the
+    first byte are 'Invalid encoding flag', the compression bit is 'Invalid point G2, expected 96/192 bytes', and a non-canonical x.c1 + k p whose
+    value reaches bit 381 is rejected rather than reduced -- while PointG1.fromHex(96 B) looks at the infinity bit only.  Vectors: the reference
+    itself (tools/gen_golden3.mjs), every flag combination over valid points, the zero encoding and garbage."""
+    def want(result):
+        return {'ok': 0, 'zero': 1}.get(result, 2 if 'not on curve' in result else 3 if 'subgroup' in result else 6 if 'encoding flag' in result else 8)
+    for key, prog, a in (('g1_raw96_flags', 'G1_FROM_RAW', 96), ('g2_raw192_flags', 'G2_FROM_RAW', 192)):
+        vs = golden3[key]
+        n = len(vs)
+        assert {v['flag'] for v in vs} == {0, 0x20, 0x40, 0x60, 0x80, 0xa0, 0xc0, 0xe0}
+        inb = vmsim_py.buf(b''.join(hx(v['hex']) for v in vs)); out = vmsim_py.buf(a * n); st = vmsim_py.buf(n)
+        vmsim_py.run(sim, prog, n, {0: (inb, a), 6: (out, a), 7: (st, 1)})
+        for i, v in enumerate(vs):
+            assert st.raw[i] == want(v['result']), (key, i, hex(v['flag']), v['result'], st.raw[i])
+            assert out.raw[a * i:a * (i + 1)] == (hx(v['aff']) if v['result'] == 'ok' else bytes(a)), (key, i)
+    assert {v['result'] for v in golden3['g2_raw192_flags']} >= {'ok', 'zero', 'Invalid encoding flag: 32', 'Invalid encoding flag: 96', 'Invalid encoding flag: 224', 'Invalid point G2, expected 96/192 bytes'}
+
+
 def test_lane_split_programs(sim, oracle, golden):
     """The latency variants (every K_DOT lane-op spread over four adjacent lanes, one item per wavefront): same results as the golden pairs --
     Miller value, and the whole pairing with the lane-split Miller and exponentiation programs."""
