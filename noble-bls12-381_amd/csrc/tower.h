@@ -125,18 +125,47 @@ static inline SFp12 cyclotomic_sqr(const SFp12& x) {              // math.ts:824
   return {{scale(t3 - x.c0.c0, 2) + t3, scale(t5 - x.c0.c1, 2) + t5, scale(t7 - x.c0.c2, 2) + t7},
           {scale(t9 + x.c1.c0, 2) + t9, scale(t4 + x.c1.c1, 2) + t4, scale(t6 + x.c1.c2, 2) + t6}};
 }
+// The same squaring on the TRIPLED element (round 3).  Every output of the Granger-Scott squaring is 3 t -+ 2 g with t quadratic in the input; the
+// factor 3 is a multiplier on the reduced sum (28 instructions per lane-op) and forces a second carry pass.  With G = 3 g carried instead of g:
+//   3 (3 t(g) -+ 2 g) = 9 t(g) -+ 6 g = t(G) -+ 2 G            (t is quadratic: t(3 g) = 9 t(g))
+// so the tripled state squares WITHOUT a multiplier, and a product with an untripled base keeps the factor ((3 g) b = 3 (g b)).  cyclotomic_exp_x
+// triples its input once and multiplies by 1/3 at the end; the element computed is the same.
+static inline SFp12 cyclotomic_sqr_tripled(const SFp12& x) {
+  SFp2 t3, t4, t5, t6, t7, t8;
+  fp4_square(x.c0.c0, x.c1.c1, t3, t4);
+  fp4_square(x.c1.c0, x.c0.c2, t5, t6);
+  fp4_square(x.c0.c1, x.c1.c2, t7, t8);
+  SFp2 t9 = scale(mul(mulnr(x.c0.c1), x.c1.c2), 2);
+  (void)t8;
+  return {{t3 - scale(x.c0.c0, 2), t5 - scale(x.c0.c1, 2), t7 - scale(x.c0.c2, 2)},
+          {t9 + scale(x.c1.c0, 2), t4 + scale(x.c1.c1, 2), t6 + scale(x.c1.c2, 2)}};
+}
+static inline SFp12 mul_fp(const SFp12& a, const SFp& k) {
+  auto m2 = [&](const SFp2& v) { return SFp2{mul(v.c0, k), mul(v.c1, k)}; };
+  return {{m2(a.c0.c0), m2(a.c0.c1), m2(a.c0.c2)}, {m2(a.c1.c0), m2(a.c1.c1), m2(a.c1.c2)}};
+}
 // z^|x| for unitary z (math.ts:845-852).  The reference starts from ONE and squares through all 64 bits; the
 // leading squarings of ONE are identities, so starting at the top set bit gives the same element.
 // `reload` (optional): fetches a again where it is multiplied in (five times): the base then does not occupy twelve LDS slots throughout the 63
 // squarings (EXPX: 42 -> 30 slots, twelve instead of ten wavefronts per CU); the loads cost five cheap steps
 template <class Reload>
 static inline SFp12 cyclotomic_exp_x(const SFp12& a, Reload reload) {
-  SFp12 z = a;   // after bit 63
+  static const bool tripled = !getenv("NBLS_CYCSQR_PLAIN");   // A/B switch, read once per process (the old formulas: multiplier 3 in every squaring lane-op)
+  if (!tripled) {
+    SFp12 z = a;   // after bit 63
+    for (int i = 62; i >= 0; i--) {
+      z = mat(cyclotomic_sqr(z));
+      if ((NBLS_X >> i) & 1) z = mat(mul(z, reload()));
+    }
+    return z;
+  }
+  Builder* B = Builder::cur();
+  SFp12 z = mat(mul_fp(a, SFp(B->small_const(3))));   // 3 a as one product per coefficient (bound ~1; a sum a + a + a would carry three times the input's bound into the first squaring)
   for (int i = 62; i >= 0; i--) {
-    z = mat(cyclotomic_sqr(z));
+    z = mat(cyclotomic_sqr_tripled(z));
     if ((NBLS_X >> i) & 1) z = mat(mul(z, reload()));
   }
-  return z;
+  return mul_fp(z, SFp(B->frac_const(1, 3)));
 }
 static inline SFp12 cyclotomic_exp_x(const SFp12& a) { return cyclotomic_exp_x(a, [&]() { return a; }); }
 

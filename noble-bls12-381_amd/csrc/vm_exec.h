@@ -106,12 +106,46 @@ NBLS_HD void dot_combine(u32* A, const u32* X, u32 shape, u32 neg) {
   }
 }
 
+// v_mad_i64_i32 / v_mad_u64_u32 are VOP3B instructions: besides the 64-bit result they write a carry-out SGPR pair (SDST), and the compiler hands every
+// multiply-add the same dead pair.  Round-3 experiment (tools/ubench/mad_sdst.hip, tools/exp_sdst.sh; profiles/round3_sdst_ab.txt): in a pure stream of
+// inline-assembly multiply-adds a rotation over four pairs issues 18-28 % faster than one pair -- but in the kernel, with the product block and the
+// reduction written as inline assembly with rotating pairs (NBLS_SDST_PAIRS = 2 / 4 / 8), a lone wavefront is 6-16 % SLOWER (3.27-3.58 ms against
+// 3.08 ms per 4096-pairing call) and a saturated launch unchanged: the hazard recogniser pads every inline-assembly group with s_nop, and the
+// compiler's own schedule of the block is already better than what the micro-benchmark's single-pair stream suggested.  Kept as a build-time switch
+// (default 0 = plain C, the compiler's schedule); the simulator always uses the plain C form.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NBLS_SDST_PAIRS)
+#define NBLS_SDST_PAIRS 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && NBLS_SDST_PAIRS > 0
+#define NBLS_MAD_ROT 1
+#define NBLS_ASM_MADI(ACC, A, B, SD, C0, C1) asm volatile("v_mad_i64_i32 %0, " SD ", %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B) : C0, C1)
+#define NBLS_ASM_MADU(ACC, A, B, SD, C0, C1) asm volatile("v_mad_u64_u32 %0, " SD ", %1, %2, %0" : "+v"(ACC) : "v"(A), "s"(B) : C0, C1)
+#define NBLS_ROT_CASES(M, ACC, A, B, K) \
+  switch ((K) % NBLS_SDST_PAIRS) { \
+    case 0: M(ACC, A, B, "s[84:85]", "s84", "s85"); break; \
+    case 1: M(ACC, A, B, "s[86:87]", "s86", "s87"); break; \
+    case 2: M(ACC, A, B, "s[88:89]", "s88", "s89"); break; \
+    case 3: M(ACC, A, B, "s[90:91]", "s90", "s91"); break; \
+    case 4: M(ACC, A, B, "s[92:93]", "s92", "s93"); break; \
+    case 5: M(ACC, A, B, "s[94:95]", "s94", "s95"); break; \
+    case 6: M(ACC, A, B, "s[96:97]", "s96", "s97"); break; \
+    default: M(ACC, A, B, "s[98:99]", "s98", "s99"); break; \
+  }
+__device__ __forceinline__ void madi_rot(u64& acc, u32 a, u32 b, int k) { NBLS_ROT_CASES(NBLS_ASM_MADI, acc, a, b, k) }
+__device__ __forceinline__ void madu_rot(u64& acc, u32 m, u32 p, int k) { NBLS_ROT_CASES(NBLS_ASM_MADU, acc, m, p, k) }
+#endif
 // acc[i+j] += a[j] * b[i] on signed limbs: 196 in-place v_mad_i64_i32, no carries
 NBLS_HD void mac28(u64* acc, const u32* a, const u32* b) {
 #pragma unroll
   for (int i = 0; i < NL; i++) {
 #pragma unroll
-    for (int j = 0; j < NL; j++) acc[i + j] = (u64)((i64)acc[i + j] + (i64)(i32)a[j] * (i64)(i32)b[i]);
+    for (int j = 0; j < NL; j++) {
+#if defined(NBLS_MAD_ROT)
+      madi_rot(acc[i + j], a[j], b[i], i * NL + j);
+#else
+      acc[i + j] = (u64)((i64)acc[i + j] + (i64)(i32)a[j] * (i64)(i32)b[i]);
+#endif
+    }
   }
 }
 // acc = offs * p * R (the bias that keeps a reduction with negative products non-negative)
@@ -127,7 +161,13 @@ NBLS_HD void redc28(u32* r, u64* acc) {
   for (int i = 0; i < NL; i++) {
     const u32 m = ((u32)acc[i] * NBLS_N0_28) & LMASK;
 #pragma unroll
-    for (int j = 0; j < NL; j++) acc[i + j] += (u64)m * P[j];
+    for (int j = 0; j < NL; j++) {
+#if defined(NBLS_MAD_ROT)
+      madu_rot(acc[i + j], m, P[j], i * NL + j);
+#else
+      acc[i + j] += (u64)m * P[j];
+#endif
+    }
     acc[i + 1] = (u64)((i64)acc[i + 1] + ((i64)acc[i] >> 28));
   }
   i64 c = 0;

@@ -30,7 +30,7 @@ static napi_value throw_code(napi_env env, int code) { char m[128]; snprintf(m, 
 
 static int get_bytes(napi_env env, napi_value v, uint8_t** data, size_t* len) {
   bool is_ta = false; napi_is_typedarray(env, v, &is_ta);
-  if (is_ta) { napi_typedarray_type t; napi_value ab; size_t off; void* d; if (napi_get_typedarray_info(env, v, &t, len, &d, &ab, &off) != napi_ok) return 0; if (t == napi_uint32_array) *len *= 4; *data = (uint8_t*)d; return 1; }
+  if (is_ta) { napi_typedarray_type t; napi_value ab; size_t off; void* d; if (napi_get_typedarray_info(env, v, &t, len, &d, &ab, &off) != napi_ok) return 0; if (t == napi_uint32_array || t == napi_int32_array) *len *= 4;   /* length in bytes */ *data = (uint8_t*)d; return 1; }
   bool is_buf = false; napi_is_buffer(env, v, &is_buf);
   if (is_buf) { void* d; if (napi_get_buffer_info(env, v, &d, len) != napi_ok) return 0; *data = (uint8_t*)d; return 1; }
   return 0;
