@@ -310,7 +310,7 @@ def main():
         roof = {
             'bound': 'valu-int32-mad', 'kernel': 'nbls_vm_kernel (all step programs of one pairing batch)',
             'achieved': round(achieved, 4), 'peak': round(PEAK_TMAD, 3), 'unit': 'TMAD32/s', 'frac': round(achieved / PEAK_TMAD, 4),
-            'traffic': traffic,
+            'traffic': traffic, 'traffic_source': 'profiles/hbm_traffic.json (rocprofv3 PMC passes of this batch size, FETCH_SIZE x 2 + WRITE_SIZE; a committed measurement, not taken in this run)' if traffic is not None else None,
             'valu_issue_busy': valu_busy,    # SQ_INSTS_VALU x 4 clocks / (kernel time x 2.4 GHz x 1024 SIMDs) from the PMC pass in profiles/ (same batch size, one batch at a time)
             'frac_at_value': round(value / world * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL / 1e12 / PEAK_TMAD, 4),
             'frac_note': 'achieved/frac: the kernels of ONE %d-pairing call running alone (sum of the HIP-event durations of its nbls_vm_kernel launches; profiles/ holds the rocprofv3 kernel trace of the same command); frac_at_value: the same algorithmic work at the rate of `value` (%d calls overlapping on %d streams; profiles/ holds a kernel trace taken with the same --inflight)' % (n, D, D),
@@ -386,7 +386,19 @@ def main():
             c1 = time.perf_counter()
             oracle.pairing_batch(g1s[:96 * 64], g2s[:192 * 64], True, False, threads=1)
             cdt1 = time.perf_counter() - c1
-            cpu = {'value': round(sample / cdt, 2), 'unit': 'pairings/s', 'cores': threads, 'kind': 'port',
+            # the same algorithm in the reference's own language and number representation: JavaScript BigInt on one core (oracle/js_bigint_pairing.js;
+            # the reference itself cannot travel to this box -- BASELINE.md section 4 holds its measured ratio to the reference under the same Node)
+            jsb = None
+            try:
+                import shutil, subprocess
+                if shutil.which('node'):
+                    jr = json.loads(subprocess.run(['node', os.path.join(ROOT, 'oracle', 'js_bigint_pairing.js'), '5'], capture_output=True, text=True, timeout=120).stdout.strip().splitlines()[-1])
+                    jsb = {'value': jr['pairings_per_s'], 'unit': 'pairings/s', 'cores': 1, 'kind': 'port', 'language': 'JavaScript BigInt (node %s)' % jr['node'], 'sample': '%d pairings in %.1f s, single thread' % (jr['pairings'], jr['seconds']),
+                           'checked_against_reference_vector': bool(jr['ok']), 'ratio_to_reference': 1.18,
+                           'reference_estimate': round(jr['pairings_per_s'] / 1.18, 2), 'note': 'the reference algorithm over the facade\'s BigInt field classes; ratio_to_reference = this code / the real reference under the same Node in the build container (BASELINE.md section 4)'}
+            except Exception as e:   # noqa: BLE001
+                jsb = {'error': repr(e)}
+            cpu = {'value': round(sample / cdt, 2), 'unit': 'pairings/s', 'cores': threads, 'kind': 'port', 'js_bigint': jsb,
                    'sample': '%d pairings of the same workload on %d host threads (oracle/ C restatement; timed on %d and on %d threads, the faster is reported); 1 thread: %.1f pairings/s' % (sample, threads, all_threads, max(1, all_threads // 2), 64 / cdt1),
                    'host_cpu_count': cores,
                    'reference_figure': {'value': 38.6, 'unit': 'pairings/s per core', 'source': 'BASELINE.md section 2: the reference itself (noble-bls12-381 v1.4.0, TypeScript / bigint) under Node 12 in the build container; it does not travel to the GPU box, so the port above is what is timed here'}}
@@ -448,8 +460,10 @@ def main():
             cdt = time.perf_counter() - c0
             FPMUL_VERIFY = 13294 + 12452 + 610       # SURVEY.md 8(d), per signature: validity + Miller loop + product term; hash-to-G2; key decompression
             v_ach = nv * FPMUL_VERIFY * MAD_PER_FPMUL / vdt_dev / 1e12
+            FPMUL_VERIFY_EXEC = FPMUL_VERIFY - 3351      # the reference re-checks the subgroup of every H(m) (PointG2.assertValidity, 3,351 Fp multiplications); the engine does not (a hash output is in the subgroup by construction)
             vbatch = {'metric': 'verifyBatch sigs/sec', 'n_signatures': nv, 'value': round(nv / vdt_dev, 2), 'unit': 'sigs/s',
                       'roofline': {'bound': 'valu-int32-mad', 'achieved': round(v_ach, 4), 'peak': round(PEAK_TMAD, 3), 'unit': 'TMAD32/s', 'frac': round(v_ach / PEAK_TMAD, 4),
+                                   'frac_executed': round(nv * FPMUL_VERIFY_EXEC * MAD_PER_FPMUL / vdt_dev / 1e12 / PEAK_TMAD, 4), 'fpmul_executed_algorithm': FPMUL_VERIFY_EXEC,
                                    'note': 'algorithmic work per signature %d Fp multiplications x %d MAD32 (SURVEY 8(d)) over the wall time of the call (all kernels of all three streams)' % (FPMUL_VERIFY, MAD_PER_FPMUL)},
                       'note': 'distinct 32-byte messages, 48-byte keys, one 96-byte aggregate signature; decompress + hash-to-G2 + %d Miller loops + 1 final exp on the GPU; inputs (incl. expand_message_xmd output) resident in HBM' % (nv + 1),
                       'ms': round(vdt_dev * 1e3, 3),

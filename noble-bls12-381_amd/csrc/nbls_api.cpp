@@ -15,6 +15,7 @@
 
 extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream);
 extern "C" int nbls_fp_inv_launch(unsigned n, const void* in, void* out, void* stream);
+extern "C" int nbls_flag_compact_launch(unsigned n, const void* flags, void* list, void* count, void* stream);
 extern "C" int nbls_xmd_launch(unsigned n, const void* msgs, const void* offsets, const void* dst, unsigned dst_len, void* out, unsigned len_in_bytes, void* stream);
 extern "C" int nbls_msm_keys_launch(unsigned n, unsigned nwin, const void* scalars, void* keys, void* vals, void* stream);
 extern "C" int nbls_msm_decompose_launch(unsigned n, unsigned dims, const void* scalars, void* out, void* stream);
@@ -38,6 +39,7 @@ static const size_t LINES_CHUNK = 131072;   // pairs whose line tables are in HB
 #define EXPORT extern "C" __attribute__((visibility("default")))
 static std::recursive_mutex g_null_mu;   // locked in place of a context's mutex when the caller passed no context (the call then fails with NBLS_EINVAL)
 
+static const size_t EXPC_MIN_DEFAULT = (size_t)1 << 40;   // items from which the cyclotomic exponentiations run with compressed squarings (expx below): never, unless asked for
 struct DevProgram {
   Step* steps = nullptr; u32* descs = nullptr; u32* consts = nullptr;
   const Program* p = nullptr;
@@ -67,6 +69,9 @@ struct nbls_ctx {
   uint8_t* ident_g1 = nullptr; uint8_t* ident_g2 = nullptr;   // projective identity (0 : 1 : 0), raw
   size_t cap_F = 0, cap_io = 0;
   size_t split_min = SPLIT_MILLER_MIN;   // nbls_set_tuning(NBLS_TUNE_SPLIT_MILLER_MIN)
+  // cyclotomic exponentiation with compressed squarings (expx): scratch per item -- compressed powers, decompression scratch, redo flags and list -- and two redo counters (one per half)
+  uint8_t *KS = nullptr, *KD = nullptr, *Kflag = nullptr; uint32_t *Klist = nullptr, *Kcount = nullptr;
+  size_t expc_min = getenv("NBLS_EXPC_MIN") ? (size_t)atol(getenv("NBLS_EXPC_MIN")) : EXPC_MIN_DEFAULT;   // nbls_set_tuning(NBLS_TUNE_EXPC_MIN)
   u32* qp_table = nullptr;      // multiples of p for the weak reduction (vm_exec.h weak_reduce), device copy
   uint8_t* unit_lines = nullptr;   // a line table whose 68 lines are all 1 (c0 = 1, c1 = c2 = 0): the neutral partner of an odd last pair
   uint8_t* partial = nullptr;   // 576 bytes: the Fp12 partial of the *_partial entry points (multi-GPU reductions)
@@ -158,13 +163,18 @@ static int run_inv(nbls_ctx* ctx, size_t n, hipStream_t s) {
 static int ensure_scratch(nbls_ctx* ctx, size_t n) {
   if (n <= ctx->cap_F) return NBLS_OK;
   size_t cap = n + n / 8 + 64;
-  if (ctx->F) { hipFree(ctx->F); hipFree(ctx->F2); hipFree(ctx->N); hipFree(ctx->NI); for (auto& t : ctx->T) { hipFree(t); t = nullptr; } }
-  ctx->F = ctx->F2 = ctx->N = ctx->NI = nullptr; ctx->cap_F = 0;
+  if (ctx->F) { hipFree(ctx->F); hipFree(ctx->F2); hipFree(ctx->N); hipFree(ctx->NI); for (auto& t : ctx->T) { hipFree(t); t = nullptr; } hipFree(ctx->KS); hipFree(ctx->KD); hipFree(ctx->Kflag); hipFree(ctx->Klist); hipFree(ctx->Kcount); }
+  ctx->F = ctx->F2 = ctx->N = ctx->NI = ctx->KS = ctx->KD = ctx->Kflag = nullptr; ctx->Klist = ctx->Kcount = nullptr; ctx->cap_F = 0;
   HIPCHK(hipMalloc(&ctx->F, (cap + 2) * F12));
   HIPCHK(hipMalloc(&ctx->F2, (cap / 2 + 2) * F12));
   HIPCHK(hipMalloc(&ctx->N, cap * RAW));
   HIPCHK(hipMalloc(&ctx->NI, cap * RAW));
   for (auto& t : ctx->T) HIPCHK(hipMalloc(&t, cap * F12));
+  HIPCHK(hipMalloc(&ctx->KS, cap * EXPC_SQ_ELEMS * RAW));
+  HIPCHK(hipMalloc(&ctx->KD, cap * EXPC_DEC_ELEMS * RAW));
+  HIPCHK(hipMalloc(&ctx->Kflag, cap));
+  HIPCHK(hipMalloc(&ctx->Klist, cap * 4));
+  HIPCHK(hipMalloc(&ctx->Kcount, 8));
   ctx->cap_F = cap;
   return NBLS_OK;
 }
@@ -255,19 +265,43 @@ static int reduce_product(nbls_ctx* ctx, size_t n, uint8_t** result, hipStream_t
   *result = src;
   return NBLS_OK;
 }
+// out = conj(in^|x|) for n unitary raw Fp12 elements (cyclotomicExp + conjugate, math.ts:845-852, 862).  Default: ONE program, 63 Granger-Scott squarings
+// on the tripled state and five products on twelve lanes per item (P_EXPX; its lane-split variant up to LS_MAX items).
+// Opt-in from expc_min items on (NBLS_TUNE_EXPC_MIN / NBLS_EXPC_MIN; default never): Karabina's compressed squarings -- 57 squarings on the four
+// coordinates (g2, g3, g4, g5) at EIGHT lanes per item (P_EXPC_SQ), the powers 2^16, 2^48, 2^57 decompressed around one Fp inversion per item
+// (P_EXPC_DEC_A -> inversion kernel -> P_EXPC_DEC_B, which also squares on to 2^60, 2^62, 2^63 and multiplies the six powers).  17 % fewer instructions
+// per item, but measured (profiles/round3_expc_ab.txt, tools/exp_expc.sh): 65,536 pairings 24.42 against 24.56 ms, 16,384 pairings 7.50 against
+// 7.20 ms, twelve 4096-batches in flight 2.67 against 2.70 M/s -- the squaring program runs 22 % better than the plain one per instruction, but the
+// decompression programs (50 live slots: two wavefronts per SIMD; 16 load / store / flag steps) run at 40-67 % of its rate and the five extra
+// inversion launches cost what is left.  Kept because it is correct on every input and the squaring kernel is the fastest code in the library: the
+// decompression is what a future round has to make cheaper.  The decompression divides by g2: an item with a vanishing g2 (the unit element, or a crafted
+// input) is flagged by DEC_B and recomputed by the plain program over an index list kept on the device, so the result is the reference's for every input.
+static int expx(nbls_ctx* ctx, size_t n, uint8_t* in, uint8_t* out, hipStream_t s) {
+  int r;
+  if (n < ctx->expc_min) return run(ctx, ls_variant(P_EXPX, n), n, {B(3, in, F12), B(5, out, F12)}, s);
+  const size_t KSB = (size_t)EXPC_SQ_ELEMS * RAW, KDB = (size_t)EXPC_DEC_ELEMS * RAW;
+  if ((r = run(ctx, P_EXPC_SQ, n, {B(3, in, F12), B(5, ctx->KS, KSB)}, s))) return r;
+  if ((r = run(ctx, P_EXPC_DEC_A, n, {B(3, ctx->KS, KSB), B(4, ctx->N, RAW), B(5, ctx->KD, KDB)}, s))) return r;
+  if ((r = run_inv(ctx, n, s))) return r;                 // N / NI are free once FE_EASY has run
+  if ((r = run(ctx, P_EXPC_DEC_B, n, {B(3, ctx->KS, KSB), B(4, ctx->NI, RAW), B(6, ctx->KD, KDB), B(5, out, F12), B(7, ctx->Kflag, 1)}, s))) return r;
+  uint32_t* count = ctx->Kcount + (ctx->ioff ? 1 : 0);    // the two halves of a split call run concurrently
+  uint32_t* list = ctx->Klist + ctx->ioff;
+  if (nbls_flag_compact_launch((unsigned)n, ctx->Kflag + ctx->ioff, list, count, s)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+  return run(ctx, P_EXPX, n, {B(3, in, F12), B(5, out, F12)}, s, count, list);   // workgroups beyond the listed items exit at once
+}
 // n raw Fp12 in `f_raw` (norms already in ctx->N) -> finalExponentiate -> wire bytes at d_out (math.ts:856-874)
 static int final_exp_pipeline(nbls_ctx* ctx, size_t n, uint8_t* f_raw, void* d_out, hipStream_t s) {
   int r;
   uint8_t** T = ctx->T;
   if ((r = run_inv(ctx, n, s))) return r;
   if ((r = run(ctx, P_FE_EASY, n, {B(3, f_raw, F12), B(4, ctx->NI, RAW), B(5, T[0], F12)}, s))) return r;
-  if ((r = run(ctx, ls_variant(P_EXPX, n), n, {B(3, T[0], F12), B(5, T[1], F12)}, s))) return r;                       // t2
+  if ((r = expx(ctx, n, T[0], T[1], s))) return r;   // t2
   if ((r = run(ctx, P_FE_MID1, n, {B(3, T[0], F12), B(5, T[1], F12), B(6, T[2], F12)}, s))) return r;   // t3
-  if ((r = run(ctx, ls_variant(P_EXPX, n), n, {B(3, T[2], F12), B(5, T[3], F12)}, s))) return r;                       // t4
-  if ((r = run(ctx, ls_variant(P_EXPX, n), n, {B(3, T[3], F12), B(5, T[4], F12)}, s))) return r;                       // t5
-  if ((r = run(ctx, ls_variant(P_EXPX, n), n, {B(3, T[4], F12), B(5, T[6], F12)}, s))) return r;                       // t6' (parked in T7's buffer)
+  if ((r = expx(ctx, n, T[2], T[3], s))) return r;   // t4
+  if ((r = expx(ctx, n, T[3], T[4], s))) return r;   // t5
+  if ((r = expx(ctx, n, T[4], T[6], s))) return r;   // t6' (parked in T7's buffer)
   if ((r = run(ctx, P_FE_MID2, n, {B(3, T[6], F12), B(5, T[1], F12), B(6, T[5], F12)}, s))) return r;   // t6
-  if ((r = run(ctx, ls_variant(P_EXPX, n), n, {B(3, T[5], F12), B(5, T[6], F12)}, s))) return r;                       // t7
+  if ((r = expx(ctx, n, T[5], T[6], s))) return r;   // t7
   return run(ctx, P_FE_FINAL, n, {B(0, T[0], F12), B(1, T[1], F12), B(2, T[2], F12), B(3, T[3], F12), B(4, T[4], F12), B(5, T[5], F12), B(6, T[6], F12), B(7, d_out, 576)}, s);
 }
 // one raw Fp12 -> final exponentiation (or plain encoding) -> wire bytes on device
@@ -334,7 +368,7 @@ EXPORT void nbls_destroy(nbls_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   for (auto& d : ctx->prog) { if (d.steps) hipFree(d.steps); if (d.descs) hipFree(d.descs); if (d.consts) hipFree(d.consts); }
-  for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->gen_g1, ctx->side_scratch, ctx->L, ctx->partial, ctx->unit_lines}) if (p) hipFree(p);
+  for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->gen_g1, ctx->side_scratch, ctx->L, ctx->partial, ctx->unit_lines, ctx->KS, ctx->KD, ctx->Kflag, (uint8_t*)ctx->Klist, (uint8_t*)ctx->Kcount}) if (p) hipFree(p);
   for (uint8_t* p : ctx->T) if (p) hipFree(p);
   for (uint8_t* p : ctx->sb) if (p) hipFree(p);
   for (uint8_t* p : ctx->nib) if (p) hipFree(p);
@@ -801,6 +835,7 @@ EXPORT int nbls_set_tuning(nbls_ctx* ctx, int key, long long value) {
   switch (key) {
     case NBLS_TUNE_SPLIT_MILLER_MIN: if (value < 0) return NBLS_EINVAL; ctx->split_min = (size_t)value; return NBLS_OK;
     case NBLS_TUNE_HALVES_MIN: if (value < 0) return NBLS_EINVAL; ctx->halves_min = value == 0 ? (size_t)-1 : (size_t)value; return NBLS_OK;
+    case NBLS_TUNE_EXPC_MIN: if (value < 0) return NBLS_EINVAL; ctx->expc_min = (size_t)value; return NBLS_OK;
     default: return NBLS_EINVAL;
   }
 }

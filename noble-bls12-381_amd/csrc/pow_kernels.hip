@@ -203,6 +203,21 @@ extern "C" int nbls_fp_pow_launch(unsigned n, const void* in, void* out, const v
   return (int)hipGetLastError();
 }
 
+// list[k] = index of the k-th item whose int8 flag is set, *count = their number (order irrelevant): the items of a compressed cyclotomic exponentiation that
+// met a zero denominator and are recomputed by the plain program over this index list (nbls_api.cpp expx)
+namespace nbls {
+__global__ void nbls_flag_compact_kernel(unsigned n, const signed char* __restrict__ flags, u32* __restrict__ list, u32* __restrict__ count) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flags[i]) list[atomicAdd(count, 1u)] = i;
+}
+}
+extern "C" int nbls_flag_compact_launch(unsigned n, const void* flags, void* list, void* count, void* stream) {
+  if (n == 0) return 0;
+  if (hipMemsetAsync(count, 0, 4, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
+  hipLaunchKernelGGL(nbls::nbls_flag_compact_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, (const signed char*)flags, (nbls::u32*)list, (nbls::u32*)count);
+  return (int)hipGetLastError();
+}
+
 extern "C" int nbls_fp_inv_launch(unsigned n, const void* in, void* out, void* stream) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(nbls::nbls_fp_inv_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, (const nbls::u32*)in, (nbls::u32*)out);

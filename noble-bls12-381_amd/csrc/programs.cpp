@@ -12,6 +12,7 @@
 #include "tower.h"
 #include "curve.h"
 #include "codec.h"
+#include "vm_exec.h"
 
 namespace nbls {
 
@@ -286,6 +287,85 @@ static Program build(ProgId id) {
         outputw_fp12(conj(cyclotomic_exp_x(inputw_fp12(3, 0), [&]() { return inputw_fp12(3, 0); })), 5, 0);
       } else outputw_fp12(conj(cyclotomic_exp_x(inputw_fp12(3, 0))), 5, 0);
       return B.compile(ls ? "expx_ls" : "expx", ls ? 12 : EXPX_W);
+    }
+    case P_EXPC_SQ: {
+      // raw Fp12 element order: c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2 (two raw elements each)
+      auto ld = [&](int i) { return SFp2{inputw(3, 96 * i), inputw(3, 96 * i + 48)}; };
+      SCyc4 a = {ld(3), ld(2), ld(1), ld(5)};
+      const SFp three = SFp(B.small_const(3));
+      auto m3 = [&](const SFp2& v) { return SFp2{mul(v.c0, three), mul(v.c1, three)}; };
+      SCyc4 z = mat(SCyc4{m3(a.g2), m3(a.g3), m3(a.g4), m3(a.g5)});
+      int slot = 0;
+      for (int k = 1; k <= EXPC_TOP; k++) {
+        z = mat(compressed_sqr_tripled(z));
+        if ((NBLS_X >> k) & 1) {
+          const SFp2* c[4] = {&z.g2, &z.g3, &z.g4, &z.g5};
+          for (int e = 0; e < 4; e++) { outputw(c[e]->c0, 5, (8 * slot + 2 * e) * 48); outputw(c[e]->c1, 5, (8 * slot + 2 * e + 1) * 48); }
+          slot++;
+        }
+      }
+      B.store_batch = 8;
+      return B.compile("expc_sq", env_int("NBLS_EXPC_SQ_W", 8));
+    }
+    case P_EXPC_DEC_A: {
+      // scratch layout (buf 5, EXPC_DEC_ELEMS raw elements): w_j = numerator * conj(g2) (2 x 3) | all-but-one products (3) | the same / 3 (3) | v_j (2 x 3) | zero flag
+      auto ld = [&](int j, int e) { return SFp2{inputw(3, (8 * j + 2 * e) * 48), inputw(3, (8 * j + 2 * e + 1) * 48)}; };
+      const SFp third = SFp(B.frac_const(1, 3));
+      SFp n[EXPC_POWERS], z[EXPC_POWERS];
+      for (int j = 0; j < EXPC_POWERS; j++) {
+        SFp2 g2 = ld(j, 0), g3 = ld(j, 1), g4 = ld(j, 2), g5 = ld(j, 3);
+        SFp d0 = scale(g2.c0, 2), d1 = scale(g2.c1, 2);
+        SFp nj = SFp(materialize(mul(d0, d0) + mul(d1, d1)));                 // |2 g2|^2 = 4 |g2|^2: the 4 of the denominator rides in the doubled operands
+        z[j] = f_and(is_zero(g2.c0), is_zero(g2.c1));
+        n[j] = select(z[j], fp_one(), nj);                                    // a vanishing g2 must not wipe out the other inverses; the item is flagged and redone
+        SFp2 num = mat(mulnr(sqr(g5)) + scale(sqr(g4), 3) - scale(g3, 6));    // on the tripled state: 3 g1 = (xi G5^2 + 3 G4^2 - 6 G3) / (4 G2)
+        SFp2 w = mul(num, conj(g2));
+        outputw(w.c0, 5, (2 * j) * 48); outputw(w.c1, 5, (2 * j + 1) * 48);
+        // the part of the tripled g0 = xi (2 G1 G1/3 + G2/3 G5 - G3 G4) + 3 that does not need g1
+        SFp2 u2 = mat(mul_fp(g2, third));
+        SFp2 v = mul(mulnr(u2), g5) - mul(mulnr(g3), g4);
+        outputw(v.c0, 5, (4 * EXPC_POWERS + 2 * j) * 48); outputw(v.c1, 5, (4 * EXPC_POWERS + 2 * j + 1) * 48);
+      }
+      // inverse of n_j = (n_0 n_1 n_2)^-1 * (product of the other two)
+      static_assert(EXPC_POWERS == 3, "the product tree below is written for three denominators");
+      SFp abo[3] = {SFp(materialize(mul(n[1], n[2]))), SFp(materialize(mul(n[0], n[2]))), SFp(materialize(mul(n[0], n[1])))};
+      outputw(mul(abo[2], n[2]), 4, 0);
+      for (int j = 0; j < EXPC_POWERS; j++) {
+        outputw(abo[j], 5, (2 * EXPC_POWERS + j) * 48);
+        outputw(mul(abo[j], third), 5, (3 * EXPC_POWERS + j) * 48);
+      }
+      outputw(f_or(f_or(z[0], z[1]), z[2]), 5, (6 * EXPC_POWERS) * 48);
+      return B.compile("expc_dec_a", env_int("NBLS_EXPC_DECA_W", 12));
+    }
+    case P_EXPC_DEC_B: {
+      auto ld = [&](int j, int e) { return SFp2{inputw(3, (8 * j + 2 * e) * 48), inputw(3, (8 * j + 2 * e + 1) * 48)}; };
+      const SFp ninv = inputw(4, 0);
+      SFp12 d[EXPC_POWERS];   // the tripled elements (3 A)^(2^16), (3 A)^(2^48), (3 A)^(2^57), decompressed
+      for (int j = 0; j < EXPC_POWERS; j++) {
+        SFp2 w = {inputw(6, (2 * j) * 48), inputw(6, (2 * j + 1) * 48)};
+        SFp inv = SFp(materialize(mul(ninv, inputw(6, (2 * EXPC_POWERS + j) * 48))));    // 1 / |2 g2|^2
+        SFp inv3 = SFp(materialize(mul(ninv, inputw(6, (3 * EXPC_POWERS + j) * 48))));   // a third of it
+        SFp2 g1 = mat(mul_fp(w, inv)), u1 = mat(mul_fp(w, inv3));                       // tripled g1, and g1 itself
+        SFp2 v = {inputw(6, (4 * EXPC_POWERS + 2 * j) * 48), inputw(6, (4 * EXPC_POWERS + 2 * j + 1) * 48)};
+        SFp2 g0 = mul(mulnr(scale(g1, 2)), u1) + v;
+        g0.c0 = g0.c0 + SFp(B.small_const(3));
+        d[j] = {{mat(g0), ld(j, 2), ld(j, 1)}, {ld(j, 0), g1, ld(j, 3)}};
+      }
+      // A^|x| = A^(2^16) A^(2^48) A^(2^57) A^(2^60) A^(2^62) A^(2^63): the three top powers by plain squarings of the decompressed 2^57 power (3 + 2 + 1)
+      SFp12 acc = mat(mul(d[0], d[1])), t = d[2];
+      acc = mat(mul(acc, t));
+      const int runs[3] = {3, 2, 1};
+      for (int r = 0; r < 3; r++) {
+        for (int k = 0; k < runs[r]; k++) t = mat(cyclotomic_sqr_tripled(t));
+        acc = mat(mul(acc, t));
+      }
+      // six tripled factors: divide by 3^6
+      u32 c[NLIMBS]; memcpy(c, NBLS_INV3, NLIMBS * 4);
+      for (int k = 1; k < 6; k++) { u32 t2[NLIMBS]; mont_mul28(t2, c, NBLS_INV3); csub_p(t2); memcpy(c, t2, NLIMBS * 4); }
+      outputw_fp12(conj(mul_fp(acc, constant(c))), 5, 0);
+      status_out({{f_not(inputw(6, (6 * EXPC_POWERS) * 48)), 1}}, 7);
+      B.sched_window = env_int("NBLS_EXPC_DEC_WINDOW", 150);
+      return B.compile("expc_dec_b", env_int("NBLS_EXPC_DECB_W", 12));
     }
     case P_FE_MID1: {
       SFp12 a = inputw_fp12(3, 0), b = inputw_fp12(5, 0);

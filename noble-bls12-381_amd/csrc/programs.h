@@ -64,8 +64,16 @@ enum ProgId {
   // lane-split variants (Program::lsplit = 4: every K_DOT lane-op on four adjacent lanes, one item per wavefront) for launches of at most one wavefront
   // per SIMD: the same formulas, a third fewer instructions per wavefront
   P_MILLER_BYTES_LS, P_MILLER_RAW_LS, P_MILLER_FE_LS, P_EXPX_LS,
+  // cyclotomic exponentiation with Karabina's compressed squarings (round 3): the same map as P_EXPX in three programs around one Fp inversion
+  P_EXPC_SQ,           // A (buf 3) -> the compressed coordinates (g2, g3, g4, g5) of (3 A)^(2^k) for k = 16, 48, 57 (buf 5: 3 x 8 raw elements): 57 compressed squarings, 8 lanes per item
+  P_EXPC_DEC_A,        // compressed powers (buf 3) -> product of the three |2 g2|^2 (buf 4: the element to invert), numerators times conj(g2), all-but-one products (and a third of them), the g1-free part of g0, zero flag (buf 5: 19 raw elements)
+  P_EXPC_DEC_B,        // compressed powers (3), inverse (4), DEC_A scratch (6) -> conj(A^|x|) (buf 5), int8 status (buf 7): 1 = some g2 was zero, the item must be recomputed by P_EXPX
   P_COUNT
 };
+// |x| = 2^63 + 2^62 + 2^60 + 2^57 + 2^48 + 2^16: the compressed chain runs to 2^57 and its values at the set bits 16, 48, 57 are decompressed; the powers
+// 2^60, 2^62, 2^63 follow from the decompressed 2^57 power by 3 + 2 + 1 plain squarings (cheaper than three more decompressions)
+static const int EXPC_POWERS = 3, EXPC_TOP = 57;
+static const int EXPC_SQ_ELEMS = 8 * EXPC_POWERS, EXPC_DEC_ELEMS = 6 * EXPC_POWERS + 1;   // raw elements per item of the two scratch areas
 static const int N_LINES = 68;                 // 63 doubling steps + 5 addition steps (bits of |x|)
 static const int LINE_ELEMS = 6 * N_LINES;     // raw field elements per line table
 static const int MSM_WINDOW_BITS = 12;

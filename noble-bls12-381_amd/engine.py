@@ -342,6 +342,10 @@ class Engine:
     def fp12_product_final_dev(self, n, d_in, d_out, final_exp=True, stream=None):
         self._chk(self.lib.nbls_fp12_product_final_dev(self.h, n, d_in, int(final_exp), d_out, stream))
 
+    def set_expc_min(self, n):
+        """items from which the final exponentiation uses compressed cyclotomic squarings (NBLS_TUNE_EXPC_MIN; 0 = always)"""
+        self._chk(self.lib.nbls_set_tuning(self.h, 3, n))
+
     def set_split_miller_min(self, n):
         """pairs from which the Miller loop runs as LINES + ACC (0: always, a huge value: never)"""
         self._chk(self.lib.nbls_set_tuning(self.h, 1, n))

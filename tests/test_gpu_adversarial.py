@@ -68,6 +68,51 @@ def test_final_exp_extremes(eng, oracle):
         assert out[576 * i:576 * (i + 1)] == oracle.un('fp12_final_exp', e, 576), (i, [hex(v)[:12] for v in c])
 
 
+@pytest.mark.parametrize('n', [1, 7, 8, 9, 41, 300])
+def test_final_exp_compressed_squarings(eng, oracle, n):
+    """The compressed-squaring form of the five cyclotomic exponentiations (Karabina; csrc/nbls_api.cpp expx, forced with NBLS_TUNE_EXPC_MIN = 0) on the
+    extremal Fp12 inputs, random ones, and the inputs whose compressed coordinates vanish (the unit element, elements of Fp6 and of Fp2: their easy
+    part is 1) scattered over the batch -- those are flagged on the device and recomputed by the plain program.  Batch sizes around the wavefront fills
+    (8 items per wavefront in the squaring program, 5 in the decompression).  Every result against the oracle (math.ts:856-874)."""
+    rnd = random.Random(1000 + n)
+    cases = _fp12_cases()
+    one = fp(1) + bytes(528)
+    items = []
+    for i in range(n):
+        k = i % 11
+        if k == 3: items.append(one)
+        elif k == 6: c = cases[rnd.randrange(len(cases))]; c = c if any(c[:6]) else [2] * 6; items.append(b''.join(fp(v) for v in c[:6]) + bytes(288))      # a non-zero element of Fp6
+        elif k == 9: items.append(fp(rnd.randrange(1, P)) + fp(rnd.randrange(P)) + bytes(480))                            # an element of Fp2
+        elif k % 2: items.append(b''.join(fp(rnd.randrange(P)) for _ in range(12)))
+        else: items.append(b''.join(fp(v) for v in cases[rnd.randrange(len(cases))]))
+    blob = b''.join(items)
+    eng.set_expc_min(0)
+    try:
+        out = eng.final_exp_batch(blob)
+    finally:
+        eng.set_expc_min(1 << 40)
+    assert out == eng.final_exp_batch(blob)                      # the plain program (the default)
+    for i in range(n):
+        assert out[576 * i:576 * (i + 1)] == oracle.un('fp12_final_exp', items[i], 576), (n, i, i % 11)
+
+
+def test_pairings_with_compressed_squarings(eng, oracle):
+    """9000 pairings in one call with the compressed squarings switched on: the call runs as two halves on two streams (two redo lists and counters in
+    flight at once); all results against the multi-threaded oracle"""
+    n = 9000
+    rnd = random.Random(9)
+    g1, g2 = oracle.g1_generator(), oracle.g2_generator()
+    P64 = [oracle.g1_mul(g1, rnd.randrange(1, 2 ** 250))[1] for _ in range(48)]; Q64 = [oracle.g2_mul(g2, rnd.randrange(1, 2 ** 250))[1] for _ in range(48)]
+    G1 = b''.join(P64[i % 48] for i in range(n)); G2 = b''.join(Q64[(i // 48 + 5 * i) % 48] for i in range(n))
+    eng.set_expc_min(0)
+    try:
+        out, st = eng.pairing_batch(G1, G2, True, False)
+    finally:
+        eng.set_expc_min(1 << 40)
+    ref, _ = oracle.pairing_batch(G1, G2, True, False, threads=64)
+    assert out == ref
+
+
 def _coordinate_cases():
     """(G1, G2) wire pairs whose coordinates are arbitrary field elements (not curve points): the Miller loop is polynomial arithmetic and
     must agree with the oracle on any input"""

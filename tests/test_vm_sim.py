@@ -399,13 +399,41 @@ def test_lane_split_programs(sim, oracle, golden):
         assert out.raw[576 * i:576 * (i + 1)] == hx(golden['pairs'][i]['pairing']), i
 
 
+def test_compressed_exponentiation(sim, golden, testdata):
+    """Karabina's compressed squarings (round 3; EXPC_SQ -> EXPC_DEC_A -> inversion -> EXPC_DEC_B, csrc/nbls_api.cpp expx): the same final exponentiation,
+    bit for bit, on the reference's finalExponentiate known answer (test/pairing.test.ts:65-96), reference-run Fp12 values, and the inputs whose
+    compressed coordinates vanish -- the unit element and an element of Fp6 (its easy part is 1): those are flagged and recomputed by the plain program"""
+    one = (1).to_bytes(48, 'big') + bytes(528)
+    sub = hx(golden['fp12'][1]['a'])[:288] + bytes(288)            # c1 = 0: an element of Fp6, f^(p^6) / f = 1
+    fin = [hx(testdata['finalexp_in'])] + [hx(v['a']) for v in golden['fp12'][:5]] + [one, sub] + [hx(v['miller']) for v in golden['pairs'][:3]]
+    n = len(fin)       # 11 items: EXPC_SQ runs 8 per wavefront, the decompression programs 5
+    F = C.create_string_buffer(vmsim_py.F12 * n); N = C.create_string_buffer(vmsim_py.RAW * n)
+    out = C.create_string_buffer(576 * n); ref = C.create_string_buffer(576 * n)
+    blob = b''.join(fin)
+    vmsim_py.run(sim, 'NORM_BYTES', n, {2: (C.create_string_buffer(blob, len(blob)), 576), 3: (F, vmsim_py.F12), 4: (N, vmsim_py.RAW)})
+    vmsim_py.final_exp(sim, n, F, N, out, expx='EXPC')
+    vmsim_py.final_exp(sim, n, F, N, ref)
+    assert out.raw == ref.raw
+    assert out.raw[:576] == hx(testdata['finalexp_out'])
+    for i in range(5):
+        assert out.raw[576 * (i + 1):576 * (i + 2)] == hx(golden['fp12'][i]['finalexp']), i
+    assert out.raw[576 * 6:576 * 7] == one and out.raw[576 * 7:576 * 8] == one
+    for i in range(3):
+        assert out.raw[576 * (8 + i):576 * (9 + i)] == hx(golden['pairs'][i]['pairing']), i
+    # the flags: exactly the two degenerate items, in every one of the five exponentiations' first stage
+    T0 = C.create_string_buffer(vmsim_py.F12 * n); NI = C.create_string_buffer(vmsim_py.RAW * n); T1 = C.create_string_buffer(vmsim_py.F12 * n)
+    sim.nbls_sim_fp_inv(C.c_uint(n), N, NI)
+    vmsim_py.run(sim, 'FE_EASY', n, {3: (F, vmsim_py.F12), 4: (NI, vmsim_py.RAW), 5: (T0, vmsim_py.F12)})
+    assert vmsim_py.expx_compressed(sim, n, T0, T1) == [6, 7]
+
+
 def test_plain_formula_switches():
-    """NBLS_DBL_PLAIN / NBLS_MUL12_PLAIN select the formulas that the difference-of-squares doublings and the split Fp12 middle product replaced (DESIGN.md
+    """NBLS_DBL_PLAIN / NBLS_MUL12_PLAIN / NBLS_CYCSQR_PLAIN select the formulas that the difference-of-squares doublings, the split Fp12 middle product and the tripled-state cyclotomic squaring replaced (DESIGN.md
     section 3.3; they exist for A/B timing).  Both must stay bit-exact: the tests that cover the point chains, the line tables and the Fp12 products run again
     in a fresh process with the switches set (the switches are read once per process)."""
     import os, subprocess, sys
-    env = dict(os.environ, NBLS_DBL_PLAIN='1', NBLS_MUL12_PLAIN='1')
-    sel = 'validity or hash_to_g2 or scalar_mul or full_pairing or split_miller or final_exp'
+    env = dict(os.environ, NBLS_DBL_PLAIN='1', NBLS_MUL12_PLAIN='1', NBLS_CYCSQR_PLAIN='1')
+    sel = 'validity or hash_to_g2 or scalar_mul or full_pairing or split_miller or final_exp or compressed_exponentiation'
     r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-p', 'no:cacheprovider', os.path.abspath(__file__), '-k', sel], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'passed' in r.stdout

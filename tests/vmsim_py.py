@@ -17,7 +17,7 @@ def raw_elem(v):
 
 
 PROGS = ['MILLER_BYTES', 'MILLER_RAW', 'MILLER_FE', 'NORM_RAW', 'NORM_BYTES', 'FE_EASY', 'EXPX', 'FE_MID1', 'FE_MID2', 'FE_FINAL', 'MUL2', 'RAW_TO_BYTES', 'G1_VALIDATE', 'G2_VALIDATE', 'G1_DEC_A', 'G1_DEC_B', 'G2_DEC_A', 'G2_DEC_B', 'H2C_A', 'H2C_B',
-         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'G1_COMPRESS', 'G2_COMPRESS', 'H2C1_A', 'ENC1_A', 'H2C1_B', 'ENC1_B', 'G1_CLEAR', 'ENC2_A', 'ENC2_B', 'G1_MUL', 'G2_MUL', 'G1_ADD_AB', 'G2_ADD_AB', 'G1_HORNER', 'G2_HORNER', 'G1_SHIFTADD', 'G2_SHIFTADD', 'G1_MSM_PREP', 'G2_MSM_PREP', 'LINES_PQ', 'LINES_Q', 'LINES_BYTES', 'LINES_FROM_BYTES', 'ACC_BYTES', 'ACC_RAW', 'ACC_FE', 'ACC2_RAW', 'ACC_Q', 'G2_DEC_A192', 'G2_DEC_B192', 'G2_DEC_B_HEX', 'G1_FROM_RAW', 'G2_FROM_RAW', 'G2_SWAP', 'H2C_C1', 'H2C_C2', 'ACC4_RAW', 'MILLER_BYTES_LS', 'MILLER_RAW_LS', 'MILLER_FE_LS', 'EXPX_LS']
+         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'G1_COMPRESS', 'G2_COMPRESS', 'H2C1_A', 'ENC1_A', 'H2C1_B', 'ENC1_B', 'G1_CLEAR', 'ENC2_A', 'ENC2_B', 'G1_MUL', 'G2_MUL', 'G1_ADD_AB', 'G2_ADD_AB', 'G1_HORNER', 'G2_HORNER', 'G1_SHIFTADD', 'G2_SHIFTADD', 'G1_MSM_PREP', 'G2_MSM_PREP', 'LINES_PQ', 'LINES_Q', 'LINES_BYTES', 'LINES_FROM_BYTES', 'ACC_BYTES', 'ACC_RAW', 'ACC_FE', 'ACC2_RAW', 'ACC_Q', 'G2_DEC_A192', 'G2_DEC_B192', 'G2_DEC_B_HEX', 'G1_FROM_RAW', 'G2_FROM_RAW', 'G2_SWAP', 'H2C_C1', 'H2C_C2', 'ACC4_RAW', 'MILLER_BYTES_LS', 'MILLER_RAW_LS', 'MILLER_FE_LS', 'EXPX_LS', 'EXPC_SQ', 'EXPC_DEC_A', 'EXPC_DEC_B']
 P = {n: i for i, n in enumerate(PROGS)}
 
 
@@ -38,19 +38,43 @@ def run(lib, prog, n, bufs):
     assert r == 0
 
 
+EXPC_SQ_BYTES, EXPC_DEC_BYTES = 24 * RAW, 19 * RAW
+
+
+def expx_compressed(lib, n, src, dst):
+    """expx_compressed() of csrc/nbls_api.cpp on the simulator: Karabina's compressed squarings (EXPC_SQ), decompression around one inversion
+    (EXPC_DEC_A, fp_inv, EXPC_DEC_B), flagged items (a vanishing g2) recomputed by the plain program.  Returns the flags."""
+    KS = C.create_string_buffer(EXPC_SQ_BYTES * n); KD = C.create_string_buffer(EXPC_DEC_BYTES * n)
+    KN = C.create_string_buffer(RAW * n); KNI = C.create_string_buffer(RAW * n); st = C.create_string_buffer(n)
+    run(lib, 'EXPC_SQ', n, {3: (src, F12), 5: (KS, EXPC_SQ_BYTES)})
+    run(lib, 'EXPC_DEC_A', n, {3: (KS, EXPC_SQ_BYTES), 4: (KN, RAW), 5: (KD, EXPC_DEC_BYTES)})
+    lib.nbls_sim_fp_inv(C.c_uint(n), KN, KNI)
+    run(lib, 'EXPC_DEC_B', n, {3: (KS, EXPC_SQ_BYTES), 4: (KNI, RAW), 6: (KD, EXPC_DEC_BYTES), 5: (dst, F12), 7: (st, 1)})
+    flagged = [i for i in range(n) if st.raw[i]]
+    for i in flagged:        # the device runs P_EXPX over an index list of the flagged items, in place
+        a = C.create_string_buffer(src.raw[F12 * i:F12 * (i + 1)], F12); b = C.create_string_buffer(F12)
+        run(lib, 'EXPX', 1, {3: (a, F12), 5: (b, F12)})
+        C.memmove(C.addressof(dst) + F12 * i, b, F12)
+    return flagged
+
+
 def final_exp(lib, n, F, N, out, expx='EXPX'):
-    """The launch sequence of final_exp_pipeline() in csrc/nbls_api.cpp, on the simulator."""
+    """The launch sequence of final_exp_pipeline() in csrc/nbls_api.cpp, on the simulator (expx='EXPC': the compressed-squaring form of the five exponentiations)."""
     NI = C.create_string_buffer(RAW * n)
     T = [C.create_string_buffer(F12 * n) for _ in range(7)]
     lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
     run(lib, 'FE_EASY', n, {3: (F, F12), 4: (NI, RAW), 5: (T[0], F12)})
-    run(lib, expx, n, {3: (T[0], F12), 5: (T[1], F12)})
+    if expx == 'EXPC':
+        ex = lambda a, b: expx_compressed(lib, n, a, b)
+    else:
+        ex = lambda a, b: run(lib, expx, n, {3: (a, F12), 5: (b, F12)})
+    ex(T[0], T[1])
     run(lib, 'FE_MID1', n, {3: (T[0], F12), 5: (T[1], F12), 6: (T[2], F12)})
-    run(lib, expx, n, {3: (T[2], F12), 5: (T[3], F12)})
-    run(lib, expx, n, {3: (T[3], F12), 5: (T[4], F12)})
-    run(lib, expx, n, {3: (T[4], F12), 5: (T[6], F12)})
+    ex(T[2], T[3])
+    ex(T[3], T[4])
+    ex(T[4], T[6])
     run(lib, 'FE_MID2', n, {3: (T[6], F12), 5: (T[1], F12), 6: (T[5], F12)})
-    run(lib, expx, n, {3: (T[5], F12), 5: (T[6], F12)})
+    ex(T[5], T[6])
     bufs = {i: (T[i], F12) for i in range(7)}
     bufs[7] = (out, 576)
     run(lib, 'FE_FINAL', n, bufs)
