@@ -70,6 +70,7 @@ def main():
     ap.add_argument('--sign-batch', type=int, default=8192, help='signatures produced in the sign leg (SURVEY 8(f).1); 0 disables')
     ap.add_argument('--large-batch', type=int, default=65536, help='pairings of the saturated single-call leg (roofline at a launch that fills every SIMD three wavefronts deep); 0 disables')
     ap.add_argument('--product-terms', type=int, default=262144, help='terms of the sharded multi-pairing product leg (BASELINE configs[4]); 0 disables')
+    ap.add_argument('--mark-timed-region', action='store_true', help='bracket the timed steps with two tiny torch fill kernels, so that a rocprofv3 kernel trace of the run shows where the timed region starts and ends (tools/profile_round3.sh)')
     ap.add_argument('--dry-launch', action='store_true', help='launch check without a GPU: the ranks of --gpus N rendezvous over gloo, all-reduce their ranks and rank 0 prints one JSON line (tests/test_bench_launch.py)')
     args = ap.parse_args()
 
@@ -156,6 +157,8 @@ def main():
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
+    if args.mark_timed_region:
+        mark = torch.empty(3, dtype=torch.float32, device='cuda'); mark.fill_(1.0); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -163,6 +166,8 @@ def main():
     if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if args.mark_timed_region:
+        mark.fill_(2.0); torch.cuda.synchronize()
     if multi:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

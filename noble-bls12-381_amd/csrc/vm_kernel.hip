@@ -8,6 +8,7 @@
 // multiply-adds.  Per-lane data (LDS byte offsets) comes from the lane descriptors, fetched one round / one step ahead.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 #include "vm_exec.h"
 
@@ -145,20 +146,23 @@ extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, vo
   using namespace nbls;
   if (ka->n_items == 0) return 0;
   unsigned blocks = (ka->n_items + ka->G - 1) / ka->G;
-  // the dynamic-LDS limit is a per-device function attribute: set it once on every device a launch is made on
+  // the dynamic-LDS limit is a per-device function attribute: set it once on every device a launch is made on.  The common case (already set) takes no
+  // lock: twelve host threads launch through here concurrently when twelve calls are kept in flight
+  static std::atomic<bool> attr_set[64];
   static std::mutex attr_mu;
-  static bool attr_set[64] = {false};
   {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    std::lock_guard<std::mutex> g(attr_mu);
-    if (!attr_set[dev]) {
-      hipFuncSetAttribute((const void*)nbls_vm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute((const void*)nbls_vm_kernel_fair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute((const void*)nbls_vm_kernel_sc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute((const void*)nbls_vm_kernel_ls4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute((const void*)nbls_vm_kernel_fair_sc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set[dev] = true;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+      std::lock_guard<std::mutex> g(attr_mu);
+      if (!attr_set[dev].load(std::memory_order_relaxed)) {
+        hipFuncSetAttribute((const void*)nbls_vm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)nbls_vm_kernel_fair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)nbls_vm_kernel_sc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)nbls_vm_kernel_ls4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)nbls_vm_kernel_fair_sc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set[dev].store(true, std::memory_order_release);
+      }
     }
   }
   static const unsigned lds_floor = getenv("NBLS_LDS_FLOOR") ? (unsigned)atoi(getenv("NBLS_LDS_FLOOR")) : 0u;   // placement studies: caps workgroups per CU at 160 KB / floor

@@ -26,5 +26,5 @@ for path in sys.argv[1:]:
     out[str(n)] = {'bytes_per_step': round(2 * fetch + write), 'fetch_size_bytes_raw': round(fetch), 'write_size_bytes': round(write),
                    'valu_wave_instructions_per_step': round(valu), 'valu_issue_busy': round(valu * 4 / (t_us * 1e-6 * 2.4e9 * 1024), 4),
                    'algorithmic_bytes_per_step': ALG(n), 'programs': progs,
-                   'note': 'round 2 (tools/profile_round2.sh -> tools/pmc_summary.py -> tools/hbm_traffic.py): sums over the launches of one pairing call (expx x5); FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md; valu_issue_busy = SQ_INSTS_VALU x 4 clocks / (kernel time under the counter pass x 2.4 GHz x 1024 SIMDs)'}
+                   'note': 'round 3 (tools/profile_round3.sh -> tools/pmc_summary.py -> tools/hbm_traffic.py): sums over the launches of one pairing call (expx x5); FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md; valu_issue_busy = SQ_INSTS_VALU x 4 clocks / (kernel time under the counter pass x 2.4 GHz x 1024 SIMDs)'}
 json.dump(out, sys.stdout, indent=1)
