@@ -70,6 +70,7 @@ def main():
     ap.add_argument('--sign-batch', type=int, default=8192, help='signatures produced in the sign leg (SURVEY 8(f).1); 0 disables')
     ap.add_argument('--large-batch', type=int, default=65536, help='pairings of the saturated single-call leg (roofline at a launch that fills every SIMD three wavefronts deep); 0 disables')
     ap.add_argument('--product-terms', type=int, default=262144, help='terms of the sharded multi-pairing product leg (BASELINE configs[4]); 0 disables')
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'], help='torch.distributed backend of an N > 1 run: nccl (= RCCL, the real thing) or gloo, which lets several ranks share one GPU (rank r uses device r mod device count) so that the whole N-rank job -- launcher, sharded legs, barriers -- runs on a one-GPU box (RCCL refuses two ranks on one device); tests/test_gpu_rccl.py')
     ap.add_argument('--mark-timed-region', action='store_true', help='bracket the timed steps with two tiny torch fill kernels, so that a rocprofv3 kernel trace of the run shows where the timed region starts and ends (tools/profile_round3.sh)')
     ap.add_argument('--dry-launch', action='store_true', help='launch check without a GPU: the ranks of --gpus N rendezvous over gloo, all-reduce their ranks and rank 0 prints one JSON line (tests/test_bench_launch.py)')
     args = ap.parse_args()
@@ -108,6 +109,8 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the engine has no CPU path)')
+    if args.dist_backend == 'gloo':
+        local_rank = local_rank % torch.cuda.device_count()      # ranks may share a GPU under gloo
     torch.cuda.set_device(local_rank)
     multi = world > 1 or args.force_dist      # every collective below is gated on this
     if multi:
@@ -116,7 +119,10 @@ def main():
         if args.force_dist:
             for k, v in (('MASTER_PORT', '29517'), ('RANK', '0'), ('WORLD_SIZE', '1'), ('NBLS_FORCE_COLLECTIVES', '1')): os.environ.setdefault(k, v)
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        if args.dist_backend == 'gloo':
+            dist.init_process_group(backend='gloo')
+        else:
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
     pkg = importlib.import_module('noble-bls12-381_amd')
     import oracle_py
     oracle = oracle_py.load(rebuild=not os.path.exists(os.path.join(ROOT, 'oracle', 'libnbls_oracle.so')))
@@ -246,8 +252,7 @@ def main():
             psum, _ = eng.point_sum(aff_l, g2=True)                      # this rank's share of the aggregate signature (affine, 192 B)
             d_ps = torch.frombuffer(bytearray(psum), dtype=torch.uint8).cuda()
             if multi:
-                allps = torch.empty(192 * world, dtype=torch.uint8, device='cuda')
-                dist.all_gather_into_tensor(allps, d_ps)
+                allps = par.all_gather_bytes(d_ps)
                 agg_sig, _ = eng.point_sum(bytes(allps.cpu().numpy().tobytes()), g2=True)
             else:
                 agg_sig = psum
@@ -560,7 +565,7 @@ def main():
             'single_call': {'pairings_per_s': round(n * args.steps / dt_serial, 2), 'ms_per_batch': round(dt_serial / args.steps * 1e3, 4), 'roofline_frac': roof['frac'] if roof else None,
                             'note': 'one %d-pairing call at a time on one stream (this rank): the latency of a call; its roofline is the top-level `roofline` object' % n},
             'single_stream': {'pairings_per_s': round(n * args.steps / dt_serial, 2), 'ms_per_batch': round(dt_serial / args.steps * 1e3, 4), 'note': 'alias of single_call (round-1 name)'},
-            'rccl_ranks': world if multi else None,
+            'rccl_ranks': world if (multi and args.dist_backend == 'nccl') else None, 'dist_backend': args.dist_backend if multi else None,
             'roofline': roof, 'cpu_baseline': cpu, 'product': product, 'verify_batch': vbatch if vbatch is not None else vshard, 'verify_batch_sharded': vshard if vbatch is not None else None, 'sign': sleg, 'aggregate': aleg, 'msm': mleg,
         }
         out_line = json.dumps(line)

@@ -21,6 +21,21 @@ def _collective(group):
     return dist.get_world_size(group) > 1 or os.environ.get('NBLS_FORCE_COLLECTIVES') == '1'
 
 
+def all_gather_bytes(part, group=None):
+    """all-gather of one small uint8 tensor per rank into one tensor (rank order).  RCCL gathers device tensors directly; gloo (CPU tests, and GPU runs whose
+    ranks share a device) has no all-gather for device tensors, so the bytes are staged through the host there."""
+    import torch.distributed as dist
+    w = dist.get_world_size(group)
+    if part.is_cuda and dist.get_backend(group) == 'gloo':
+        host = part.cpu()
+        out = torch.empty(w * host.numel(), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host, group=group)
+        return out.to(part.device)
+    out = torch.empty(w * part.numel(), dtype=part.dtype, device=part.device)
+    dist.all_gather_into_tensor(out, part, group=group)
+    return out
+
+
 class EngineBackend:
     """GPU backend: device-resident uint8 tensors, work enqueued on the current torch stream."""
 
@@ -59,9 +74,7 @@ def miller_product_sharded(backend, g1_local, g2_local, group=None, final_exp=Tr
     import torch.distributed as dist
     part = backend.local_product(g1_local, g2_local)
     if _collective(group):
-        w = dist.get_world_size(group)
-        gathered = torch.empty(w * 576, dtype=torch.uint8, device=part.device)
-        dist.all_gather_into_tensor(gathered, part, group=group)
+        gathered = all_gather_bytes(part, group)
     else:
         gathered = part
     return backend.finish(gathered, final_exp)
@@ -87,14 +100,12 @@ def verify_batch_sharded(backend, sig96, msgs_local, pks_local, group=None):
             raise
         err, zero, part = e, False, torch.zeros(576, dtype=torch.uint8, device=pks_local.device if hasattr(pks_local, 'device') else 'cpu')
     if multi:
-        w = dist.get_world_size(group)
         flag = torch.tensor([2 if err is not None else (1 if zero else 0)], dtype=torch.int32, device=part.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
         if int(flag.item()) == 2:
             raise err if err is not None else RuntimeError('verify_batch_sharded: an input failed to decode on another rank')
         zero = bool(flag.item())
-        gathered = torch.empty(w * 576, dtype=torch.uint8, device=part.device)
-        dist.all_gather_into_tensor(gathered, part, group=group)
+        gathered = all_gather_bytes(part, group)
     else:
         gathered = part
     if zero:

@@ -63,3 +63,26 @@ def test_bench_distributed_branches_one_rank():
     assert out.returncode == 0, out.stdout + out.stderr
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])      # RCCL prints its version banner on stdout too
     assert line['rccl_ranks'] == 1 and line['n_gpus'] == 1 and line['product']['result_is_one'] and line['verify_batch']['n_signatures'] == 64
+
+
+def test_bench_two_ranks_self_launched():
+    """`python bench.py --gpus 2` with no launcher around it, on the GPU box: bench.py starts two ranks under torch.distributed.run, each with its own HIP
+    contexts and three streams; the ranks synthesise their own inputs (seeded by rank), run the timed steps between barriers, shard the
+    product and verifyBatch legs (all-gather of two 576-byte partials + flag all-reduce), and rank 0 prints ONE line with n_gpus = 2.  RCCL refuses two
+    ranks on one device, so on a one-GPU box the ranks share GPU 0 and exchange through gloo (--dist-backend gloo); with two or more GPUs the same test
+    runs over RCCL, one rank per device."""
+    import json
+    import torch
+    backend = 'nccl' if torch.cuda.device_count() >= 2 else 'gloo'
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dist-backend', backend, '--steps', '6', '--warmup', '2', '--batch', '512', '--inflight', '3',
+           '--verify-batch', '128', '--product-terms', '512', '--sign-batch', '0', '--msm-points', '0', '--large-batch', '0', '--no-cpu-baseline']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-3000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['dist_backend'] == backend and line['value'] > 0
+    assert line['product']['result_is_one'] and '2 x 576' in line['product']['exchange']
+    assert line['verify_batch']['n_signatures'] == 128 and 'sharded over 2 rank' in line['verify_batch']['note']
