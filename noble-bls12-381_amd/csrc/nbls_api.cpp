@@ -269,12 +269,12 @@ static int reduce_product(nbls_ctx* ctx, size_t n, uint8_t** result, hipStream_t
 // on the tripled state and five products on twelve lanes per item (P_EXPX; its lane-split variant up to LS_MAX items).
 // Opt-in from expc_min items on (NBLS_TUNE_EXPC_MIN / NBLS_EXPC_MIN; default never): Karabina's compressed squarings -- 57 squarings on the four
 // coordinates (g2, g3, g4, g5) at EIGHT lanes per item (P_EXPC_SQ), the powers 2^16, 2^48, 2^57 decompressed around one Fp inversion per item
-// (P_EXPC_DEC_A -> inversion kernel -> P_EXPC_DEC_B, which also squares on to 2^60, 2^62, 2^63 and multiplies the six powers).  17 % fewer instructions
-// per item, but measured (profiles/round3_expc_ab.txt, tools/exp_expc.sh): 65,536 pairings 24.42 against 24.56 ms, 16,384 pairings 7.50 against
-// 7.20 ms, twelve 4096-batches in flight 2.67 against 2.70 M/s -- the squaring program runs 22 % better than the plain one per instruction, but the
-// decompression programs (50 live slots: two wavefronts per SIMD; 16 load / store / flag steps) run at 40-67 % of its rate and the five extra
-// inversion launches cost what is left.  Kept because it is correct on every input and the squaring kernel is the fastest code in the library: the
-// decompression is what a future round has to make cheaper.  The decompression divides by g2: an item with a vanishing g2 (the unit element, or a crafted
+// (P_EXPC_DEC_A -> inversion kernel -> P_EXPC_DEC_B, which also squares on to 2^60, 2^62, 2^63 and multiplies the six powers).  15 % fewer instructions
+// per item, and measured no faster (profiles/round3_pmc_expc.csv, round3_expc_ab.txt; tools/pmc_expc.sh, tools/exp_expc.sh): alone at 65,536 items
+// 1.18 + 0.17 + 1.00 ms + a 0.16 ms inversion launch against 2.45 ms for P_EXPX; twelve 4096-batches in flight 2.67 against 2.70 M pairings/s.  The squaring
+// program issues at EXPX's rate; the decompression program keeps 50 slots live (two wavefronts per SIMD) and the exponent's set bits are too spread for a
+// compressed form that cannot multiply.  Kept because it is correct on every input and answers the question whether it pays; the
+// decompression divides by g2: an item with a vanishing g2 (the unit element, or a crafted
 // input) is flagged by DEC_B and recomputed by the plain program over an index list kept on the device, so the result is the reference's for every input.
 static int expx(nbls_ctx* ctx, size_t n, uint8_t* in, uint8_t* out, hipStream_t s) {
   int r;
