@@ -14,6 +14,7 @@
 #include <thread>
 
 extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream);
+#include "aot.h"
 extern "C" int nbls_fp_inv_launch(unsigned n, const void* in, void* out, void* stream);
 extern "C" int nbls_flag_compact_launch(unsigned n, const void* flags, void* list, void* count, void* stream);
 extern "C" int nbls_xmd_launch(unsigned n, const void* msgs, const void* offsets, const void* dst, unsigned dst_len, void* out, unsigned len_in_bytes, void* stream);
@@ -43,6 +44,7 @@ static const size_t EXPC_MIN_DEFAULT = (size_t)1 << 40;   // items from which th
 struct DevProgram {
   Step* steps = nullptr; u32* descs = nullptr; u32* consts = nullptr;
   const Program* p = nullptr;
+  int aot = -1; AotStep* aot_steps = nullptr;   // ahead-of-time kernel of this program (aot.h) and the translated step list, when every step's signature is in the kernel's table
 };
 
 struct nbls_ctx {
@@ -98,6 +100,8 @@ static bool checked_mode() {
   return on;
 #endif
 }
+// NBLS_AOT=0 keeps every program on the interpreter (A/B runs, profiles of the interpreter)
+static bool aot_enabled() { static const bool on = !(getenv("NBLS_AOT") && atoi(getenv("NBLS_AOT")) == 0); return on; }
 static int upload(nbls_ctx* ctx, ProgId id) {
   DevProgram& d = ctx->prog[id];
   if (d.p) return NBLS_OK;
@@ -109,6 +113,16 @@ static int upload(nbls_ctx* ctx, ProgId id) {
   HIPCHK(hipMemcpy(d.steps, p.steps.data(), p.steps.size() * sizeof(Step), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d.descs, p.descs.data(), p.descs.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d.consts, p.consts.data(), p.consts.size() * 4, hipMemcpyHostToDevice));
+  // ahead-of-time kernel (aot.h): translate the step list; a program whose signatures are not all in the kernel's table (build / environment mismatch) stays on the interpreter
+  const int k = aot_enabled() ? nbls_aot_index((int)id) : -1;
+  if (k >= 0) {
+    std::vector<AotStep> as(p.steps.size());
+    if (nbls_aot_translate(k, p.steps.data(), (unsigned)p.steps.size(), as.data()) == 0) {
+      HIPCHK(hipMalloc(&d.aot_steps, as.size() * sizeof(AotStep)));
+      HIPCHK(hipMemcpy(d.aot_steps, as.data(), as.size() * sizeof(AotStep), hipMemcpyHostToDevice));
+      d.aot = k;
+    } else fprintf(stderr, "nbls: %s: step signatures differ from the ahead-of-time kernel's table; running on the interpreter\n", p.name.c_str());
+  }
   d.p = &p;
   return NBLS_OK;
 }
@@ -146,7 +160,8 @@ static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pa
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->timing) { e0 = timing_event(ctx); e1 = timing_event(ctx); hipEventRecord(e0, s); }
-  int e = nbls_vm_launch(&ka, d.p->lds_bytes(), s);
+  ka.aot_steps = d.aot_steps;
+  int e = d.aot >= 0 ? nbls_aot_launch(d.aot, &ka, d.p->lds_bytes(), s) : nbls_vm_launch(&ka, d.p->lds_bytes(), s);
   if (ctx->timing) { hipEventRecord(e1, s); ctx->tev.push_back({(int)id, {e0, e1}}); }
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
   return NBLS_OK;
@@ -367,7 +382,7 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
 EXPORT void nbls_destroy(nbls_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
-  for (auto& d : ctx->prog) { if (d.steps) hipFree(d.steps); if (d.descs) hipFree(d.descs); if (d.consts) hipFree(d.consts); }
+  for (auto& d : ctx->prog) { if (d.steps) hipFree(d.steps); if (d.descs) hipFree(d.descs); if (d.consts) hipFree(d.consts); if (d.aot_steps) hipFree(d.aot_steps); }
   for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->gen_g1, ctx->side_scratch, ctx->L, ctx->partial, ctx->unit_lines, ctx->KS, ctx->KD, ctx->Kflag, (uint8_t*)ctx->Klist, (uint8_t*)ctx->Kcount}) if (p) hipFree(p);
   for (uint8_t* p : ctx->T) if (p) hipFree(p);
   for (uint8_t* p : ctx->sb) if (p) hipFree(p);

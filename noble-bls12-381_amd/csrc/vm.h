@@ -102,6 +102,8 @@ struct KernelArgs {
   const uint32_t* item_index;    // optional (NULL): buffers are addressed with item_index[item] instead of item (gathered operands, results scattered back in place)
   const uint32_t* n_items_dev;   // optional (NULL): the item count lives in device memory (min with n_items, which then only sizes the launch)
   uint64_t* hwid_out;       // optional (NULL): per workgroup, HW_ID | XCC_ID << 32 of its wavefront -- placement studies (tools/placement.py)
+  const void* aot_steps;    // ahead-of-time kernels (aot.h): the translated step list (AotStep per step); unused by the interpreter
+  uint32_t fair;            // ahead-of-time kernels: 1 = lower the own priority with progress (the interpreter has separate _fair instantiations)
 };
 
 }  // namespace nbls
