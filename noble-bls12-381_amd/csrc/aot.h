@@ -1,17 +1,26 @@
 // aot.h -- ahead-of-time specialised kernels for the hot step programs (round 4).
 //
 // The generic kernel (vm_kernel.hip) interprets a step list: per step it decodes a 32-byte header on the scalar unit and branches on the
-// kind, on the number of product rounds, on the operand shape of every operand of every round and on the number of post-added terms
-// (~59 taken branches per step).  The hot programs -- the cyclotomic exponentiation (math.ts:845-852), the Miller accumulation
-// (math.ts:1376-1386) and the line computation (math.ts:1337-1368) -- use only a handful of distinct step SIGNATURES (kind, rounds,
-// flags, shapes, post-added terms: 10 / 12 / 18 of them; 62 of EXPX's 97 steps are ONE signature, the cyclotomic squaring).  At build time
-// `aot_gen` (aot_gen.cpp: the host compiler run over the programs listed below) writes the signature table of every listed program to
-// aot_sigs.inc, and aot_kernel.hip instantiates, per program, ONE kernel whose step loop is a jump over that table: every signature is a
-// straight-line body with the rounds unrolled, the shapes, flags and term counts resolved at compile time (no header decode, no shape
-// dispatch, no round loop) and the same mac28 / redc28 arithmetic as the interpreter (vm_exec.h), so results are bit-identical.
-// At run time a program's step list is translated into (signature id, active lanes, descriptor offset) words; a program whose steps are
-// not all in its kernel's table (a build / environment mismatch) falls back to the interpreter.
+// kind, on the number of product rounds, on the operand shape of every operand of every round and on the number of post-added terms.
+// The hot programs -- the cyclotomic exponentiation (math.ts:845-852), the Miller accumulation (math.ts:1376-1386) and the line computation
+// (math.ts:1337-1368) -- use only a handful of distinct step SIGNATURES (10 / 12 / 18 of them; 62 of EXPX's 97 steps are ONE signature, the
+// cyclotomic squaring).  At build time `aot_gen` (aot_gen.cpp: the host compiler run over the programs listed below) writes the signature table
+// of every listed program to aot_sigs.inc, and aot_kernel.hip instantiates, per program, ONE kernel whose step loop is a jump over that table:
+// every signature is a straight-line body with the rounds unrolled and the shapes, flags and term counts resolved at compile time.
+//
+// First measurement (round 4): specialising the interpreter's own step code this way changes nothing for EXPX and ACC_FE (1132 against ~1170 VALU
+// instructions per squaring step, same time): the interpreter's dispatch was never the cost.  What a specialised body CAN do, because it is not shared with
+// other shapes, is a cheaper formulation of the work around the multiply-adds (aot_exec.h):
+//   * descriptors hold ABSOLUTE LDS addresses per physical lane (no address arithmetic), idle lanes get a descriptor that reads the zero constant and writes
+//     a junk slot (no lane predicate);
+//   * the finish of a K_DOT lane-op stays in the 64-bit columns: multiplier as a shift, post-added terms as one multiply-add per limb with a per-lane signed
+//     coefficient (t -+ 2 g is ONE term), the bias offs * p and the weak reduction's - q p as ONE multiply-add pass with the coefficient offs - q, q estimated
+//     from the top two columns (no table, no global load) -- and ONE carry pass at the end instead of two.
+// A translated program is a list of (signature id, descriptor block); a program whose steps are not all in its kernel's table (a build / environment mismatch)
+// stays on the interpreter.
 #pragma once
+#include <string>
+#include <vector>
 #include "vm.h"
 #include "programs.h"
 
@@ -24,16 +33,41 @@
 
 namespace nbls {
 
-struct AotSig { uint32_t kind, p0, p1, lin, sh0, sh1, stride; };
-static inline bool operator==(const AotSig& a, const AotSig& b) { return a.kind == b.kind && a.p0 == b.p0 && a.p1 == b.p1 && a.lin == b.lin && a.sh0 == b.sh0 && a.sh1 == b.sh1 && a.stride == b.stride; }
-static inline AotSig aot_sig_of(const Step& st) { return AotSig{st.kind, st.p0, st.p1, st.lin, st.shape[0], st.shape[1], st.stride}; }
-// one step of the translated list (scalar loads): x = signature id | active lanes << 8 | descriptor stride (words) << 16 ; y = word offset of the step's descriptors
+// K_DOT flags of a signature
+static const uint32_t AF_MULTSH = 1;   // some lane multiplies the reduced sum by 2 or 4 (a shift of the columns)
+static const uint32_t AF_MULT3 = 2;    // some lane multiplies by 3
+static const uint32_t AF_OFFS = 4;     // some lane adds a multiple of p (keeps a sum with negative products non-negative)
+static const uint32_t AF_WRED = 8;     // weak reduction after the post-added terms
+static const uint32_t AF_HALVE = 16;   // some lane halves its result
+// Signature of a step.  K_DOT: p0 = product rounds, flags = AF_*, t = post-added terms after merging equal slots (max over the lanes), sh0 / sh1 = round shapes
+// (vm.h SH_*).  K_LIN: p0 = added terms, t = subtracted terms, flags = AF_WRED | AF_HALVE.  K_LOAD: p0 = bytes.  K_STORE: p0 = 1 raw.
+struct AotSig { uint32_t kind, p0, flags, t, sh0, sh1; };
+static inline bool operator==(const AotSig& a, const AotSig& b) { return a.kind == b.kind && a.p0 == b.p0 && a.flags == b.flags && a.t == b.t && a.sh0 == b.sh0 && a.sh1 == b.sh1; }
+// one step of a translated program (scalar loads): x = signature id | 16-byte words per lane << 8 ; y = index (in 16-byte words) of the step's descriptor block.
+// A block is laid out [word][64 lanes]: a wavefront's load of word w is one contiguous kilobyte.
 struct AotStep { uint32_t x, y; };
+// Lane descriptor words (absolute LDS byte addresses):
+//   K_DOT : w0 = dst | (m >> 1) << 16 (2 bits) | (m == 3) << 18 | halve << 19 | offs << 20 (4 bits) ; w1 = per-lane term signs (4 bits per round, shape mode 3) ;
+//           then t post-added terms: address | coefficient << 16 (signed 16 bits), the header padded to whole 16-byte words ; then one 16-byte word per
+//           product round: a0, a1, b0, b1
+//   K_LIN : w0 = dst | halve << 16 ; then p0 + t term addresses, two 16-bit fields per word (added ones first)
+//   K_LOAD / K_LOADW / K_STORE / K_STOREW : w0 = slot | buffer << 16 | active << 31 ; w1 = byte offset inside the item
+static const int AOT_DOT_HDR = 2;
+static inline uint32_t aot_dot_hdr_quads(uint32_t t) { return (AOT_DOT_HDR + t + 3) / 4; }   // 16-byte words of a K_DOT descriptor before its rounds
+struct AotProgram {
+  std::vector<AotSig> sigs;          // distinct signatures in order of first use
+  std::vector<uint32_t> sig_count;   // steps per signature
+  std::vector<AotStep> steps;        // x holds an index into `sigs` until remapped to a kernel's table
+  std::vector<uint32_t> descs;       // 4 words per 16-byte word
+  uint32_t lds_bytes = 0;            // the program's LDS image + the junk slot idle lanes write to
+};
+// Translate a compiled program.  Returns an empty string, or why the program cannot run on an ahead-of-time kernel (lane split, a step kind the kernels do not implement).
+std::string aot_translate(const Program& p, AotProgram& out);
 
 }  // namespace nbls
 
-// host side (aot_kernel.hip)
+// kernel side (aot_kernel.hip)
 extern "C" int nbls_aot_index(int prog_id);   // index of the ahead-of-time kernel for a ProgId, or -1
-// translate a compiled program for kernel `k`: fills `out` (one AotStep per step) and returns 0, or -1 when a step's signature is not in the kernel's table
-extern "C" int nbls_aot_translate(int k, const nbls::Step* steps, unsigned nsteps, nbls::AotStep* out);
+// remap the signature indices of a translated program to kernel k's table: 0, or -1 when a signature is not in the table
+extern "C" int nbls_aot_bind(int k, nbls::AotProgram* ap);
 extern "C" int nbls_aot_launch(int k, const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream);

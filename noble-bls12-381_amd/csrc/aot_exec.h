@@ -1,0 +1,214 @@
+// aot_exec.h -- step bodies of the ahead-of-time kernels (aot.h), written once and compiled twice like vm_exec.h: into aot_kernel.hip (gfx950) and into the
+// test-only host simulator (vm_sim.cpp), which executes translated programs without a GPU.
+//
+// Arithmetic: the interpreter's (vm_exec.h: signed 28-bit limbs, mac28 into 28 lazy 64-bit columns, one Montgomery reduction per lane-op).  What differs is
+// everything AROUND the multiply-adds, which a body that serves one signature only can afford to specialise:
+//   * operand addresses are absolute (no address arithmetic), there is no lane predicate (idle lanes compute on the zero constant into a junk slot);
+//   * K_DOT finish in the 64-bit columns (aot_dot_finish): post-added terms enter the columns as ONE multiply-add per limb with a signed per-lane coefficient,
+//     the bias offs * p and the weak reduction's - q p as ONE multiply-add pass with the coefficient offs - q (q from the top two columns: no table, no global
+//     load), then ONE carry pass.  A result can therefore differ from the interpreter's by a multiple of p (the two weak reductions estimate q differently);
+//     both satisfy the bounds the host compiler books (value >= 0, below 3.02 p after a weak reduction), and every canonical output is the same.
+#pragma once
+#include "aot.h"
+#include "vm_exec.h"
+
+namespace nbls {
+
+// rows of the Montgomery reduction on the signed columns WITHOUT the closing carry pass: afterwards the value is sum_k acc[NL + k] 2^(28 k) (signed columns)
+NBLS_HD void redc28_rows(u64* acc) {
+  const u32 P[NL] = NBLS_P28;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    const u32 m = ((u32)acc[i] * NBLS_N0_28) & LMASK;
+#pragma unroll
+    for (int j = 0; j < NL; j++) acc[i + j] += (u64)m * P[j];
+    acc[i + 1] = (u64)((i64)acc[i + 1] + ((i64)acc[i] >> 28));
+  }
+}
+// closing carry pass: columns c[0..13] (signed 64-bit) -> normalised limbs, the top limb keeps the rest
+NBLS_HD void carry_cols(u32* r, const u64* c) {
+  i64 cy = 0;
+#pragma unroll
+  for (int k = 0; k < NL - 1; k++) { const i64 v = (i64)c[k] + cy; r[k] = (u32)v & LMASK; cy = v >> 28; }
+  r[NL - 1] = (u32)((i64)c[NL - 1] + cy);
+}
+static const i32 AOT_P_TOP = 106513;      // floor(p / 2^364)
+static const i32 AOT_Q_MARGIN = 330;      // the estimate below is off by less than 130 (columns 11 and lower: |c| < 2^63 -> |c / 2^56| < 128); twice that and a bit
+// Finish of a K_DOT lane-op in the columns.  acc: the 28 columns after the product rounds (no bias inside).  Semantics as vm_exec.h dot_finish:
+//   dst = m * (REDC(sum) + offs p) + sum_t coef_t X_t  [weakly reduced]  [halved]
+template <u32 FLAGS, u32 T, typename LDSP>
+NBLS_HD void aot_dot_finish(u32* r, u64* acc, const u32 w0, const u32* post, LDSP lds) {
+  const u32 P[NL] = NBLS_P28;
+  redc28_rows(acc);
+  u64* c = acc + NL;
+  i32 boffs = (FLAGS & AF_OFFS) ? (i32)((w0 >> 20) & 0xfu) : 0;
+  if (FLAGS & (AF_MULTSH | AF_MULT3)) {
+    // a multiplier on the reduced sum: the columns may be as large as 2^62.9, so they are carried to limbs first (the interpreter's order of operations)
+    if (FLAGS & AF_OFFS) {
+#pragma unroll
+      for (int k = 0; k < NL; k++) c[k] = (u64)((i64)c[k] + (i64)boffs * (i64)P[k]);
+    }
+    u32 t[NL];
+    carry_cols(t, c);
+    const u32 sh = (w0 >> 16) & 3u, m3 = (FLAGS & AF_MULT3) ? (0u - ((w0 >> 18) & 1u)) : 0u;
+#pragma unroll
+    for (int k = 0; k < NL; k++) c[k] = (u64)((t[k] << sh) + (t[k] & m3));   // m = 1 .. 4 as (r << (m >> 1)) + (m == 3 ? r : 0)   // limbs below 2^31: m <= 4, top limb below 2^29 (values below 2047 p)
+    boffs = 0;
+  }
+#pragma unroll
+  for (u32 t = 0; t < T; t++) {
+    u32 X[NL];
+    ld14(X, lds, post[t] & 0xffffu);
+    const i32 coef = (i32)post[t] >> 16;
+#pragma unroll
+    for (int k = 0; k < NL; k++) c[k] = (u64)((i64)c[k] + (i64)(i32)X[k] * (i64)coef);
+  }
+  i32 f = boffs;
+  if (FLAGS & AF_WRED) {
+    // q <= V / p from V / 2^364 = c[13] + c[12] / 2^28 + (less than 130), with the pending bias counted in
+    const i64 est = (i64)c[NL - 1] + ((i64)c[NL - 2] >> 28);
+    i32 e = (i32)est + boffs * AOT_P_TOP - AOT_Q_MARGIN;
+    e = e < 0 ? 0 : e;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 q = __umulhi((u32)e, 2642610142u) >> 16;     // floor(2^48 / 106514)
+#else
+    const u32 q = (u32)(((u64)(u32)e * 2642610142u) >> 48);
+#endif
+    f = boffs - (i32)q;
+  }
+  if (((FLAGS & AF_OFFS) && !(FLAGS & (AF_MULTSH | AF_MULT3))) || (FLAGS & AF_WRED)) {
+#pragma unroll
+    for (int k = 0; k < NL; k++) c[k] = (u64)((i64)c[k] + (i64)f * (i64)(i32)P[k]);
+  }
+  carry_cols(r, c);
+  if (FLAGS & AF_HALVE) { if (w0 & (1u << 19)) halve28(r); }
+}
+
+// K_LIN with absolute addresses: dst = sum of the added slots - sum of the subtracted ones [weakly reduced] [halved]; fields: 16 bits each, from word 1
+template <u32 NADD, u32 NSUB, u32 FLAGS, typename LDSP, typename W>
+NBLS_HD u32 aot_lin(u32* r, LDSP lds, W&& word, const u32* __restrict__ qp_table) {
+  const u32 w0 = word(0);
+  auto field = [&](u32 t) { return (word(1 + t / 2) >> (16 * (t & 1))) & 0xffffu; };
+  ld14(r, lds, field(0));
+#pragma unroll
+  for (u32 t = 1; t < NADD; t++) {
+    u32 X[NL];
+    ld14(X, lds, field(t));
+#pragma unroll
+    for (int i = 0; i < NL; i++) r[i] += X[i];
+  }
+#pragma unroll
+  for (u32 t = NADD; t < NADD + NSUB; t++) {
+    u32 X[NL];
+    ld14(X, lds, field(t));
+#pragma unroll
+    for (int i = 0; i < NL; i++) r[i] -= X[i];
+  }
+  if (FLAGS & AF_WRED) weak_reduce(r, qp_table);
+  carry_norm(r);
+  if (FLAGS & AF_HALVE) { if (w0 & (1u << 16)) halve28(r); }
+  return w0 & 0xffffu;
+}
+
+// buffer steps: w0 = slot | buffer << 16 | active << 31, w1 = byte offset
+template <u32 KIND, u32 P0, typename LDSP>
+NBLS_HD void aot_io(LDSP lds, const u32 w0, const u32 off, const u32 item, const bool live, const IOBuf* bufs) {
+  const u32 slot = w0 & 0xffffu;
+  const bool act = live && (w0 >> 31);
+  const IOBuf& b = bufs[(w0 >> 16) & 7u];
+  u32* g = (u32*)(b.ptr + (u64)item * b.stride + off);
+  if (KIND == K_LOADW) {
+    u32 x[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) x[i] = act ? g[i] : 0u;
+    st14(lds, slot, x);   // inactive lanes: the junk slot
+  } else if (KIND == K_LOAD) {
+    const int nw = P0 ? (int)P0 / 4 : 12;
+    u32 w[12], x[NL];
+#pragma unroll
+    for (int i = 0; i < 12; i++) w[i] = (act && i < nw) ? bswap32(g[nw - 1 - i]) : 0u;
+    words_to_limbs(x, w);
+    st14(lds, slot, x);
+  } else if (KIND == K_STOREW) {
+    u32 x[NL];
+    ld14(x, lds, slot);
+    if (act) {
+#pragma unroll
+      for (int i = 0; i < NL; i++) g[i] = x[i];
+      g[14] = 0; g[15] = 0;
+    }
+  } else {   // K_STORE
+    u32 x[NL], w[12];
+    ld14(x, lds, slot);
+    if (P0 == 0) csub_p(x);
+    limbs_to_words(w, x);
+    if (act) {
+#pragma unroll
+      for (int i = 0; i < 12; i++) g[11 - i] = bswap32(w[i]);
+    }
+  }
+}
+
+// The columns are made opaque between product rounds: the optimiser would otherwise re-associate every column's sum over ALL rounds of an unrolled body
+// (every round's operands live at once: 330-480 registers); the scheduling barrier keeps the LDS reads of later rounds from being hoisted to the top.
+NBLS_HD void aot_round_fence(u64* acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int c = 0; c < 2 * NL - 1; c++) asm volatile("" : "+v"(acc[c]));
+  __builtin_amdgcn_sched_barrier(0);
+#else
+  (void)acc;
+#endif
+}
+NBLS_HD u32 aot_word(const V4& q, u32 i) { return i == 0 ? q.x : i == 1 ? q.y : i == 2 ? q.z : q.w; }
+
+// One step of a translated program for one lane.  `D::quad(i)` returns 16-byte word i of the lane's descriptor (device: the first three were fetched a step
+// ahead, the others are loaded here, a round ahead of their use); `commit(dst, limbs)` stores a result (device: at once -- LDS operations of a wavefront execute in
+// order, so every read of the step precedes it; simulator: after all lanes of the step).
+template <u32 KIND, u32 P0, u32 FLAGS, u32 T, u32 SH0, u32 SH1, typename D, typename LDSP, typename Commit>
+NBLS_HD void aot_step(const D& desc, LDSP lds, const u32 item, const bool live, const IOBuf* bufs, const u32* __restrict__ qp_table, Commit&& commit) {
+  if constexpr (KIND == K_DOT) {
+    const u32 HQ = (AOT_DOT_HDR + T + 3) / 4;
+    const V4 h0 = desc.quad(0);
+    u32 post[T > 0 ? T : 1];
+#pragma unroll
+    for (u32 t = 0; t < T; t++) post[t] = aot_word(desc.quad((AOT_DOT_HDR + t) / 4), (AOT_DOT_HDR + t) & 3u);
+    u64 acc[2 * NL];
+#pragma unroll
+    for (int i = 0; i < 2 * NL; i++) acc[i] = 0;
+    V4 cur = desc.quad(HQ);
+#pragma unroll
+    for (u32 r = 0; r < P0; r++) {
+      V4 nx = cur;
+      if (r + 1 < P0) nx = desc.quad(HQ + r + 1);
+      const u32 shape = ((r < 4 ? SH0 : SH1) >> (8 * (r & 3))) & 0xffu;
+      const u32 neg = (h0.y >> (4 * r)) & 15u;
+      // the shape is a compile-time constant after unrolling: dot_combine's branches fold
+      {
+        const u32 sa = shape & 7u, sb = (shape >> SH_B_SHIFT) & 7u;
+        u32 A[NL], B[NL], X[NL], Y[NL];
+        ld14(A, lds, cur.x);
+        if (sa & 3u) ld14(X, lds, cur.y);
+        ld14(B, lds, cur.z);
+        if (sb & 3u) ld14(Y, lds, cur.w);
+        dot_combine(A, X, sa, neg & 3u);
+        dot_combine(B, Y, sb, (neg >> 2) & 3u);
+        mac28(acc, A, B);
+      }
+      aot_round_fence(acc);
+      cur = nx;
+    }
+    u32 res[NL];
+    aot_dot_finish<FLAGS, T>(res, acc, h0.x, post, lds);
+    commit(h0.x & 0xffffu, res);
+  } else if constexpr (KIND == K_LIN) {
+    u32 res[NL];
+    const u32 dst = aot_lin<P0, T, FLAGS>(res, lds, [&](u32 i) { return aot_word(desc.quad(i / 4), i & 3u); }, qp_table);
+    commit(dst, res);
+  } else {
+    const V4 h0 = desc.quad(0);
+    aot_io<KIND, P0>(lds, h0.x, h0.y, item, live, bufs);
+  }
+}
+
+}  // namespace nbls

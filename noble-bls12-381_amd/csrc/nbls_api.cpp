@@ -44,7 +44,7 @@ static const size_t EXPC_MIN_DEFAULT = (size_t)1 << 40;   // items from which th
 struct DevProgram {
   Step* steps = nullptr; u32* descs = nullptr; u32* consts = nullptr;
   const Program* p = nullptr;
-  int aot = -1; AotStep* aot_steps = nullptr;   // ahead-of-time kernel of this program (aot.h) and the translated step list, when every step's signature is in the kernel's table
+  int aot = -1; AotStep* aot_steps = nullptr; u32* aot_descs = nullptr; u32 aot_lds = 0;   // ahead-of-time kernel of this program (aot.h) and the translated program, when every step's signature is in the kernel's table
 };
 
 struct nbls_ctx {
@@ -113,15 +113,18 @@ static int upload(nbls_ctx* ctx, ProgId id) {
   HIPCHK(hipMemcpy(d.steps, p.steps.data(), p.steps.size() * sizeof(Step), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d.descs, p.descs.data(), p.descs.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d.consts, p.consts.data(), p.consts.size() * 4, hipMemcpyHostToDevice));
-  // ahead-of-time kernel (aot.h): translate the step list; a program whose signatures are not all in the kernel's table (build / environment mismatch) stays on the interpreter
+  // ahead-of-time kernel (aot.h): translate the program; one whose signatures are not all in the kernel's table (build / environment mismatch) stays on the interpreter
   const int k = aot_enabled() ? nbls_aot_index((int)id) : -1;
   if (k >= 0) {
-    std::vector<AotStep> as(p.steps.size());
-    if (nbls_aot_translate(k, p.steps.data(), (unsigned)p.steps.size(), as.data()) == 0) {
-      HIPCHK(hipMalloc(&d.aot_steps, as.size() * sizeof(AotStep)));
-      HIPCHK(hipMemcpy(d.aot_steps, as.data(), as.size() * sizeof(AotStep), hipMemcpyHostToDevice));
-      d.aot = k;
-    } else fprintf(stderr, "nbls: %s: step signatures differ from the ahead-of-time kernel's table; running on the interpreter\n", p.name.c_str());
+    AotProgram ap;
+    const std::string why = aot_translate(p, ap);
+    if (why.empty() && nbls_aot_bind(k, &ap) == 0) {
+      HIPCHK(hipMalloc(&d.aot_steps, ap.steps.size() * sizeof(AotStep)));
+      HIPCHK(hipMalloc(&d.aot_descs, ap.descs.size() * 4));
+      HIPCHK(hipMemcpy(d.aot_steps, ap.steps.data(), ap.steps.size() * sizeof(AotStep), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(d.aot_descs, ap.descs.data(), ap.descs.size() * 4, hipMemcpyHostToDevice));
+      d.aot = k; d.aot_lds = ap.lds_bytes;
+    } else fprintf(stderr, "nbls: %s: %s; running on the interpreter\n", p.name.c_str(), why.empty() ? "step signatures differ from the ahead-of-time kernel's table" : why.c_str());
   }
   d.p = &p;
   return NBLS_OK;
@@ -160,8 +163,9 @@ static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pa
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->timing) { e0 = timing_event(ctx); e1 = timing_event(ctx); hipEventRecord(e0, s); }
-  ka.aot_steps = d.aot_steps;
-  int e = d.aot >= 0 ? nbls_aot_launch(d.aot, &ka, d.p->lds_bytes(), s) : nbls_vm_launch(&ka, d.p->lds_bytes(), s);
+  int e;
+  if (d.aot >= 0) { ka.aot_steps = d.aot_steps; ka.descs = d.aot_descs; e = nbls_aot_launch(d.aot, &ka, d.aot_lds, s); }
+  else e = nbls_vm_launch(&ka, d.p->lds_bytes(), s);
   if (ctx->timing) { hipEventRecord(e1, s); ctx->tev.push_back({(int)id, {e0, e1}}); }
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
   return NBLS_OK;
@@ -382,7 +386,7 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
 EXPORT void nbls_destroy(nbls_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
-  for (auto& d : ctx->prog) { if (d.steps) hipFree(d.steps); if (d.descs) hipFree(d.descs); if (d.consts) hipFree(d.consts); if (d.aot_steps) hipFree(d.aot_steps); }
+  for (auto& d : ctx->prog) { if (d.steps) hipFree(d.steps); if (d.descs) hipFree(d.descs); if (d.consts) hipFree(d.consts); if (d.aot_steps) hipFree(d.aot_steps); if (d.aot_descs) hipFree(d.aot_descs); }
   for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->gen_g1, ctx->side_scratch, ctx->L, ctx->partial, ctx->unit_lines, ctx->KS, ctx->KD, ctx->Kflag, (uint8_t*)ctx->Klist, (uint8_t*)ctx->Kcount}) if (p) hipFree(p);
   for (uint8_t* p : ctx->T) if (p) hipFree(p);
   for (uint8_t* p : ctx->sb) if (p) hipFree(p);

@@ -9,6 +9,8 @@
 #include "vm_exec.h"
 #include "consts_gen.h"
 #include "fp_inv.h"
+#include "aot_exec.h"
+#include "aot_sigs.inc"
 
 using namespace nbls;
 
@@ -58,12 +60,67 @@ static void sim_run(const Program& p, unsigned n_items, const IOBuf* bufs) {
   }
 }
 
+// ---- translated programs (aot.h) on the host: the step bodies of the ahead-of-time kernels (aot_exec.h), every lane's results committed after all lanes of the
+// step have read their operands (on the device the LDS operations of a wavefront execute in order)
+struct HostDesc {
+  const u32* blk; u32 lane;   // blk: word 0 of lane 0
+  V4 quad(u32 i) const { const u32* q = blk + ((size_t)i * 64 + lane) * 4; return V4{q[0], q[1], q[2], q[3]}; }
+};
+struct Pend { u32 dst; u32 v[NL]; };
+#define SIM_CASE(ID, KIND, P0, FLAGS, T, SH0, SH1, CNT) \
+  case ID: aot_step<KIND, P0, FLAGS, T, SH0, SH1>(d, lds, item, live, bufs, qp, [&](u32 dst, const u32* res) { Pend pd; pd.dst = dst; memcpy(pd.v, res, NL * 4); pend.push_back(pd); }); break;
+#define SIM_TABLE(NAME, PID)                                                                                                              \
+  static const AotSig sim_sigs_##NAME[] = {AOT_SIGS_##NAME(SIM_ROW)};                                                                      \
+  static void sim_step_##NAME(u32 sig, const HostDesc& d, char* lds, u32 item, bool live, const IOBuf* bufs, const u32* qp, std::vector<Pend>& pend) { \
+    switch (sig) { AOT_SIGS_##NAME(SIM_CASE) default: abort(); }                                                                          \
+  }
+#define SIM_ROW(ID, KIND, P0, FLAGS, T, SH0, SH1, CNT) {KIND, P0, FLAGS, T, SH0, SH1},
+NBLS_AOT_PROGRAMS(SIM_TABLE)
+typedef void (*SimStepFn)(u32, const HostDesc&, char*, u32, bool, const IOBuf*, const u32*, std::vector<Pend>&);
+struct SimKernel { int prog_id; SimStepFn fn; const AotSig* sigs; unsigned nsigs; };
+#define SIM_ENTRY(NAME, PID) {(int)PID, sim_step_##NAME, sim_sigs_##NAME, (unsigned)(sizeof(sim_sigs_##NAME) / sizeof(AotSig))},
+static const SimKernel g_sim_kernels[] = {NBLS_AOT_PROGRAMS(SIM_ENTRY)};
+static int g_sim_aot = 0;
+// 0: ran; -2: the program has no ahead-of-time kernel; -3: its signatures are not in the kernel's table
+static int sim_run_aot(int prog, unsigned n_items, const IOBuf* bufs) {
+  const SimKernel* K = nullptr;
+  for (auto& k : g_sim_kernels) if (k.prog_id == prog) K = &k;
+  if (!K) return -2;
+  const Program& p = get_program((ProgId)prog);
+  AotProgram ap;
+  if (!aot_translate(p, ap).empty()) return -3;
+  std::vector<unsigned> map(ap.sigs.size());
+  for (size_t i = 0; i < ap.sigs.size(); i++) { unsigned id = 0; while (id < K->nsigs && !(K->sigs[id] == ap.sigs[i])) id++; if (id == K->nsigs) return -3; map[i] = id; }
+  const u32* qp_table = qp_table_words();
+  std::vector<V4> lds4((size_t)ap.lds_bytes / 16 + 1);
+  char* lds = (char*)lds4.data();
+  const unsigned blocks = (n_items + p.G - 1) / p.G;
+  for (unsigned blk = 0; blk < blocks; blk++) {
+    memset(lds, 0xde, (size_t)ap.lds_bytes);
+    for (unsigned g = 0; g < (p.shared_consts ? 1u : p.G); g++) for (unsigned c = 0; c < p.nconst; c++) memcpy(lds + g * p.inst_bytes() + c * p.slot_bytes, p.consts.data() + c * RAW_WORDS, NL * 4);
+    for (size_t s = 0; s < ap.steps.size(); s++) {
+      std::vector<Pend> pend;
+      for (unsigned lane = 0; lane < 64; lane++) {
+        const unsigned inst = lane / p.W, item = blk * p.G + inst;
+        HostDesc d; d.blk = ap.descs.data() + (size_t)ap.steps[s].y * 4; d.lane = lane;
+        K->fn(map[ap.steps[s].x & 0xffu], d, lds, item, inst < p.G && item < n_items, bufs, qp_table, pend);
+      }
+      for (auto& pd : pend) st14(lds, pd.dst, pd.v);
+    }
+  }
+  return 0;
+}
+
 extern "C" {
+// translated programs (aot.h) instead of the interpreter's semantics for the programs that have an ahead-of-time kernel: 0 off, 1 on
+__attribute__((visibility("default"))) void nbls_sim_set_aot(int on) { g_sim_aot = on; }
+__attribute__((visibility("default"))) int nbls_sim_has_aot(int prog) { for (auto& k : g_sim_kernels) if (k.prog_id == prog) return 1; return 0; }
 // bufs: 8 pointers + 8 strides
 __attribute__((visibility("default"))) int nbls_sim_run(int prog, unsigned n_items, uint8_t** ptrs, const uint64_t* strides) {
   if (prog < 0 || prog >= P_COUNT) return -1;
   IOBuf b[MAX_BUFS];
   for (int i = 0; i < MAX_BUFS; i++) { b[i].ptr = ptrs[i]; b[i].stride = strides[i]; }
+  if (g_sim_aot) { const int r = sim_run_aot(prog, n_items, b); if (r != -2) return r; }
   sim_run(get_program((ProgId)prog), n_items, b);
   return 0;
 }
