@@ -29,7 +29,12 @@
   X(expx, P_EXPX)            \
   X(acc_fe, P_ACC_FE)        \
   X(lines_pq, P_LINES_PQ)    \
-  X(acc4_raw, P_ACC4_RAW)
+  X(acc4_raw, P_ACC4_RAW)    \
+  X(fe_easy, P_FE_EASY)      \
+  X(fe_mid1, P_FE_MID1)      \
+  X(fe_mid2, P_FE_MID2)      \
+  X(fe_final, P_FE_FINAL)    \
+  X(miller_fe, P_MILLER_FE)
 
 namespace nbls {
 

@@ -60,10 +60,10 @@ __device__ __forceinline__ void aot_body(const KernelArgs& ka, Dispatch&& dispat
 #endif
 #define NBLS_AOT_OCC __attribute__((amdgpu_waves_per_eu(NBLS_AOT_WAVES, NBLS_AOT_WAVES)))
 #define AOT_CASE(ID, KIND, P0, FLAGS, T, SH0, SH1, CNT) \
-  case ID: aot_step<KIND, P0, FLAGS, T, SH0, SH1>(d, lds, item, live, ka.bufs, ka.qp_table, [&](u32 dst, const u32* res) { st14(lds, dst, res); }); break;
+  case ID: aot_step<KIND, P0, FLAGS, T, SH0, SH1>(d, lds, item, live, ka.bufs, ka.qp_table, [&](u32 dst, const u32* res) __attribute__((always_inline)) { st14(lds, dst, res); }); break;
 #define AOT_KERNEL(NAME, PID)                                                                            \
   extern "C" __global__ void __launch_bounds__(64) NBLS_AOT_OCC nbls_aot_##NAME(KernelArgs ka) {         \
-    aot_body(ka, [&](u32 sig, const DevDesc& d, char* lds, u32 item, bool live) {                        \
+    aot_body(ka, [&](u32 sig, const DevDesc& d, char* lds, u32 item, bool live) __attribute__((always_inline)) {                      \
       switch (sig) { AOT_SIGS_##NAME(AOT_CASE) default: break; }                                         \
     });                                                                                                  \
   }

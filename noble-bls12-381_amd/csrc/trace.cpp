@@ -202,7 +202,11 @@ int materialize(const SFp& x, bool halve_it) {
   // common multiplier m of the products: every |coef| / m must be 1, or 2 with one single-atom operand (2x = x + x)
   int g = 0; for (auto& p : prods) { int a = std::abs(p.second), b = g; while (b) { int t = a % b; a = b; b = t; } g = a; }
   int mult = 1;
-  for (int m = 4; m >= 1; m--) {
+  for (int i = 0; i < 4; i++) {
+    // the largest multiplier first (a factor costs the lane-op a shift of its result), or -- prefer_doubling -- the smallest: the factor then rides in doubled
+    // single-slot operands (x + x), which is free in a step whose rounds form two-term operands for other lanes anyway, and a lane-op without a multiplier
+    // finishes in one carry pass
+    const int m = B->prefer_doubling ? 1 + i : 4 - i;
     if (g % m) continue;
     bool ok = true;
     for (auto& p : prods) {

@@ -19,7 +19,7 @@ def sim():
 def test_listed_programs_translate(sim):
     for name in ('EXPX', 'ACC_FE', 'ACC4_RAW', 'LINES_PQ'):
         assert sim.nbls_sim_has_aot(vmsim_py.P[name]) == 1, name
-    assert sim.nbls_sim_has_aot(vmsim_py.P['FE_EASY']) == 0
+    assert sim.nbls_sim_has_aot(vmsim_py.P['G1_VALIDATE']) == 0
 
 
 def test_final_exponentiation_through_translated_expx(sim, oracle, golden, testdata):
