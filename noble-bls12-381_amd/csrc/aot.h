@@ -34,7 +34,15 @@
   X(fe_mid1, P_FE_MID1)      \
   X(fe_mid2, P_FE_MID2)      \
   X(fe_final, P_FE_FINAL)    \
-  X(miller_fe, P_MILLER_FE)
+  X(miller_fe, P_MILLER_FE)  \
+  X(mul2, P_MUL2)            \
+  X(h2c_a, P_H2C_A)          \
+  X(h2c_b, P_H2C_B)          \
+  X(h2c_c1, P_H2C_C1)        \
+  X(h2c_c2, P_H2C_C2)        \
+  X(g1_dec_a, P_G1_DEC_A)    \
+  X(g1_dec_b, P_G1_DEC_B)    \
+  X(g2_to_affine, P_G2_TO_AFFINE)
 
 namespace nbls {
 
@@ -57,6 +65,7 @@ struct AotStep { uint32_t x, y; };
 //           product round: a0, a1, b0, b1
 //   K_LIN : w0 = dst | halve << 16 ; then p0 + t term addresses, two 16-bit fields per word (added ones first)
 //   K_LOAD / K_LOADW / K_STORE / K_STOREW : w0 = slot | buffer << 16 | active << 31 ; w1 = byte offset inside the item
+//   every other kind : the interpreter's descriptor (vm.h) with its 16-bit fields made absolute; K_STATUS: bit 31 of w0 = active
 static const int AOT_DOT_HDR = 2;
 static inline uint32_t aot_dot_hdr_quads(uint32_t t) { return (AOT_DOT_HDR + t + 3) / 4; }   // 16-byte words of a K_DOT descriptor before its rounds
 struct AotProgram {

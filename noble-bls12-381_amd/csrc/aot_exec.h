@@ -75,6 +75,9 @@ NBLS_HD void aot_dot_finish(u32* r, u64* acc, const u32 w0, const u32* post, LDS
     const u32 q = (u32)(((u64)(u32)e * 2642610142u) >> 48);
 #endif
     f = boffs - (i32)q;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(f));   // one multiply-add pass with the coefficient offs - q (the optimiser otherwise splits it into offs * P[k] and - q * P[k])
+#endif
   }
   if (((FLAGS & AF_OFFS) && !(FLAGS & (AF_MULTSH | AF_MULT3))) || (FLAGS & AF_WRED)) {
 #pragma unroll
@@ -205,9 +208,23 @@ NBLS_HD void aot_step(const D& desc, LDSP lds, const u32 item, const bool live, 
     u32 res[NL];
     const u32 dst = aot_lin<P0, T, FLAGS>(res, lds, [&](u32 i) { return aot_word(desc.quad(i / 4), i & 3u); }, qp_table);
     commit(dst, res);
-  } else {
+  } else if constexpr (KIND == K_LOAD || KIND == K_LOADW || KIND == K_STORE || KIND == K_STOREW) {
     const V4 h0 = desc.quad(0);
     aot_io<KIND, P0>(lds, h0.x, h0.y, item, live, bufs);
+  } else {
+    // flags, selects, comparisons, status: the interpreter's lane code on absolute addresses (instance base 0)
+    Step st;
+    st.kind = (uint8_t)KIND; st.nlanes = 64; st.p0 = (uint8_t)P0; st.p1 = 0; st.desc_off = 0; st.stride = KIND == K_STATUS ? 8 : 4; st.lin = 0;
+    st.shape[0] = st.shape[1] = 0; st.rsv[0] = st.rsv[1] = 0;
+    const V4 h0 = desc.quad(0);
+    u32 d[8] = {h0.x, h0.y, h0.z, h0.w, 0, 0, 0, 0};
+    if (KIND == K_STATUS) { const V4 h1 = desc.quad(1); d[4] = h1.x; d[5] = h1.y; d[6] = h1.z; d[7] = h1.w; }
+    LaneCtx cx;
+    cx.inst = 0; cx.item = item; cx.shared = false;
+    cx.live = KIND == K_STATUS ? (live && (h0.x >> 31)) : live;
+    u32 res[NL];
+    const u32 dst = exec_lane(st, d, lds, cx, bufs, res, qp_table);
+    if (dst != 0xffffffffu) commit(dst, res);
   }
 }
 

@@ -89,6 +89,31 @@ std::string aot_translate(const Program& p, AotProgram& out) {
         }
         break;
       }
+      case K_ISZ: case K_CANON: case K_SEL: case K_CMP: case K_FLAG: case K_BITAND: case K_BIT: case K_STATUS: {
+        // the remaining kinds run the interpreter's own lane code (vm_exec.h exec_lane) on descriptors whose 16-bit fields are absolute addresses
+        sg.p0 = st.p0;
+        const u32 nw = st.kind == K_STATUS ? 8u : 2u;
+        for (u32 lane = 0; lane < 64; lane++) {
+          std::vector<u32>& w = lane_words[lane]; w.assign(nw, 0);
+          u32 g, li;
+          if (!active(lane, g, li)) { w[0] = st.kind == K_STATUS ? 0u : junk; continue; }   // sources: the zero constant; a status step with no flags and the active bit clear
+          const u32* d = old_desc(li);
+          auto lo = [&](u32 x) { return abs_addr(x & 0xffffu, g); };
+          auto hi = [&](u32 x) { return abs_addr(x >> 16, g) << 16; };
+          switch (st.kind) {
+            case K_ISZ: case K_CANON: w[0] = lo(d[0]) | hi(d[0]); break;
+            case K_SEL: w[0] = lo(d[0]) | hi(d[0]); w[1] = lo(d[1]) | hi(d[1]); break;
+            case K_CMP: case K_FLAG: case K_BITAND: w[0] = lo(d[0]); w[1] = lo(d[1]) | hi(d[1]); break;
+            case K_BIT: w[0] = lo(d[0]) | hi(d[0]); w[1] = d[1]; break;
+            default: {   // K_STATUS: w0 = flag count | buffer << 16 ; then flag address | code << 16
+              const u32 n = d[0] & 0xffu;
+              w[0] = n | (d[0] & (7u << 16)) | (1u << 31);
+              for (u32 k = 0; k < n && k < 7; k++) w[1 + k] = lo(d[1 + k]) | (d[1 + k] & 0xffff0000u);
+            }
+          }
+        }
+        break;
+      }
       default: return p.name + ": step kind " + std::to_string((int)st.kind) + " has no ahead-of-time body";
     }
     // signature index
