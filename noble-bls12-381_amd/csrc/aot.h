@@ -24,25 +24,25 @@
 #include "vm.h"
 #include "programs.h"
 
-// programs with an ahead-of-time kernel: X(name, ProgId)
-#define NBLS_AOT_PROGRAMS(X) \
-  X(expx, P_EXPX)            \
-  X(acc_fe, P_ACC_FE)        \
-  X(lines_pq, P_LINES_PQ)    \
-  X(acc4_raw, P_ACC4_RAW)    \
-  X(fe_easy, P_FE_EASY)      \
-  X(fe_mid1, P_FE_MID1)      \
-  X(fe_mid2, P_FE_MID2)      \
-  X(fe_final, P_FE_FINAL)    \
-  X(miller_fe, P_MILLER_FE)  \
-  X(mul2, P_MUL2)            \
-  X(h2c_a, P_H2C_A)          \
-  X(h2c_b, P_H2C_B)          \
-  X(h2c_c1, P_H2C_C1)        \
-  X(h2c_c2, P_H2C_C2)        \
-  X(g1_dec_a, P_G1_DEC_A)    \
-  X(g1_dec_b, P_G1_DEC_B)    \
-  X(g2_to_affine, P_G2_TO_AFFINE)
+// Ahead-of-time kernels: X(kernel name, up to four ProgIds it serves; P_COUNT = none).  A kernel's signature table is the union over its programs; programs that
+// share a kernel (and the lanes per item) can run as a CHAIN -- one launch that executes them back to back for the same items, values passing through the same
+// HBM scratch as between separate launches but without a grid-wide boundary: the seven launches EXPX, FE_MID1, EXPX x 3, FE_MID2, EXPX in the middle of a final
+// exponentiation (math.ts:862-867) are one.
+#define NBLS_AOT_KERNELS(X)                            \
+  X(expx, P_EXPX, P_FE_MID1, P_FE_MID2, P_COUNT)       \
+  X(acc_fe, P_ACC_FE, P_COUNT, P_COUNT, P_COUNT)       \
+  X(lines_pq, P_LINES_PQ, P_COUNT, P_COUNT, P_COUNT)   \
+  X(acc4_raw, P_ACC4_RAW, P_COUNT, P_COUNT, P_COUNT)   \
+  X(fe_easy, P_FE_EASY, P_COUNT, P_COUNT, P_COUNT)     \
+  X(fe_final, P_FE_FINAL, P_COUNT, P_COUNT, P_COUNT)   \
+  X(miller_fe, P_MILLER_FE, P_COUNT, P_COUNT, P_COUNT) \
+  X(mul2, P_MUL2, P_COUNT, P_COUNT, P_COUNT)           \
+  X(h2c_a, P_H2C_A, P_COUNT, P_COUNT, P_COUNT)         \
+  X(h2c_b, P_H2C_B, P_COUNT, P_COUNT, P_COUNT)         \
+  X(h2c_c1, P_H2C_C1, P_COUNT, P_COUNT, P_COUNT)       \
+  X(h2c_c2, P_H2C_C2, P_COUNT, P_COUNT, P_COUNT)       \
+  X(g1_dec, P_G1_DEC_A, P_G1_DEC_B, P_COUNT, P_COUNT)  \
+  X(g2_to_affine, P_G2_TO_AFFINE, P_COUNT, P_COUNT, P_COUNT)
 
 namespace nbls {
 
@@ -75,13 +75,26 @@ struct AotProgram {
   std::vector<uint32_t> descs;       // 4 words per 16-byte word
   uint32_t lds_bytes = 0;            // the program's LDS image + the junk slot idle lanes write to
 };
+// Launch arguments of an ahead-of-time kernel: up to AOT_MAX_SEGS programs executed back to back by every wavefront for its items (a chain; one segment = one
+// program with its own constants, LDS layout and buffer bindings; all segments share the lanes per item).
+static const int AOT_MAX_SEGS = 8;
+struct AotSeg {
+  const AotStep* steps; const uint32_t* descs; const uint32_t* consts;
+  uint32_t nsteps, nconst, inst_bytes, slot_bytes, shared_consts, pad;
+  IOBuf bufs[MAX_BUFS];
+};
+struct AotArgs {
+  AotSeg seg[AOT_MAX_SEGS];
+  uint32_t nseg, W, G, n_items, fair, pad;
+  const uint32_t* qp_table; const uint32_t* item_index; const uint32_t* n_items_dev;
+};
 // Translate a compiled program.  Returns an empty string, or why the program cannot run on an ahead-of-time kernel (lane split, a step kind the kernels do not implement).
 std::string aot_translate(const Program& p, AotProgram& out);
 
 }  // namespace nbls
 
 // kernel side (aot_kernel.hip)
-extern "C" int nbls_aot_index(int prog_id);   // index of the ahead-of-time kernel for a ProgId, or -1
+extern "C" int nbls_aot_index(int prog_id);   // index of the ahead-of-time kernel that serves a ProgId, or -1
 // remap the signature indices of a translated program to kernel k's table: 0, or -1 when a signature is not in the table
 extern "C" int nbls_aot_bind(int k, nbls::AotProgram* ap);
-extern "C" int nbls_aot_launch(int k, const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream);
+extern "C" int nbls_aot_launch(int k, const nbls::AotArgs* a, unsigned lds_bytes, void* stream);

@@ -18,39 +18,47 @@ struct DevDesc {
 };
 
 template <class Dispatch>
-__device__ __forceinline__ void aot_body(const KernelArgs& ka, Dispatch&& dispatch) {
+__device__ __forceinline__ void aot_body(const AotArgs& ka, Dispatch&& dispatch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds = smem;
   const u32 lane = threadIdx.x;
   u32 n_items = ka.n_items;
   if (ka.n_items_dev) { const u32 v = *ka.n_items_dev; n_items = v < n_items ? v : n_items; if (blockIdx.x * ka.G >= n_items) return; }
-  // constants: replicated at the start of every instance region, or one shared copy at the start of the LDS image
-  const u32 per_inst = ka.nconst * NL, copies = ka.shared_consts ? 1u : ka.G;
-  for (u32 i = lane; i < copies * per_inst; i += 64) {
-    const u32 g = i / per_inst, r = i - g * per_inst, c = r / NL, l = r - c * NL;
-    *(u32*)(lds + g * ka.inst_bytes + c * ka.slot_bytes + 4 * l) = ka.consts[c * RAW_WORDS + l];
-  }
   const u32 inst_id = lane / ka.W;
   u32 item = blockIdx.x * ka.G + inst_id;
   const bool live = inst_id < ka.G && item < n_items;
   if (ka.item_index && live) item = ka.item_index[item];
-  __syncthreads();   // single wave: orders the constant fill before first use
-  const V4* descs4 = (const V4*)ka.descs + lane;
-  const uint2* as = (const uint2*)ka.aot_steps;
-  const u32 nsteps = ka.nsteps;
-  uint2 h = as[0], nh = as[nsteps > 1 ? 1 : 0];
-  DevDesc d;
-  d.blk = descs4 + (size_t)h.y; d.q0 = d.blk[0]; d.q1 = d.blk[64]; d.q2 = d.blk[128];
-  const u32 quarter = (nsteps >> 2) + 1;
   const bool fair = ka.fair != 0;
   if (fair) __builtin_amdgcn_s_setprio(3);
-  for (u32 s = 0; s < nsteps; s++) {
-    if (fair) { if (s == quarter) __builtin_amdgcn_s_setprio(2); else if (s == 3 * quarter) __builtin_amdgcn_s_setprio(1); }
-    const uint2 nnh = as[(s + 2 < nsteps) ? s + 2 : nsteps - 1];
-    DevDesc nd;
-    nd.blk = descs4 + (size_t)nh.y; nd.q0 = nd.blk[0]; nd.q1 = nd.blk[64]; nd.q2 = nd.blk[128];   // the stream is padded: three words exist behind every block start
-    dispatch(h.x & 0xffu, d, lds, item, live);
-    h = nh; nh = nnh; d = nd;
+  u32 total = 0, done = 0;
+  for (u32 g = 0; g < ka.nseg; g++) total += ka.seg[g].nsteps;
+  const u32 quarter = (total >> 2) + 1;
+  for (u32 g = 0; g < ka.nseg; g++) {
+    const AotSeg& sg = ka.seg[g];
+    // a later segment of a chain reads, possibly on other lanes, scratch elements an earlier one stored: workgroup-scope release / acquire (one wavefront per
+    // workgroup: the stores are complete and visible before the loads are issued); the LDS image is rebuilt for the segment's own layout
+    if (g) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    // constants: replicated at the start of every instance region, or one shared copy at the start of the LDS image
+    const u32 per_inst = sg.nconst * NL, copies = sg.shared_consts ? 1u : ka.G;
+    for (u32 i = lane; i < copies * per_inst; i += 64) {
+      const u32 c0 = i / per_inst, r = i - c0 * per_inst, c = r / NL, l = r - c * NL;
+      *(u32*)(lds + c0 * sg.inst_bytes + c * sg.slot_bytes + 4 * l) = sg.consts[c * RAW_WORDS + l];
+    }
+    __syncthreads();   // single wave: orders the constant fill before first use
+    const V4* descs4 = (const V4*)sg.descs + lane;
+    const uint2* as = (const uint2*)sg.steps;
+    const u32 nsteps = sg.nsteps;
+    uint2 h = as[0], nh = as[nsteps > 1 ? 1 : 0];
+    DevDesc d;
+    d.blk = descs4 + (size_t)h.y; d.q0 = d.blk[0]; d.q1 = d.blk[64]; d.q2 = d.blk[128];
+    for (u32 s = 0; s < nsteps; s++, done++) {
+      if (fair) { if (done == quarter) __builtin_amdgcn_s_setprio(2); else if (done == 3 * quarter) __builtin_amdgcn_s_setprio(1); }
+      const uint2 nnh = as[(s + 2 < nsteps) ? s + 2 : nsteps - 1];
+      DevDesc nd;
+      nd.blk = descs4 + (size_t)nh.y; nd.q0 = nd.blk[0]; nd.q1 = nd.blk[64]; nd.q2 = nd.blk[128];   // the stream is padded: three words exist behind every block start
+      dispatch(h.x & 0xffu, d, lds, item, live, sg.bufs);
+      h = nh; nh = nnh; d = nd;
+    }
   }
 }
 
@@ -60,28 +68,29 @@ __device__ __forceinline__ void aot_body(const KernelArgs& ka, Dispatch&& dispat
 #endif
 #define NBLS_AOT_OCC __attribute__((amdgpu_waves_per_eu(NBLS_AOT_WAVES, NBLS_AOT_WAVES)))
 #define AOT_CASE(ID, KIND, P0, FLAGS, T, SH0, SH1, CNT) \
-  case ID: aot_step<KIND, P0, FLAGS, T, SH0, SH1>(d, lds, item, live, ka.bufs, ka.qp_table, [&](u32 dst, const u32* res) __attribute__((always_inline)) { st14(lds, dst, res); }); break;
-#define AOT_KERNEL(NAME, PID)                                                                            \
-  extern "C" __global__ void __launch_bounds__(64) NBLS_AOT_OCC nbls_aot_##NAME(KernelArgs ka) {         \
-    aot_body(ka, [&](u32 sig, const DevDesc& d, char* lds, u32 item, bool live) __attribute__((always_inline)) {                      \
-      switch (sig) { AOT_SIGS_##NAME(AOT_CASE) default: break; }                                         \
-    });                                                                                                  \
+  case ID: aot_step<KIND, P0, FLAGS, T, SH0, SH1>(d, lds, item, live, bufs, ka.qp_table, [&](u32 dst, const u32* res) __attribute__((always_inline)) { st14(lds, dst, res); }); break;
+#define AOT_KERNEL(NAME, P0, P1, P2, P3)                                                                                       \
+  extern "C" __global__ void __launch_bounds__(64) NBLS_AOT_OCC nbls_aot_##NAME(AotArgs ka) {                                  \
+    aot_body(ka, [&](u32 sig, const DevDesc& d, char* lds, u32 item, bool live, const IOBuf* bufs) __attribute__((always_inline)) { \
+      switch (sig) { AOT_SIGS_##NAME(AOT_CASE) default: break; }                                                               \
+    });                                                                                                                        \
   }
-NBLS_AOT_PROGRAMS(AOT_KERNEL)
+NBLS_AOT_KERNELS(AOT_KERNEL)
 
 // ---- host side
 #define AOT_ROW(ID, KIND, P0, FLAGS, T, SH0, SH1, CNT) {KIND, P0, FLAGS, T, SH0, SH1},
-#define AOT_TABLE(NAME, PID) static const AotSig sigs_##NAME[] = {AOT_SIGS_##NAME(AOT_ROW)};
-NBLS_AOT_PROGRAMS(AOT_TABLE)
-struct AotKernel { int prog_id; const void* fn; const AotSig* sigs; unsigned nsigs; };
-#define AOT_ENTRY(NAME, PID) {(int)PID, (const void*)nbls_aot_##NAME, sigs_##NAME, (unsigned)(sizeof(sigs_##NAME) / sizeof(AotSig))},
-static const AotKernel g_kernels[] = {NBLS_AOT_PROGRAMS(AOT_ENTRY)};
+#define AOT_TABLE(NAME, P0, P1, P2, P3) static const AotSig sigs_##NAME[] = {AOT_SIGS_##NAME(AOT_ROW)};
+NBLS_AOT_KERNELS(AOT_TABLE)
+struct AotKernel { int prog_id[4]; const void* fn; const AotSig* sigs; unsigned nsigs; };
+#define AOT_ENTRY(NAME, P0, P1, P2, P3) {{(int)P0, (int)P1, (int)P2, (int)P3}, (const void*)nbls_aot_##NAME, sigs_##NAME, (unsigned)(sizeof(sigs_##NAME) / sizeof(AotSig))},
+static const AotKernel g_kernels[] = {NBLS_AOT_KERNELS(AOT_ENTRY)};
 static const int g_nkernels = (int)(sizeof(g_kernels) / sizeof(g_kernels[0]));
 
 }  // namespace nbls
 
 extern "C" int nbls_aot_index(int prog_id) {
-  for (int k = 0; k < nbls::g_nkernels; k++) if (nbls::g_kernels[k].prog_id == prog_id) return k;
+  if (prog_id < 0 || prog_id >= (int)nbls::P_COUNT) return -1;
+  for (int k = 0; k < nbls::g_nkernels; k++) for (int j = 0; j < 4; j++) if (nbls::g_kernels[k].prog_id[j] == prog_id) return k;
   return -1;
 }
 extern "C" int nbls_aot_bind(int k, nbls::AotProgram* ap) {
@@ -98,7 +107,7 @@ extern "C" int nbls_aot_bind(int k, nbls::AotProgram* ap) {
   for (auto& s : ap->steps) s.x = (s.x & ~0xffu) | map[s.x & 0xffu];
   return 0;
 }
-extern "C" int nbls_aot_launch(int k, const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream) {
+extern "C" int nbls_aot_launch(int k, const nbls::AotArgs* ka, unsigned lds_bytes, void* stream) {
   using namespace nbls;
   if (k < 0 || k >= g_nkernels) return -1;
   if (ka->n_items == 0) return 0;
@@ -116,7 +125,7 @@ extern "C" int nbls_aot_launch(int k, const nbls::KernelArgs* ka, unsigned lds_b
       }
     }
   }
-  KernelArgs a = *ka;
+  AotArgs a = *ka;
   a.fair = (blocks > 1024 && blocks <= 4096) ? 1u : 0u;   // launches of 2..4 wavefronts per SIMD (vm_kernel.hip)
   void* args[] = {&a};
   const hipError_t e = hipLaunchKernel(g_kernels[k].fn, dim3(blocks), dim3(64), args, lds_bytes, (hipStream_t)stream);

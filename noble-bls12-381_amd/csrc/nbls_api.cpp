@@ -34,7 +34,7 @@ static_assert(P_COUNT <= NBLS_N_PROGRAMS, "nbls_timing_read's arrays (NBLS_N_PRO
 static const size_t RAW = RAW_FP_BYTES;     // one raw field element in HBM scratch (14 limbs + padding)
 static const size_t F12 = 12 * RAW;        // raw Fp12
 static const size_t LINE_BYTES = (size_t)LINE_ELEMS * RAW;   // one line table: 68 triples of Fp2 as raw elements (26,112 B)
-static const size_t SPLIT_MILLER_MIN = 49152;   // pairs from which the Miller loop runs as LINES + ACC (see nbls_pairing_batch_dev)
+static const size_t SPLIT_MILLER_MIN = 4096;   // pairs from which the Miller loop runs as LINES + ACC (see nbls_pairing_batch_dev; round 4: with the ahead-of-time kernels the two programs win from 4096 pairs, tools/sweep_modes.sh)
 static const size_t LINES_CHUNK = 131072;   // pairs whose line tables are in HBM at a time (3.4 GB of the 288); larger batches run chunk by chunk on the same stream
 
 #define EXPORT extern "C" __attribute__((visibility("default")))
@@ -135,6 +135,11 @@ static hipEvent_t timing_event(nbls_ctx* ctx) {
   hipEvent_t e = nullptr; hipEventCreate(&e); return e;
 }
 
+static void aot_seg(AotSeg& g, const DevProgram& d, const IOBuf* bufs) {
+  g.steps = d.aot_steps; g.descs = d.aot_descs; g.consts = d.consts;
+  g.nsteps = (u32)d.p->steps.size(); g.nconst = d.p->nconst; g.inst_bytes = d.p->inst_bytes(); g.slot_bytes = d.p->slot_bytes; g.shared_consts = d.p->shared_consts ? 1u : 0u;
+  for (int k = 0; k < MAX_BUFS; k++) g.bufs[k] = bufs[k];
+}
 static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pair<int, std::pair<const void*, size_t>>> bufs, hipStream_t s, const uint32_t* n_dev = nullptr, const uint32_t* item_index = nullptr) {
   int r = upload(ctx, id); if (r) return r;
   const DevProgram& d = ctx->prog[id];
@@ -164,8 +169,12 @@ static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pa
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->timing) { e0 = timing_event(ctx); e1 = timing_event(ctx); hipEventRecord(e0, s); }
   int e;
-  if (d.aot >= 0) { ka.aot_steps = d.aot_steps; ka.descs = d.aot_descs; e = nbls_aot_launch(d.aot, &ka, d.aot_lds, s); }
-  else e = nbls_vm_launch(&ka, d.p->lds_bytes(), s);
+  if (d.aot >= 0) {
+    AotArgs a; memset(&a, 0, sizeof a);
+    aot_seg(a.seg[0], d, ka.bufs);
+    a.nseg = 1; a.W = ka.W; a.G = ka.G; a.n_items = ka.n_items; a.qp_table = ka.qp_table; a.item_index = ka.item_index; a.n_items_dev = ka.n_items_dev;
+    e = nbls_aot_launch(d.aot, &a, d.aot_lds, s);
+  } else e = nbls_vm_launch(&ka, d.p->lds_bytes(), s);
   if (ctx->timing) { hipEventRecord(e1, s); ctx->tev.push_back({(int)id, {e0, e1}}); }
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
   return NBLS_OK;
@@ -175,6 +184,41 @@ static int run_inv(nbls_ctx* ctx, size_t n, hipStream_t s) {
   if (ctx->timing) { e0 = timing_event(ctx); e1 = timing_event(ctx); hipEventRecord(e0, s); }
   int e = nbls_fp_inv_launch((unsigned)n, ctx->N + ctx->ioff * RAW, ctx->NI + ctx->ioff * RAW, s);
   if (ctx->timing) { hipEventRecord(e1, s); ctx->tev.push_back({(int)P_COUNT, {e0, e1}}); }
+  if (e) { ctx->last_hip = e; return NBLS_EHIP; }
+  return NBLS_OK;
+}
+
+// A chain: several programs executed back to back by ONE launch (aot.h): every wavefront runs them in order for its own items, the values between them pass
+// through the HBM scratch buffers the separate launches would use.  Falls back to one launch per program when some program is not on an ahead-of-time kernel,
+// when the programs do not share a kernel / the lanes per item, or in checked mode (whose per-launch buffer checks live in run()).
+typedef std::initializer_list<std::pair<int, std::pair<const void*, size_t>>> BufList;
+struct ChainLink { ProgId id; BufList bufs; };
+// items up to which the middle of the final exponentiation runs as one chain: measured equal to seven launches up to 4096 pairings per call (2.371 against 2.374 ms;
+// twelve calls in flight 2.99 against 3.02 M pairings/s) and slower where a call runs as two halves on two streams (16,384: 6.53 against 6.28 ms), whose launches fill each other's tails
+static size_t chain_max() { static const size_t v = getenv("NBLS_CHAIN_MAX") ? (size_t)atol(getenv("NBLS_CHAIN_MAX")) : 8192; return v; }
+static bool chains_enabled() { static const bool on = !(getenv("NBLS_CHAIN") && atoi(getenv("NBLS_CHAIN")) == 0); return on; }
+static int run_chain(nbls_ctx* ctx, size_t n, std::initializer_list<ChainLink> links, hipStream_t s) {
+  int r;
+  bool fuse = chains_enabled() && !checked_mode() && links.size() <= (size_t)AOT_MAX_SEGS;
+  int k = -1; u32 W = 0, G = 0, lds = 0;
+  for (auto& l : links) {
+    if ((r = upload(ctx, l.id))) return r;
+    const DevProgram& d = ctx->prog[l.id];
+    if (d.aot < 0 || (k >= 0 && (d.aot != k || d.p->W != W || d.p->G != G))) fuse = false;
+    k = d.aot; W = d.p->W; G = d.p->G; lds = std::max(lds, d.aot_lds);
+  }
+  if (!fuse) { for (auto& l : links) if ((r = run(ctx, l.id, n, l.bufs, s))) return r; return NBLS_OK; }
+  AotArgs a; memset(&a, 0, sizeof a);
+  for (auto& l : links) {
+    IOBuf bufs[MAX_BUFS]; memset(bufs, 0, sizeof bufs);
+    for (auto& b : l.bufs) { bufs[b.first].ptr = (uint8_t*)b.second.first + ctx->ioff * b.second.second; bufs[b.first].stride = b.second.second; }
+    aot_seg(a.seg[a.nseg++], ctx->prog[l.id], bufs);
+  }
+  a.W = W; a.G = G; a.n_items = (u32)n; a.qp_table = ctx->qp_table;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->timing) { e0 = timing_event(ctx); e1 = timing_event(ctx); hipEventRecord(e0, s); }
+  const int e = nbls_aot_launch(k, &a, lds, s);
+  if (ctx->timing) { hipEventRecord(e1, s); ctx->tev.push_back({(int)links.begin()->id, {e0, e1}}); }   // the whole chain is booked on its first program
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
   return NBLS_OK;
 }
@@ -262,7 +306,9 @@ static inline BufArg B(int idx, const void* p, size_t stride) { return {idx, {p,
 // Launches of at most one wavefront per SIMD take the time of one wavefront's instruction stream, so up to LS_MAX items (one item per wavefront
 // on 1024 SIMDs) the lane-split variants run: the same formulas with every lane-op's products shared by four lanes (a third fewer instructions per
 // wavefront; csrc/vm_kernel.hip nbls_vm_kernel_ls4).  NBLS_LS_MAX overrides (0 = never).
-static size_t ls_max() { static const size_t v = getenv("NBLS_LS_MAX") ? (size_t)atol(getenv("NBLS_LS_MAX")) : 1024; return v; }
+// lane-split programs (interpreter, one item per wavefront) for launches of up to this many items.  Round 4: 0 -- the ahead-of-time kernels are faster at every
+// size (1024 pairings 2.22 against 2.54 ms, one pairing likewise); NBLS_LS_MAX=1024 restores the round-3 behaviour
+static size_t ls_max() { static const size_t v = getenv("NBLS_LS_MAX") ? (size_t)atol(getenv("NBLS_LS_MAX")) : 0; return v; }
 static ProgId ls_variant(ProgId id, size_t n) {
   if (n > ls_max()) return id;
   switch (id) {
@@ -314,6 +360,18 @@ static int final_exp_pipeline(nbls_ctx* ctx, size_t n, uint8_t* f_raw, void* d_o
   uint8_t** T = ctx->T;
   if ((r = run_inv(ctx, n, s))) return r;
   if ((r = run(ctx, P_FE_EASY, n, {B(3, f_raw, F12), B(4, ctx->NI, RAW), B(5, T[0], F12)}, s))) return r;
+  if (n < ctx->expc_min && n < chain_max() && ls_variant(P_EXPX, n) == P_EXPX) {
+    // the seven launches between the easy part and the final product as one chain (math.ts:862-867): t2 = t1^x, t3 = conj(t1^2) t2, t4 = t3^x, t5 = t4^x,
+    // t6' = t5^x, t6 = t6' t2^2, t7 = t6^x
+    if ((r = run_chain(ctx, n, {{P_EXPX, {B(3, T[0], F12), B(5, T[1], F12)}},
+                                {P_FE_MID1, {B(3, T[0], F12), B(5, T[1], F12), B(6, T[2], F12)}},
+                                {P_EXPX, {B(3, T[2], F12), B(5, T[3], F12)}},
+                                {P_EXPX, {B(3, T[3], F12), B(5, T[4], F12)}},
+                                {P_EXPX, {B(3, T[4], F12), B(5, T[6], F12)}},
+                                {P_FE_MID2, {B(3, T[6], F12), B(5, T[1], F12), B(6, T[5], F12)}},
+                                {P_EXPX, {B(3, T[5], F12), B(5, T[6], F12)}}}, s))) return r;
+    return run(ctx, P_FE_FINAL, n, {B(0, T[0], F12), B(1, T[1], F12), B(2, T[2], F12), B(3, T[3], F12), B(4, T[4], F12), B(5, T[5], F12), B(6, T[6], F12), B(7, d_out, 576)}, s);
+  }
   if ((r = expx(ctx, n, T[0], T[1], s))) return r;   // t2
   if ((r = run(ctx, P_FE_MID1, n, {B(3, T[0], F12), B(5, T[1], F12), B(6, T[2], F12)}, s))) return r;   // t3
   if ((r = expx(ctx, n, T[2], T[3], s))) return r;   // t4

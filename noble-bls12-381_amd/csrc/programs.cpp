@@ -9,6 +9,7 @@
 //   5  F' : second raw Fp12 scratch (product reduction output)
 #include "programs.h"
 #include <mutex>
+#include "aot.h"
 #include "tower.h"
 #include "curve.h"
 #include "codec.h"
@@ -229,8 +230,18 @@ static const int EXPX_W = env_int("NBLS_EXPX_W", 12);
 // ACC_WINDOW keeps the line loads about one and a half iterations ahead of their use (they would otherwise all be hoisted to the front and pin 408 slots)
 static const int LINES_W = env_int("NBLS_LINES_W", 10), ACC_W = env_int("NBLS_ACC_W", 12), ACC_WINDOW = env_int("NBLS_ACC_WINDOW", 330);   // an Fp12 op has exactly 12 lane-ops: 5 items per wave, no idle lane (+5..9 % over 16 lanes once >= 2 waves share a SIMD)
 
+// programs that run on an ahead-of-time kernel (aot.h): their descriptors hold absolute addresses, so ONE shared copy of the constants costs nothing
+// (the interpreter pays three instructions per operand for it) and frees the replicated copies' LDS: FE_MID1 13,440 -> 11,904 B, which keeps twelve
+// workgroups per CU for the chained final exponentiation
+static bool aot_listed(ProgId id) {
+#define AOT_HAS(NAME, P0, P1, P2, P3) if (id == P0 || id == P1 || id == P2 || id == P3) return true;
+  NBLS_AOT_KERNELS(AOT_HAS)
+#undef AOT_HAS
+  return false;
+}
 static Program build(ProgId id) {
   Builder B;
+  if (aot_listed(id) && env_int("NBLS_AOT_SHARED_CONSTS", 1)) B.shared_consts = 1;
   // the Fp12 squaring has 6 coefficients of 7 products next to 6 of 6: capping lane-ops at 6 products moves the seventh into a light
   // step that has free lanes (-4 % instructions); with two point chains per item (MILLER_RAW2) those steps are full, so no cap there
   if (id == P_MILLER_BYTES || id == P_MILLER_RAW || id == P_MILLER_FE) B.max_dot = env_int("NBLS_MILLER_MAXDOT", 6);
@@ -370,11 +381,13 @@ static Program build(ProgId id) {
     case P_FE_MID1: {
       SFp12 a = inputw_fp12(3, 0), b = inputw_fp12(5, 0);
       outputw_fp12(mul(conj(mat(cyclotomic_sqr(a))), b), 6, 0);
+      B.sched_window = env_int("NBLS_FE_MID_WINDOW", 0);
       return B.compile("fe_mid1", env_int("NBLS_FE_MID_W", 12));
     }
     case P_FE_MID2: {
       SFp12 a = inputw_fp12(3, 0), b = inputw_fp12(5, 0);
       outputw_fp12(mul(a, mat(cyclotomic_sqr(b))), 6, 0);
+      B.sched_window = env_int("NBLS_FE_MID_WINDOW", 0);
       return B.compile("fe_mid2", env_int("NBLS_FE_MID_W", 12));
     }
     case P_FE_FINAL: {

@@ -493,7 +493,7 @@ Program Builder::compile(const std::string& name, int W) {
   P.slot_bytes = 64;
   // constants: a copy per instance (operand address = base + offset) unless that costs real LDS: with 8 or 16 instances per wavefront the copies
   // of a dozen constants are 5-10 KB and push the point programs from 8 to 6 wavefronts per CU; those keep one shared copy, marked by bit 1
-  P.shared_consts = getenv("NBLS_SHARED_CONSTS") ? atoi(getenv("NBLS_SHARED_CONSTS")) != 0 : P.G >= 8;
+  P.shared_consts = getenv("NBLS_SHARED_CONSTS") ? atoi(getenv("NBLS_SHARED_CONSTS")) != 0 : shared_consts >= 0 ? shared_consts != 0 : P.G >= 8;
   {   // slot stride: 80 bytes where the larger image still leaves room for twelve workgroups per CU (three wavefronts per SIMD is what the register budget
       // allows anyway); NBLS_SLOT_BYTES = 64 / 80 forces one or the other
     const char* e = getenv("NBLS_SLOT_BYTES");

@@ -96,6 +96,7 @@ struct Builder {
   bool use_wred = getenv("NBLS_NO_WRED") == nullptr;   // large post-added terms: weak reduction (table of multiples of p) instead of folding them into the dot product
   int store_batch = 0;   // > 0: a store step is issued as soon as this many stores are ready (programs that stream results out: the values do not linger in LDS)
   int lane_split = 1;    // see Program::lsplit (compile(name, W) takes the LOGICAL lanes per item; the program runs on W * lane_split)
+  int shared_consts = -1;   // -1: one shared copy of the constants for programs with eight or more items per wavefront (compile()); 0 / 1: replicated / shared
   int sched_window = 0;  // scheduler look-ahead limit in critical-path units (0 = unlimited), see compile()
   bool prefer_doubling = !(getenv("NBLS_PREFER_DBL") && atoi(getenv("NBLS_PREFER_DBL")) == 0);   // materialize(): integer factors of a lane-op's products as doubled operands rather than a multiplier on the reduced sum
   static Builder*& cur() { static thread_local Builder* b = nullptr; return b; }

@@ -69,22 +69,22 @@ struct HostDesc {
 struct Pend { u32 dst; u32 v[NL]; };
 #define SIM_CASE(ID, KIND, P0, FLAGS, T, SH0, SH1, CNT) \
   case ID: aot_step<KIND, P0, FLAGS, T, SH0, SH1>(d, lds, item, live, bufs, qp, [&](u32 dst, const u32* res) { Pend pd; pd.dst = dst; memcpy(pd.v, res, NL * 4); pend.push_back(pd); }); break;
-#define SIM_TABLE(NAME, PID)                                                                                                              \
+#define SIM_TABLE(NAME, Q0, Q1, Q2, Q3)                                                                                                        \
   static const AotSig sim_sigs_##NAME[] = {AOT_SIGS_##NAME(SIM_ROW)};                                                                      \
   static void sim_step_##NAME(u32 sig, const HostDesc& d, char* lds, u32 item, bool live, const IOBuf* bufs, const u32* qp, std::vector<Pend>& pend) { \
     switch (sig) { AOT_SIGS_##NAME(SIM_CASE) default: abort(); }                                                                          \
   }
 #define SIM_ROW(ID, KIND, P0, FLAGS, T, SH0, SH1, CNT) {KIND, P0, FLAGS, T, SH0, SH1},
-NBLS_AOT_PROGRAMS(SIM_TABLE)
+NBLS_AOT_KERNELS(SIM_TABLE)
 typedef void (*SimStepFn)(u32, const HostDesc&, char*, u32, bool, const IOBuf*, const u32*, std::vector<Pend>&);
-struct SimKernel { int prog_id; SimStepFn fn; const AotSig* sigs; unsigned nsigs; };
-#define SIM_ENTRY(NAME, PID) {(int)PID, sim_step_##NAME, sim_sigs_##NAME, (unsigned)(sizeof(sim_sigs_##NAME) / sizeof(AotSig))},
-static const SimKernel g_sim_kernels[] = {NBLS_AOT_PROGRAMS(SIM_ENTRY)};
+struct SimKernel { int prog_id[4]; SimStepFn fn; const AotSig* sigs; unsigned nsigs; };
+#define SIM_ENTRY(NAME, Q0, Q1, Q2, Q3) {{(int)Q0, (int)Q1, (int)Q2, (int)Q3}, sim_step_##NAME, sim_sigs_##NAME, (unsigned)(sizeof(sim_sigs_##NAME) / sizeof(AotSig))},
+static const SimKernel g_sim_kernels[] = {NBLS_AOT_KERNELS(SIM_ENTRY)};
 static int g_sim_aot = 0;
 // 0: ran; -2: the program has no ahead-of-time kernel; -3: its signatures are not in the kernel's table
 static int sim_run_aot(int prog, unsigned n_items, const IOBuf* bufs) {
   const SimKernel* K = nullptr;
-  for (auto& k : g_sim_kernels) if (k.prog_id == prog) K = &k;
+  if (prog >= 0 && prog < (int)P_COUNT) for (auto& k : g_sim_kernels) for (int j = 0; j < 4; j++) if (k.prog_id[j] == prog) K = &k;
   if (!K) return -2;
   const Program& p = get_program((ProgId)prog);
   AotProgram ap;
@@ -114,7 +114,7 @@ static int sim_run_aot(int prog, unsigned n_items, const IOBuf* bufs) {
 extern "C" {
 // translated programs (aot.h) instead of the interpreter's semantics for the programs that have an ahead-of-time kernel: 0 off, 1 on
 __attribute__((visibility("default"))) void nbls_sim_set_aot(int on) { g_sim_aot = on; }
-__attribute__((visibility("default"))) int nbls_sim_has_aot(int prog) { for (auto& k : g_sim_kernels) if (k.prog_id == prog) return 1; return 0; }
+__attribute__((visibility("default"))) int nbls_sim_has_aot(int prog) { if (prog < 0 || prog >= (int)P_COUNT) return 0; for (auto& k : g_sim_kernels) for (int j = 0; j < 4; j++) if (k.prog_id[j] == prog) return 1; return 0; }
 // bufs: 8 pointers + 8 strides
 __attribute__((visibility("default"))) int nbls_sim_run(int prog, unsigned n_items, uint8_t** ptrs, const uint64_t* strides) {
   if (prog < 0 || prog >= P_COUNT) return -1;
