@@ -30,19 +30,21 @@
 // exponentiation (math.ts:862-867) are one.
 #define NBLS_AOT_KERNELS(X)                            \
   X(expx, P_EXPX, P_FE_MID1, P_FE_MID2, P_COUNT)       \
-  X(acc_fe, P_ACC_FE, P_COUNT, P_COUNT, P_COUNT)       \
+  X(acc_fe, P_ACC_FE, P_ACC_RAW, P_ACC_BYTES, P_COUNT) \
   X(lines_pq, P_LINES_PQ, P_COUNT, P_COUNT, P_COUNT)   \
   X(acc4_raw, P_ACC4_RAW, P_COUNT, P_COUNT, P_COUNT)   \
   X(fe_easy, P_FE_EASY, P_COUNT, P_COUNT, P_COUNT)     \
   X(fe_final, P_FE_FINAL, P_COUNT, P_COUNT, P_COUNT)   \
-  X(miller_fe, P_MILLER_FE, P_COUNT, P_COUNT, P_COUNT) \
+  X(miller_fe, P_MILLER_FE, P_MILLER_RAW, P_MILLER_BYTES, P_COUNT) \
   X(mul2, P_MUL2, P_COUNT, P_COUNT, P_COUNT)           \
   X(h2c_a, P_H2C_A, P_COUNT, P_COUNT, P_COUNT)         \
   X(h2c_b, P_H2C_B, P_COUNT, P_COUNT, P_COUNT)         \
   X(h2c_c1, P_H2C_C1, P_COUNT, P_COUNT, P_COUNT)       \
   X(h2c_c2, P_H2C_C2, P_COUNT, P_COUNT, P_COUNT)       \
   X(g1_dec, P_G1_DEC_A, P_G1_DEC_B, P_COUNT, P_COUNT)  \
-  X(g2_to_affine, P_G2_TO_AFFINE, P_COUNT, P_COUNT, P_COUNT)
+  X(g2_dec, P_G2_DEC_A, P_G2_DEC_B, P_COUNT, P_COUNT)  \
+  X(norm, P_NORM_RAW, P_NORM_BYTES, P_RAW_TO_BYTES, P_COUNT) \
+  X(g2_to_affine, P_G2_TO_AFFINE, P_G2_NORM, P_COUNT, P_COUNT)
 
 namespace nbls {
 
