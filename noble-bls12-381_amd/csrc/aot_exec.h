@@ -9,6 +9,7 @@
 //     load), then ONE carry pass.  A result can therefore differ from the interpreter's by a multiple of p (the two weak reductions estimate q differently);
 //     both satisfy the bounds the host compiler books (value >= 0, below 3.02 p after a weak reduction), and every canonical output is the same.
 #pragma once
+#include <type_traits>
 #include "aot.h"
 #include "vm_exec.h"
 
@@ -152,6 +153,43 @@ NBLS_HD void aot_io(LDSP lds, const u32 w0, const u32 off, const u32 item, const
   }
 }
 
+// Column budget instead of operand normalisation.  The host compiler keeps a lane-op's 64-bit columns from overflowing by normalising sum operands first
+// (a carry pass of 39 instructions per operand, paid by the whole wavefront as soon as one lane needs it: 312 of the 2,199 instructions of an Fp12 squaring step).
+// A specialised body knows every round's operand shapes, so it can bound every COLUMN instead: a round with operand magnitudes ca, cb (1 for a slot or a
+// difference: limbs inside (-2^28, 2^28); 2 for a sum or a mixed-sign operand) adds at most terms(k) * ca * cb units of 2^56 to column k, terms(k) = the
+// number of limb products that fall into it (k + 1 up to 14, then down).  A column that would pass 113 units (2^63 = 128; 14 for the reduction's own m * p rows,
+// one of slack) is compressed first -- its part above 2^28 moves into the next column, four instructions -- and operands are multiplied un-normalised.  Only the
+// middle columns ever need it: ~21 column compressions per Fp12 squaring step.
+struct AotCompressPlan { u32 before[MAX_DOT_PRODUCTS + 1]; };
+constexpr u32 aot_shape_units(u32 mode) { return (mode == 1u || mode == 3u) ? 2u : 1u; }
+constexpr AotCompressPlan aot_compress_plan(u32 P0, u32 SH0, u32 SH1) {
+  AotCompressPlan pl = {};
+  u32 B[2 * NL] = {};
+  const u32 LIMIT = 113;
+  for (u32 r = 0; r < P0 && r < (u32)MAX_DOT_PRODUCTS; r++) {
+    const u32 shape = ((r < 4 ? SH0 : SH1) >> (8 * (r & 3))) & 0xffu;
+    const u32 add = aot_shape_units(shape & 3u) * aot_shape_units((shape >> SH_B_SHIFT) & 3u);
+    u32 mask = 0;
+    for (u32 k = 0; k < 2 * NL - 1; k++) { const u32 terms = k < (u32)NL ? k + 1 : 2 * NL - 1 - k; if (B[k] + terms * add > LIMIT) mask |= 1u << k; }
+    for (u32 k = 0; k < 2 * NL - 1; k++) if (mask & (1u << k)) { B[k + 1] += 1; B[k] = 1; }
+    for (u32 k = 0; k < 2 * NL - 1; k++) { const u32 terms = k < (u32)NL ? k + 1 : 2 * NL - 1 - k; B[k] += terms * add; }
+    pl.before[r] = mask;
+  }
+  return pl;
+}
+// does any round of the signature carry a "normalise first" flag (the only signatures whose bodies change)
+constexpr bool aot_has_norm(u32 SH0, u32 SH1) { return ((SH0 | SH1) & 0x24242424u) != 0; }
+template <u32 MASK>
+NBLS_HD void aot_compress_columns(u64* acc) {
+#pragma unroll
+  for (int k = 0; k < 2 * NL - 1; k++) {
+    if (MASK & (1u << k)) {
+      acc[k + 1] = (u64)((i64)acc[k + 1] + ((i64)acc[k] >> 28));
+      acc[k] &= (u64)LMASK;
+    }
+  }
+}
+
 // The columns are made opaque between product rounds: the optimiser would otherwise re-associate every column's sum over ALL rounds of an unrolled body
 // (every round's operands live at once: 330-480 registers); the scheduling barrier keeps the LDS reads of later rounds from being hoisted to the top.
 NBLS_HD void aot_round_fence(u64* acc) {
@@ -180,15 +218,18 @@ NBLS_HD void aot_step(const D& desc, LDSP lds, const u32 item, const bool live, 
 #pragma unroll
     for (int i = 0; i < 2 * NL; i++) acc[i] = 0;
     V4 cur = desc.quad(HQ);
-#pragma unroll
-    for (u32 r = 0; r < P0; r++) {
+    // rounds with compile-time index (the compression plan is a constant expression of the signature)
+    auto do_round = [&](auto RC) __attribute__((always_inline)) {
+      constexpr u32 r = decltype(RC)::value;
+      constexpr bool budget = aot_has_norm(SH0, SH1);   // signatures without normalised operands keep the host compiler's own budget (sum of ca * cb <= 8)
+      constexpr u32 cmask = budget ? aot_compress_plan(P0, SH0, SH1).before[r] : 0u;
       V4 nx = cur;
       if (r + 1 < P0) nx = desc.quad(HQ + r + 1);
-      const u32 shape = ((r < 4 ? SH0 : SH1) >> (8 * (r & 3))) & 0xffu;
+      constexpr u32 shape = ((r < 4 ? SH0 : SH1) >> (8 * (r & 3))) & 0xffu;
       const u32 neg = (h0.y >> (4 * r)) & 15u;
-      // the shape is a compile-time constant after unrolling: dot_combine's branches fold
+      if (cmask) aot_compress_columns<cmask>(acc);
       {
-        const u32 sa = shape & 7u, sb = (shape >> SH_B_SHIFT) & 7u;
+        constexpr u32 sa = shape & (budget ? 3u : 7u), sb = (shape >> SH_B_SHIFT) & (budget ? 3u : 7u);   // under the column budget operands are never normalised
         u32 A[NL], B[NL], X[NL], Y[NL];
         ld14(A, lds, cur.x);
         if (sa & 3u) ld14(X, lds, cur.y);
@@ -200,7 +241,15 @@ NBLS_HD void aot_step(const D& desc, LDSP lds, const u32 item, const bool live, 
       }
       aot_round_fence(acc);
       cur = nx;
-    }
+    };
+    if constexpr (P0 > 0) do_round(std::integral_constant<u32, 0>{});
+    if constexpr (P0 > 1) do_round(std::integral_constant<u32, 1>{});
+    if constexpr (P0 > 2) do_round(std::integral_constant<u32, 2>{});
+    if constexpr (P0 > 3) do_round(std::integral_constant<u32, 3>{});
+    if constexpr (P0 > 4) do_round(std::integral_constant<u32, 4>{});
+    if constexpr (P0 > 5) do_round(std::integral_constant<u32, 5>{});
+    if constexpr (P0 > 6) do_round(std::integral_constant<u32, 6>{});
+    if constexpr (P0 > 7) do_round(std::integral_constant<u32, 7>{});
     u32 res[NL];
     aot_dot_finish<FLAGS, T>(res, acc, h0.x, post, lds);
     commit(h0.x & 0xffffu, res);
