@@ -78,6 +78,32 @@ int nbls_pairing_prepared(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, const 
 int nbls_final_exp_batch(nbls_ctx* ctx, size_t n, const uint8_t* in_fp12, uint8_t* out_fp12);
 int nbls_final_exp_batch_dev(nbls_ctx* ctx, size_t n, const void* d_in_fp12, void* d_out_fp12, void* stream);
 
+/* Single tower operations on the device (round 4): the reference's own unit-test surface for Fp / Fp2 / Fp6 / Fp12 (test/fp.test.ts, fp2.test.ts, fp12.test.ts) as
+ * one batched entry point, so that the tower rows of the scope table have known-answer tests of their own on the GPU and not only through pairings.
+ * field = 1, 2, 6, 12 (elements of 48 * field wire bytes, Fp.toBytes / Fp2.toBytes / Fp12.toBytes order); op = NBLS_TOP_*; param = the power of a Frobenius map.
+ * a: n elements; b: n elements (binary operations) or n Fp2 elements (sparse products); c, d: n Fp2 elements (sparse products); unused operands NULL.
+ * Replaces: Fp add / subtract / negate / multiply / square / invert (math.ts:223-273, 134-156), Fp2 ... multiplyByB / mulByNonresidue / frobeniusMap / invert
+ * (math.ts:451-539), Fp6 ... multiplyBy1 / multiplyBy01 / frobeniusMap / invert (math.ts:601-688), Fp12 ... multiplyBy014 / conjugate / frobeniusMap / invert /
+ * cyclotomicSquare / cyclotomicExp(x) (math.ts:732-852).  Inverting zero is undefined (the reference throws): the output element is then unspecified.
+ * Returns NBLS_EINVAL for a combination the reference does not have (e.g. conjugate on Fp6). */
+#define NBLS_TOP_ADD 0
+#define NBLS_TOP_SUB 1
+#define NBLS_TOP_NEG 2
+#define NBLS_TOP_MUL 3
+#define NBLS_TOP_SQR 4
+#define NBLS_TOP_INV 5
+#define NBLS_TOP_FROBENIUS 6        /* Fp2, Fp6, Fp12: frobeniusMap(param), 0 <= param <= 11 */
+#define NBLS_TOP_CONJUGATE 7        /* Fp2 (= frobeniusMap(1)), Fp12 */
+#define NBLS_TOP_MUL_BY_NONRESIDUE 8 /* Fp2: * (1 + u); Fp6: * v */
+#define NBLS_TOP_MUL_BY_B 9         /* Fp2: * 4 (1 + u) */
+#define NBLS_TOP_MUL_BY_1 10        /* Fp6: multiplyBy1(b) */
+#define NBLS_TOP_MUL_BY_01 11       /* Fp6: multiplyBy01(b, c) */
+#define NBLS_TOP_MUL_BY_014 12      /* Fp12: multiplyBy014(b, c, d) */
+#define NBLS_TOP_CYCLOTOMIC_SQUARE 13 /* Fp12, unitary input */
+#define NBLS_TOP_CYCLOTOMIC_EXP 14  /* Fp12, unitary input: cyclotomicExp(CURVE.x) */
+int nbls_tower_op_batch(nbls_ctx* ctx, int field, int op, int param, size_t n, const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d, uint8_t* out);
+
+
 /* Raw device partial product for multi-GPU reductions: prod_i millerLoop(P_i,Q_i) WITHOUT final exponentiation as
  * 576 wire bytes on the device (one per rank; ranks exchange them and finish with nbls_fp12_product_final_dev). */
 int nbls_fp12_product_final_dev(nbls_ctx* ctx, size_t n, const void* d_in_fp12, int final_exp, void* d_out_fp12, void* stream);

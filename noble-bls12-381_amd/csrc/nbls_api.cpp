@@ -15,6 +15,8 @@
 
 extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream);
 #include "aot.h"
+#include <map>
+#include <tuple>
 extern "C" int nbls_fp_inv_launch(unsigned n, const void* in, void* out, void* stream);
 extern "C" int nbls_flag_compact_launch(unsigned n, const void* flags, void* list, void* count, void* stream);
 extern "C" int nbls_xmd_launch(unsigned n, const void* msgs, const void* offsets, const void* dst, unsigned dst_len, void* out, unsigned len_in_bytes, void* stream);
@@ -52,6 +54,7 @@ struct nbls_ctx {
   hipStream_t stream = nullptr;
   std::recursive_mutex mu;   // held for the whole of every exported call (host-level calls re-enter it through the *_dev entry points)
   DevProgram prog[P_COUNT];
+  std::map<std::tuple<int, int, int, int>, DevProgram> tower;   // single tower operations (nbls_tower_op_batch), uploaded on first use
   // scratch (device)
   uint8_t *F = nullptr, *F2 = nullptr, *N = nullptr, *NI = nullptr, *io_g1 = nullptr, *io_g2 = nullptr, *io_f12 = nullptr, *one12 = nullptr;
   uint8_t* T[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // t1..t7 of the final exponentiation, raw Fp12
@@ -102,10 +105,14 @@ static bool checked_mode() {
 }
 // NBLS_AOT=0 keeps every program on the interpreter (A/B runs, profiles of the interpreter)
 static bool aot_enabled() { static const bool on = !(getenv("NBLS_AOT") && atoi(getenv("NBLS_AOT")) == 0); return on; }
+static int upload_program(nbls_ctx* ctx, DevProgram& d, const Program& p, const int k);
 static int upload(nbls_ctx* ctx, ProgId id) {
   DevProgram& d = ctx->prog[id];
   if (d.p) return NBLS_OK;
-  const Program& p = get_program(id);
+  return upload_program(ctx, d, get_program(id), aot_enabled() ? nbls_aot_index((int)id) : -1);
+}
+// k: index of the ahead-of-time kernel that serves the program, or -1
+static int upload_program(nbls_ctx* ctx, DevProgram& d, const Program& p, const int k) {
   if (checked_mode()) { const std::string e = verify_program(p); if (!e.empty()) { fprintf(stderr, "nbls (checked): %s\n", e.c_str()); return NBLS_EINVAL; } }
   HIPCHK(hipMalloc(&d.steps, p.steps.size() * sizeof(Step)));
   HIPCHK(hipMalloc(&d.descs, p.descs.size() * 4 + 64));
@@ -114,7 +121,6 @@ static int upload(nbls_ctx* ctx, ProgId id) {
   HIPCHK(hipMemcpy(d.descs, p.descs.data(), p.descs.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d.consts, p.consts.data(), p.consts.size() * 4, hipMemcpyHostToDevice));
   // ahead-of-time kernel (aot.h): translate the program; one whose signatures are not all in the kernel's table (build / environment mismatch) stays on the interpreter
-  const int k = aot_enabled() ? nbls_aot_index((int)id) : -1;
   if (k >= 0) {
     AotProgram ap;
     const std::string why = aot_translate(p, ap);
@@ -140,9 +146,13 @@ static void aot_seg(AotSeg& g, const DevProgram& d, const IOBuf* bufs) {
   g.nsteps = (u32)d.p->steps.size(); g.nconst = d.p->nconst; g.inst_bytes = d.p->inst_bytes(); g.slot_bytes = d.p->slot_bytes; g.shared_consts = d.p->shared_consts ? 1u : 0u;
   for (int k = 0; k < MAX_BUFS; k++) g.bufs[k] = bufs[k];
 }
+static int run_dev(nbls_ctx* ctx, const DevProgram& d, int id, size_t n, std::initializer_list<std::pair<int, std::pair<const void*, size_t>>> bufs, hipStream_t s, const uint32_t* n_dev, const uint32_t* item_index);
 static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pair<int, std::pair<const void*, size_t>>> bufs, hipStream_t s, const uint32_t* n_dev = nullptr, const uint32_t* item_index = nullptr) {
   int r = upload(ctx, id); if (r) return r;
-  const DevProgram& d = ctx->prog[id];
+  return run_dev(ctx, ctx->prog[id], (int)id, n, bufs, s, n_dev, item_index);
+}
+// id: the timing slot of the launch (a ProgId), or -1 for programs outside the registry (single tower operations)
+static int run_dev(nbls_ctx* ctx, const DevProgram& d, int id, size_t n, std::initializer_list<std::pair<int, std::pair<const void*, size_t>>> bufs, hipStream_t s, const uint32_t* n_dev, const uint32_t* item_index) {
   KernelArgs ka; memset(&ka, 0, sizeof ka);
   ka.steps = d.steps; ka.descs = d.descs; ka.consts = d.consts; ka.qp_table = ctx->qp_table;
   ka.nsteps = (u32)d.p->steps.size(); ka.nconst = d.p->nconst; ka.W = d.p->W; ka.G = d.p->G; ka.slot_bytes = d.p->slot_bytes; ka.inst_bytes = d.p->inst_bytes(); ka.shared_consts = d.p->shared_consts ? 1u : 0u; ka.lsplit = d.p->lsplit; ka.n_items = (u32)n; ka.n_items_dev = n_dev; ka.item_index = item_index;
@@ -175,7 +185,7 @@ static int run(nbls_ctx* ctx, ProgId id, size_t n, std::initializer_list<std::pa
     a.nseg = 1; a.W = ka.W; a.G = ka.G; a.n_items = ka.n_items; a.qp_table = ka.qp_table; a.item_index = ka.item_index; a.n_items_dev = ka.n_items_dev;
     e = nbls_aot_launch(d.aot, &a, d.aot_lds, s);
   } else e = nbls_vm_launch(&ka, d.p->lds_bytes(), s);
-  if (ctx->timing) { hipEventRecord(e1, s); ctx->tev.push_back({(int)id, {e0, e1}}); }
+  if (ctx->timing) { hipEventRecord(e1, s); if (id >= 0) ctx->tev.push_back({id, {e0, e1}}); else { ctx->ev_pool.push_back(e0); ctx->ev_pool.push_back(e1); } }
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
   return NBLS_OK;
 }
@@ -444,6 +454,7 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
 EXPORT void nbls_destroy(nbls_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
+  for (auto& kv : ctx->tower) { DevProgram& d = kv.second; if (d.steps) hipFree(d.steps); if (d.descs) hipFree(d.descs); if (d.consts) hipFree(d.consts); }
   for (auto& d : ctx->prog) { if (d.steps) hipFree(d.steps); if (d.descs) hipFree(d.descs); if (d.consts) hipFree(d.consts); if (d.aot_steps) hipFree(d.aot_steps); if (d.aot_descs) hipFree(d.aot_descs); }
   for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->gen_g1, ctx->side_scratch, ctx->L, ctx->partial, ctx->unit_lines, ctx->KS, ctx->KD, ctx->Kflag, (uint8_t*)ctx->Klist, (uint8_t*)ctx->Kcount}) if (p) hipFree(p);
   for (uint8_t* p : ctx->T) if (p) hipFree(p);
@@ -673,6 +684,49 @@ EXPORT int nbls_final_exp_batch(nbls_ctx* ctx, size_t n, const uint8_t* in, uint
   std::lock_guard<std::recursive_mutex> g(ctx->mu);
   HIPCHK(hipMemcpyAsync(out, d_out, n * 576, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  return NBLS_OK;
+}
+
+// One tower operation on n elements (include/nbls.h): wire bytes in and out, everything on the device.  Inversions are two programs around the inversion kernel.
+EXPORT int nbls_tower_op_batch(nbls_ctx* ctx, int field, int op, int param, size_t n, const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d, uint8_t* out) {
+  std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);
+  if (!ctx || (n && (!a || !out))) return NBLS_EINVAL;
+  const Program* p0 = get_tower_program(field, op, param, 0);
+  if (!p0) return NBLS_EINVAL;
+  if (n == 0) return NBLS_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  StreamOrder order_(ctx, s);
+  const size_t esz = 48 * (size_t)field;
+  // operand sizes: b is a full element for the binary operations, an Fp2 for the sparse products; c, d are Fp2
+  const bool sparse = op == 10 || op == 11 || op == 12;
+  const size_t bsz = b ? (sparse ? 96 : esz) : 0, csz = c ? 96 : 0, dsz = d ? 96 : 0;
+  if ((p0->buf_extent[1] && !b) || (p0->buf_extent[2] && !c) || (p0->buf_extent[3] && !d)) return NBLS_EINVAL;
+  int r;
+  if ((r = ensure_scratch(ctx, n))) return r;
+  const size_t need = n * (2 * esz + bsz + csz + dsz);
+  uint8_t* io = nullptr;
+  HIPCHK(hipMalloc(&io, need));
+  uint8_t *da = io, *db = da + n * esz, *dc = db + n * bsz, *dd = dc + n * csz, *dout = dd + n * dsz;
+  auto fail = [&](int code) { hipFree(io); return code; };
+  if (hipMemcpyAsync(da, a, n * esz, hipMemcpyHostToDevice, s) != hipSuccess) return fail(NBLS_EHIP);
+  if (b && hipMemcpyAsync(db, b, n * bsz, hipMemcpyHostToDevice, s) != hipSuccess) return fail(NBLS_EHIP);
+  if (c && hipMemcpyAsync(dc, c, n * csz, hipMemcpyHostToDevice, s) != hipSuccess) return fail(NBLS_EHIP);
+  if (d && hipMemcpyAsync(dd, d, n * dsz, hipMemcpyHostToDevice, s) != hipSuccess) return fail(NBLS_EHIP);
+  auto launch = [&](int part) -> int {
+    const Program* p = get_tower_program(field, op, param, part);
+    if (!p) return NBLS_EINVAL;
+    DevProgram& dp = ctx->tower[std::make_tuple(field, op, param, part)];
+    if (!dp.p) { const int e = upload_program(ctx, dp, *p, -1); if (e) return e; }
+    return run_dev(ctx, dp, -1, n, {B(0, da, esz), B(1, db, bsz), B(2, dc, csz), B(3, dd, dsz), B(4, ctx->N, RAW), B(5, ctx->NI, RAW), B(7, dout, esz)}, s, nullptr, nullptr);
+  };
+  if ((r = launch(0))) return fail(r);
+  if (op == 5) {   // NBLS_TOP_INV
+    if ((r = run_inv(ctx, n, s))) return fail(r);
+    if ((r = launch(1))) return fail(r);
+  }
+  if (hipMemcpyAsync(out, dout, n * esz, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return fail(NBLS_EHIP);
+  hipFree(io);
   return NBLS_OK;
 }
 

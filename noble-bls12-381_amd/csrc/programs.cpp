@@ -654,6 +654,134 @@ static Program build(ProgId id) {
   return Program();
 }
 
+
+// ---------------------------------------------------------------- single tower operations (nbls_tower_op_batch)
+// op codes = include/nbls.h NBLS_TOP_*
+namespace {
+enum { T_ADD = 0, T_SUB, T_NEG, T_MUL, T_SQR, T_INV, T_FROB, T_CONJ, T_MULNR, T_MUL_BY_B, T_MUL_BY_1, T_MUL_BY_01, T_MUL_BY_014, T_CYC_SQR, T_CYC_EXP, T_COUNT };
+SFp6 in_fp6(int buf, int off) { return {input_fp2(buf, off), input_fp2(buf, off + 96), input_fp2(buf, off + 192)}; }
+void out_fp6(const SFp6& a, int buf, int off) { output_fp2(a.c0, buf, off); output_fp2(a.c1, buf, off + 96); output_fp2(a.c2, buf, off + 192); }
+// inverses: Fp2.invert math.ts:522-526, Fp6.invert 672-680, Fp12.invert 793-797 -- everything around the one Fp inversion (the inversion kernel)
+struct Inv6 { SFp2 T0, T1, T2, d; };
+Inv6 inv6_chain(const SFp6& t) {
+  Inv6 c;
+  c.T0 = mat(sqr(t.c0) - mulnr(mul(t.c2, t.c1)));
+  c.T1 = mat(mulnr(sqr(t.c2)) - mul(t.c0, t.c1));
+  c.T2 = mat(sqr(t.c1) - mul(t.c0, t.c2));
+  c.d = mat(mulnr(mul(t.c2, c.T1) + mul(t.c1, c.T2)) + mul(t.c0, c.T0));
+  return c;
+}
+SFp6 inv6_finish(const Inv6& c, const SFp& ninv) {
+  SFp2 dinv = {mul(c.d.c0, ninv), -mul(c.d.c1, ninv)};
+  return {mul(dinv, c.T0), mul(dinv, c.T1), mul(dinv, c.T2)};
+}
+Program build_tower(int field, int op, int param, int part) {
+  Builder B;
+  char name[64]; snprintf(name, sizeof name, "tower_f%d_op%d_%d_%d", field, op, param, part);
+  const int W = field == 12 ? 12 : field == 6 ? 6 : field == 2 ? 2 : 1;
+  if (field == 1) {
+    SFp a = input(0, 0);
+    if (op == T_INV) { if (part == 0) outputw(a, 4, 0); else output(inputw(5, 0), 7, 0); return B.compile(name, 4); }
+    SFp r;
+    switch (op) {
+      case T_ADD: r = a + input(1, 0); break;
+      case T_SUB: r = a - input(1, 0); break;
+      case T_NEG: r = -a; break;
+      case T_MUL: r = mul(a, input(1, 0)); break;
+      case T_SQR: r = sqr(a); break;
+      default: return Program();
+    }
+    output(r, 7, 0);
+    return B.compile(name, 4);
+  }
+  if (field == 2) {
+    SFp2 a = input_fp2(0, 0);
+    if (op == T_INV) {
+      if (part == 0) outputw(sqr(a.c0) + sqr(a.c1), 4, 0);
+      else { SFp ni = inputw(5, 0); output_fp2({mul(a.c0, ni), -mul(a.c1, ni)}, 7, 0); }
+      return B.compile(name, 4);
+    }
+    SFp2 r;
+    switch (op) {
+      case T_ADD: r = a + input_fp2(1, 0); break;
+      case T_SUB: r = a - input_fp2(1, 0); break;
+      case T_NEG: r = -a; break;
+      case T_MUL: r = mul(a, input_fp2(1, 0)); break;
+      case T_SQR: r = sqr(a); break;
+      case T_FROB: r = frob(a, param); break;
+      case T_CONJ: r = conj(a); break;
+      case T_MULNR: r = mulnr(a); break;
+      case T_MUL_BY_B: r = mul_by_b(a); break;
+      default: return Program();
+    }
+    output_fp2(r, 7, 0);
+    return B.compile(name, 4);
+  }
+  if (field == 6) {
+    SFp6 a = in_fp6(0, 0);
+    if (op == T_INV) {
+      Inv6 c = inv6_chain(a);
+      if (part == 0) outputw(sqr(c.d.c0) + sqr(c.d.c1), 4, 0);
+      else out_fp6(inv6_finish(c, inputw(5, 0)), 7, 0);
+      return B.compile(name, 8);
+    }
+    SFp6 r;
+    switch (op) {
+      case T_ADD: r = a + in_fp6(1, 0); break;
+      case T_SUB: r = a - in_fp6(1, 0); break;
+      case T_NEG: r = -a; break;
+      case T_MUL: r = mul(a, in_fp6(1, 0)); break;
+      case T_SQR: r = sqr(a); break;
+      case T_FROB: r = frob(a, param); break;
+      case T_MULNR: r = mulnr(a); break;
+      case T_MUL_BY_1: r = mul_by_1(a, input_fp2(1, 0)); break;
+      case T_MUL_BY_01: r = mul_by_01(a, input_fp2(1, 0), input_fp2(2, 0)); break;
+      default: return Program();
+    }
+    out_fp6(r, 7, 0);
+    return B.compile(name, 8);
+  }
+  if (field == 12) {
+    SFp12 a = mat(input_fp12(0, 0));
+    if (op == T_INV) {
+      InvChain c = inv_chain(a);
+      if (part == 0) outputw(c.n, 4, 0);
+      else output_fp12(inv_finish(a, c, inputw(5, 0)), 7, 0);
+      return B.compile(name, 16);
+    }
+    SFp12 r;
+    switch (op) {
+      case T_ADD: { SFp12 b = input_fp12(1, 0); r = {a.c0 + b.c0, a.c1 + b.c1}; break; }
+      case T_SUB: { SFp12 b = input_fp12(1, 0); r = {a.c0 - b.c0, a.c1 - b.c1}; break; }
+      case T_NEG: r = {-a.c0, -a.c1}; break;
+      case T_MUL: r = mul(a, mat(input_fp12(1, 0))); break;
+      case T_SQR: r = sqr(a); break;
+      case T_FROB: r = frob(a, param); break;
+      case T_CONJ: r = conj(a); break;
+      case T_MUL_BY_014: r = mul_by_014(a, input_fp2(1, 0), input_fp2(2, 0), input_fp2(3, 0)); break;
+      case T_CYC_SQR: r = cyclotomic_sqr(a); break;
+      case T_CYC_EXP: r = cyclotomic_exp_x(a); break;
+      default: return Program();
+    }
+    output_fp12(r, 7, 0);
+    return B.compile(name, op == T_CYC_EXP ? 12 : 16);
+  }
+  (void)W;
+  return Program();
+}
+}  // namespace
+const Program* get_tower_program(int field, int op, int param, int part) {
+  static std::map<std::tuple<int, int, int, int>, Program> cache;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> g(mu);
+  if (!(field == 1 || field == 2 || field == 6 || field == 12) || op < 0 || op >= T_COUNT || part < 0 || part > 1 || (part == 1 && op != T_INV)) return nullptr;
+  if (op != T_FROB) param = 0; else if (param < 0 || param > 11) return nullptr;
+  auto key = std::make_tuple(field, op, param, part);
+  auto it = cache.find(key);
+  if (it == cache.end()) it = cache.emplace(key, build_tower(field, op, param, part)).first;
+  return it->second.steps.empty() ? nullptr : &it->second;
+}
+
 const Program& get_program(ProgId id) {
   static Program cache[P_COUNT];
   static bool built[P_COUNT];

@@ -78,5 +78,10 @@ static const int N_LINES = 68;                 // 63 doubling steps + 5 addition
 static const int LINE_ELEMS = 6 * N_LINES;     // raw field elements per line table
 static const int MSM_WINDOW_BITS = 12;
 const Program& get_program(ProgId id);
+// Single tower operations as step programs (nbls_tower_op_batch, include/nbls.h: KATs of math.ts:223-273, 451-539, 601-688, 732-852 on the device), built on first use.
+// field 1 / 2 / 6 / 12; op = NBLS_TOP_* ; part 0 = the operation (or the first half of an inversion: x -> element to invert), 1 = the second half of an inversion.
+// Buffers: 0 a, 1 b, 2 c, 3 d (wire bytes, 48 * field each; b / c / d of a sparse product are Fp2), 7 out; inversions: 4 the Fp element to invert (raw), 5 its inverse (raw).
+// Returns nullptr for a combination the reference does not have.
+const Program* get_tower_program(int field, int op, int param, int part);
 void print_stats(const Program& p);
 }  // namespace nbls

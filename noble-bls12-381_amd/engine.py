@@ -369,6 +369,15 @@ class Engine:
     def timing_enable(self, on=True):
         self._chk(self.lib.nbls_timing_enable(self.h, int(on)))
 
+    def tower_op(self, field, op, a, b=None, c=None, d=None, param=0):
+        """one tower operation (include/nbls.h NBLS_TOP_*) on len(a) / (48 * field) elements given as wire bytes -> wire bytes"""
+        esz = 48 * field
+        n = len(a) // esz
+        out = C.create_string_buffer(n * esz)
+        args = [C.c_char_p(x) if x is not None else None for x in (a, b, c, d)]
+        self._chk(self.lib.nbls_tower_op_batch(self.h, C.c_int(field), C.c_int(op), C.c_int(param), C.c_size_t(n), args[0], args[1], args[2], args[3], out))
+        return out.raw
+
     def timing_read(self):
         """-> {kernel name: (total ms, launches)} since timing_enable(True)"""
         n = len(PROGRAMS) + 1
