@@ -407,12 +407,26 @@ async function signBatch(messages, privateKeys) {
   const msgs = messages.map(ensureBytes);
   const offs = new Uint32Array(msgs.length + 1);
   msgs.forEach((m, i) => { offs[i + 1] = offs[i] + m.length; });
-  const { out } = native.signBatch(concat(...msgs), offs, stringToBytes(htfDefaults.DST), concat(...privateKeys.map(keyBytes)));
+  const { out } = await native.signBatchAsync(concat(...msgs), offs, stringToBytes(htfDefaults.DST), concat(...privateKeys.map(keyBytes)));   // worker thread: the event loop keeps running
   return msgs.map((_, i) => new PointG2(out.slice(192 * i, 192 * i + 192)).toSignature());
 }
 
-// reference index.ts:756-767: e(-P, H(m)) * e(G, S) == 1 with one final exponentiation
+// reference index.ts:756-767: e(-P, H(m)) * e(G, S) == 1 with one final exponentiation.
+// Wire-format inputs (96-byte signature, 48-byte key, message bytes: what a caller of the reference normally passes) take ONE engine call on a worker thread
+// (nbls_verify_batch with n = 1: key decode + subgroup check, hash-to-G2 and signature decode overlap on three streams, then two Miller loops and one final
+// exponentiation) and leave the event loop free; anything else -- point objects, other encodings, and every input the fast path rejects -- goes through the
+// step-by-step form below, which raises the reference's exceptions.
 async function verify(signature, message, publicKey) {
+  ensureInit();
+  if (!(signature instanceof PointG2) && !(message instanceof PointG2) && !(publicKey instanceof PointG1)) {
+    let sig, msg, pk;
+    try { sig = ensureBytes(signature); msg = ensureBytes(message); pk = ensureBytes(publicKey); } catch (e) { sig = null; }
+    // the infinity flag (bit 6 of the first byte) is left to the slow path: the reference throws 'No pairings at point of Infinity' where verifyBatch's engine call answers false
+    if (sig && sig.length === 96 && pk.length === 48 && !(sig[0] & 0x40) && !(pk[0] & 0x40)) {
+      const r = await native.verifyBatchAsync(sig, msg, Uint32Array.of(0, msg.length), pk, stringToBytes(htfDefaults.DST));
+      if (!r.code) return r.ok;
+    }
+  }
   const P = normP1(publicKey);
   const Hm = await normP2Hash(message);
   const S = normP2(signature);

@@ -246,6 +246,42 @@ static napi_value VerifyBatchAsync(napi_env env, napi_callback_info info) {
   return promise;
 }
 
+
+/* signBatchAsync(msgs, offsets, dst, keys32) -> Promise<{out: n*192 affine signature points, status}>: nbls_sign_batch on a libuv worker thread (the reference's
+ * sign is async, index.ts:744-752).  The output arrays are created here, on the main thread, and kept alive by references like the inputs. */
+typedef struct {
+  napi_async_work work; napi_deferred deferred; napi_ref refs[6];
+  const uint8_t *msgs, *dst, *keys; const uint32_t* offs; size_t n, dst_len; uint8_t *out; int8_t* st;
+  nbls_ctx* c; int rc;
+} sign_job;
+static void sign_execute(napi_env env, void* data) { sign_job* j = (sign_job*)data; (void)env;
+  j->rc = p_nbls_sign_batch(j->c, j->n, j->msgs, j->offs, j->dst, j->dst_len, j->keys, j->out, j->st); }
+static void sign_complete(napi_env env, napi_status status, void* data) {
+  sign_job* j = (sign_job*)data;
+  if (status != napi_ok || j->rc) {
+    char m[128]; snprintf(m, sizeof m, "nbls: %s (code %d)", p_nbls_strerror ? p_nbls_strerror(j->rc) : "error", j->rc);
+    napi_value msg, err; napi_create_string_utf8(env, m, NAPI_AUTO_LENGTH, &msg); napi_create_error(env, NULL, msg, &err); napi_reject_deferred(env, j->deferred, err);
+  } else {
+    napi_value vo, vs; napi_get_reference_value(env, j->refs[4], &vo); napi_get_reference_value(env, j->refs[5], &vs);
+    napi_resolve_deferred(env, j->deferred, result2(env, vo, vs));
+  }
+  for (int i = 0; i < 6; i++) napi_delete_reference(env, j->refs[i]);
+  napi_delete_async_work(env, j->work); free(j);
+}
+static napi_value SignBatchAsync(napi_env env, napi_callback_info info) {
+  ARGS(4); NEED_CTX(); BYTES(0, msgs, lm); BYTES(1, offs, lo); BYTES(2, dst, ld); BYTES(3, keys, lk); (void)lm;
+  COUNT_FROM_OFFSETS(n, lo); if (lk != n * 32) { napi_throw_range_error(env, NULL, "bad key array length"); return NULL; }
+  sign_job* j = (sign_job*)calloc(1, sizeof *j); if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+  uint8_t *out, *st; napi_value vo = new_u8(env, n * 192, &out), vs = new_u8(env, n, &st);
+  j->msgs = msgs; j->offs = (const uint32_t*)offs; j->dst = dst; j->dst_len = ld; j->keys = keys; j->n = n; j->out = out; j->st = (int8_t*)st; j->c = pool_take();
+  for (int i = 0; i < 4; i++) napi_create_reference(env, argv[i], 1, &j->refs[i]);
+  napi_create_reference(env, vo, 1, &j->refs[4]); napi_create_reference(env, vs, 1, &j->refs[5]);
+  napi_value promise, name; napi_create_promise(env, &j->deferred, &promise); napi_create_string_utf8(env, "nbls_sign_batch", NAPI_AUTO_LENGTH, &name);
+  if (napi_create_async_work(env, NULL, name, sign_execute, sign_complete, j, &j->work) != napi_ok || napi_queue_async_work(env, j->work) != napi_ok) {
+    for (int i = 0; i < 6; i++) napi_delete_reference(env, j->refs[i]); free(j); napi_throw_error(env, NULL, "napi_create_async_work failed"); return NULL; }
+  return promise;
+}
+
 static napi_value ModuleInit(napi_env env, napi_value exports) {
   const char* path = getenv("NBLS_LIB");
   char buf[4096];
@@ -264,7 +300,7 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
     {"g1Validate", 0, G1Validate, 0, 0, 0, napi_enumerable, 0}, {"g2Validate", 0, G2Validate, 0, 0, 0, napi_enumerable, 0}, {"g1Sum", 0, G1Sum, 0, 0, 0, napi_enumerable, 0},
     {"g2Sum", 0, G2Sum, 0, 0, 0, napi_enumerable, 0}, {"hashToG2", 0, HashToG2, 0, 0, 0, napi_enumerable, 0}, {"verifyBatch", 0, VerifyBatch, 0, 0, 0, napi_enumerable, 0},
     {"g1Mul", 0, G1Mul, 0, 0, 0, napi_enumerable, 0}, {"g2Mul", 0, G2Mul, 0, 0, 0, napi_enumerable, 0}, {"signBatch", 0, SignBatch, 0, 0, 0, napi_enumerable, 0},
-    {"hashToCurve", 0, HashToCurve, 0, 0, 0, napi_enumerable, 0}, {"g1Msm", 0, G1Msm, 0, 0, 0, napi_enumerable, 0}, {"g2Msm", 0, G2Msm, 0, 0, 0, napi_enumerable, 0}, {"verifyBatchAsync", 0, VerifyBatchAsync, 0, 0, 0, napi_enumerable, 0},
+    {"hashToCurve", 0, HashToCurve, 0, 0, 0, napi_enumerable, 0}, {"g1Msm", 0, G1Msm, 0, 0, 0, napi_enumerable, 0}, {"g2Msm", 0, G2Msm, 0, 0, 0, napi_enumerable, 0}, {"verifyBatchAsync", 0, VerifyBatchAsync, 0, 0, 0, napi_enumerable, 0}, {"signBatchAsync", 0, SignBatchAsync, 0, 0, 0, napi_enumerable, 0},
     {"initMulti", 0, InitMulti, 0, 0, 0, napi_enumerable, 0}, {"g2Prepare", 0, G2Prepare, 0, 0, 0, napi_enumerable, 0}, {"pairingPrepared", 0, PairingPrepared, 0, 0, 0, napi_enumerable, 0},
     {"decodePoints", 0, DecodePoints, 0, 0, 0, napi_enumerable, 0}, {"clearCofactor", 0, ClearCofactor, 0, 0, 0, napi_enumerable, 0}};
   napi_define_properties(env, exports, sizeof d / sizeof d[0], d);

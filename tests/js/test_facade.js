@@ -237,5 +237,34 @@ const hex = bls.utils.bytesToHex, un = bls.utils.hexToBytes;
   const many = await Promise.all([bls.verifyBatch(vb.agg_sig, vb.msgs, vb.pks), bls.verifyBatch(vb.agg_sig, m2, vb.pks), bls.verifyBatch(vb.agg_sig, vb.msgs, p2),
     bls.verifyBatch(vb.agg_sig, vb.msgs, vb.pks), bls.verifyBatch(vb.agg_sig, vb.msgs, vb.pks), bls.verifyBatch(vb.agg_sig, m2, vb.pks)]);
   assert.deepStrictEqual(many, [true, false, false, true, true, false]);
+  // verify / sign of wire-format inputs run on a worker thread (reference: both are async, index.ts:744-767): the event loop keeps turning while the GPU works,
+  // exceptions are the reference's, and the wall time of one call from JavaScript is reported (what a user of the facade gets; bench.py records the same figures)
+  {
+    const s0 = gold.sigs[0];
+    let ticks = 0, live = true;
+    const spin = () => { if (live) { ticks++; setImmediate(spin); } };
+    setImmediate(spin);
+    const t0 = process.hrtime.bigint();
+    const N = 20;
+    for (let i = 0; i < N; i++) assert.strictEqual(await bls.verify(s0.sig, s0.msg, s0.pk), true);
+    const t1 = process.hrtime.bigint();
+    const ticksVerify = ticks;
+    const keys = gold.sigs.slice(0, 4);
+    const sigs = [];
+    for (const v of keys) sigs.push(hex(await bls.sign(v.msg, v.sk)));
+    const t2 = process.hrtime.bigint();
+    live = false;
+    assert.deepStrictEqual(sigs, keys.map((v) => v.sig));
+    assert.ok(ticksVerify >= N, 'the event loop did not run during verify(): ' + ticksVerify + ' turns in ' + N + ' calls');
+    assert.ok(ticks > ticksVerify, 'the event loop did not run during sign()');
+    console.log('facade timing: verify %s ms per call (event-loop turns meanwhile: %d), sign %s ms per call', (Number(t1 - t0) / 1e6 / N).toFixed(3), ticksVerify, (Number(t2 - t1) / 1e6 / keys.length).toFixed(3));
+    // the fast path must raise what the reference raises: an undecodable key, a key off the subgroup, the point at infinity
+    const bad = vb.pks[0].slice(0, 2) + 'ff' + vb.pks[0].slice(4);
+    await assert.rejects(() => bls.verify(s0.sig, s0.msg, bad), (e) => e instanceof Error);
+    const inf1 = 'c0' + '00'.repeat(47), inf2 = 'c0' + '00'.repeat(95);
+    await assert.rejects(() => bls.verify(s0.sig, s0.msg, inf1), /No pairings at point of Infinity/);
+    await assert.rejects(() => bls.verify(inf2, s0.msg, s0.pk), /No pairings at point of Infinity/);
+    assert.strictEqual(await bls.verify(s0.sig, s0.msg, gold.sigs[1].pk), false);
+  }
   console.log('JS facade ok');
 })().catch((e) => { console.error(e); process.exit(1); });
