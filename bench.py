@@ -60,7 +60,7 @@ def main():
     ap.add_argument('--steps', type=int, default=512, help='timed steps (default: about one second of GPU time)')
     ap.add_argument('--warmup', type=int, default=16)
     ap.add_argument('--batch', type=int, default=BATCH)
-    ap.add_argument('--inflight', type=int, default=12, help='batches kept in flight on separate HIP streams during the timed steps (1 = strictly one batch at a time)')
+    ap.add_argument('--inflight', type=int, default=None, help='batches kept in flight on separate HIP streams during the timed steps (1 = strictly one batch at a time)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-dist', action='store_true', help='run the torch.distributed / RCCL code paths (process group, barriers, all-gathers, sharded legs) even with one rank: the only way to execute them on a one-GPU box')
     ap.add_argument('--verify-batch', type=int, default=65536, help='signatures in the verifyBatch leg (BASELINE configs[2]); 0 disables')
@@ -126,8 +126,8 @@ def main():
     pkg = importlib.import_module('noble-bls12-381_amd')
     import oracle_py
     oracle = oracle_py.load(rebuild=not os.path.exists(os.path.join(ROOT, 'oracle', 'libnbls_oracle.so')))
-    D = max(1, args.inflight)
-    if args.steps < 4 * D and D > 8:
+    D = max(1, args.inflight if args.inflight is not None else 12)
+    if args.inflight is None and args.steps < 4 * D and D > 8:   # an explicit --inflight is taken as given
         # few timed steps (the driver's --steps 20): every stream should carry the same number of batches, or the streams with one batch more
         # finish alone -- take the depth in 8..D that leaves the smallest remainder (20 steps: 10 streams x 2 batches; measured 2.49 M/s against 2.47 M/s at 12)
         D = min(range(8, D + 1), key=lambda d: ((-args.steps) % d, -d))
@@ -180,7 +180,7 @@ def main():
         dt = float(t.item())
     # strictly serial figure (one batch at a time on one stream) = per-batch latency, this rank
     torch.cuda.synchronize()
-    eng.set_split_miller_min(49152)     # the single-call legs use the library's default (latency-oriented) choice of Miller programs (SPLIT_MILLER_MIN in csrc/nbls_api.cpp)
+    eng.set_split_miller_min(4096)      # the single-call legs use the library's default choice of Miller programs (SPLIT_MILLER_MIN in csrc/nbls_api.cpp; the in-flight contexts were set to 0)
     serial_steps = max(8, min(args.steps, 320))
     s0 = time.perf_counter()
     for _ in range(serial_steps):
@@ -234,6 +234,8 @@ def main():
                        'ms_per_product': round(pdt / preps * 1e3, 3), 'exchange': 'all-gather of %d x 576 B Fp12 partials' % world if world > 1 else 'none (1 rank)', 'result_is_one': True}
             del t1, t2
     except Exception as e:   # noqa: BLE001
+        if multi:
+            raise     # the leg contains collectives: a rank that skipped them would leave its peers waiting; with several ranks the job fails as a whole
         product = {'error': repr(e)}
 
     # ---- secondary leg (N > 1): verifyBatch of --verify-batch signatures with the (key, message) pairs sharded over the ranks
@@ -284,11 +286,14 @@ def main():
                       'note': 'distinct 32-byte messages, 48-byte keys, one 96-byte aggregate signature; (key, message) pairs sharded over %d rank(s): decompress + hash-to-G2 + Miller product per rank, all-gather of 576 B Fp12 partials, shared final exponentiation; inputs (incl. expand_message_xmd output) resident in HBM' % world}
             del d_uni, d_pk
     except Exception as e:   # noqa: BLE001
+        if multi:
+            raise     # see the product leg: collectives inside
         vshard = {'error': repr(e)}
 
     # ---- roofline leg: per-kernel HIP-event durations of the same step (separate untimed passes)
     roof = None
     cpu = None
+    facade = None
     if rank == 0:
         eng.timing_enable(True)
         reps = 5
@@ -318,7 +323,7 @@ def main():
         except OSError:
             pass
         roof = {
-            'bound': 'valu-int32-mad', 'kernel': 'nbls_vm_kernel (all step programs of one pairing batch)',
+            'bound': 'valu-int32-mad', 'kernel': 'nbls_aot_* (the ahead-of-time kernels of the step programs of one pairing batch: lines_pq / acc_fe or miller_fe, fe_easy, expx chain, fe_final) + nbls_fp_inv_kernel',
             'achieved': round(achieved, 4), 'peak': round(PEAK_TMAD, 3), 'unit': 'TMAD32/s', 'frac': round(achieved / PEAK_TMAD, 4),
             'traffic': traffic, 'traffic_source': 'profiles/hbm_traffic.json (rocprofv3 PMC passes of this batch size, FETCH_SIZE x 2 + WRITE_SIZE; a committed measurement, not taken in this run)' if traffic is not None else None,
             'valu_issue_busy': valu_busy,    # SQ_INSTS_VALU x 4 clocks / (kernel time x 2.4 GHz x 1024 SIMDs) from the PMC pass in profiles/ (same batch size, one batch at a time)
@@ -402,16 +407,40 @@ def main():
             try:
                 import shutil, subprocess
                 if shutil.which('node'):
-                    jr = json.loads(subprocess.run(['node', os.path.join(ROOT, 'oracle', 'js_bigint_pairing.js'), '5'], capture_output=True, text=True, timeout=120).stdout.strip().splitlines()[-1])
+                    js = os.path.join(ROOT, 'oracle', 'js_bigint_pairing.js')
+                    jr = json.loads(subprocess.run(['node', js, '5'], capture_output=True, text=True, timeout=120).stdout.strip().splitlines()[-1])
+                    # the same on every host core at once: N single-threaded processes (the reference is single-threaded; a user with N cores runs N of them)
+                    procs = [subprocess.Popen(['node', js, '5'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(cores)]
+                    outs = [p.communicate(timeout=300)[0] for p in procs]
+                    rs = [json.loads(o.strip().splitlines()[-1]) for o in outs if o.strip()]
+                    try:
+                        ratio = json.load(open(os.path.join(ROOT, 'profiles', 'reference_ratio.json')))
+                    except Exception:   # noqa: BLE001
+                        ratio = None
+                    rr = ratio['ratio'] if ratio else None
                     jsb = {'value': jr['pairings_per_s'], 'unit': 'pairings/s', 'cores': 1, 'kind': 'port', 'language': 'JavaScript BigInt (node %s)' % jr['node'], 'sample': '%d pairings in %.1f s, single thread' % (jr['pairings'], jr['seconds']),
-                           'checked_against_reference_vector': bool(jr['ok']), 'ratio_to_reference': 1.18,
-                           'reference_estimate': round(jr['pairings_per_s'] / 1.18, 2), 'note': 'the reference algorithm over the facade\'s BigInt field classes; ratio_to_reference = this code / the real reference under the same Node in the build container (BASELINE.md section 4)'}
+                           'checked_against_reference_vector': bool(jr['ok']),
+                           'all_cores': {'value': round(sum(r['pairings_per_s'] for r in rs), 2), 'unit': 'pairings/s', 'cores': len(rs), 'sample': '%d single-threaded processes side by side, %d pairings in %.1f s each on average' % (len(rs), sum(r['pairings'] for r in rs) // max(1, len(rs)), sum(r['seconds'] for r in rs) / max(1, len(rs))),
+                                         'all_checked': all(r['ok'] for r in rs)},
+                           'ratio_to_reference': rr, 'ratio_source': 'profiles/reference_ratio.json (tools/measure_reference_ratio.py in the build container, %s): this code / the real reference under the same Node' % (ratio['date'] if ratio else 'missing'),
+                           'reference_estimate': {'one_core': round(jr['pairings_per_s'] / rr, 2), 'all_cores': round(sum(r['pairings_per_s'] for r in rs) / rr, 2), 'note': 'derived: measured here / committed ratio; the reference itself cannot travel to this box'} if rr else None,
+                           'note': 'the reference algorithm over the facade\'s BigInt field classes (oracle/js_bigint_pairing.js)'}
             except Exception as e:   # noqa: BLE001
                 jsb = {'error': repr(e)}
             cpu = {'value': round(sample / cdt, 2), 'unit': 'pairings/s', 'cores': threads, 'kind': 'port', 'js_bigint': jsb,
                    'sample': '%d pairings of the same workload on %d host threads (oracle/ C restatement; timed on %d and on %d threads, the faster is reported); 1 thread: %.1f pairings/s' % (sample, threads, all_threads, max(1, all_threads // 2), 64 / cdt1),
                    'host_cpu_count': cores,
                    'reference_figure': {'value': 38.6, 'unit': 'pairings/s per core', 'source': 'BASELINE.md section 2: the reference itself (noble-bls12-381 v1.4.0, TypeScript / bigint) under Node 12 in the build container; it does not travel to the GPU box, so the port above is what is timed here'}}
+        # the JS facade from JavaScript: await bls.verify(...) / await bls.sign(...) as a user of the reference would call them (tools/bench_facade.js)
+        facade = None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                import shutil, subprocess
+                addon = os.path.join(ROOT, 'noble-bls12-381_amd', 'js', 'nbls_napi.node')
+                if shutil.which('node') and os.path.exists(addon):
+                    facade = json.loads(subprocess.run(['node', os.path.join(ROOT, 'tools', 'bench_facade.js')], capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1])
+            except Exception as e:   # noqa: BLE001
+                facade = {'error': repr(e)}
         vbatch = None
         if world == 1 and args.verify_batch > 0:
             nv = args.verify_batch
@@ -419,7 +448,15 @@ def main():
             th = min(cores, 256)
             sks = [(int.from_bytes(hashlib.sha256(b'nbls-bench-sk' + i.to_bytes(4, 'big')).digest(), 'big') % (2 ** 254) + 1).to_bytes(32, 'big') for i in range(nv)]
             msgs = [hashlib.sha256(b'msg' + i.to_bytes(4, 'big')).digest() for i in range(nv)]
-            pks, sig = oracle.aggregate_sign(msgs, sks, threads=th)
+            # inputs made on the GPU (getPublicKey + sign ladders, point sum, compression: ~0.1 s instead of ~20 s of host threads), checked against the oracle on a sample:
+            # the keys and the first signatures must be the oracle's, and the aggregate over the sample must verify on the CPU
+            pks = eng.get_public_keys(sks)
+            aff, _ = eng.sign_batch_affine(msgs, sks)
+            sig = eng.compress_g2(eng.point_sum(aff, g2=True)[0])
+            ns_chk = min(nv, 32)
+            for i in range(0, ns_chk, 8):
+                assert pks[i] == oracle.get_public_key(sks[i]) and eng.compress_g2(aff[192 * i:192 * i + 192]) == oracle.sign(msgs[i], sks[i])[1], 'verifyBatch input check against the oracle failed'
+            assert oracle.verify_batch_mt(eng.compress_g2(eng.point_sum(aff[:192 * ns_chk], g2=True)[0]), msgs[:ns_chk], pks[:ns_chk], threads=min(th, 32)), 'verifyBatch sample does not verify on the CPU'
             assert eng.verify_batch(sig, msgs, pks) is True, 'verifyBatch parity (true case) failed'
             bad = list(msgs); bad[nv // 2] = bytes([bad[nv // 2][0] ^ 1]) + bad[nv // 2][1:]
             assert eng.verify_batch(sig, bad, pks) is False, 'verifyBatch parity (false case) failed'
@@ -428,16 +465,18 @@ def main():
             for _ in range(vreps):
                 eng.verify_batch(sig, msgs, pks)
             vdt = (time.perf_counter() - v0) / vreps
-            # inputs resident in HBM, SHA-256 expansion excluded (done once by the oracle, outside the timed region)
-            uni = b''.join(oracle.expand_message_xmd(m, oracle_py.DST_DEFAULT, 256) for m in msgs)
+            # everything resident in HBM: signature, message bytes + offsets, compressed keys; SHA-256 expand_message_xmd is part of the timed call
+            import numpy as np
             d_sig = torch.frombuffer(bytearray(sig), dtype=torch.uint8).cuda()
-            d_uni = torch.frombuffer(bytearray(uni), dtype=torch.uint8).cuda()
+            d_msg = torch.frombuffer(bytearray(b''.join(msgs)), dtype=torch.uint8).cuda()
+            d_off = torch.from_numpy(np.cumsum([0] + [len(m) for m in msgs], dtype=np.uint32).astype(np.int32)).cuda()
             d_pk = torch.frombuffer(bytearray(b''.join(pks)), dtype=torch.uint8).cuda()
-            assert eng.verify_batch_dev(nv, d_sig.data_ptr(), d_uni.data_ptr(), d_pk.data_ptr()) is True
+            vcall = lambda e: e.verify_batch_msgs_dev(nv, d_sig.data_ptr(), d_msg.data_ptr(), d_off.data_ptr(), d_pk.data_ptr())
+            assert vcall(eng) is True
             torch.cuda.synchronize()
             v1 = time.perf_counter()
             for _ in range(vreps):
-                eng.verify_batch_dev(nv, d_sig.data_ptr(), d_uni.data_ptr(), d_pk.data_ptr())
+                vcall(eng)
             vdt_dev = (time.perf_counter() - v1) / vreps
             # two calls in flight (two engine contexts, two host threads; ctypes drops the GIL inside the call): the single-item tail of one call (product
             # tree + one final exponentiation, ~2.3 ms of pure latency) runs under the bulk of the next -- the sustained rate of a service verifying batch after batch
@@ -445,11 +484,11 @@ def main():
             VF = max(2, args.verify_inflight)
             vengs = [eng] + [pipe.engines[i] if i < D else pkg.Engine(local_rank) for i in range(1, VF)]
             for e in vengs[1:]:
-                assert e.verify_batch_dev(nv, d_sig.data_ptr(), d_uni.data_ptr(), d_pk.data_ptr()) is True
+                assert vcall(e) is True
             preps = max(2, vreps)
             def _loop(e):
                 for _ in range(preps):
-                    e.verify_batch_dev(nv, d_sig.data_ptr(), d_uni.data_ptr(), d_pk.data_ptr())
+                    vcall(e)
             torch.cuda.synchronize()
             ths = [threading.Thread(target=_loop, args=(e,)) for e in vengs]
             p1 = time.perf_counter()
@@ -457,14 +496,14 @@ def main():
             for t in ths: t.join()
             vdt_pipe = (time.perf_counter() - p1) / (VF * preps)
             # latency of ONE verify (the reference's verify, index.ts:756-767: decode key and signature, hash the message, 2 Miller loops, 1 final exponentiation)
-            sig1 = oracle.sign(msgs[0], sks[0])[1]
+            sig1 = eng.compress_g2(aff[:192])
             assert eng.verify_batch(sig1, msgs[:1], pks[:1]) is True
             l0 = time.perf_counter()
             for _ in range(5):
                 eng.verify_batch(sig1, msgs[:1], pks[:1])
             single_ms = (time.perf_counter() - l0) / 5 * 1e3
             ns = min(nv, 2048)
-            sig_s = oracle.aggregate_sign(msgs[:ns], sks[:ns], threads=th)[1]
+            sig_s = eng.compress_g2(eng.point_sum(aff[:192 * ns], g2=True)[0])
             c0 = time.perf_counter()
             okc = oracle.verify_batch_mt(sig_s, msgs[:ns], pks[:ns], threads=min(th, 64))
             cdt = time.perf_counter() - c0
@@ -475,7 +514,7 @@ def main():
                       'roofline': {'bound': 'valu-int32-mad', 'achieved': round(v_ach, 4), 'peak': round(PEAK_TMAD, 3), 'unit': 'TMAD32/s', 'frac': round(v_ach / PEAK_TMAD, 4),
                                    'frac_executed': round(nv * FPMUL_VERIFY_EXEC * MAD_PER_FPMUL / vdt_dev / 1e12 / PEAK_TMAD, 4), 'fpmul_executed_algorithm': FPMUL_VERIFY_EXEC,
                                    'note': 'algorithmic work per signature %d Fp multiplications x %d MAD32 (SURVEY 8(d)) over the wall time of the call (all kernels of all three streams)' % (FPMUL_VERIFY, MAD_PER_FPMUL)},
-                      'note': 'distinct 32-byte messages, 48-byte keys, one 96-byte aggregate signature; decompress + hash-to-G2 + %d Miller loops + 1 final exp on the GPU; inputs (incl. expand_message_xmd output) resident in HBM' % (nv + 1),
+                      'note': 'distinct 32-byte messages, 48-byte keys, one 96-byte aggregate signature; SHA-256 expand_message_xmd + decompress + hash-to-G2 + %d Miller loops + 1 final exp on the GPU in the timed call; inputs (signature, message bytes, keys) resident in HBM' % (nv + 1),
                       'ms': round(vdt_dev * 1e3, 3),
                       'in_flight': {'calls_in_flight': VF, 'sigs_per_s': round(nv / vdt_pipe, 2), 'ms_per_call_amortised': round(vdt_pipe * 1e3, 3), 'roofline_frac': round(nv * FPMUL_VERIFY * MAD_PER_FPMUL / vdt_pipe / 1e12 / PEAK_TMAD, 4),
                                         'note': '%d verifyBatch calls of %d signatures overlapping (one context and host thread each): the latency-bound tail of one call runs under the bulk of the others; `value` / `ms` above are ONE call at a time' % (VF, nv)},
@@ -566,7 +605,7 @@ def main():
                             'note': 'one %d-pairing call at a time on one stream (this rank): the latency of a call; its roofline is the top-level `roofline` object' % n},
             'single_stream': {'pairings_per_s': round(n * args.steps / dt_serial, 2), 'ms_per_batch': round(dt_serial / args.steps * 1e3, 4), 'note': 'alias of single_call (round-1 name)'},
             'rccl_ranks': world if (multi and args.dist_backend == 'nccl') else None, 'dist_backend': args.dist_backend if multi else None,
-            'roofline': roof, 'cpu_baseline': cpu, 'product': product, 'verify_batch': vbatch if vbatch is not None else vshard, 'verify_batch_sharded': vshard if vbatch is not None else None, 'sign': sleg, 'aggregate': aleg, 'msm': mleg,
+            'roofline': roof, 'cpu_baseline': cpu, 'facade': facade, 'product': product, 'verify_batch': vbatch if vbatch is not None else vshard, 'verify_batch_sharded': vshard if vbatch is not None else None, 'sign': sleg, 'aggregate': aleg, 'msm': mleg,
         }
         out_line = json.dumps(line)
     else:

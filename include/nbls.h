@@ -184,6 +184,10 @@ int nbls_sign_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t
 int nbls_verify_batch(nbls_ctx* ctx, size_t n, const uint8_t* sig96, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
                       const uint8_t* dst, size_t dst_len, int* ok);
 /* Same, inputs already in HBM: signature, 256-byte expand_message_xmd outputs, compressed keys.  Synchronises (returns *ok). */
+/* Same with the MESSAGES resident in HBM (bytes + n + 1 uint32 offsets relative to d_msgs): expand_message_xmd runs on the device first, on the same stream
+ * (the whole of verifyBatch index.ts:792-821 for wire-format inputs with nothing done on the host).  dst_len <= 255. */
+int nbls_verify_batch_msgs_dev(nbls_ctx* ctx, size_t n, const void* d_sig96, const void* d_msgs, const void* d_offsets, const void* d_pk48, const uint8_t* dst, size_t dst_len,
+                               int* ok, void* stream);
 int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_sig96, const void* d_uniform256, const void* d_pk48, int* ok,
                                  int8_t* pk_status /* n, may be NULL */, void* stream);
 

@@ -54,6 +54,7 @@ struct nbls_ctx {
   hipStream_t stream = nullptr;
   std::recursive_mutex mu;   // held for the whole of every exported call (host-level calls re-enter it through the *_dev entry points)
   DevProgram prog[P_COUNT];
+  std::vector<uint8_t> dst_host; uint8_t* dst_dev = nullptr;   // hash-to-curve domain-separation tag last used by nbls_verify_batch_msgs_dev, and its device copy
   std::map<std::tuple<int, int, int, int>, DevProgram> tower;   // single tower operations (nbls_tower_op_batch), uploaded on first use
   // scratch (device)
   uint8_t *F = nullptr, *F2 = nullptr, *N = nullptr, *NI = nullptr, *io_g1 = nullptr, *io_g2 = nullptr, *io_f12 = nullptr, *one12 = nullptr;
@@ -454,6 +455,7 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
 EXPORT void nbls_destroy(nbls_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
+  if (ctx->dst_dev) hipFree(ctx->dst_dev);
   for (auto& kv : ctx->tower) { DevProgram& d = kv.second; if (d.steps) hipFree(d.steps); if (d.descs) hipFree(d.descs); if (d.consts) hipFree(d.consts); }
   for (auto& d : ctx->prog) { if (d.steps) hipFree(d.steps); if (d.descs) hipFree(d.descs); if (d.consts) hipFree(d.consts); if (d.aot_steps) hipFree(d.aot_steps); if (d.aot_descs) hipFree(d.aot_descs); }
   for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->gen_g1, ctx->side_scratch, ctx->L, ctx->partial, ctx->unit_lines, ctx->KS, ctx->KD, ctx->Kflag, (uint8_t*)ctx->Klist, (uint8_t*)ctx->Kcount}) if (p) hipFree(p);
@@ -1343,6 +1345,31 @@ EXPORT int nbls_verify_batch(nbls_ctx* ctx, size_t n, const uint8_t* sig96, cons
     d_sig = c + n * 48; d_uni = b; d_pk = c;
   }
   return nbls_verify_batch_dev_inputs(ctx, n, d_sig, d_uni, d_pk, ok, nullptr, nullptr);
+}
+// verifyBatch with EVERYTHING resident in HBM (bench.py's verifyBatch value): signature, the message bytes with their n + 1 offsets (uint32, relative to d_msgs),
+// compressed keys.  SHA-256 expand_message_xmd (index.ts:207-231) runs first, on the same stream, then the call continues as nbls_verify_batch_dev_inputs.
+EXPORT int nbls_verify_batch_msgs_dev(nbls_ctx* ctx, size_t n, const void* d_sig96, const void* d_msgs, const void* d_offsets, const void* d_pk48, const uint8_t* dst, size_t dst_len, int* ok, void* stream) {
+  std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);
+  if (!ctx || !ok || !n || !d_sig96 || !d_offsets || !d_pk48 || !dst || dst_len > 255) return NBLS_EINVAL;
+  uint8_t *dd, *du;
+  {
+    std::lock_guard<std::recursive_mutex> g_(ctx->mu); HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    StreamOrder order_(ctx, s);
+    int r;
+    if ((r = need(ctx, 8, n * 256, &du))) return r;
+    // the domain-separation tag is kept on the device between calls (a service verifies under one tag): no copy, no synchronisation in the steady state
+    if (!ctx->dst_dev) HIPCHK(hipMalloc(&ctx->dst_dev, 256));
+    if (ctx->dst_host.size() != dst_len || memcmp(ctx->dst_host.data(), dst, dst_len)) {
+      HIPCHK(hipStreamSynchronize(s));   // an earlier call may still read the old tag
+      HIPCHK(hipMemcpy(ctx->dst_dev, dst, dst_len, hipMemcpyHostToDevice));
+      ctx->dst_host.assign(dst, dst + dst_len);
+    }
+    dd = ctx->dst_dev;
+    const int e = nbls_xmd_launch((unsigned)n, (const uint8_t*)d_msgs, (const uint8_t*)d_offsets, dd, (unsigned)dst_len, du, 256, s);
+    if (e) { ctx->last_hip = e; return NBLS_EHIP; }
+  }
+  return nbls_verify_batch_dev_inputs(ctx, n, d_sig96, du, d_pk48, ok, nullptr, stream);
 }
 // Same with inputs resident in HBM: signature (96 B), expand_message_xmd outputs (256 B per message), public keys (48 B each).
 // decode + hash stage shared by verifyBatch and its multi-GPU shard: keys -> G1 points, messages -> G2 hash points, and (when a

@@ -59,6 +59,7 @@ def load_library():
     lib.nbls_sign_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, vp]
     lib.nbls_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, sz, C.POINTER(i32)]
     lib.nbls_verify_batch_dev_inputs.argtypes = [vp, sz, vp, vp, vp, C.POINTER(i32), vp, vp]
+    lib.nbls_verify_batch_msgs_dev.argtypes = [vp, sz, vp, vp, vp, vp, vp, sz, C.POINTER(i32), vp]
     lib.nbls_verify_batch_partial_dev.argtypes = [vp, sz, vp, vp, vp, vp, C.POINTER(i32), vp, vp]
     lib.nbls_g2_prepare.argtypes = [vp, sz, vp, vp]
     lib.nbls_g2_prepare_dev.argtypes = [vp, sz, vp, vp, vp]
@@ -320,6 +321,12 @@ class Engine:
     def verify_batch_dev(self, n, d_sig, d_uniform, d_pk, stream=None):
         ok = C.c_int(0)
         self._chk(self.lib.nbls_verify_batch_dev_inputs(self.h, n, d_sig, d_uniform, d_pk, C.byref(ok), None, stream))
+        return bool(ok.value)
+
+    def verify_batch_msgs_dev(self, n, d_sig, d_msgs, d_offsets, d_pk, dst=DST_DEFAULT, stream=None):
+        """verifyBatch with signature, message bytes + uint32 offsets and compressed keys resident in HBM: expand_message_xmd runs on the device as part of the call"""
+        ok = C.c_int32(0)
+        self._chk(self.lib.nbls_verify_batch_msgs_dev(self.h, n, d_sig, d_msgs, d_offsets, d_pk, dst, len(dst), C.byref(ok), stream))
         return bool(ok.value)
 
     def verify_batch_partial_dev(self, n, d_sig, d_uniform, d_pk, d_out, stream=None):
