@@ -231,7 +231,7 @@ int nbls_device_synchronize(nbls_ctx* ctx);
 /* Placement study (tools/placement.py): runs one step program on n scratch items; out_blocks[5b..5b+4] = HW_ID | XCC_ID << 32, start tick, end tick (s_memtime), start, end time (s_memrealtime, 100 MHz) of workgroup b. */
 int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks);
 /* Per-kernel HIP-event timing (benchmark roofline leg): ms[i]/counts[i] for program i, last entry = inversion kernel. */
-#define NBLS_N_PROGRAMS 96
+#define NBLS_N_PROGRAMS 128
 /* Tuning knobs of a context (defaults are the measured optimum; tests use them to force a code path).
  * NBLS_TUNE_SPLIT_MILLER_MIN: number of pairs from which the Miller loop runs as two programs (line tables through HBM) instead of one. */
 #define NBLS_TUNE_SPLIT_MILLER_MIN 1

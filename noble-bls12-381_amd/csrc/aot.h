@@ -32,7 +32,7 @@
   X(expx, P_EXPX, P_FE_MID1, P_FE_MID2, P_COUNT)       \
   X(acc_fe, P_ACC_FE, P_ACC_RAW, P_ACC_BYTES, P_COUNT) \
   X(lines_pq, P_LINES_PQ, P_COUNT, P_COUNT, P_COUNT)   \
-  X(acc4_raw, P_ACC4_RAW, P_COUNT, P_COUNT, P_COUNT)   \
+  X(acc4_raw, P_ACC4_RAW, P_ACC8_RAW, P_COUNT, P_COUNT) \
   X(fe_easy, P_FE_EASY, P_COUNT, P_COUNT, P_COUNT)     \
   X(fe_final, P_FE_FINAL, P_COUNT, P_COUNT, P_COUNT)   \
   X(miller_fe, P_MILLER_FE, P_MILLER_RAW, P_MILLER_BYTES, P_COUNT) \

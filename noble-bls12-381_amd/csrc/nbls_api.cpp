@@ -75,6 +75,7 @@ struct nbls_ctx {
   uint8_t* ident_g1 = nullptr; uint8_t* ident_g2 = nullptr;   // projective identity (0 : 1 : 0), raw
   size_t cap_F = 0, cap_io = 0;
   size_t split_min = SPLIT_MILLER_MIN;   // nbls_set_tuning(NBLS_TUNE_SPLIT_MILLER_MIN)
+  size_t acc8_min = getenv("NBLS_ACC8_MIN") ? (size_t)atol(getenv("NBLS_ACC8_MIN")) : 131072;   // pairs per product call from which eight line tables share an accumulator (below: four).  Measured (tools/ab_acc8.sh): at 65,537 pairs the halves have 4096 groups of eight = 820 wavefronts, less than one per SIMD, and the call is slower (24.5 against 23.4 ms); at 2^18 terms 33.2 against 33.8 ms
   // cyclotomic exponentiation with compressed squarings (expx): scratch per item -- compressed powers, decompression scratch, redo flags and list -- and two redo counters (one per half)
   uint8_t *KS = nullptr, *KD = nullptr, *Kflag = nullptr; uint32_t *Klist = nullptr, *Kcount = nullptr;
   size_t expc_min = getenv("NBLS_EXPC_MIN") ? (size_t)atol(getenv("NBLS_EXPC_MIN")) : EXPC_MIN_DEFAULT;   // nbls_set_tuning(NBLS_TUNE_EXPC_MIN)
@@ -604,25 +605,28 @@ EXPORT int nbls_miller_product_dev(nbls_ctx* ctx, size_t n, const void* d_g1, co
       // four pairs per item with ONE accumulator: f <- (f l1 l2 l3 l4)^2 per bit, a single Fp12 squaring for four Miller loops (16 % fewer
       // products per pair than two per item).  A last group of fewer than four pairs is filled up with the unit table (every line = 1:
       // multiplying by it changes nothing) instead of getting a launch -- and the latency of a whole Miller loop -- of its own.
-      if ((r = ensure_lines(ctx, n + 3))) return r;
+      // round 4: EIGHT pairs per accumulator from acc8_min pairs per call (one squaring per eight line tables: 1,921 instead of 2,196 instructions per pair and bit)
+      const size_t GR = n >= ctx->acc8_min ? 8 : 4;
+      const ProgId acc = GR == 8 ? P_ACC8_RAW : P_ACC4_RAW;
+      if ((r = ensure_lines(ctx, n + GR - 1))) return r;
       m = 0;
-      for (size_t o = 0; o < n; o += LINES_CHUNK) {   // LINES_CHUNK is a multiple of four: a chunk boundary never splits a group
-        const size_t c = n - o < LINES_CHUNK ? n - o : LINES_CHUNK, c4 = (c + 3) / 4;
-        // a large chunk runs as two halves (whole groups of four) on two streams, like nbls_pairing_batch_dev: the tail of LINES / ACC4 of one half under the other
-        const size_t h = (c >= ctx->halves_min && ctx->ioff == 0) ? ((c / 2 + 3) & ~(size_t)3) : c;
+      for (size_t o = 0; o < n; o += LINES_CHUNK) {   // LINES_CHUNK is a multiple of eight: a chunk boundary never splits a group
+        const size_t c = n - o < LINES_CHUNK ? n - o : LINES_CHUNK, cg = (c + GR - 1) / GR;
+        // a large chunk runs as two halves (whole groups) on two streams, like nbls_pairing_batch_dev: the tail of LINES / ACC of one half under the other
+        const size_t h = (c >= ctx->halves_min && ctx->ioff == 0) ? ((c / 2 + GR - 1) & ~(GR - 1)) : c;
         if (h < c && !ctx->half_stream && (hipStreamCreateWithFlags(&ctx->half_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_half_fork, hipEventDisableTiming) != hipSuccess ||
                                            hipEventCreateWithFlags(&ctx->ev_half_join, hipEventDisableTiming) != hipSuccess)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
         if (h < c) { HIPCHK(hipEventRecord(ctx->ev_half_fork, s)); HIPCHK(hipStreamWaitEvent(ctx->half_stream, ctx->ev_half_fork, 0)); }
         for (size_t lo = 0; lo < c; lo += h) {
-          const size_t cc = lo ? c - lo : h, g4 = (cc + 3) / 4;      // two parts: [0, h) and everything behind it
+          const size_t cc = lo ? c - lo : h, gg = (cc + GR - 1) / GR;      // two parts: [0, h) and everything behind it
           hipStream_t sh = lo ? ctx->half_stream : s;
           if ((r = run(ctx, P_LINES_PQ, cc, {B(0, (const uint8_t*)d_g1 + (o + lo) * 96, 96), B(1, (const uint8_t*)d_g2 + (o + lo) * 192, 192), B(3, ctx->L + lo * LINE_BYTES, LINE_BYTES)}, sh))) return r;
-          for (size_t k = cc; k < 4 * g4; k++) HIPCHK(hipMemcpyAsync(ctx->L + (lo + k) * LINE_BYTES, ctx->unit_lines, LINE_BYTES, hipMemcpyDeviceToDevice, sh));
-          if ((r = run(ctx, P_ACC4_RAW, g4, {B(3, ctx->L + lo * LINE_BYTES, 4 * LINE_BYTES), B(5, ctx->F + (m + lo / 4) * F12, F12)}, sh))) return r;
+          for (size_t k = cc; k < GR * gg; k++) HIPCHK(hipMemcpyAsync(ctx->L + (lo + k) * LINE_BYTES, ctx->unit_lines, LINE_BYTES, hipMemcpyDeviceToDevice, sh));
+          if ((r = run(ctx, acc, gg, {B(3, ctx->L + lo * LINE_BYTES, GR * LINE_BYTES), B(5, ctx->F + (m + lo / GR) * F12, F12)}, sh))) return r;
           if (lo) break;
         }
         if (h < c) { HIPCHK(hipEventRecord(ctx->ev_half_join, ctx->half_stream)); HIPCHK(hipStreamWaitEvent(s, ctx->ev_half_join, 0)); }
-        m += c4;
+        m += cg;
       }
     }
     if ((r = reduce_product(ctx, m, &res, s))) return r;

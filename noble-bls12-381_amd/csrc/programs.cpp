@@ -643,6 +643,9 @@ static Program build(ProgId id) {
     }
     case P_ACC2_RAW: { B.sched_window = ACC_WINDOW; outputw_fp12(trace_acc(2, 3), 5, 0); return B.compile("acc2_raw", ACC_W); }
     case P_ACC4_RAW: { B.sched_window = ACC_WINDOW; outputw_fp12(trace_acc(4, 3), 5, 0); return B.compile("acc4_raw", ACC_W); }
+    case P_ACC8_RAW: {   // window 250: 24 slots, the 80-byte slot stride fits twelve workgroups per CU (330: 30 slots)
+      B.sched_window = env_int("NBLS_ACC8_WINDOW", 250); outputw_fp12(trace_acc(8, 3), 5, 0); return B.compile("acc8_raw", ACC_W);
+    }
     case P_ACC_Q: {
       B.sched_window = ACC_WINDOW;
       std::vector<SFp> Px{input(0, 0)}, Py{input(0, 48)};

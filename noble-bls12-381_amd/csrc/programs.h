@@ -68,6 +68,7 @@ enum ProgId {
   P_EXPC_SQ,           // A (buf 3) -> the compressed coordinates (g2, g3, g4, g5) of (3 A)^(2^k) for k = 16, 48, 57 (buf 5: 3 x 8 raw elements): 57 compressed squarings, 8 lanes per item
   P_EXPC_DEC_A,        // compressed powers (buf 3) -> product of the three |2 g2|^2 (buf 4: the element to invert), numerators times conj(g2), all-but-one products (and a third of them), the g1-free part of g0, zero flag (buf 5: 19 raw elements)
   P_EXPC_DEC_B,        // compressed powers (3), inverse (4), DEC_A scratch (6) -> conj(A^|x|) (buf 5), int8 status (buf 7): 1 = some g2 was zero, the item must be recomputed by P_EXPX
+  P_ACC8_RAW,          // eight folded line tables per item (buf 3) -> F (buf 5): one Fp12 squaring per bit for eight Miller loops (round 4: verifyBatch / products of 32,768 pairs and more)
   P_COUNT
 };
 // |x| = 2^63 + 2^62 + 2^60 + 2^57 + 2^48 + 2^16: the compressed chain runs to 2^57 and its values at the set bits 16, 48, 57 are decompressed; the powers

@@ -323,6 +323,15 @@ def test_split_miller(sim, oracle, golden):
     for i in range(g):
         k = min(4, n - 4 * i)
         assert out.raw[576 * i:576 * i + 576] == oracle.miller_product(g1[384 * i:384 * i + 96 * k], g2[768 * i:768 * i + 192 * k], final_exp=False), i
+    # eight tables per item (round 4: products of 32,768 pairs and more), the last group filled up the same way
+    g8 = (n + 7) // 8
+    L8 = C.create_string_buffer(L.raw[:LINE_BYTES * n] + unit * (8 * g8 - n), LINE_BYTES * 8 * g8)
+    F8 = C.create_string_buffer(vmsim_py.F12 * g8)
+    vmsim_py.run(sim, 'ACC8_RAW', g8, {3: (L8, 8 * LINE_BYTES), 5: (F8, vmsim_py.F12)})
+    vmsim_py.run(sim, 'RAW_TO_BYTES', g8, {3: (F8, vmsim_py.F12), 2: (out, 576)})
+    for i in range(g8):
+        k = min(8, n - 8 * i)
+        assert out.raw[576 * i:576 * i + 576] == oracle.miller_product(g1[768 * i:768 * i + 96 * k], g2[1536 * i:1536 * i + 192 * k], final_exp=False), i
     # prepared lines (not folded) + G1: PointG1.millerLoop(Q) with Q.pairingPrecomputes() (index.ts:452-454, 703-711); one table shared by
     # every item (stride 0) pairs every P with the same Q
     LQ = _lines(sim, g1, g2, n, folded=False)
