@@ -200,13 +200,18 @@ int nbls_verify_batch_partial_dev(nbls_ctx* ctx, size_t n, const void* d_sig96 /
                                   void* d_out_fp12, int* zero_flag, int8_t* pk_status /* n, may be NULL */, void* stream);
 
 /* The same as one device's share of a product that is spread over several GPUs, from HOST inputs: on return *d_partial points at 576 wire
- * bytes on the context's device, ready for hipMemcpyPeer / a collective; the call returns when the partial is complete.  *d_partial is
- * IN/OUT: set it to a caller-owned 576-byte device buffer (on the context's device) to receive the partial there -- required when several
- * threads may use the context, because each call then owns its partial -- or to NULL to use a buffer owned by the context (valid only until
- * the context's next *_partial call).  An empty shard (n = 0, product only) yields the unit element. */
+ * bytes on the context's device, ready for hipMemcpyPeer / a collective; the call returns when the partial is complete.  *d_partial is a pure
+ * OUT parameter (ABI 2; ABI 1 of round 3 read it as well): it receives a buffer owned by the context, valid only until the context's next
+ * *_partial call.  The `_into` forms write the partial to a caller-owned 576-byte device buffer on the context's device instead -- required when
+ * several threads may use the context, because each call then owns its partial; a pointer that is not device memory of that device is refused
+ * (NBLS_EINVAL).  An empty shard (n = 0, product only) yields the unit element. */
 int nbls_miller_product_partial(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, const uint8_t* g2_aff, int validate, void** d_partial, int8_t* status);
 int nbls_verify_batch_partial(nbls_ctx* ctx, size_t n, const uint8_t* sig96 /* or NULL */, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
                               const uint8_t* dst, size_t dst_len, void** d_partial, int* zero_flag, int8_t* pk_status /* n, may be NULL */);
+int nbls_miller_product_partial_into(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, const uint8_t* g2_aff, int validate, void* d_dst576, int8_t* status);
+int nbls_verify_batch_partial_into(nbls_ctx* ctx, size_t n, const uint8_t* sig96 /* or NULL */, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
+                                   const uint8_t* dst, size_t dst_len, void* d_dst576, int* zero_flag, int8_t* pk_status /* n, may be NULL */);
+int nbls_abi_version(void);   /* 2: *_partial take *d_partial as OUT only, *_partial_into added, nbls_tower_op_batch, nbls_verify_batch_msgs_dev */
 int nbls_context_device(nbls_ctx* ctx);
 
 /* Several GPUs of one node behind one handle (one context, host thread and stream per device; contiguous shards).  n_devices = 0 takes every

@@ -245,12 +245,18 @@ static int ensure_scratch(nbls_ctx* ctx, size_t n) {
   HIPCHK(hipMalloc(&ctx->N, cap * RAW));
   HIPCHK(hipMalloc(&ctx->NI, cap * RAW));
   for (auto& t : ctx->T) HIPCHK(hipMalloc(&t, cap * F12));
+  ctx->cap_F = cap;
+  return NBLS_OK;
+}
+// scratch of the compressed-squaring exponentiation (2.8 KB per item): only a context that runs that path -- off by default, NBLS_TUNE_EXPC_MIN -- ever allocates it
+static int ensure_expc_scratch(nbls_ctx* ctx) {
+  if (ctx->KS) return NBLS_OK;     // sized with F / T (ensure_scratch frees it when they grow)
+  const size_t cap = ctx->cap_F;
   HIPCHK(hipMalloc(&ctx->KS, cap * EXPC_SQ_ELEMS * RAW));
   HIPCHK(hipMalloc(&ctx->KD, cap * EXPC_DEC_ELEMS * RAW));
   HIPCHK(hipMalloc(&ctx->Kflag, cap));
   HIPCHK(hipMalloc(&ctx->Klist, cap * 4));
   HIPCHK(hipMalloc(&ctx->Kcount, 8));
-  ctx->cap_F = cap;
   return NBLS_OK;
 }
 static int ensure_io(nbls_ctx* ctx, size_t n) {
@@ -357,6 +363,7 @@ static int expx(nbls_ctx* ctx, size_t n, uint8_t* in, uint8_t* out, hipStream_t 
   int r;
   if (n < ctx->expc_min) return run(ctx, ls_variant(P_EXPX, n), n, {B(3, in, F12), B(5, out, F12)}, s);
   const size_t KSB = (size_t)EXPC_SQ_ELEMS * RAW, KDB = (size_t)EXPC_DEC_ELEMS * RAW;
+  if ((r = ensure_expc_scratch(ctx))) return r;
   if ((r = run(ctx, P_EXPC_SQ, n, {B(3, in, F12), B(5, ctx->KS, KSB)}, s))) return r;
   if ((r = run(ctx, P_EXPC_DEC_A, n, {B(3, ctx->KS, KSB), B(4, ctx->N, RAW), B(5, ctx->KD, KDB)}, s))) return r;
   if ((r = run_inv(ctx, n, s))) return r;                 // N / NI are free once FE_EASY has run
@@ -1469,19 +1476,25 @@ EXPORT int nbls_verify_batch_partial_dev(nbls_ctx* ctx, size_t n, const void* d_
 }
 
 // ---- one device's share of a product that is spread over several GPUs, from HOST inputs: the partial stays on this context's device so that
-// the caller can move it to the reducing device with hipMemcpyPeer (nbls_multi.cpp) or hand it to a collective.  *d_partial is IN/OUT: a non-NULL
-// value names a caller-owned 576-byte buffer on this context's device that receives the partial (what nbls_multi.cpp passes: one buffer per call,
-// so that calls racing on one context cannot see each other's partials); NULL selects a buffer owned by the context, valid only until the
-// context's next *_partial call.  The call returns when the partial is complete.
-static int partial_buffer(nbls_ctx* ctx, void** d_partial, uint8_t** dst) {
-  if (*d_partial) { *dst = (uint8_t*)*d_partial; return NBLS_OK; }
+// the caller can move it to the reducing device with hipMemcpyPeer (nbls_multi.cpp) or hand it to a collective.  `*_into`: the partial lands in a caller-owned
+// 576-byte buffer on this context's device (what nbls_multi.cpp passes: one buffer per call, so that calls racing on one context cannot see each other's
+// partials); the plain names return a buffer owned by the context, valid only until the context's next *_partial call.  The call returns when the partial is complete.
+// destination of a partial: the caller's buffer (`*_into`: it must be device memory of at least 576 bytes on the context's device -- checked with
+// hipPointerGetAttributes, a wild pointer is refused instead of written through), or -- the original entry points, whose *d_partial is a pure OUT
+// parameter again (ABI 2; round 3 had silently made it IN/OUT) -- a buffer owned by the context
+static int partial_buffer(nbls_ctx* ctx, void* d_dst, uint8_t** dst) {
+  if (d_dst) {
+    hipPointerAttribute_t at; memset(&at, 0, sizeof at);
+    if (hipPointerGetAttributes(&at, d_dst) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != ctx->device) { (void)hipGetLastError(); return NBLS_EINVAL; }
+    *dst = (uint8_t*)d_dst; return NBLS_OK;
+  }
   if (!ctx->partial) HIPCHK(hipMalloc(&ctx->partial, 576));
   *dst = ctx->partial;
   return NBLS_OK;
 }
-EXPORT int nbls_miller_product_partial(nbls_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2, int validate, void** d_partial, int8_t* status) {
+static int miller_product_partial_core(nbls_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2, int validate, void* d_dst, void** d_partial, int8_t* status) {
   std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);
-  if (!ctx || !d_partial || (n && (!g1 || !g2))) return NBLS_EINVAL;
+  if (!ctx || (n && (!g1 || !g2))) return NBLS_EINVAL;
   int r;
   if (status) memset(status, 0, n);
   if (validate && n) {
@@ -1493,7 +1506,7 @@ EXPORT int nbls_miller_product_partial(nbls_ctx* ctx, size_t n, const uint8_t* g
   }
   LOCKED(ctx);
   uint8_t* part;
-  if ((r = partial_buffer(ctx, d_partial, &part))) return r;
+  if ((r = partial_buffer(ctx, d_dst, &part))) return r;
   if (n) {
     if ((r = ensure_io(ctx, n))) return r;
     HIPCHK(hipMemcpyAsync(ctx->io_g1, g1, n * 96, hipMemcpyHostToDevice, s));
@@ -1501,16 +1514,25 @@ EXPORT int nbls_miller_product_partial(nbls_ctx* ctx, size_t n, const uint8_t* g
   }
   if ((r = nbls_miller_product_dev(ctx, n, ctx->io_g1, ctx->io_g2, 0, part, s))) return r;
   HIPCHK(hipStreamSynchronize(s));
-  *d_partial = part;
+  if (d_partial) *d_partial = part;
   return NBLS_OK;
 }
-EXPORT int nbls_verify_batch_partial(nbls_ctx* ctx, size_t n, const uint8_t* sig96 /* or NULL */, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
-                                     const uint8_t* dst, size_t dst_len, void** d_partial, int* zero_flag, int8_t* pk_status) {
+EXPORT int nbls_miller_product_partial(nbls_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2, int validate, void** d_partial, int8_t* status) {
+  if (!d_partial) return NBLS_EINVAL;
+  return miller_product_partial_core(ctx, n, g1, g2, validate, nullptr, d_partial, status);
+}
+EXPORT int nbls_miller_product_partial_into(nbls_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2, int validate, void* d_dst, int8_t* status) {
+  if (!d_dst) return NBLS_EINVAL;
+  return miller_product_partial_core(ctx, n, g1, g2, validate, d_dst, nullptr, status);
+}
+EXPORT int nbls_abi_version(void) { return 2; }
+static int verify_batch_partial_core(nbls_ctx* ctx, size_t n, const uint8_t* sig96 /* or NULL */, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
+                                     const uint8_t* dst, size_t dst_len, void* d_dst, void** d_partial, int* zero_flag, int8_t* pk_status) {
   std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);
-  if (!ctx || !d_partial || !zero_flag || !n || !offsets || !pk48 || !dst) return NBLS_EINVAL;
+  if (!ctx || !zero_flag || !n || !offsets || !pk48 || !dst) return NBLS_EINVAL;
   LOCKED(ctx);
   uint8_t *b, *c, *part; int r;
-  if ((r = partial_buffer(ctx, d_partial, &part))) return r;
+  if ((r = partial_buffer(ctx, d_dst, &part))) return r;
   if ((r = dev_expand(ctx, n, msgs, offsets, dst, dst_len, &b, s))) return r;
   if ((r = need(ctx, 9, n * 48 + 96, &c))) return r;
   HIPCHK(hipMemcpyAsync(c, pk48, n * 48, hipMemcpyHostToDevice, s));
@@ -1518,7 +1540,17 @@ EXPORT int nbls_verify_batch_partial(nbls_ctx* ctx, size_t n, const uint8_t* sig
   HIPCHK(hipStreamSynchronize(s));
   if ((r = nbls_verify_batch_partial_dev(ctx, n, sig96 ? c + n * 48 : nullptr, b, c, part, zero_flag, pk_status, nullptr))) return r;
   HIPCHK(hipStreamSynchronize(s));
-  *d_partial = part;
+  if (d_partial) *d_partial = part;
   return NBLS_OK;
+}
+EXPORT int nbls_verify_batch_partial(nbls_ctx* ctx, size_t n, const uint8_t* sig96, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
+                                     const uint8_t* dst, size_t dst_len, void** d_partial, int* zero_flag, int8_t* pk_status) {
+  if (!d_partial) return NBLS_EINVAL;
+  return verify_batch_partial_core(ctx, n, sig96, msgs, offsets, pk48, dst, dst_len, nullptr, d_partial, zero_flag, pk_status);
+}
+EXPORT int nbls_verify_batch_partial_into(nbls_ctx* ctx, size_t n, const uint8_t* sig96, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
+                                          const uint8_t* dst, size_t dst_len, void* d_dst, int* zero_flag, int8_t* pk_status) {
+  if (!d_dst) return NBLS_EINVAL;
+  return verify_batch_partial_core(ctx, n, sig96, msgs, offsets, pk48, dst, dst_len, d_dst, nullptr, zero_flag, pk_status);
 }
 EXPORT int nbls_context_device(nbls_ctx* ctx) { return ctx ? ctx->device : -1; }

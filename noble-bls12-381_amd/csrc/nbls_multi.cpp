@@ -139,7 +139,7 @@ EXPORT int nbls_multi_miller_product(nbls_multi* m, size_t n, const uint8_t* g1,
   int r = on_every_device(G, [&](size_t g) {
     size_t lo, hi; shard(n, G, g, &lo, &hi);   // an empty shard contributes the unit element
     void* p = b->part[g];
-    return nbls_miller_product_partial(m->ctx[g], hi - lo, g1 + lo * 96, g2 + lo * 192, validate, &p, status ? status + lo : nullptr);
+    return nbls_miller_product_partial_into(m->ctx[g], hi - lo, g1 + lo * 96, g2 + lo * 192, validate, p, status ? status + lo : nullptr);
   });
   if (r) { if (r == NBLS_EDECODE) memset(out, 0, 576); return r; }   // as nbls_miller_product: a rejected input zeroes the output
   return finish(m, b, G, final_exp, out);
@@ -159,7 +159,7 @@ EXPORT int nbls_multi_verify_batch(nbls_multi* m, size_t n, const uint8_t* sig96
   int r = on_every_device(G, [&](size_t g) {
     size_t lo, hi; shard(n, G, g, &lo, &hi);
     void* p = b->part[g];
-    return nbls_verify_batch_partial(m->ctx[g], hi - lo, g == 0 ? sig96 : nullptr, msgs, offsets + lo, pk48 + lo * 48, dst, dst_len, &p, &zero[g], nullptr);
+    return nbls_verify_batch_partial_into(m->ctx[g], hi - lo, g == 0 ? sig96 : nullptr, msgs, offsets + lo, pk48 + lo * 48, dst, dst_len, p, &zero[g], nullptr);
   });
   if (r) return r;
   for (int z : zero) if (z) { *ok = 0; return NBLS_OK; }   // a zero point: pairing() throws, verifyBatch answers false

@@ -2,7 +2,7 @@
 # VGPR / SGPR / spill / LDS figures of every kernel of libnbls.so, read from the code-object metadata the compiler emits (hipcc -S of each .hip file with the
 # flags of csrc/Makefile) -- no GPU needed.  Usage: tools/kernel_resources.sh | grep -v rocprim > profiles/round3_kernel_resources.txt   (the hipCUB sort kernels of the MSM are left out)
 cd "$(dirname "$0")/../noble-bls12-381_amd/csrc"
-for f in vm_kernel.hip pow_kernels.hip xmd_kernel.hip msm_kernels.hip; do
+for f in vm_kernel.hip aot_kernel.hip pow_kernels.hip xmd_kernel.hip msm_kernels.hip; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -align-all-nofallthru-blocks=6 -I../../include -S --cuda-device-only -o /tmp/kres_$$.s $f 2>/dev/null
   python3 - /tmp/kres_$$.s $f <<'PY'
 import re, sys

@@ -20,6 +20,10 @@ oracle = oracle_py.load()
 uni = b''.join(oracle.expand_message_xmd(m, oracle_py.DST_DEFAULT, 256) for m in msgs)
 d_sig = torch.frombuffer(bytearray(sig), dtype=torch.uint8).cuda(); d_uni = torch.frombuffer(bytearray(uni), dtype=torch.uint8).cuda(); d_pk = torch.frombuffer(bytearray(b''.join(pks)), dtype=torch.uint8).cuda()
 assert eng.verify_batch_dev(n, d_sig.data_ptr(), d_uni.data_ptr(), d_pk.data_ptr()) is True
+if os.environ.get('NBLS_VB_NOTIMING'):     # for a kernel trace of the call as it runs in production (per-kernel HIP events make the host wait between launches)
+    torch.cuda.synchronize(); time.sleep(0.05)
+    t0 = time.perf_counter(); eng.verify_batch_dev(n, d_sig.data_ptr(), d_uni.data_ptr(), d_pk.data_ptr()); dt = time.perf_counter() - t0
+    print('verify_batch_dev %d: %.2f ms (no per-kernel timing)' % (n, dt * 1e3)); sys.exit(0)
 eng.timing_enable(True)
 t0 = time.perf_counter(); eng.verify_batch_dev(n, d_sig.data_ptr(), d_uni.data_ptr(), d_pk.data_ptr()); dt = time.perf_counter() - t0
 tm = eng.timing_read()

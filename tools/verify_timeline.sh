@@ -5,14 +5,14 @@
 export TMPDIR=/tmp
 n=${1:-1}; tag=${2:-n$n}
 out=$PWD/gpurun_out/verify_timeline_$tag; rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --output-format csv -d $out -- python tools/verify_breakdown.py $n > $out/run.log 2>&1
+NBLS_VB_NOTIMING=1 rocprofv3 --kernel-trace --output-format csv -d $out -- python tools/verify_breakdown.py $n > $out/run.log 2>&1
 f=$(find $out -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY' | tee $out/timeline.txt
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # the last call: kernels after the last gap of more than 0.5 ms... verify_breakdown runs the timed call last; take the trailing 60 kernels and cut at the largest gap
-tail = rows[-80:]
+tail = rows[-120:]
 gaps = [(int(tail[i]['Start_Timestamp']) - int(tail[i - 1]['End_Timestamp']), i) for i in range(1, len(tail))]
 cut = max(gaps)[1] if gaps else 0
 last = tail[cut:]
