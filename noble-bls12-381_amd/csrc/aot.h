@@ -28,23 +28,38 @@
 // share a kernel (and the lanes per item) can run as a CHAIN -- one launch that executes them back to back for the same items, values passing through the same
 // HBM scratch as between separate launches but without a grid-wide boundary: the seven launches EXPX, FE_MID1, EXPX x 3, FE_MID2, EXPX in the middle of a final
 // exponentiation (math.ts:862-867) are one.
-#define NBLS_AOT_KERNELS(X)                            \
-  X(expx, P_EXPX, P_FE_MID1, P_FE_MID2, P_COUNT)       \
-  X(acc_fe, P_ACC_FE, P_ACC_RAW, P_ACC_BYTES, P_COUNT) \
-  X(lines_pq, P_LINES_PQ, P_COUNT, P_COUNT, P_COUNT)   \
-  X(acc4_raw, P_ACC4_RAW, P_ACC8_RAW, P_COUNT, P_COUNT) \
-  X(fe_easy, P_FE_EASY, P_COUNT, P_COUNT, P_COUNT)     \
-  X(fe_final, P_FE_FINAL, P_COUNT, P_COUNT, P_COUNT)   \
-  X(miller_fe, P_MILLER_FE, P_MILLER_RAW, P_MILLER_BYTES, P_COUNT) \
-  X(mul2, P_MUL2, P_COUNT, P_COUNT, P_COUNT)           \
-  X(h2c_a, P_H2C_A, P_COUNT, P_COUNT, P_COUNT)         \
-  X(h2c_b, P_H2C_B, P_COUNT, P_COUNT, P_COUNT)         \
-  X(h2c_c1, P_H2C_C1, P_COUNT, P_COUNT, P_COUNT)       \
-  X(h2c_c2, P_H2C_C2, P_COUNT, P_COUNT, P_COUNT)       \
-  X(g1_dec, P_G1_DEC_A, P_G1_DEC_B, P_COUNT, P_COUNT)  \
-  X(g2_dec, P_G2_DEC_A, P_G2_DEC_B, P_COUNT, P_COUNT)  \
-  X(norm, P_NORM_RAW, P_NORM_BYTES, P_RAW_TO_BYTES, P_COUNT) \
-  X(g2_to_affine, P_G2_TO_AFFINE, P_G2_NORM, P_COUNT, P_COUNT)
+#define NBLS_AOT_PARTS 8   /* aot_kernel.hip is compiled once per part (Makefile): X's first argument is the part that holds the kernel's device code */
+#define NBLS_AOT_KERNELS(X)                                                  \
+  X(0, expx, P_EXPX, P_FE_MID1, P_FE_MID2, P_COUNT)                          \
+  X(0, acc_fe, P_ACC_FE, P_ACC_RAW, P_ACC_BYTES, P_COUNT)                    \
+  X(0, lines_pq, P_LINES_PQ, P_COUNT, P_COUNT, P_COUNT)                      \
+  X(0, acc4_raw, P_ACC4_RAW, P_ACC8_RAW, P_ACC2_RAW, P_COUNT)                \
+  X(1, fe_easy, P_FE_EASY, P_COUNT, P_COUNT, P_COUNT)                        \
+  X(1, fe_final, P_FE_FINAL, P_COUNT, P_COUNT, P_COUNT)                      \
+  X(1, miller_fe, P_MILLER_FE, P_MILLER_RAW, P_MILLER_BYTES, P_COUNT)        \
+  X(1, mul2, P_MUL2, P_COUNT, P_COUNT, P_COUNT)                              \
+  X(1, norm, P_NORM_RAW, P_NORM_BYTES, P_RAW_TO_BYTES, P_COUNT)              \
+  X(2, h2c_a, P_H2C_A, P_COUNT, P_COUNT, P_COUNT)                            \
+  X(2, h2c_b, P_H2C_B, P_COUNT, P_COUNT, P_COUNT)                            \
+  X(2, h2c_c1, P_H2C_C1, P_COUNT, P_COUNT, P_COUNT)                          \
+  X(2, h2c_c2, P_H2C_C2, P_COUNT, P_COUNT, P_COUNT)                          \
+  X(2, g1_dec, P_G1_DEC_A, P_G1_DEC_B, P_COUNT, P_COUNT)                     \
+  X(2, g2_dec, P_G2_DEC_A, P_G2_DEC_B, P_COUNT, P_COUNT)                     \
+  X(2, g2_to_affine, P_G2_TO_AFFINE, P_G2_NORM, P_G2_TO_PROJ, P_G2_ADD2)     \
+  X(3, g2_mul, P_G2_MUL, P_COUNT, P_COUNT, P_COUNT)                          \
+  X(3, g1_mul, P_G1_MUL, P_COUNT, P_COUNT, P_COUNT)                          \
+  X(4, g1_validate, P_G1_VALIDATE, P_COUNT, P_COUNT, P_COUNT)                \
+  X(4, g2_validate, P_G2_VALIDATE, P_COUNT, P_COUNT, P_COUNT)                \
+  X(4, g1_sum, P_G1_TO_PROJ, P_G1_ADD2, P_G1_NORM, P_G1_TO_AFFINE)           \
+  X(5, g1_msm, P_G1_ADD_AB, P_G1_HORNER, P_G1_SHIFTADD, P_G1_MSM_PREP)       \
+  X(5, g2_msm, P_G2_ADD_AB, P_G2_HORNER, P_G2_SHIFTADD, P_G2_MSM_PREP)       \
+  X(6, lines_q, P_LINES_Q, P_ACC_Q, P_LINES_BYTES, P_LINES_FROM_BYTES)       \
+  X(6, miller_raw2, P_MILLER_RAW2, P_COUNT, P_COUNT, P_COUNT)                \
+  X(6, g2_dec192, P_G2_DEC_A192, P_G2_DEC_B192, P_G2_DEC_B_HEX, P_G2_SWAP)   \
+  X(6, from_raw, P_G1_FROM_RAW, P_G2_FROM_RAW, P_G1_COMPRESS, P_G2_COMPRESS) \
+  X(7, h2c1, P_H2C1_A, P_H2C1_B, P_ENC1_A, P_ENC1_B)                         \
+  X(7, g1_clear, P_G1_CLEAR, P_COUNT, P_COUNT, P_COUNT)                      \
+  X(7, enc2, P_ENC2_A, P_ENC2_B, P_COUNT, P_COUNT)
 
 namespace nbls {
 

@@ -69,20 +69,30 @@ __device__ __forceinline__ void aot_body(const AotArgs& ka, Dispatch&& dispatch)
 #define NBLS_AOT_OCC __attribute__((amdgpu_waves_per_eu(NBLS_AOT_WAVES, NBLS_AOT_WAVES)))
 #define AOT_CASE(ID, KIND, P0, FLAGS, T, SH0, SH1, CNT) \
   case ID: aot_step<KIND, P0, FLAGS, T, SH0, SH1>(d, lds, item, live, bufs, ka.qp_table, [&](u32 dst, const u32* res) __attribute__((always_inline)) { st14(lds, dst, res); }); break;
-#define AOT_KERNEL(NAME, P0, P1, P2, P3)                                                                                       \
+// this translation unit is compiled NBLS_AOT_PARTS times (Makefile: -DNBLS_AOT_PART=i); every part declares all kernels and defines its own
+#if !defined(NBLS_AOT_PART)
+#define NBLS_AOT_PART 0
+#endif
+#define AOT_DECL(PART, NAME, P0, P1, P2, P3) extern "C" __global__ void nbls_aot_##NAME(AotArgs ka);
+NBLS_AOT_KERNELS(AOT_DECL)
+#define AOT_KERNEL_BODY(NAME)                                                                                                  \
   extern "C" __global__ void __launch_bounds__(64) NBLS_AOT_OCC nbls_aot_##NAME(AotArgs ka) {                                  \
     aot_body(ka, [&](u32 sig, const DevDesc& d, char* lds, u32 item, bool live, const IOBuf* bufs) __attribute__((always_inline)) { \
       switch (sig) { AOT_SIGS_##NAME(AOT_CASE) default: break; }                                                               \
     });                                                                                                                        \
   }
-NBLS_AOT_KERNELS(AOT_KERNEL)
+#include "aot_parts.inc"   // generated: AOT_KERNEL_BODY(name) for the kernels of this part
 
 // ---- host side
 #define AOT_ROW(ID, KIND, P0, FLAGS, T, SH0, SH1, CNT) {KIND, P0, FLAGS, T, SH0, SH1},
-#define AOT_TABLE(NAME, P0, P1, P2, P3) static const AotSig sigs_##NAME[] = {AOT_SIGS_##NAME(AOT_ROW)};
+}  // namespace nbls
+
+#if NBLS_AOT_PART == 0
+namespace nbls {
+#define AOT_TABLE(PART, NAME, P0, P1, P2, P3) static const AotSig sigs_##NAME[] = {AOT_SIGS_##NAME(AOT_ROW)};
 NBLS_AOT_KERNELS(AOT_TABLE)
 struct AotKernel { int prog_id[4]; const void* fn; const AotSig* sigs; unsigned nsigs; };
-#define AOT_ENTRY(NAME, P0, P1, P2, P3) {{(int)P0, (int)P1, (int)P2, (int)P3}, (const void*)nbls_aot_##NAME, sigs_##NAME, (unsigned)(sizeof(sigs_##NAME) / sizeof(AotSig))},
+#define AOT_ENTRY(PART, NAME, P0, P1, P2, P3) {{(int)P0, (int)P1, (int)P2, (int)P3}, (const void*)nbls_aot_##NAME, sigs_##NAME, (unsigned)(sizeof(sigs_##NAME) / sizeof(AotSig))},
 static const AotKernel g_kernels[] = {NBLS_AOT_KERNELS(AOT_ENTRY)};
 static const int g_nkernels = (int)(sizeof(g_kernels) / sizeof(g_kernels[0]));
 
@@ -131,3 +141,4 @@ extern "C" int nbls_aot_launch(int k, const nbls::AotArgs* ka, unsigned lds_byte
   const hipError_t e = hipLaunchKernel(g_kernels[k].fn, dim3(blocks), dim3(64), args, lds_bytes, (hipStream_t)stream);
   return e == hipSuccess ? (int)hipGetLastError() : (int)e;
 }
+#endif   // NBLS_AOT_PART == 0

@@ -234,7 +234,7 @@ static const int LINES_W = env_int("NBLS_LINES_W", 10), ACC_W = env_int("NBLS_AC
 // (the interpreter pays three instructions per operand for it) and frees the replicated copies' LDS: FE_MID1 13,440 -> 11,904 B, which keeps twelve
 // workgroups per CU for the chained final exponentiation
 static bool aot_listed(ProgId id) {
-#define AOT_HAS(NAME, P0, P1, P2, P3) if (id == P0 || id == P1 || id == P2 || id == P3) return true;
+#define AOT_HAS(PART, NAME, P0, P1, P2, P3) if (id == P0 || id == P1 || id == P2 || id == P3) return true;
   NBLS_AOT_KERNELS(AOT_HAS)
 #undef AOT_HAS
   return false;

@@ -69,7 +69,7 @@ struct HostDesc {
 struct Pend { u32 dst; u32 v[NL]; };
 #define SIM_CASE(ID, KIND, P0, FLAGS, T, SH0, SH1, CNT) \
   case ID: aot_step<KIND, P0, FLAGS, T, SH0, SH1>(d, lds, item, live, bufs, qp, [&](u32 dst, const u32* res) { Pend pd; pd.dst = dst; memcpy(pd.v, res, NL * 4); pend.push_back(pd); }); break;
-#define SIM_TABLE(NAME, Q0, Q1, Q2, Q3)                                                                                                        \
+#define SIM_TABLE(PART, NAME, Q0, Q1, Q2, Q3)                                                                                                        \
   static const AotSig sim_sigs_##NAME[] = {AOT_SIGS_##NAME(SIM_ROW)};                                                                      \
   static void sim_step_##NAME(u32 sig, const HostDesc& d, char* lds, u32 item, bool live, const IOBuf* bufs, const u32* qp, std::vector<Pend>& pend) { \
     switch (sig) { AOT_SIGS_##NAME(SIM_CASE) default: abort(); }                                                                          \
@@ -78,7 +78,7 @@ struct Pend { u32 dst; u32 v[NL]; };
 NBLS_AOT_KERNELS(SIM_TABLE)
 typedef void (*SimStepFn)(u32, const HostDesc&, char*, u32, bool, const IOBuf*, const u32*, std::vector<Pend>&);
 struct SimKernel { int prog_id[4]; SimStepFn fn; const AotSig* sigs; unsigned nsigs; };
-#define SIM_ENTRY(NAME, Q0, Q1, Q2, Q3) {{(int)Q0, (int)Q1, (int)Q2, (int)Q3}, sim_step_##NAME, sim_sigs_##NAME, (unsigned)(sizeof(sim_sigs_##NAME) / sizeof(AotSig))},
+#define SIM_ENTRY(PART, NAME, Q0, Q1, Q2, Q3) {{(int)Q0, (int)Q1, (int)Q2, (int)Q3}, sim_step_##NAME, sim_sigs_##NAME, (unsigned)(sizeof(sim_sigs_##NAME) / sizeof(AotSig))},
 static const SimKernel g_sim_kernels[] = {NBLS_AOT_KERNELS(SIM_ENTRY)};
 static int g_sim_aot = 0;
 // 0: ran; -2: the program has no ahead-of-time kernel; -3: its signatures are not in the kernel's table

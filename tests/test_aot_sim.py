@@ -19,7 +19,7 @@ def sim():
 def test_listed_programs_translate(sim):
     for name in ('EXPX', 'ACC_FE', 'ACC4_RAW', 'LINES_PQ'):
         assert sim.nbls_sim_has_aot(vmsim_py.P[name]) == 1, name
-    assert sim.nbls_sim_has_aot(vmsim_py.P['G1_VALIDATE']) == 0
+    assert sim.nbls_sim_has_aot(vmsim_py.P['EXPX_LS']) == 0     # lane-split programs stay on the interpreter
 
 
 def test_final_exponentiation_through_translated_expx(sim, oracle, golden, testdata):
