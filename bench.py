@@ -125,6 +125,12 @@ def main():
             dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
     pkg = importlib.import_module('noble-bls12-381_amd')
     import oracle_py
+    ranks_seen = None
+    if multi:   # a real collective over the job's backend before anything is timed: how many distinct ranks answered (the SCALE record can check that RCCL saw N of them)
+        dev_ = 'cpu' if args.dist_backend == 'gloo' else 'cuda'     # gloo gathers host tensors (ranks may share a GPU there)
+        mine = torch.tensor([rank], dtype=torch.int32, device=dev_); everyone = torch.empty(world, dtype=torch.int32, device=dev_)
+        dist.all_gather_into_tensor(everyone, mine)
+        ranks_seen = len(set(everyone.cpu().tolist()))
     oracle = oracle_py.load(rebuild=not os.path.exists(os.path.join(ROOT, 'oracle', 'libnbls_oracle.so')))
     D = max(1, args.inflight if args.inflight is not None else 12)
     if args.inflight is None and args.steps < 4 * D and D > 8:   # an explicit --inflight is taken as given
@@ -604,7 +610,7 @@ def main():
             'single_call': {'pairings_per_s': round(n * args.steps / dt_serial, 2), 'ms_per_batch': round(dt_serial / args.steps * 1e3, 4), 'roofline_frac': roof['frac'] if roof else None,
                             'note': 'one %d-pairing call at a time on one stream (this rank): the latency of a call; its roofline is the top-level `roofline` object' % n},
             'single_stream': {'pairings_per_s': round(n * args.steps / dt_serial, 2), 'ms_per_batch': round(dt_serial / args.steps * 1e3, 4), 'note': 'alias of single_call (round-1 name)'},
-            'rccl_ranks': world if (multi and args.dist_backend == 'nccl') else None, 'dist_backend': args.dist_backend if multi else None,
+            'rccl_ranks': ranks_seen if (multi and args.dist_backend == 'nccl') else None, 'ranks_in_all_gather': ranks_seen, 'dist_backend': args.dist_backend if multi else None,
             'roofline': roof, 'cpu_baseline': cpu, 'facade': facade, 'product': product, 'verify_batch': vbatch if vbatch is not None else vshard, 'verify_batch_sharded': vshard if vbatch is not None else None, 'sign': sleg, 'aggregate': aleg, 'msm': mleg,
         }
         out_line = json.dumps(line)

@@ -223,6 +223,7 @@ int nbls_init_multi(int n_devices, const int* device_ids, nbls_multi** out);
 void nbls_destroy_multi(nbls_multi* m);
 int nbls_multi_device_count(const nbls_multi* m);
 nbls_ctx* nbls_multi_context(nbls_multi* m, int i);
+int nbls_multi_peer_access(const nbls_multi* m, int i);   /* 1: copies between device i and the reducing (first listed) device go peer to peer over xGMI; 0: staged by the runtime; -1: bad index */
 int nbls_multi_pairing_batch(nbls_multi* m, size_t n, const uint8_t* g1_aff, const uint8_t* g2_aff, int with_final_exp, int validate,
                              uint8_t* out_fp12, int8_t* status);
 int nbls_multi_miller_product(nbls_multi* m, size_t n, const uint8_t* g1_aff, const uint8_t* g2_aff, int final_exp, int validate,

@@ -25,6 +25,7 @@ struct CallBuffers {
 struct nbls_multi {
   std::vector<nbls_ctx*> ctx;
   std::vector<int> dev;
+  std::vector<int> peer;               // per device: 1 = peer access to / from the reducing device enabled (nbls_multi_peer_access)
   std::mutex mu;                       // guards `free_sets` only
   std::vector<CallBuffers*> free_sets;
   std::vector<CallBuffers*> all_sets;
@@ -82,11 +83,27 @@ EXPORT int nbls_init_multi(int n_devices, const int* device_ids, nbls_multi** ou
   }
   { CallBuffers* b = take_set(m); if (!b) { nbls_destroy_multi(m); return NBLS_EHIP; } give_set(m, b); }   // the first call's buffers
   // peer access lets hipMemcpyPeer go straight over xGMI; without it the copy is staged, which is still correct
-  for (size_t i = 1; i < m->dev.size(); i++) { int can = 0; if (hipDeviceCanAccessPeer(&can, m->dev[0], m->dev[i]) == hipSuccess && can) { hipSetDevice(m->dev[0]); hipDeviceEnablePeerAccess(m->dev[i], 0); } }
+  // (round 4: both directions between the reducing device -- the FIRST listed one, whatever its id -- and every other device, and the outcome is kept for
+  // nbls_multi_peer_access so that a test on a multi-GPU box can say whether the gather really went peer to peer)
+  m->peer.assign(m->dev.size(), 1);
+  for (size_t i = 1; i < m->dev.size(); i++) {
+    if (m->dev[i] == m->dev[0]) continue;   // the same device listed twice: a plain device-to-device copy
+    int can01 = 0, can10 = 0;
+    const bool ok = hipDeviceCanAccessPeer(&can01, m->dev[0], m->dev[i]) == hipSuccess && can01 && hipDeviceCanAccessPeer(&can10, m->dev[i], m->dev[0]) == hipSuccess && can10;
+    if (ok) {
+      hipError_t e1 = hipSuccess, e2 = hipSuccess;
+      if (hipSetDevice(m->dev[0]) == hipSuccess) e1 = hipDeviceEnablePeerAccess(m->dev[i], 0);
+      if (hipSetDevice(m->dev[i]) == hipSuccess) e2 = hipDeviceEnablePeerAccess(m->dev[0], 0);
+      m->peer[i] = (e1 == hipSuccess || e1 == hipErrorPeerAccessAlreadyEnabled) && (e2 == hipSuccess || e2 == hipErrorPeerAccessAlreadyEnabled) ? 1 : 0;
+    } else m->peer[i] = 0;
+  }
   (void)hipGetLastError();
+  hipSetDevice(m->dev[0]);
   *out = m;
   return NBLS_OK;
 }
+// 1: copies between device i of the handle and the reducing (first) device go peer to peer (or i is that device); 0: staged through the host by the runtime; -1: bad index
+EXPORT int nbls_multi_peer_access(const nbls_multi* m, int i) { return m && i >= 0 && i < (int)m->peer.size() ? m->peer[i] : -1; }
 EXPORT int nbls_multi_device_count(const nbls_multi* m) { return m ? (int)m->ctx.size() : 0; }
 EXPORT nbls_ctx* nbls_multi_context(nbls_multi* m, int i) { return m && i >= 0 && i < (int)m->ctx.size() ? m->ctx[i] : nullptr; }
 

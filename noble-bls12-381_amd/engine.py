@@ -78,6 +78,7 @@ def load_library():
     lib.nbls_init_multi.argtypes = [i32, C.POINTER(i32), C.POINTER(vp)]
     lib.nbls_destroy_multi.argtypes = [vp]
     lib.nbls_multi_device_count.argtypes = [vp]
+    lib.nbls_multi_peer_access.argtypes = [vp, i32]
     lib.nbls_multi_pairing_batch.argtypes = [vp, sz, vp, vp, i32, i32, vp, vp]
     lib.nbls_multi_miller_product.argtypes = [vp, sz, vp, vp, i32, i32, vp, vp]
     lib.nbls_multi_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, sz, C.POINTER(i32)]

@@ -33,3 +33,21 @@ def test_gpus_flag_three_ranks():
 def test_single_rank_needs_no_launcher():
     d = _run(['--gpus', '1', '--dry-launch'])
     assert d['n_gpus'] == 1 and d['rank_sum'] == 1
+
+
+def test_gpus_flag_eight_ranks():
+    """the driver's scaling run: `python bench.py --gpus 8` -> eight ranks, one JSON line, every rank in the all-reduce (1 + 2 + ... + 8 = 36)"""
+    d = _run(['--gpus', '8', '--dry-launch'])
+    assert d['n_gpus'] == 8 and d['gpus_flag'] == 8 and d['rank_sum'] == 36
+
+
+def test_driver_launcher_command_line():
+    """the same under the launcher the driver uses for N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N"""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4', '--master-addr', '127.0.0.1', '--master-port', '29611',
+                        os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--dry-launch'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 4 and d['rank_sum'] == 10

@@ -113,4 +113,19 @@ def test_across_real_devices(pkg, eng, oracle):
     one = (1).to_bytes(48, 'big') + bytes(528)
     assert m.miller_product(P2 + negP, Q2 + Q2, True)[0] == one
     assert m.miller_product(P2 + negP, Q2 + Q2, True)[0] == eng.miller_product(P2 + negP, Q2 + Q2, True)[0]
+    # did the 576-byte partials travel peer to peer (xGMI) or staged by the runtime?  Reported either way; on a node whose devices are peers it must be peer to peer
+    peers = m.peer_access()
+    can = [torch.cuda.can_device_access_peer(0, g) for g in range(1, G)]
+    print('peer access to the reducing device:', peers, 'torch says', can)
+    assert peers[0] == 1 and all(p == 1 for p, c in zip(peers[1:], can) if c)
     m.close()
+    # a reducing device other than device 0: the LAST device leads, the others follow in reverse order
+    order = list(range(G - 1, -1, -1))
+    m2 = pkg.MultiEngine(order)
+    k = 2048 * G
+    sub1, sub2 = P2[:96 * k] + negP[:96 * k], Q2[:192 * k] + Q2[:192 * k]
+    assert m2.miller_product(sub1, sub2, True)[0] == one
+    vs = 512 * G
+    assert m2.pairing_batch(G1[:96 * vs], G2[:192 * vs], True, False)[0] == (ref * reps)[:576 * vs]
+    assert all(p in (0, 1) for p in m2.peer_access())
+    m2.close()
