@@ -211,6 +211,7 @@ int nbls_verify_batch_partial(nbls_ctx* ctx, size_t n, const uint8_t* sig96 /* o
 int nbls_miller_product_partial_into(nbls_ctx* ctx, size_t n, const uint8_t* g1_aff, const uint8_t* g2_aff, int validate, void* d_dst576, int8_t* status);
 int nbls_verify_batch_partial_into(nbls_ctx* ctx, size_t n, const uint8_t* sig96 /* or NULL */, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
                                    const uint8_t* dst, size_t dst_len, void* d_dst576, int* zero_flag, int8_t* pk_status /* n, may be NULL */);
+const char* nbls_config_describe(void);   /* "NBLS_X=value(env|default) ...": every environment switch the library has read so far and the value in force -- print it next to an A/B result */
 int nbls_abi_version(void);   /* 2: *_partial take *d_partial as OUT only, *_partial_into added, nbls_tower_op_batch, nbls_verify_batch_msgs_dev */
 int nbls_context_device(nbls_ctx* ctx);
 

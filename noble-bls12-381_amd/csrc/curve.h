@@ -6,6 +6,7 @@
 // cases instead; the group elements produced are the same.
 #pragma once
 #include <cassert>
+#include "config.h"
 #include "tower.h"
 
 namespace nbls {
@@ -73,7 +74,7 @@ template <class F> static inline Pt<F> pt_dbl_n(const Pt<F>& p, int n) { Pt<F> r
 // products) the two squares go to two lanes, U = S^2 and V = 12 t2^2 = 3 (2 t2)(2 t2), and y' = U - V is never formed: every use of y in the next doubling
 // is a product operand (y^2, y z, x y), where a two-term form is a pre-addition.  Four lanes x one product in both levels; y is summed once, when the run ends.
 template <> inline Pt<SFp> pt_dbl_n<SFp>(const Pt<SFp>& p, int n) {
-  static const bool lazy_y = !getenv("NBLS_DBL_PLAIN");
+  static const bool lazy_y = !env_set("NBLS_DBL_PLAIN");
   if (n < 4 || !lazy_y) { Pt<SFp> r = p; for (int i = 0; i < n; i++) r = pt_dbl(r); return r; }   // short runs (the 3-bit windows of the ladders): the closing sum costs a step, measured slower
   SFp x = p.x, y = p.y, z = p.z;
   for (int i = 0; i < n; i++) {
@@ -91,7 +92,7 @@ template <> inline Pt<SFp2> pt_dbl_n<SFp2>(const Pt<SFp2>& p, int n) {
     // n2 = -t2 = -3(1 + u) d^2: as POSITIVE terms of the sums a = t0 + 3 n2 and b' = -b = n2 - t0 it needs no bound contraction
     // (a subtracted term must stay below 6p, and this lane-op's result is bounded by ~6.1p)
     SFp2 t0 = mat(sqr(y)), t1 = mat(mul(y, d)), n2 = mat(-scale(mulnr(sqr(d)), 3)), xy = mat(mul(x, y));
-    static const bool two_squares = !getenv("NBLS_DBL_PLAIN");
+    static const bool two_squares = !env_set("NBLS_DBL_PLAIN");
     if (two_squares) {
       // y' = -a nb - 8 t0 n2 = t0^2 - 6 t0 n2 - 3 n2^2 = S^2 - 12 n2^2 with S = t0 - 3 n2: a difference of two Fp2 SQUARES costs two limb products per
       // coefficient where the sum of two Fp2 products costs four -- the second level of a doubling is then ONE product round instead of two.  The

@@ -2,6 +2,7 @@
 // management and the launch pipelines.  No CPU arithmetic path exists here: if HIP or the GPU is unavailable every
 // entry point fails with NBLS_ENOGPU / NBLS_EHIP.
 #include <hip/hip_runtime.h>
+#include "config.h"
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -70,15 +71,15 @@ struct nbls_ctx {
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; uint8_t* side_scratch = nullptr;
   // large pairing batches run as two halves on two streams (nbls_pairing_batch_dev): item offset applied to every per-item buffer of a launch, second stream, events
   size_t ioff = 0; hipStream_t half_stream = nullptr; hipEvent_t ev_half_fork = nullptr, ev_half_join = nullptr;
-  size_t halves_min = getenv("NBLS_HALVES_MIN") ? (atol(getenv("NBLS_HALVES_MIN")) > 0 ? (size_t)atol(getenv("NBLS_HALVES_MIN")) : (size_t)-1) : 8192;   // NBLS_HALVES_MIN=0: never (profiles of kernels running alone)
+  size_t halves_min = env_long("NBLS_HALVES_MIN", 8192) > 0 ? (size_t)env_long("NBLS_HALVES_MIN", 8192) : (size_t)-1;   // NBLS_HALVES_MIN=0: never (profiles of kernels running alone)
   hipStream_t side2 = nullptr; hipEvent_t ev_join2 = nullptr;   // verifyBatch: key decoding runs beside message hashing (their exponentiation kernels are latency-bound and leave issue slots free)
   uint8_t* ident_g1 = nullptr; uint8_t* ident_g2 = nullptr;   // projective identity (0 : 1 : 0), raw
   size_t cap_F = 0, cap_io = 0;
   size_t split_min = SPLIT_MILLER_MIN;   // nbls_set_tuning(NBLS_TUNE_SPLIT_MILLER_MIN)
-  size_t acc8_min = getenv("NBLS_ACC8_MIN") ? (size_t)atol(getenv("NBLS_ACC8_MIN")) : 131072;   // pairs per product call from which eight line tables share an accumulator (below: four).  Measured (tools/ab_acc8.sh): at 65,537 pairs the halves have 4096 groups of eight = 820 wavefronts, less than one per SIMD, and the call is slower (24.5 against 23.4 ms); at 2^18 terms 33.2 against 33.8 ms
+  size_t acc8_min = (size_t)env_long("NBLS_ACC8_MIN", 131072);   // pairs per product call from which eight line tables share an accumulator (below: four).  Measured (tools/ab_acc8.sh): at 65,537 pairs the halves have 4096 groups of eight = 820 wavefronts, less than one per SIMD, and the call is slower (24.5 against 23.4 ms); at 2^18 terms 33.2 against 33.8 ms
   // cyclotomic exponentiation with compressed squarings (expx): scratch per item -- compressed powers, decompression scratch, redo flags and list -- and two redo counters (one per half)
   uint8_t *KS = nullptr, *KD = nullptr, *Kflag = nullptr; uint32_t *Klist = nullptr, *Kcount = nullptr;
-  size_t expc_min = getenv("NBLS_EXPC_MIN") ? (size_t)atol(getenv("NBLS_EXPC_MIN")) : EXPC_MIN_DEFAULT;   // nbls_set_tuning(NBLS_TUNE_EXPC_MIN)
+  size_t expc_min = (size_t)env_long("NBLS_EXPC_MIN", (long)EXPC_MIN_DEFAULT);   // nbls_set_tuning(NBLS_TUNE_EXPC_MIN)
   u32* qp_table = nullptr;      // multiples of p for the weak reduction (vm_exec.h weak_reduce), device copy
   uint8_t* unit_lines = nullptr;   // a line table whose 68 lines are all 1 (c0 = 1, c1 = c2 = 0): the neutral partner of an odd last pair
   uint8_t* partial = nullptr;   // 576 bytes: the Fp12 partial of the *_partial entry points (multi-GPU reductions)
@@ -101,12 +102,12 @@ static bool checked_mode() {
 #if defined(NBLS_CHECKED)
   return true;
 #else
-  static const bool on = getenv("NBLS_CHECKED") && atoi(getenv("NBLS_CHECKED")) != 0;
+  static const bool on = env_long("NBLS_CHECKED", 0) != 0;
   return on;
 #endif
 }
 // NBLS_AOT=0 keeps every program on the interpreter (A/B runs, profiles of the interpreter)
-static bool aot_enabled() { static const bool on = !(getenv("NBLS_AOT") && atoi(getenv("NBLS_AOT")) == 0); return on; }
+static bool aot_enabled() { static const bool on = env_long("NBLS_AOT", 1) != 0; return on; }
 static int upload_program(nbls_ctx* ctx, DevProgram& d, const Program& p, const int k);
 static int upload(nbls_ctx* ctx, ProgId id) {
   DevProgram& d = ctx->prog[id];
@@ -207,8 +208,8 @@ typedef std::initializer_list<std::pair<int, std::pair<const void*, size_t>>> Bu
 struct ChainLink { ProgId id; BufList bufs; };
 // items up to which the middle of the final exponentiation runs as one chain: measured equal to seven launches up to 4096 pairings per call (2.371 against 2.374 ms;
 // twelve calls in flight 2.99 against 3.02 M pairings/s) and slower where a call runs as two halves on two streams (16,384: 6.53 against 6.28 ms), whose launches fill each other's tails
-static size_t chain_max() { static const size_t v = getenv("NBLS_CHAIN_MAX") ? (size_t)atol(getenv("NBLS_CHAIN_MAX")) : 8192; return v; }
-static bool chains_enabled() { static const bool on = !(getenv("NBLS_CHAIN") && atoi(getenv("NBLS_CHAIN")) == 0); return on; }
+static size_t chain_max() { static const size_t v = (size_t)env_long("NBLS_CHAIN_MAX", 8192); return v; }
+static bool chains_enabled() { static const bool on = env_long("NBLS_CHAIN", 1) != 0; return on; }
 static int run_chain(nbls_ctx* ctx, size_t n, std::initializer_list<ChainLink> links, hipStream_t s) {
   int r;
   bool fuse = chains_enabled() && !checked_mode() && links.size() <= (size_t)AOT_MAX_SEGS;
@@ -326,7 +327,7 @@ static inline BufArg B(int idx, const void* p, size_t stride) { return {idx, {p,
 // wavefront; csrc/vm_kernel.hip nbls_vm_kernel_ls4).  NBLS_LS_MAX overrides (0 = never).
 // lane-split programs (interpreter, one item per wavefront) for launches of up to this many items.  Round 4: 0 -- the ahead-of-time kernels are faster at every
 // size (1024 pairings 2.22 against 2.54 ms, one pairing likewise); NBLS_LS_MAX=1024 restores the round-3 behaviour
-static size_t ls_max() { static const size_t v = getenv("NBLS_LS_MAX") ? (size_t)atol(getenv("NBLS_LS_MAX")) : 0; return v; }
+static size_t ls_max() { static const size_t v = (size_t)env_long("NBLS_LS_MAX", 0); return v; }
 static ProgId ls_variant(ProgId id, size_t n) {
   if (n > ls_max()) return id;
   switch (id) {
@@ -533,7 +534,7 @@ static int pairing_core(nbls_ctx* ctx, size_t n, const void* d_g1, const void* d
   // wavefronts per SIMD deep takes the time of its longest instruction stream, so batches below 49,152 pairs keep the fused program (measured:
   // 4096 pairs 1.22 ms against 1.39 ms, 32,768 10.3 against 10.4 ms, 65,536 12.2 against 11.5 ms, 131,072 23.6 against 21.9 ms); with several
   // calls in flight the instruction count is what matters (pipeline.py sets the threshold to 0).  NBLS_FUSED_MILLER = 1 / 0 forces one or the other.
-  static const int fused_mode = getenv("NBLS_FUSED_MILLER") ? atoi(getenv("NBLS_FUSED_MILLER")) : -1;
+  static const int fused_mode = (int)env_long("NBLS_FUSED_MILLER", -1);
   const bool fused = fused_mode >= 0 ? fused_mode != 0 : (!two_programs && n < ctx->split_min);
   if (fused) {
     if (!with_final_exp) return run(ctx, ls_variant(P_MILLER_BYTES, n), n, {B(0, d_g1, 96), B(1, d_g2, 192), B(2, d_out, 576)}, s);
@@ -598,7 +599,7 @@ EXPORT int nbls_miller_product_dev(nbls_ctx* ctx, size_t n, const void* d_g1, co
   else {
     // pairs are taken two at a time with a shared accumulator (one Fp12 squaring per bit for both); an odd last pair runs alone
     const size_t n2 = n / 2; size_t m = n2 + (n & 1);
-    static const int fused_mode = getenv("NBLS_FUSED_MILLER") ? atoi(getenv("NBLS_FUSED_MILLER")) : -1;
+    static const int fused_mode = (int)env_long("NBLS_FUSED_MILLER", -1);
     const bool fused = fused_mode >= 0 ? fused_mode != 0 : n < ctx->split_min;
     if (fused && n <= 4096) {
       // up to one wavefront per SIMD (4 pairs per wavefront): the call takes the time of ONE wavefront's instruction stream whatever it computes, so every
@@ -768,7 +769,7 @@ EXPORT int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks) {
   std::lock_guard<std::recursive_mutex> g(ctx->mu); HIPCHK(hipSetDevice(ctx->device));
   int r = ensure_scratch(ctx, n); if (r) return r;
   if ((r = ensure_io(ctx, n))) return r;
-  const ProgId pid = getenv("NBLS_PROBE_MILLER") ? P_MILLER_FE : P_EXPX;   // NBLS_PROBE_MILLER: probe the (4x longer) Miller program instead
+  const ProgId pid = env_set("NBLS_PROBE_MILLER") ? P_MILLER_FE : P_EXPX;   // NBLS_PROBE_MILLER: probe the (4x longer) Miller program instead
   r = upload(ctx, pid); if (r) return r;
   const DevProgram& d = ctx->prog[pid];
   const size_t blocks = (n + d.p->G - 1) / d.p->G;
@@ -1413,7 +1414,7 @@ static int verify_stage(nbls_ctx* ctx, size_t n, const void* d_sig96, const void
   // contain a per-lane exponentiation kernel that fills the chip only two wavefronts deep and issues at half rate, so running
   // them side by side costs little more than the longer one.  Scratch slots 14..16 / 17 for the key chain (0..6 / 11 belong to the hash,
   // 7..9 / 12 hold the staged messages, keys and expand_message_xmd output of the host-buffer entry point).
-  static const bool overlap = !getenv("NBLS_VERIFY_NO_OVERLAP");
+  static const bool overlap = !env_set("NBLS_VERIFY_NO_OVERLAP");
   if (overlap) {
     if (!ctx->side2 && (hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming) != hipSuccess)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
     if (!ctx->ev_fork && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
@@ -1526,6 +1527,8 @@ EXPORT int nbls_miller_product_partial_into(nbls_ctx* ctx, size_t n, const uint8
   return miller_product_partial_core(ctx, n, g1, g2, validate, d_dst, nullptr, status);
 }
 EXPORT int nbls_abi_version(void) { return 2; }
+// every environment switch the library has read so far, with the value in force (config.h); the string lives until the next call on this thread
+EXPORT const char* nbls_config_describe(void) { static thread_local std::string s; s = env_describe(); return s.c_str(); }
 static int verify_batch_partial_core(nbls_ctx* ctx, size_t n, const uint8_t* sig96 /* or NULL */, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
                                      const uint8_t* dst, size_t dst_len, void* d_dst, void** d_partial, int* zero_flag, int8_t* pk_status) {
   std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);

@@ -8,6 +8,7 @@
 //   4  N  : raw Fp scratch, 48 B/item (norm to invert / its inverse)
 //   5  F' : second raw Fp12 scratch (product reduction output)
 #include "programs.h"
+#include "config.h"
 #include <mutex>
 #include "aot.h"
 #include "tower.h"
@@ -117,7 +118,7 @@ static void trace_lines(const SFp2& Qx, const SFp2& Qy, const LineSink& out) {
     SFp2 t0 = mat(sqr(Ry)), t2 = mat(scale(mulnr(sqr(D)), 3)), t4 = mat(mul(Ry, D)), c1 = mat(scale(sqr(Rx), 3)), rxry = mat(mul(Rx, Ry));
     SFp2 A = halve(t0 - scale(t2, 3)), Bh = halve(t0 + scale(t2, 3));
     SFp2 nRy;
-    static const bool two_squares = !getenv("NBLS_DBL_PLAIN");
+    static const bool two_squares = !env_set("NBLS_DBL_PLAIN");
     if (out.Px && two_squares) {
       // Ry' = B^2 - 3 t2^2 is a difference of two Fp2 squares: two limb products per coefficient (B^2: (b0 + b1)(b0 - b1), 2 b0 b1; 3 t2^2: (t0' + t1')(3 t0' - 3 t1'),
       // 2 t0' (3 t1') with the factor 3 carried by sums) where B^2 - t2 t3 costs three, so the second level is one full product round.  The three sums take the lanes that
@@ -218,7 +219,7 @@ static void load_points(SFp& Px, SFp& Py, SFp2& Qx, SFp2& Qy) {
 }
 
 // lanes per work item (instances per wave = 64 / W): an Fp12 lane-op step has 12 heavy lanes
-static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
+static int env_int(const char* name, int dflt) { return (int)env_long(name, dflt); }
 static const int MILLER_W = env_int("NBLS_MILLER_W", 16);
 // lanes per item of the point programs.  A G1 operation has at most ~4 independent field products per dependency level, so 4 lanes
 // per item take the same number of steps as 8 with twice the items per wavefront (G1 decode + subgroup check 5.6 -> 3.9 ms at

@@ -5,6 +5,7 @@
 // formulas are used so that pairing(P, Q, false) is bit-exact too.
 #pragma once
 #include "trace.h"
+#include "config.h"
 #include "consts_gen.h"
 
 namespace nbls {
@@ -76,7 +77,7 @@ static inline SFp12 mul(const SFp12& a, const SFp12& b) {         // math.ts:748
   SFp6 v = mul(sa, sb);
   // The middle product alone would be six lanes of six limb products (three rounds) beside six idle lanes: every coefficient is cut into two lane-ops of
   // three products on all twelve lanes (a round and a half), and the halves meet in the sum that forms c1 anyway (v - t1 - t2 becomes vl + vh - t1 - t2).
-  static const bool split_mid = !getenv("NBLS_MUL12_PLAIN");
+  static const bool split_mid = !env_set("NBLS_MUL12_PLAIN");
   if (split_mid) {
     // each half takes one of the subtracted terms as a post-subtraction of its lane-op (offset inside the accumulator), so the closing sum has two positive terms and needs no k p constant
     auto halves = [](const SFp& x, const SFp& s1, const SFp& s2) {
@@ -168,7 +169,7 @@ static inline SFp12 mul_fp(const SFp12& a, const SFp& k) {
 // squarings (EXPX: 42 -> 30 slots, twelve instead of ten wavefronts per CU); the loads cost five cheap steps
 template <class Reload>
 static inline SFp12 cyclotomic_exp_x(const SFp12& a, Reload reload) {
-  static const bool tripled = !getenv("NBLS_CYCSQR_PLAIN");   // A/B switch, read once per process (the old formulas: multiplier 3 in every squaring lane-op)
+  static const bool tripled = !env_set("NBLS_CYCSQR_PLAIN");   // A/B switch, read once per process (the old formulas: multiplier 3 in every squaring lane-op)
   if (!tripled) {
     SFp12 z = a;   // after bit 63
     for (int i = 62; i >= 0; i--) {

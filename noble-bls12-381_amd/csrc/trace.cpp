@@ -1,5 +1,6 @@
 // trace.cpp -- form materialisation, scheduler, slot allocator and descriptor emitter of the wave VM (see trace.h).
 #include "trace.h"
+#include "config.h"
 #include <cassert>
 #include <cmath>
 #include <queue>
@@ -92,7 +93,7 @@ int Builder::kp_atom(int k) {
   assert(k >= 1 && k <= 64);
   u32 P[NLIMBS] = NBLS_P_INIT, acc[NLIMBS] = {0};
   for (int i = 0; i < k; i++) { for (int j = 0; j < NLIMBS; j++) acc[j] += P[j]; carry_norm(acc); }
-  int id = const_atom(acc); nodes[id].bound = k; if (getenv("NBLS_DUMP_KP")) fprintf(stderr, "kp %d\n", k); return id;
+  int id = const_atom(acc); nodes[id].bound = k; if (env_set("NBLS_DUMP_KP")) fprintf(stderr, "kp %d\n", k); return id;
 }
 
 int Builder::contract(int atom) {
@@ -430,7 +431,7 @@ Program Builder::compile(const std::string& name, int W) {
           }
         }
         if (best >= (int)pr.size()) best = -1;
-        if (getenv("NBLS_NO_ALIGN")) { best = (int)i; best_swap = false; }
+        if (env_set("NBLS_NO_ALIGN")) { best = (int)i; best_swap = false; }
         if (best < 0) { for (size_t j = 0; j < pr.size(); j++) if (!used[j]) { best = (int)j; break; } best_swap = false; }
         DotProduct q = p;
         if (best_swap) { std::swap(q.a, q.b); std::swap(q.norm_a, q.norm_b); std::swap(q.neg0_a, q.neg0_b); }
@@ -451,9 +452,9 @@ Program Builder::compile(const std::string& name, int W) {
       }
     }
     for (size_t j = 0; j < mk; j++) { step_shapes[si].push_back({ua[j], ub[j]}); P.n_round_ops += 2; P.n_op_mode[(ua[j] & 8) ? 3 : (ua[j] & 3)]++; P.n_op_mode[(ub[j] & 8) ? 3 : (ub[j] & 3)]++; P.n_op_norm += ((ua[j] >> 2) & 1) + ((ub[j] >> 2) & 1); }
-    if (getenv("NBLS_DUMP_STEPS")) { fprintf(stderr, "%s dot step lanes=%zu k:", name.c_str(), L.size()); for (int c : L) fprintf(stderr, " %zu", nodes[c].prods.size()); fprintf(stderr, "\n"); }
-    if (getenv("NBLS_DUMP_NODES")) for (int c : L) { fprintf(stderr, "  node %d m=%d lin=%zu:", c, nodes[c].mult, nodes[c].lin.size()); for (auto& q : nodes[c].prods) fprintf(stderr, " (%d%s%d)x(%d%s%d)", q.a.s0, q.a.s1 < 0 ? "" : (q.a.n1 ? "-" : "+"), q.a.s1 < 0 ? 0 : q.a.s1, q.b.s0, q.b.s1 < 0 ? "" : (q.b.n1 ? "-" : "+"), q.b.s1 < 0 ? 0 : q.b.s1); fprintf(stderr, "\n"); }
-    if (getenv("NBLS_DUMP_FORMS")) { fprintf(stderr, "%s forms:", name.c_str()); for (size_t j = 0; j < mk; j++) fprintf(stderr, " %x/%x", ua[j], ub[j]); fprintf(stderr, "\n"); }
+    if (env_set("NBLS_DUMP_STEPS")) { fprintf(stderr, "%s dot step lanes=%zu k:", name.c_str(), L.size()); for (int c : L) fprintf(stderr, " %zu", nodes[c].prods.size()); fprintf(stderr, "\n"); }
+    if (env_set("NBLS_DUMP_NODES")) for (int c : L) { fprintf(stderr, "  node %d m=%d lin=%zu:", c, nodes[c].mult, nodes[c].lin.size()); for (auto& q : nodes[c].prods) fprintf(stderr, " (%d%s%d)x(%d%s%d)", q.a.s0, q.a.s1 < 0 ? "" : (q.a.n1 ? "-" : "+"), q.a.s1 < 0 ? 0 : q.a.s1, q.b.s0, q.b.s1 < 0 ? "" : (q.b.n1 ? "-" : "+"), q.b.s1 < 0 ? 0 : q.b.s1); fprintf(stderr, "\n"); }
+    if (env_set("NBLS_DUMP_FORMS")) { fprintf(stderr, "%s forms:", name.c_str()); for (size_t j = 0; j < mk; j++) fprintf(stderr, " %x/%x", ua[j], ub[j]); fprintf(stderr, "\n"); }
     // cost model of the step (VALU instructions per wavefront): rounds of 196 multiply-adds + 4 address additions + the shape work, one
     // reduction (196 + ~100), post-processing
     double est = 60 + 196 + 100;
@@ -493,13 +494,13 @@ Program Builder::compile(const std::string& name, int W) {
   P.slot_bytes = 64;
   // constants: a copy per instance (operand address = base + offset) unless that costs real LDS: with 8 or 16 instances per wavefront the copies
   // of a dozen constants are 5-10 KB and push the point programs from 8 to 6 wavefronts per CU; those keep one shared copy, marked by bit 1
-  P.shared_consts = getenv("NBLS_SHARED_CONSTS") ? atoi(getenv("NBLS_SHARED_CONSTS")) != 0 : shared_consts >= 0 ? shared_consts != 0 : P.G >= 8;
+  P.shared_consts = env_long("NBLS_SHARED_CONSTS", -1) >= 0 ? env_long("NBLS_SHARED_CONSTS", -1) != 0 : shared_consts >= 0 ? shared_consts != 0 : P.G >= 8;
   {   // slot stride: 80 bytes where the larger image still leaves room for twelve workgroups per CU (three wavefronts per SIMD is what the register budget
       // allows anyway); NBLS_SLOT_BYTES = 64 / 80 forces one or the other
-    const char* e = getenv("NBLS_SLOT_BYTES");
+    const long e = env_long("NBLS_SLOT_BYTES", 0);
     P.slot_bytes = 80;
     const bool fits = P.lds_bytes() <= (160u * 1024u) / 12u;
-    P.slot_bytes = e ? (atoi(e) == 80 ? 80 : 64) : (fits ? 80 : 64);
+    P.slot_bytes = e ? (e == 80 ? 80 : 64) : (fits ? 80 : 64);
   }
   assert(P.lds_bytes() < 65536 * 2 && P.inst_bytes() < 32768);
   // 6. emit
@@ -601,11 +602,11 @@ Program Builder::compile(const std::string& name, int W) {
       }
       P.descs.insert(P.descs.end(), w.begin(), w.end());
     }
-    if (getenv("NBLS_DUMP_SEQ")) fprintf(stderr, "%s step %zu kind=%d lanes=%d p0=%d p1=%d lin=0x%x\n", name.c_str(), s, st.kind, st.nlanes, st.p0, st.p1, st.lin);
+    if (env_set("NBLS_DUMP_SEQ")) fprintf(stderr, "%s step %zu kind=%d lanes=%d p0=%d p1=%d lin=0x%x\n", name.c_str(), s, st.kind, st.nlanes, st.p0, st.p1, st.lin);
     P.steps.push_back(st);
   }
   P.consts = const_words;
-  if (getenv("NBLS_DUMP_CONTRACT")) { int nc = 0, nw = 0; for (auto& kv : contract_cache) if (nodes[kv.second].live) nc++; for (auto& n : nodes) if (n.live && n.wred) nw++; fprintf(stderr, "%s: %d live contraction lane-ops, %d weak reductions\n", name.c_str(), nc, nw); }
+  if (env_set("NBLS_DUMP_CONTRACT")) { int nc = 0, nw = 0; for (auto& kv : contract_cache) if (nodes[kv.second].live) nc++; for (auto& n : nodes) if (n.live && n.wred) nw++; fprintf(stderr, "%s: %d live contraction lane-ops, %d weak reductions\n", name.c_str(), nc, nw); }
   return P;
 }
 

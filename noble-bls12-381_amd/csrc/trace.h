@@ -12,6 +12,7 @@
 // steps: an Fp12 coefficient is produced directly from the operand slots.  Every atom is kept in [0, 2p).
 #pragma once
 #include <algorithm>
+#include "config.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -93,12 +94,12 @@ struct Builder {
   int max_dot = MAX_DOT_PRODUCTS;   // products per lane-op: a lower cap splits heavy lane-ops (first chunk, then the rest + the first as a post-added term) so that the few heaviest lanes do not set the length of a step
   int light_max = 2;     // lane-ops with at most this many products form the "light" class of the scheduler (they ride in the free lanes of heavy steps; MAX_DOT_PRODUCTS = one class)
   double neg_cap = 6.0;  // negated linear terms above this bound are contracted first (their bound is paid as a +k p offset)
-  bool use_wred = getenv("NBLS_NO_WRED") == nullptr;   // large post-added terms: weak reduction (table of multiples of p) instead of folding them into the dot product
+  bool use_wred = !env_set("NBLS_NO_WRED");   // large post-added terms: weak reduction (table of multiples of p) instead of folding them into the dot product
   int store_batch = 0;   // > 0: a store step is issued as soon as this many stores are ready (programs that stream results out: the values do not linger in LDS)
   int lane_split = 1;    // see Program::lsplit (compile(name, W) takes the LOGICAL lanes per item; the program runs on W * lane_split)
   int shared_consts = -1;   // -1: one shared copy of the constants for programs with eight or more items per wavefront (compile()); 0 / 1: replicated / shared
   int sched_window = 0;  // scheduler look-ahead limit in critical-path units (0 = unlimited), see compile()
-  bool prefer_doubling = !(getenv("NBLS_PREFER_DBL") && atoi(getenv("NBLS_PREFER_DBL")) == 0);   // materialize(): integer factors of a lane-op's products as doubled operands rather than a multiplier on the reduced sum
+  bool prefer_doubling = env_long("NBLS_PREFER_DBL", 1) != 0;   // materialize(): integer factors of a lane-op's products as doubled operands rather than a multiplier on the reduced sum
   static Builder*& cur() { static thread_local Builder* b = nullptr; return b; }
   Builder();
   ~Builder() { if (cur() == this) cur() = nullptr; }

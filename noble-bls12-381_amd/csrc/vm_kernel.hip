@@ -7,6 +7,7 @@
 // juggling -- a round is: four address additions, the LDS reads, the limb-wise combine the round's shape asks for, 196
 // multiply-adds.  Per-lane data (LDS byte offsets) comes from the lane descriptors, fetched one round / one step ahead.
 #include <hip/hip_runtime.h>
+#include "config.h"
 #include <cstdlib>
 #include <atomic>
 #include <mutex>
@@ -165,13 +166,13 @@ extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, vo
       }
     }
   }
-  static const unsigned lds_floor = getenv("NBLS_LDS_FLOOR") ? (unsigned)atoi(getenv("NBLS_LDS_FLOOR")) : 0u;   // placement studies: caps workgroups per CU at 160 KB / floor
+  static const unsigned lds_floor = (unsigned)env_long("NBLS_LDS_FLOOR", 0);   // placement studies: caps workgroups per CU at 160 KB / floor
   if (lds_bytes < lds_floor) lds_bytes = lds_floor;
   if (ka->lsplit == 4) {
     if (ka->shared_consts) return -1;   // lane-split programs are compiled with replicated constants only
     hipLaunchKernelGGL(nbls_vm_kernel_ls4, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, *ka);
   } else {
-    static const int fair_mode = getenv("NBLS_FAIR") ? atoi(getenv("NBLS_FAIR")) : -1;   // 0 never, 1 always, unset: launches of 2..4 wavefronts per SIMD
+    static const int fair_mode = (int)env_long("NBLS_FAIR", -1);   // 0 never, 1 always, unset: launches of 2..4 wavefronts per SIMD
     const bool fair = fair_mode >= 0 ? fair_mode != 0 : (blocks > 1024 && blocks <= 4096);
     if (ka->shared_consts) {
       if (fair) hipLaunchKernelGGL(nbls_vm_kernel_fair_sc, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, *ka);

@@ -26,6 +26,7 @@ def load_library():
         raise NblsError('libnbls.so is not built (run __graft_entry__.build() or make -C noble-bls12-381_amd/csrc)')
     lib = C.CDLL(p)
     lib.nbls_strerror.restype = C.c_char_p
+    lib.nbls_config_describe.restype = C.c_char_p
     vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
     lib.nbls_init.argtypes = [i32, C.POINTER(vp)]
     lib.nbls_destroy.argtypes = [vp]
@@ -385,6 +386,10 @@ class Engine:
         args = [C.c_char_p(x) if x is not None else None for x in (a, b, c, d)]
         self._chk(self.lib.nbls_tower_op_batch(self.h, C.c_int(field), C.c_int(op), C.c_int(param), C.c_size_t(n), args[0], args[1], args[2], args[3], out))
         return out.raw
+
+    def config_describe(self):
+        """the environment switches the library has read so far, with the values in force"""
+        return self.lib.nbls_config_describe().decode()
 
     def timing_read(self):
         """-> {kernel name: (total ms, launches)} since timing_enable(True)"""
