@@ -102,7 +102,7 @@ def main():
 
     # the HIP runtime maps streams onto this many hardware queues (default 4): with fewer queues than batches in flight two
     # streams share a queue and their kernels serialise (must be set before the runtime initialises)
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '32')     # one hardware queue per stream in flight (round 4: 32; with 16 queues twenty streams share and lose 2 %, tools/ab_depth.sh)
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -134,9 +134,10 @@ def main():
     oracle = oracle_py.load(rebuild=not os.path.exists(os.path.join(ROOT, 'oracle', 'libnbls_oracle.so')))
     D = max(1, args.inflight if args.inflight is not None else 12)
     if args.inflight is None and args.steps < 4 * D and D > 8:   # an explicit --inflight is taken as given
-        # few timed steps (the driver's --steps 20): every stream should carry the same number of batches, or the streams with one batch more
-        # finish alone -- take the depth in 8..D that leaves the smallest remainder (20 steps: 10 streams x 2 batches; measured 2.49 M/s against 2.47 M/s at 12)
-        D = min(range(8, D + 1), key=lambda d: ((-args.steps) % d, -d))
+        # few timed steps (the driver's --steps 20): every stream should carry the same number of batches, or the streams with one batch more finish alone -- and streams
+        # that carry several batches run phase-locked, i.e. like that many large batches one after the other with every phase's tail exposed: take the depth in 8..20 that
+        # leaves the smallest remainder, the larger the better (20 steps: 20 streams x 1 batch, 2.86 M/s against 2.79 M/s for 10 x 2; tools/ab_depth.sh)
+        D = min(range(8, 21), key=lambda d: ((-args.steps) % d, -d))
     pipe = pkg.PairingPipeline(local_rank, D)     # D engine contexts, each with its own stream and scratch (noble-bls12-381_amd/pipeline.py)
     eng = pipe.engines[0]
 

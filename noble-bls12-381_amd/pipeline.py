@@ -6,7 +6,9 @@ idle.  Consecutive batches are independent, so a service keeps several of them i
 beside those of batch i on other streams.  Throughput at 4096-pairing batches rises from 1.3 M (one call at a time, 3.1 ms each) to 2.5 M pairings/s with seven to twenty batches in
 flight (bench.py; 2.15 M with four, 2.31 M with five, 2.42 M with six, 2.47 M with seven, 2.52 M with ten or twelve, 2.55 M with fourteen).  The HIP runtime
 multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue serialise (eight batches on eight queues: 2.22 M, on
-sixteen queues: 2.50 M), so set GPU_MAX_HW_QUEUES=16 in the environment before the runtime initialises when more than three batches are kept in flight.
+sixteen queues: 2.50 M), so set GPU_MAX_HW_QUEUES to at least the number of streams (bench.py: 32) in the environment before the runtime initialises when more than three batches are
+kept in flight.  Round 4: 3.10 M pairings/s with twelve batches in flight; streams that carry several batches each run phase-locked (like that many large batches one after the other), so a short
+burst of k batches is fastest on k streams (20 batches: 2.86 M on twenty streams, 2.79 M on ten).
 """
 from .engine import Engine
 
