@@ -61,6 +61,12 @@
   X(7, g1_clear, P_G1_CLEAR, P_COUNT, P_COUNT, P_COUNT)                      \
   X(7, enc2, P_ENC2_A, P_ENC2_B, P_COUNT, P_COUNT)
 
+// Lane-split kernels (latency form for launches of at most one wavefront per SIMD): ONE item per wavefront, every K_DOT lane-op spread over four adjacent
+// lanes that each accumulate a share of its products; the 28 columns are summed across the four lanes (two DPP stages) before the one reduction on the first of them.
+#define NBLS_AOT_LS_KERNELS(X)                                                              \
+  X(7, expx_ls, P_EXPX_LS, P_COUNT, P_COUNT, P_COUNT)                                      \
+  X(3, miller_ls, P_MILLER_FE_LS, P_MILLER_RAW_LS, P_MILLER_BYTES_LS, P_COUNT)
+
 namespace nbls {
 
 // K_DOT flags of a signature

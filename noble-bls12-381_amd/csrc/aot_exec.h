@@ -162,13 +162,13 @@ NBLS_HD void aot_io(LDSP lds, const u32 w0, const u32 off, const u32 item, const
 // middle columns ever need it: ~21 column compressions per Fp12 squaring step.
 struct AotCompressPlan { u32 before[MAX_DOT_PRODUCTS + 1]; };
 constexpr u32 aot_shape_units(u32 mode) { return (mode == 1u || mode == 3u) ? 2u : 1u; }
-constexpr AotCompressPlan aot_compress_plan(u32 P0, u32 SH0, u32 SH1) {
+constexpr AotCompressPlan aot_compress_plan(u32 P0, u32 SH0, u32 SH1, u32 S = 1) {   // S: lane split -- the columns of S sub-lanes are summed before the reduction, so a round counts S times
   AotCompressPlan pl = {};
   u32 B[2 * NL] = {};
   const u32 LIMIT = 113;
   for (u32 r = 0; r < P0 && r < (u32)MAX_DOT_PRODUCTS; r++) {
     const u32 shape = ((r < 4 ? SH0 : SH1) >> (8 * (r & 3))) & 0xffu;
-    const u32 add = aot_shape_units(shape & 3u) * aot_shape_units((shape >> SH_B_SHIFT) & 3u);
+    const u32 add = S * aot_shape_units(shape & 3u) * aot_shape_units((shape >> SH_B_SHIFT) & 3u);
     u32 mask = 0;
     for (u32 k = 0; k < 2 * NL - 1; k++) { const u32 terms = k < (u32)NL ? k + 1 : 2 * NL - 1 - k; if (B[k] + terms * add > LIMIT) mask |= 1u << k; }
     for (u32 k = 0; k < 2 * NL - 1; k++) if (mask & (1u << k)) { B[k + 1] += 1; B[k] = 1; }
@@ -190,6 +190,22 @@ NBLS_HD void aot_compress_columns(u64* acc) {
   }
 }
 
+// Lane split: sum of the 28 column accumulators over the four adjacent lanes of a lane-op, result in the first of them.  Two DPP stages (lane i += lane i + 1, then
+// lane i += lane i + 2, inside rows of 16 lanes; groups of four never straddle a row).  Device only: the simulator runs lane-split programs on the interpreter's semantics.
+NBLS_HD void aot_acc_sum4(u64* acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int c = 0; c < 2 * NL - 1; c++) {
+    u64 v = acc[c];
+    v += ((u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x101, 0xf, 0xf, true) << 32) | (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x101, 0xf, 0xf, true);   // row_shl:1
+    v += ((u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x102, 0xf, 0xf, true) << 32) | (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x102, 0xf, 0xf, true);   // row_shl:2
+    acc[c] = v;
+  }
+#else
+  (void)acc;
+#endif
+}
+
 // The columns are made opaque between product rounds: the optimiser would otherwise re-associate every column's sum over ALL rounds of an unrolled body
 // (every round's operands live at once: 330-480 registers); the scheduling barrier keeps the LDS reads of later rounds from being hoisted to the top.
 NBLS_HD void aot_round_fence(u64* acc) {
@@ -206,7 +222,7 @@ NBLS_HD u32 aot_word(const V4& q, u32 i) { return i == 0 ? q.x : i == 1 ? q.y : 
 // One step of a translated program for one lane.  `D::quad(i)` returns 16-byte word i of the lane's descriptor (device: the first three were fetched a step
 // ahead, the others are loaded here, a round ahead of their use); `commit(dst, limbs)` stores a result (device: at once -- LDS operations of a wavefront execute in
 // order, so every read of the step precedes it; simulator: after all lanes of the step).
-template <u32 KIND, u32 P0, u32 FLAGS, u32 T, u32 SH0, u32 SH1, typename D, typename LDSP, typename Commit>
+template <u32 KIND, u32 P0, u32 FLAGS, u32 T, u32 SH0, u32 SH1, u32 LS = 1, typename D = void, typename LDSP = char*, typename Commit = void>
 NBLS_HD void aot_step(const D& desc, LDSP lds, const u32 item, const bool live, const IOBuf* bufs, const u32* __restrict__ qp_table, Commit&& commit) {
   if constexpr (KIND == K_DOT) {
     const u32 HQ = (AOT_DOT_HDR + T + 3) / 4;
@@ -222,7 +238,7 @@ NBLS_HD void aot_step(const D& desc, LDSP lds, const u32 item, const bool live, 
     auto do_round = [&](auto RC) __attribute__((always_inline)) {
       constexpr u32 r = decltype(RC)::value;
       constexpr bool budget = aot_has_norm(SH0, SH1);   // signatures without normalised operands keep the host compiler's own budget (sum of ca * cb <= 8)
-      constexpr u32 cmask = budget ? aot_compress_plan(P0, SH0, SH1).before[r] : 0u;
+      constexpr u32 cmask = budget ? aot_compress_plan(P0, SH0, SH1, LS).before[r] : 0u;
       V4 nx = cur;
       if (r + 1 < P0) nx = desc.quad(HQ + r + 1);
       constexpr u32 shape = ((r < 4 ? SH0 : SH1) >> (8 * (r & 3))) & 0xffu;
@@ -250,6 +266,7 @@ NBLS_HD void aot_step(const D& desc, LDSP lds, const u32 item, const bool live, 
     if constexpr (P0 > 5) do_round(std::integral_constant<u32, 5>{});
     if constexpr (P0 > 6) do_round(std::integral_constant<u32, 6>{});
     if constexpr (P0 > 7) do_round(std::integral_constant<u32, 7>{});
+    if constexpr (LS > 1) aot_acc_sum4(acc);   // lane split: the columns of the four sub-lanes land in the first one (the others finish into the junk slot)
     u32 res[NL];
     aot_dot_finish<FLAGS, T>(res, acc, h0.x, post, lds);
     commit(h0.x & 0xffffu, res);

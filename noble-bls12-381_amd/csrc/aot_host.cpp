@@ -8,7 +8,8 @@ namespace nbls {
 
 std::string aot_translate(const Program& p, AotProgram& out) {
   out = AotProgram();
-  if (p.lsplit != 1) return p.name + ": lane-split programs run on the interpreter";
+  const u32 S = p.lsplit;   // lane split: a K_DOT lane-op has one descriptor per sub-lane (index = the physical lane), every other kind one per logical lane, executed by sub-lane 0
+  if (S != 1 && S != 4) return p.name + ": lane split " + std::to_string(S) + " has no ahead-of-time body";
   if (p.lds_bytes() + 64 > 65536) return p.name + ": LDS image above 64 KB (16-bit address fields)";
   const u32 junk = p.lds_bytes();             // one slot behind the image: destination of idle lanes
   out.lds_bytes = p.lds_bytes() + 64;
@@ -23,14 +24,21 @@ std::string aot_translate(const Program& p, AotProgram& out) {
     AotSig sg{st.kind, 0, 0, 0, 0, 0};
     std::vector<std::vector<u32>> lane_words(64);
     auto old_desc = [&](u32 lane_in) { return p.descs.data() + st.desc_off + (size_t)lane_in * st.stride; };
-    auto active = [&](u32 lane, u32& g, u32& li) { g = lane / p.W; li = lane - g * p.W; return g < p.G && li < st.nlanes; };
+    // li: index of the lane's descriptor in the compiled program; sub: its sub-lane (0 when the program is not split)
+    auto active = [&](u32 lane, u32& g, u32& li) {
+      g = lane / p.W; const u32 phys = lane - g * p.W;
+      if (g >= p.G) return false;
+      if (st.kind == K_DOT) { li = phys; return phys < (u32)st.nlanes * S; }
+      li = phys / S; return phys % S == 0 && li < st.nlanes;
+    };
     switch (st.kind) {
       case K_DOT: {
         const u32 nadd = st.lin & 7, nsub = (st.lin >> 4) & 7;
         // merged post-added terms of every lane-op: slot -> coefficient
-        std::vector<std::vector<std::pair<u32, int>>> post(st.nlanes);
+        const u32 ndesc = (u32)st.nlanes * S;
+        std::vector<std::vector<std::pair<u32, int>>> post(ndesc);
         u32 T = 0, flags = 0;
-        for (u32 li = 0; li < st.nlanes; li++) {
+        for (u32 li = 0; li < ndesc; li += S) {   // sub-lane 0 of every lane-op carries its destination, multiplier, bias and post-added terms
           const u32* d = old_desc(li);
           std::map<u32, int> m;
           for (u32 t = 0; t < nadd + nsub; t++) { const u32 f = (d[4 + t / 2] >> (16 * (t & 1))) & 0xffffu; if (f != 0) m[f] += t < nadd ? 1 : -1; }
@@ -51,6 +59,11 @@ std::string aot_translate(const Program& p, AotProgram& out) {
           if (!active(lane, g, li)) { w[0] = junk; w[1] = 0; for (u32 t = 0; t < T; t++) w[AOT_DOT_HDR + t] = zero; continue; }
           const u32* d = old_desc(li);
           const u32 mult = (d[0] >> 16) & 7;
+          if (li % S) {   // sub-lanes 1 .. S-1: products only; the columns are summed into sub-lane 0, which finishes the lane-op
+            w[0] = junk; w[1] = d[1];
+            for (u32 r = 0; r < st.p0; r++) for (u32 q = 0; q < 4; q++) w[HW + 4 * r + q] = abs_addr(d[DOT_HDR_WORDS + DOT_ROUND_WORDS * r + q], g);
+            continue;
+          }
           w[0] = abs_addr(d[0], g) | ((mult >> 1) << 16) | ((mult == 3 ? 1u : 0u) << 18) | (d[0] & (1u << 19)) | (d[0] & (0xfu << 20));
           w[1] = d[1];
           for (u32 t = 0; t < T; t++) w[AOT_DOT_HDR + t] = t < post[li].size() ? (abs_addr(post[li][t].first, g) | ((u32)(post[li][t].second & 0xffff) << 16)) : zero;

@@ -323,11 +323,10 @@ static inline BufArg B(int idx, const void* p, size_t stride) { return {idx, {p,
 
 // F (n raw Fp12) -> one element in F[0] (or F2[0]); returns pointer to the buffer holding the product
 // Launches of at most one wavefront per SIMD take the time of one wavefront's instruction stream, so up to LS_MAX items (one item per wavefront
-// on 1024 SIMDs) the lane-split variants run: the same formulas with every lane-op's products shared by four lanes (a third fewer instructions per
-// wavefront; csrc/vm_kernel.hip nbls_vm_kernel_ls4).  NBLS_LS_MAX overrides (0 = never).
-// lane-split programs (interpreter, one item per wavefront) for launches of up to this many items.  Round 4: 0 -- the ahead-of-time kernels are faster at every
-// size (1024 pairings 2.22 against 2.54 ms, one pairing likewise); NBLS_LS_MAX=1024 restores the round-3 behaviour
-static size_t ls_max() { static const size_t v = (size_t)env_long("NBLS_LS_MAX", 0); return v; }
+// on 1024 SIMDs) the lane-split variants run: the same formulas with every lane-op's products shared by four lanes, the columns summed across them before the one
+// reduction (ahead-of-time kernels nbls_aot_miller_ls / nbls_aot_expx_ls, aot.h NBLS_AOT_LS_KERNELS; on the interpreter nbls_vm_kernel_ls4).  Measured
+// (tools/ab_ls.sh): one pairing 1.72 against 2.09 ms, 1024 pairings 1.79 against 2.12 ms.  NBLS_LS_MAX overrides (0 = the throughput forms at every size).
+static size_t ls_max() { static const size_t v = (size_t)env_long("NBLS_LS_MAX", 1024); return v; }
 static ProgId ls_variant(ProgId id, size_t n) {
   if (n > ls_max()) return id;
   switch (id) {

@@ -153,7 +153,7 @@ def test_batch_131072_properties(eng, oracle):
 
 @pytest.mark.parametrize('ls_max', ['0', '1024'])
 def test_plain_and_lane_split_programs(ls_max):
-    """Launches of at most 1024 items run the lane-split programs (nbls_vm_kernel_ls4: every K_DOT lane-op on four adjacent lanes, columns summed by DPP); NBLS_LS_MAX=0
+    """Launches of at most 1024 items run the lane-split programs (ahead-of-time kernels nbls_aot_miller_ls / nbls_aot_expx_ls, interpreter nbls_vm_kernel_ls4: every K_DOT lane-op on four adjacent lanes, columns summed by DPP); NBLS_LS_MAX=0
     keeps the plain programs for them.  Both in turn over the whole pipeline: pairings at several batch sizes against the oracle, a Miller product and a verifyBatch.
     NBLS_LS_MAX is read once per process, hence the subprocess."""
     import subprocess, sys, textwrap

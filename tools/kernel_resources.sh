@@ -2,8 +2,10 @@
 # VGPR / SGPR / spill / LDS figures of every kernel of libnbls.so, read from the code-object metadata the compiler emits (hipcc -S of each .hip file with the
 # flags of csrc/Makefile) -- no GPU needed.  Usage: tools/kernel_resources.sh | grep -v rocprim > profiles/round3_kernel_resources.txt   (the hipCUB sort kernels of the MSM are left out)
 cd "$(dirname "$0")/../noble-bls12-381_amd/csrc"
-for f in vm_kernel.hip aot_kernel.hip pow_kernels.hip xmd_kernel.hip msm_kernels.hip; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -align-all-nofallthru-blocks=6 -I../../include -S --cuda-device-only -o /tmp/kres_$$.s $f 2>/dev/null
+# aot_kernel.hip is compiled once per part (aot.h NBLS_AOT_PARTS; Makefile -DNBLS_AOT_PART=i)
+for f in vm_kernel.hip aot_kernel.hip:0 aot_kernel.hip:1 aot_kernel.hip:2 aot_kernel.hip:3 aot_kernel.hip:4 aot_kernel.hip:5 aot_kernel.hip:6 aot_kernel.hip:7 pow_kernels.hip xmd_kernel.hip msm_kernels.hip; do
+  part=${f#*:}; [ "$part" = "$f" ] && part=0; f=${f%%:*}
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -align-all-nofallthru-blocks=6 -I../../include -DNBLS_AOT_PART=$part -S --cuda-device-only -o /tmp/kres_$$.s $f 2>/dev/null
   python3 - /tmp/kres_$$.s $f <<'PY'
 import re, sys
 txt = open(sys.argv[1]).read()
