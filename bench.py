@@ -102,7 +102,11 @@ def main():
 
     # the HIP runtime maps streams onto this many hardware queues (default 4): with fewer queues than batches in flight two
     # streams share a queue and their kernels serialise (must be set before the runtime initialises)
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', '32')     # one hardware queue per stream in flight (round 4: 32; with 16 queues twenty streams share and lose 2 %, tools/ab_depth.sh)
+    # One hardware queue per stream in flight (up to twenty, see D below) and no more than 22 in all: from ~24 user queues the process oversubscribes the device's hardware queue
+    # slots, and the legs that create further streams after the in-flight contexts (verifyBatch, sign) then pay a queue switch per launch -- with 32: verifyBatch 29.6 instead of
+    # 23.4 ms, one verify 7.7 instead of 3.7 ms, sign 17.4 instead of 6.3 ms; with 20 the twenty streams share with the default stream and lose 4 % (tools/ab_queues20.sh,
+    # profiles/round4_ab_queues20.txt).
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '22')
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -187,6 +191,7 @@ def main():
         dt = float(t.item())
     # strictly serial figure (one batch at a time on one stream) = per-batch latency, this rank
     torch.cuda.synchronize()
+    eng.set_chain_max(8192)             # ... and the chained final exponentiation (6 launches per call; the in-flight contexts run it as seven launches, pipeline.py)
     eng.set_split_miller_min(4096)      # the single-call legs use the library's default choice of Miller programs (SPLIT_MILLER_MIN in csrc/nbls_api.cpp; the in-flight contexts were set to 0)
     serial_steps = max(8, min(args.steps, 320))
     s0 = time.perf_counter()

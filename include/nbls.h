@@ -245,6 +245,8 @@ int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks);
 #define NBLS_TUNE_HALVES_MIN 2         /* pairs from which nbls_pairing_batch_dev runs a batch as two halves on two streams (default 8192; 0 = never) */
 #define NBLS_TUNE_EXPC_MIN 3           /* items from which the cyclotomic exponentiations of the final exponentiation use Karabina's compressed squarings
                                           (default: never -- 15 % fewer instructions but no faster as measured, see csrc/nbls_api.cpp expx; 0 = always) */
+#define NBLS_TUNE_CHAIN_MAX 4          /* items below which EXPX, FE_MID1, EXPX x 3, FE_MID2, EXPX of a final exponentiation are ONE launch (default 8192; 0 = seven launches:
+                                          what a caller that keeps several calls in flight on other contexts wants, csrc/nbls_api.cpp run_chain) */
 int nbls_set_tuning(nbls_ctx* ctx, int key, long long value);
 int nbls_program_count(void);                 /* number of step programs; timing slot nbls_program_count() = the inversion kernel */
 const char* nbls_program_name(int prog);

@@ -80,6 +80,7 @@ struct nbls_ctx {
   // cyclotomic exponentiation with compressed squarings (expx): scratch per item -- compressed powers, decompression scratch, redo flags and list -- and two redo counters (one per half)
   uint8_t *KS = nullptr, *KD = nullptr, *Kflag = nullptr; uint32_t *Klist = nullptr, *Kcount = nullptr;
   size_t expc_min = (size_t)env_long("NBLS_EXPC_MIN", (long)EXPC_MIN_DEFAULT);   // nbls_set_tuning(NBLS_TUNE_EXPC_MIN)
+  size_t chain_max = (size_t)env_long("NBLS_CHAIN_MAX", 8192);                  // nbls_set_tuning(NBLS_TUNE_CHAIN_MAX); see run_chain
   u32* qp_table = nullptr;      // multiples of p for the weak reduction (vm_exec.h weak_reduce), device copy
   uint8_t* unit_lines = nullptr;   // a line table whose 68 lines are all 1 (c0 = 1, c1 = c2 = 0): the neutral partner of an odd last pair
   uint8_t* partial = nullptr;   // 576 bytes: the Fp12 partial of the *_partial entry points (multi-GPU reductions)
@@ -206,9 +207,11 @@ static int run_inv(nbls_ctx* ctx, size_t n, hipStream_t s) {
 // when the programs do not share a kernel / the lanes per item, or in checked mode (whose per-launch buffer checks live in run()).
 typedef std::initializer_list<std::pair<int, std::pair<const void*, size_t>>> BufList;
 struct ChainLink { ProgId id; BufList bufs; };
-// items up to which the middle of the final exponentiation runs as one chain: measured equal to seven launches up to 4096 pairings per call (2.371 against 2.374 ms;
-// twelve calls in flight 2.99 against 3.02 M pairings/s) and slower where a call runs as two halves on two streams (16,384: 6.53 against 6.28 ms), whose launches fill each other's tails
-static size_t chain_max() { static const size_t v = (size_t)env_long("NBLS_CHAIN_MAX", 8192); return v; }
+// ctx->chain_max: items up to which the middle of the final exponentiation runs as one chain (default 8192, NBLS_CHAIN_MAX / NBLS_TUNE_CHAIN_MAX): measured equal to seven
+// launches up to 4096 pairings per call (2.371 against 2.374 ms), slower where a call runs as two halves on two streams (16,384: 6.53 against 6.28 ms), whose launches fill each
+// other's tails -- and slower with calls in flight on other streams for the same reason: a chained wavefront is 427 k instructions long, so the rounds of wavefronts at the end of a
+// burst are coarse (twenty 4096-pairing calls on twenty streams 2.82 against 2.85 M pairings/s, 512 calls twelve deep 3.05 against 3.08 M; tools/ab_chain20.sh).  PairingPipeline
+// (pipeline.py) therefore sets it to 0 for its contexts.
 static bool chains_enabled() { static const bool on = env_long("NBLS_CHAIN", 1) != 0; return on; }
 static int run_chain(nbls_ctx* ctx, size_t n, std::initializer_list<ChainLink> links, hipStream_t s) {
   int r;
@@ -379,7 +382,7 @@ static int final_exp_pipeline(nbls_ctx* ctx, size_t n, uint8_t* f_raw, void* d_o
   uint8_t** T = ctx->T;
   if ((r = run_inv(ctx, n, s))) return r;
   if ((r = run(ctx, P_FE_EASY, n, {B(3, f_raw, F12), B(4, ctx->NI, RAW), B(5, T[0], F12)}, s))) return r;
-  if (n < ctx->expc_min && n < chain_max() && ls_variant(P_EXPX, n) == P_EXPX) {
+  if (n < ctx->expc_min && n < ctx->chain_max && ls_variant(P_EXPX, n) == P_EXPX) {
     // the seven launches between the easy part and the final product as one chain (math.ts:862-867): t2 = t1^x, t3 = conj(t1^2) t2, t4 = t3^x, t5 = t4^x,
     // t6' = t5^x, t6 = t6' t2^2, t7 = t6^x
     if ((r = run_chain(ctx, n, {{P_EXPX, {B(3, T[0], F12), B(5, T[1], F12)}},
@@ -980,6 +983,7 @@ EXPORT int nbls_set_tuning(nbls_ctx* ctx, int key, long long value) {
     case NBLS_TUNE_SPLIT_MILLER_MIN: if (value < 0) return NBLS_EINVAL; ctx->split_min = (size_t)value; return NBLS_OK;
     case NBLS_TUNE_HALVES_MIN: if (value < 0) return NBLS_EINVAL; ctx->halves_min = value == 0 ? (size_t)-1 : (size_t)value; return NBLS_OK;
     case NBLS_TUNE_EXPC_MIN: if (value < 0) return NBLS_EINVAL; ctx->expc_min = (size_t)value; return NBLS_OK;
+    case NBLS_TUNE_CHAIN_MAX: if (value < 0) return NBLS_EINVAL; ctx->chain_max = (size_t)value; return NBLS_OK;
     default: return NBLS_EINVAL;
   }
 }

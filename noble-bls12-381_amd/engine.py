@@ -363,6 +363,10 @@ class Engine:
         """pairs from which pairing_batch_dev runs a batch as two halves on two streams (default 8192; 0: never)"""
         self._chk(self.lib.nbls_set_tuning(self.h, 2, n))
 
+    def set_chain_max(self, n):
+        """items below which the middle of the final exponentiation is one chained launch (NBLS_TUNE_CHAIN_MAX; default 8192, 0: one launch per program)"""
+        self._chk(self.lib.nbls_set_tuning(self.h, 4, n))
+
     def synchronize(self):
         self._chk(self.lib.nbls_device_synchronize(self.h))
 

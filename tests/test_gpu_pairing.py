@@ -224,6 +224,29 @@ def test_two_halves_execution(oracle, golden):
     eng.set_halves_min(8192)
 
 
+def test_chained_and_separate_final_exponentiation(oracle, golden):
+    """The middle of the final exponentiation (EXPX, FE_MID1, EXPX x 3, FE_MID2, EXPX; math.ts:862-867) is one chained launch below NBLS_TUNE_CHAIN_MAX items and seven launches
+    otherwise (what PairingPipeline's contexts use): same bytes either way, equal to the oracle's; sizes above the lane-split range (1024), with a partly filled last wavefront."""
+    pkg = importlib.import_module('noble-bls12-381_amd')
+    eng = pkg.Engine(0)
+    pairs = golden['pairs']
+    for n in (1027, 2050):
+        g1 = b''.join(hx(pairs[(5 * i + 2) % len(pairs)]['g1']) for i in range(n)); g2 = b''.join(hx(pairs[(3 * i + n) % len(pairs)]['g2']) for i in range(n))
+        eng.set_chain_max(8192)
+        eng.timing_enable(True)
+        chained, _ = eng.pairing_batch(g1, g2, True, False)
+        launches_chained = sum(int(v[1]) for v in eng.timing_read().values())
+        eng.set_chain_max(0)
+        separate, _ = eng.pairing_batch(g1, g2, True, False)
+        launches_separate = sum(int(v[1]) for v in eng.timing_read().values())     # reading clears the counts
+        eng.timing_enable(False)
+        assert chained == separate
+        assert launches_separate == launches_chained + 6, (launches_chained, launches_separate)     # seven launches instead of one
+        exp, _ = oracle.pairing_batch(g1, g2, True, False, threads=16)
+        assert chained == exp
+    eng.set_chain_max(8192)
+
+
 @pytest.mark.gpu
 def test_default_dispatch_thresholds(oracle, golden):
     """Batch sizes either side of the library's default dispatch thresholds (two halves from 8192 pairs, except the one-full-round window 10,753 .. 12,288),
