@@ -274,15 +274,21 @@ static inline Pt<SFp2> psi2_proj(const Pt<SFp2>& p) { return pt_mat<SFp2>({mul_f
 // its running point and their temporaries live (26 slots instead of 38: twelve wavefronts per CU instead of six -- the one-program form ran at
 // 1.5 wavefronts per SIMD and half the issue rate).  clear_cofactor_g2(P) = S + (-[x]base) with
 //   t1 = -[x]P, base = t1 + psi(P), S = psi^2(2P) - psi(P) - t1 - P.
-static inline void clear_cofactor_g2_first(const Pt<SFp2>& P, Pt<SFp2>& base, Pt<SFp2>& S) {
-  Pt<SFp2> t1 = pt_neg(pt_mul_u64(P, NBLS_X));           // [-x]P
-  Pt<SFp2> t2 = psi_proj(P);
-  Pt<SFp2> t3 = pt_add(psi2_proj(pt_dbl(P)), pt_neg(t2));
-  base = pt_add(t1, t2);
-  S = pt_add(pt_add(t3, pt_neg(t1)), pt_neg(P));
+// Round 4: the two points that do not depend on t1 -- v = psi(P) and u = psi^2(2P) - psi(P) - P -- are computed by a program of their own (P_H2C_C0); the first ladder
+// program reads v back AFTER its ladder (base = t1 + v) and hands t1 on, the second reads t1 and u after ITS ladder: result = u + (-[x]base - t1).  Every final addition then
+// sees two points and the temporaries of one addition (26 slots, eleven workgroups per CU) where the round-3 form held t1, t2, t3 and P at the end of the first ladder
+// (39 slots, seven workgroups per CU).  Same group elements, other projective representatives.
+static inline void clear_cofactor_g2_pre(const Pt<SFp2>& P, Pt<SFp2>& v, Pt<SFp2>& u) {
+  Pt<SFp2> w = pt_add(psi2_proj(pt_dbl(P)), pt_neg(P));
+  v = psi_proj(P);
+  u = pt_add(w, pt_neg(v));
 }
-static inline Pt<SFp2> clear_cofactor_g2_second(const Pt<SFp2>& base, const Pt<SFp2>& S) {
-  return pt_add(S, pt_neg(pt_mul_u64(base, NBLS_X)));
+static inline void clear_cofactor_g2_first(const Pt<SFp2>& P, const Pt<SFp2>& v, Pt<SFp2>& base, Pt<SFp2>& t1) {
+  t1 = pt_mat(pt_neg(pt_mul_u64(P, NBLS_X)));            // [-x]P
+  base = pt_add(t1, v);
+}
+static inline Pt<SFp2> clear_cofactor_g2_second(const Pt<SFp2>& base, const Pt<SFp2>& t1, const Pt<SFp2>& u) {
+  return pt_add(u, pt_add(pt_neg(pt_mul_u64(base, NBLS_X)), pt_neg(t1)));
 }
 static inline Pt<SFp2> clear_cofactor_g2(const Pt<SFp2>& P) {
   Pt<SFp2> t1 = pt_neg(pt_mul_u64(P, NBLS_X));           // [-x]P

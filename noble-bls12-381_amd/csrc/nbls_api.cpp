@@ -841,11 +841,12 @@ static int dev_decompress(nbls_ctx* ctx, bool g2, size_t n, const void* d_in, vo
   return run(ctx, pb, n, {B(0, d_in, e), B(3, X, q), B(4, R, q), B(5, Cd, q), B(6, d_out, g2 ? 192 : 96), B(7, d_status, 1)}, s);
 }
 // 256 uniform bytes per message (expand_message_xmd output) -> hash point, affine wire bytes (PointG2.hashToCurve, index.ts:481-490)
-// PointG2.clearCofactor (index.ts:659-672) on raw projective points: two programs around the second multiplication by x (programs.h P_H2C_C1 / C2).
+// PointG2.clearCofactor (index.ts:659-672) on raw projective points: three programs: the t1-independent points, then one around each multiplication by x (programs.h P_H2C_C0 / C1 / C2).
 // in -> out (may alias in), norm of Z -> N; base and S are scratch of n * 6 raw elements each
 static int dev_clear_g2(nbls_ctx* ctx, size_t n, const void* in, uint8_t* base, uint8_t* S, void* out, void* N, hipStream_t s) {
-  int r = run(ctx, P_H2C_C1, n, {B(3, in, 6 * RAW), B(6, base, 6 * RAW), B(5, S, 6 * RAW)}, s); if (r) return r;
-  return run(ctx, P_H2C_C2, n, {B(3, base, 6 * RAW), B(4, S, 6 * RAW), B(6, out, 6 * RAW), B(7, N, RAW)}, s);
+  int r = run(ctx, P_H2C_C0, n, {B(3, in, 6 * RAW), B(6, base, 6 * RAW), B(5, S, 6 * RAW)}, s); if (r) return r;     // v = psi(P) -> base, u = psi^2(2P) - psi(P) - P -> S
+  if ((r = run(ctx, P_H2C_C1, n, {B(3, in, 6 * RAW), B(6, base, 6 * RAW)}, s))) return r;                          // base = t1 + v over v, t1 = -[x]P over P
+  return run(ctx, P_H2C_C2, n, {B(3, base, 6 * RAW), B(4, in, 6 * RAW), B(5, S, 6 * RAW), B(6, out, 6 * RAW), B(7, N, RAW)}, s);   // out may be in: every item reads its t1 before its result is stored
 }
 static int dev_hash_to_g2(nbls_ctx* ctx, size_t n, const void* d_uniform, void* d_out, hipStream_t s) {
   uint8_t *T, *E, *Pw, *Q, *N, *NI, *st; int r;

@@ -589,19 +589,28 @@ static Program build(ProgId id) {
       outputw(r.x.c0, 5, 0); outputw(r.x.c1, 5, 48); outputw(r.y.c0, 5, 96); outputw(r.y.c1, 5, 144); outputw(r.z.c0, 5, 192); outputw(r.z.c1, 5, 240);
       return B.compile(id == P_G2_ADD_AB ? "g2_add_ab" : id == P_G2_HORNER ? "g2_horner" : "g2_shiftadd", 8);
     }
-    case P_H2C_C1: {
-      Pt<SFp2> p = {{inputw(3, 0), inputw(3, 48)}, {inputw(3, 96), inputw(3, 144)}, {inputw(3, 192), inputw(3, 240)}}, base, S;
-      clear_cofactor_g2_first(p, base, S);
-      const Pt<SFp2>* o[2] = {&base, &S};
+    case P_H2C_C0: {
+      Pt<SFp2> p = {{inputw(3, 0), inputw(3, 48)}, {inputw(3, 96), inputw(3, 144)}, {inputw(3, 192), inputw(3, 240)}}, v, u;
+      clear_cofactor_g2_pre(p, v, u);
+      const Pt<SFp2>* o[2] = {&v, &u};
       for (int k = 0; k < 2; k++) { const Pt<SFp2>& q = *o[k]; const int b = k ? 5 : 6; outputw(q.x.c0, b, 0); outputw(q.x.c1, b, 48); outputw(q.y.c0, b, 96); outputw(q.y.c1, b, 144); outputw(q.z.c0, b, 192); outputw(q.z.c1, b, 240); }
-      B.sched_window = env_int("NBLS_CLEAR_WINDOW", 0);   // psi(P), psi^2(2P) are ready from the start but only needed after the ladder: keep them from occupying slots throughout
+      return B.compile("h2c_c0", G2_W);
+    }
+    case P_H2C_C1: {
+      auto ld = [&](int buf) { return Pt<SFp2>{{inputw(buf, 0), inputw(buf, 48)}, {inputw(buf, 96), inputw(buf, 144)}, {inputw(buf, 192), inputw(buf, 240)}}; };
+      Pt<SFp2> p = ld(3), base, t1;
+      clear_cofactor_g2_first(p, ld(6), base, t1);
+      const Pt<SFp2>* o[2] = {&base, &t1};
+      for (int k = 0; k < 2; k++) { const Pt<SFp2>& q = *o[k]; const int b = k ? 3 : 6; outputw(q.x.c0, b, 0); outputw(q.x.c1, b, 48); outputw(q.y.c0, b, 96); outputw(q.y.c1, b, 144); outputw(q.z.c0, b, 192); outputw(q.z.c1, b, 240); }
+      B.sched_window = env_int("NBLS_CLEAR_WINDOW", 100);   // psi(P) is only needed after the ladder: its load must not occupy slots throughout
       return B.compile("h2c_c1", G2_W);
     }
     case P_H2C_C2: {
       auto ld = [&](int buf) { return Pt<SFp2>{{inputw(buf, 0), inputw(buf, 48)}, {inputw(buf, 96), inputw(buf, 144)}, {inputw(buf, 192), inputw(buf, 240)}}; };
-      Pt<SFp2> q = clear_cofactor_g2_second(ld(3), ld(4));
+      Pt<SFp2> q = clear_cofactor_g2_second(ld(3), ld(4), ld(5));
       outputw(q.x.c0, 6, 0); outputw(q.x.c1, 6, 48); outputw(q.y.c0, 6, 96); outputw(q.y.c1, 6, 144); outputw(q.z.c0, 6, 192); outputw(q.z.c1, 6, 240);
       outputw(sqr(q.z.c0) + sqr(q.z.c1), 7, 0);
+      B.sched_window = env_int("NBLS_CLEAR_WINDOW", 100);   // t1 and u likewise
       return B.compile("h2c_c2", G2_W);
     }
     case P_G2_DEC_A192: g2_decompress_A(0, 3, 4, true); return B.compile("g2_dec_a192", 4);

@@ -58,8 +58,8 @@ enum ProgId {
   P_G2_DEC_B_HEX,                 // PointG2.fromHex on 96 compressed bytes (index.ts:532-562): flag rules, root by the S bit, no subgroup check
   P_G1_FROM_RAW, P_G2_FROM_RAW,   // uncompressed 96 / 192 bytes (buf 0) -> canonical affine wire bytes (buf 6), status (buf 7)   (index.ts:317-321, 563-575)
   P_G2_SWAP,                      // x.c0 x.c1 y.c0 y.c1 <-> x.c1 x.c0 y.c1 y.c0 (buf 0 -> buf 2)   (PointG2.toHex(false), index.ts:622-629)
-  P_H2C_C1, P_H2C_C2,             // PointG2.clearCofactor (index.ts:659-672) in two halves around the second multiplication by x: projective P (3) -> base (6), S (5) ;
-                                  // base (3), S (4) -> projective result (6), norm of Z (7)
+  P_H2C_C1, P_H2C_C2,             // PointG2.clearCofactor (index.ts:659-672) one program around each multiplication by x: projective P (3), v (6) -> base = t1 + v (6), t1 = -[x]P (3, over P) ;
+                                  // base (3), t1 (4), u (5) -> projective result u - [x]base - t1 (6), norm of Z (7)
   P_ACC4_RAW,                     // four folded line tables per item (buf 3) -> F (buf 5): one Fp12 squaring per bit for four Miller loops
   // lane-split variants (Program::lsplit = 4: every K_DOT lane-op on four adjacent lanes, one item per wavefront) for launches of at most one wavefront
   // per SIMD: the same formulas, a third fewer instructions per wavefront
@@ -69,6 +69,7 @@ enum ProgId {
   P_EXPC_DEC_A,        // compressed powers (buf 3) -> product of the three |2 g2|^2 (buf 4: the element to invert), numerators times conj(g2), all-but-one products (and a third of them), the g1-free part of g0, zero flag (buf 5: 19 raw elements)
   P_EXPC_DEC_B,        // compressed powers (3), inverse (4), DEC_A scratch (6) -> conj(A^|x|) (buf 5), int8 status (buf 7): 1 = some g2 was zero, the item must be recomputed by P_EXPX
   P_ACC8_RAW,          // eight folded line tables per item (buf 3) -> F (buf 5): one Fp12 squaring per bit for eight Miller loops (round 4: verifyBatch / products of 32,768 pairs and more)
+  P_H2C_C0,            // clearCofactor, the part that does not depend on [x]P: projective P (3) -> v = psi(P) (6), u = psi^2(2P) - psi(P) - P (5), read back by P_H2C_C1 / C2 after their ladders
   P_COUNT
 };
 // |x| = 2^63 + 2^62 + 2^60 + 2^57 + 2^48 + 2^16: the compressed chain runs to 2^57 and its values at the set bits 16, 48, 57 are decompressed; the powers
