@@ -40,7 +40,7 @@
   X(1, mul2, P_MUL2, P_COUNT, P_COUNT, P_COUNT)                              \
   X(1, norm, P_NORM_RAW, P_NORM_BYTES, P_RAW_TO_BYTES, P_COUNT)              \
   X(2, h2c_a, P_H2C_A, P_COUNT, P_COUNT, P_COUNT)                            \
-  X(2, h2c_b, P_H2C_B, P_COUNT, P_COUNT, P_COUNT)                            \
+  X(2, h2c_b, P_H2C_B1, P_H2C_B2, P_COUNT, P_COUNT)                          \
   X(2, h2c_c1, P_H2C_C1, P_H2C_C0, P_COUNT, P_COUNT)                         \
   X(2, h2c_c2, P_H2C_C2, P_COUNT, P_COUNT, P_COUNT)                          \
   X(2, g1_dec, P_G1_DEC_A, P_G1_DEC_B, P_COUNT, P_COUNT)                     \

@@ -183,6 +183,18 @@ static inline SwuState swu_prepare(const SFp2& t) {
   s.uv15 = mat(mul(s.uv7, mat(mul(v7, s.v))));
   return s;
 }
+// the values swu_finish needs beside t, as twelve raw elements in HBM scratch between P_H2C_A and P_H2C_B1 (the state is cheaper to reload than to recompute:
+// 76 of the 274 products of the round-3 H2C_B were swu_prepare run a second time)
+static inline void swu_state_store(const SwuState& s, int buf, int off) {
+  const SFp2* f[6] = {&s.zt2, &s.num, &s.den, &s.v, &s.u, &s.uv7};
+  for (int k = 0; k < 6; k++) { outputw(f[k]->c0, buf, off + 96 * k); outputw(f[k]->c1, buf, off + 96 * k + 48); }
+}
+static inline SwuState swu_state_load(const SFp2& t, int buf, int off) {
+  SwuState s; s.t = t;
+  SFp2* f[6] = {&s.zt2, &s.num, &s.den, &s.v, &s.u, &s.uv7};
+  for (int k = 0; k < 6; k++) *f[k] = {inputw(buf, off + 96 * k), inputw(buf, off + 96 * k + 48)};
+  return s;
+}
 // sgn0_fp2 (math.ts:1179-1185) on Montgomery values
 static inline SFp sgn0(const SFp2& x) {
   SFp s0 = is_odd(std_canon(x.c0)), z0 = is_zero(x.c0), s1 = is_odd(std_canon(x.c1));

@@ -849,12 +849,15 @@ static int dev_clear_g2(nbls_ctx* ctx, size_t n, const void* in, uint8_t* base, 
   return run(ctx, P_H2C_C2, n, {B(3, base, 6 * RAW), B(4, in, 6 * RAW), B(5, S, 6 * RAW), B(6, out, 6 * RAW), B(7, N, RAW)}, s);   // out may be in: every item reads its t1 before its result is stored
 }
 static int dev_hash_to_g2(nbls_ctx* ctx, size_t n, const void* d_uniform, void* d_out, hipStream_t s) {
-  uint8_t *T, *E, *Pw, *Q, *N, *NI, *st; int r;
+  uint8_t *T, *E, *Pw, *Q, *N, *NI, *st, *St, *Pt2; int r;
   if ((r = need(ctx, 0, n * 4 * RAW, &T)) || (r = need(ctx, 1, n * 6 * RAW, &E)) || (r = need(ctx, 2, n * 4 * RAW, &Pw)) || (r = need(ctx, 3, n * 6 * RAW, &Q)) ||
-      (r = need(ctx, 4, n * RAW, &N)) || (r = need(ctx, 5, n * RAW, &NI)) || (r = need(ctx, 6, n, &st))) return r;
-  if ((r = run(ctx, P_H2C_A, n, {B(0, d_uniform, 256), B(3, T, 4 * RAW), B(4, E, 4 * RAW)}, s))) return r;
+      (r = need(ctx, 4, n * RAW, &N)) || (r = need(ctx, 5, n * RAW, &NI)) || (r = need(ctx, 6, n, &st)) || (r = need(ctx, 18, n * 24 * RAW, &St)) || (r = need(ctx, 19, n * 12 * RAW, &Pt2))) return r;
+  // H2C_A: per message the two field elements t (T), the exponentiation inputs (E) and the rest of the SWU state (St: twelve raw elements per map)
+  if ((r = run(ctx, P_H2C_A, n, {B(0, d_uniform, 256), B(3, T, 4 * RAW), B(4, E, 4 * RAW), B(5, St, 24 * RAW)}, s))) return r;
   if ((r = run_pow(ctx, 2, 2 * n, E, Pw, s))) return r;
-  if ((r = run(ctx, P_H2C_B, n, {B(3, T, 4 * RAW), B(5, Pw, 4 * RAW), B(6, E, 6 * RAW)}, s))) return r;        // E is free again: reuse it for the E2 point
+  // H2C_B1: one map per item (2 n items) -> its point on E2'; H2C_B2: the two points of a message -> their sum on E2 (round 3: one program, 62 slots, four workgroups per CU)
+  if ((r = run(ctx, P_H2C_B1, 2 * n, {B(3, T, 2 * RAW), B(5, Pw, 2 * RAW), B(4, St, 12 * RAW), B(6, Pt2, 6 * RAW)}, s))) return r;
+  if ((r = run(ctx, P_H2C_B2, n, {B(3, Pt2, 12 * RAW), B(6, E, 6 * RAW)}, s))) return r;        // E is free again: reuse it for the E2 point
   uint8_t* S; if ((r = need(ctx, 13, n * 6 * RAW, &S))) return r;
   if ((r = dev_clear_g2(ctx, n, E, Q, S, E, N, s))) return r;
   if ((r = run_inv_buf(ctx, n, N, NI, s))) return r;
@@ -1416,7 +1419,7 @@ static int verify_stage(nbls_ctx* ctx, size_t n, const void* d_sig96, const void
   }
   // normP1 (PointG1.fromHex of the keys) on a second stream beside normP2Hash (PointG2.hashToCurve of the messages): both chains
   // contain a per-lane exponentiation kernel that fills the chip only two wavefronts deep and issues at half rate, so running
-  // them side by side costs little more than the longer one.  Scratch slots 14..16 / 17 for the key chain (0..6 / 11 belong to the hash,
+  // them side by side costs little more than the longer one.  Scratch slots 14..16 / 17 for the key chain (0..6 / 11 / 13 / 18 / 19 belong to the hash,
   // 7..9 / 12 hold the staged messages, keys and expand_message_xmd output of the host-buffer entry point).
   static const bool overlap = !env_set("NBLS_VERIFY_NO_OVERLAP");
   if (overlap) {

@@ -427,7 +427,9 @@ static Program build(ProgId id) {
         outputw(t.c0, 3, 96 * k); outputw(t.c1, 3, 96 * k + 48);
         SwuState s = swu_prepare(t);
         outputw(s.uv15.c0, 4, 96 * k); outputw(s.uv15.c1, 4, 96 * k + 48);
+        swu_state_store(s, 5, 576 * k);
       }
+      B.store_batch = 8;   // the state goes out as it is produced (28 slots otherwise 40)
       return B.compile("h2c_a", 8);
     }
     case P_H2C_B: {
@@ -440,6 +442,19 @@ static Program build(ProgId id) {
       Pt<SFp2> q = isogeny_g2_proj(pt_add_generic(pts[0], pts[1]));   // index.ts:487-488
       outputw(q.x.c0, 6, 0); outputw(q.x.c1, 6, 48); outputw(q.y.c0, 6, 96); outputw(q.y.c1, 6, 144); outputw(q.z.c0, 6, 192); outputw(q.z.c1, 6, 240);
       return B.compile("h2c_b", 8);
+    }
+    case P_H2C_B1: {
+      SFp2 t = {inputw(3, 0), inputw(3, 48)}, gp = {inputw(5, 0), inputw(5, 48)};
+      Pt<SFp2> q = swu_finish(swu_state_load(t, 4, 0), gp);
+      outputw(q.x.c0, 6, 0); outputw(q.x.c1, 6, 48); outputw(q.y.c0, 6, 96); outputw(q.y.c1, 6, 144); outputw(q.z.c0, 6, 192); outputw(q.z.c1, 6, 240);
+      B.sched_window = env_int("NBLS_H2C_B1_WINDOW", 40);
+      return B.compile("h2c_b1", env_int("NBLS_H2C_B1_W", 8));
+    }
+    case P_H2C_B2: {
+      auto ld = [&](int off) { return Pt<SFp2>{{inputw(3, off), inputw(3, off + 48)}, {inputw(3, off + 96), inputw(3, off + 144)}, {inputw(3, off + 192), inputw(3, off + 240)}}; };
+      Pt<SFp2> q = isogeny_g2_proj(pt_add_generic(ld(0), ld(288)));   // index.ts:487-488
+      outputw(q.x.c0, 6, 0); outputw(q.x.c1, 6, 48); outputw(q.y.c0, 6, 96); outputw(q.y.c1, 6, 144); outputw(q.z.c0, 6, 192); outputw(q.z.c1, 6, 240);
+      return B.compile("h2c_b2", env_int("NBLS_H2C_B2_W", 8));
     }
     case P_H2C_C: {   // its own program: chained to H2C_B through HBM so that neither keeps more than ~40 slots live (LDS-limited occupancy)
       Pt<SFp2> p = {{inputw(3, 0), inputw(3, 48)}, {inputw(3, 96), inputw(3, 144)}, {inputw(3, 192), inputw(3, 240)}};

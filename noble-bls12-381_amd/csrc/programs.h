@@ -70,6 +70,8 @@ enum ProgId {
   P_EXPC_DEC_B,        // compressed powers (3), inverse (4), DEC_A scratch (6) -> conj(A^|x|) (buf 5), int8 status (buf 7): 1 = some g2 was zero, the item must be recomputed by P_EXPX
   P_ACC8_RAW,          // eight folded line tables per item (buf 3) -> F (buf 5): one Fp12 squaring per bit for eight Miller loops (round 4: verifyBatch / products of 32,768 pairs and more)
   P_H2C_C0,            // clearCofactor, the part that does not depend on [x]P: projective P (3) -> v = psi(P) (6), u = psi^2(2P) - psi(P) - P (5), read back by P_H2C_C1 / C2 after their ladders
+  P_H2C_B1,            // one SWU map per item (2 n items): t (buf 3: Fp2), its exponentiation (buf 5: Fp2) -> projective point on E2' (buf 6: 6 raw elements)
+  P_H2C_B2,            // the two points of a message (buf 3: 12 raw elements) -> their sum mapped to E2 by the 3-isogeny (buf 6), index.ts:487-488
   P_COUNT
 };
 // |x| = 2^63 + 2^62 + 2^60 + 2^57 + 2^48 + 2^16: the compressed chain runs to 2^57 and its values at the set bits 16, 48, 57 are decompressed; the powers

@@ -56,7 +56,7 @@ def test_translated_expx_on_extreme_elements(sim, oracle):
 
 def test_decode_and_hash_programs_translated(sim, oracle, golden, testdata):
     """the programs with flags, selects and status steps (G1 decode + subgroup check, hash-to-G2 and its cofactor clearing) through the translated form"""
-    for name in ('H2C_A', 'H2C_B', 'H2C_C0', 'H2C_C1', 'H2C_C2', 'G1_DEC_A', 'G1_DEC_B', 'G2_TO_AFFINE', 'MUL2', 'FE_MID1', 'FE_MID2'):
+    for name in ('H2C_A', 'H2C_B1', 'H2C_B2', 'H2C_C0', 'H2C_C1', 'H2C_C2', 'G1_DEC_A', 'G1_DEC_B', 'G2_TO_AFFINE', 'MUL2', 'FE_MID1', 'FE_MID2'):
         assert sim.nbls_sim_has_aot(vmsim_py.P[name]) == 1, name
     T.test_decompress_programs(sim, golden)
     T.test_hash_to_g2_program(sim, oracle, golden, testdata)
