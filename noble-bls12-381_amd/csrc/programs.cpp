@@ -418,7 +418,7 @@ static Program build(ProgId id) {
       return B.compile("g2_validate", G2_W);
     }
     case P_G1_DEC_A: g1_decompress_A(0, 3, 4); return B.compile("g1_dec_a", 4);
-    case P_G1_DEC_B: g1_decompress_B(0, 3, 4, 5, 6, 7); return B.compile("g1_dec_b", G1_W);
+    case P_G1_DEC_B: g1_decompress_B(0, 3, 4, 5, 6, 7); B.sched_window = env_int("NBLS_G1DEC_WINDOW", 0); return B.compile("g1_dec_b", G1_W);
     case P_G2_DEC_A: g2_decompress_A(0, 3, 4); return B.compile("g2_dec_a", 4);
     case P_G2_DEC_B: g2_decompress_B(0, 3, 4, 5, 6, 7); return B.compile("g2_dec_b", G2_W);
     case P_H2C_A: {
