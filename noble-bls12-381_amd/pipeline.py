@@ -11,6 +11,8 @@ surplus queues pays a queue switch (bench.py: 22; tools/ab_queues20.sh) -- in th
 kept in flight.  Round 4: 3.10 M pairings/s with twelve batches in flight; streams that carry several batches each run phase-locked (like that many large batches one after the other), so a short
 burst of k batches is fastest on k streams (20 batches: 2.86 M on twenty streams, 2.79 M on ten).
 """
+import os
+
 from .engine import Engine
 
 
@@ -27,7 +29,8 @@ class PairingPipeline:
         if depth > 1:
             for e in self.engines:
                 e.set_split_miller_min(0)
-                e.set_chain_max(0)
+                if os.environ.get('NBLS_PIPELINE_CHAIN') != '1':     # A/B switch (tools/ab_pipeline.sh)
+                    e.set_chain_max(0)
         self._next = 0
 
     @property
