@@ -457,7 +457,7 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
         hipMalloc(&ctx->ident_g1, 3 * RAW) != hipSuccess || hipMemcpy(ctx->ident_g1, id1, 3 * RAW, hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc(&ctx->ident_g2, 6 * RAW) != hipSuccess || hipMemcpy(ctx->ident_g2, id2, 6 * RAW, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   }
-  for (int i = 0; i < P_COUNT; i++) { if (i == P_G1_MUL || i == P_G2_MUL) continue;   // the scalar-multiplication ladders are uploaded on first use
+  for (int i = 0; i < P_COUNT; i++) { if (i == P_G1_MUL || i == P_G2_MUL || i == P_G1_MUL_W3 || i == P_G2_MUL_W3) continue;   // the scalar-multiplication ladders are uploaded on first use
     int r = upload(ctx, (ProgId)i); if (r) { int e = ctx->last_hip; (void)e; nbls_destroy(ctx); return r; } }
   *out = ctx;
   return NBLS_OK;
@@ -1183,7 +1183,11 @@ static int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, si
   const size_t a = g2 ? 192 : 96, p = g2 ? 6 * RAW : 3 * RAW;
   uint8_t *Pj, *N, *NI; int r;
   if ((r = need(ctx, 0, n * p, &Pj)) || (r = need(ctx, 4, n * RAW, &N)) || (r = need(ctx, 5, n * RAW, &NI))) return r;
-  if ((r = run(ctx, g2 ? P_G2_MUL : P_G1_MUL, n, {B(g2 ? 1 : 0, d_pts, pt_stride), B(2, d_scalars, 32), B(3, Pj, p), B(4, N, RAW)}, s))) return r;
+  // up to one wavefront per SIMD (16 / 8 items per wavefront) the length of one wavefront's instruction stream counts: 3-bit windows (85 additions); above, wavefronts per CU
+  // count: 2-bit windows, whose table of four leaves room for seven workgroups per CU instead of three / four (tools/mul_time.py)
+  static const size_t w3_waves = (size_t)env_long("NBLS_MUL_W3_WAVES", 1024);
+  const bool w3 = (n + (g2 ? 7 : 15)) / (g2 ? 8 : 16) <= w3_waves;
+  if ((r = run(ctx, g2 ? (w3 ? P_G2_MUL_W3 : P_G2_MUL) : (w3 ? P_G1_MUL_W3 : P_G1_MUL), n, {B(g2 ? 1 : 0, d_pts, pt_stride), B(2, d_scalars, 32), B(3, Pj, p), B(4, N, RAW)}, s))) return r;
   if ((r = run_inv_buf(ctx, n, N, NI, s))) return r;
   return run(ctx, g2 ? P_G2_TO_AFFINE : P_G1_TO_AFFINE, n, {B(3, Pj, p), B(4, NI, RAW), B(2, d_out, a), B(7, d_status, 1)}, s);
 }

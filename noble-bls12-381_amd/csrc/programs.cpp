@@ -550,23 +550,25 @@ static Program build(ProgId id) {
     }
     case P_G1_COMPRESS: g1_compress(0, 2); return B.compile("g1_compress", 2);
     case P_G2_COMPRESS: g2_compress(0, 2); return B.compile("g2_compress", 4);
-    case P_G1_MUL: {
+    case P_G1_MUL: case P_G1_MUL_W3: {
       SFp x = input(0, 0), y = input(0, 48);
       SFp k = input_raw(2, 0, 32);
-      Pt<SFp> r = pt_mul_ladder(pt_affine(x, y), k, 256, env_int("NBLS_G1MUL_WIN", 2));
+      const bool w3 = id == P_G1_MUL_W3;
+      Pt<SFp> r = pt_mul_ladder(pt_affine(x, y), k, 256, w3 ? 3 : env_int("NBLS_G1MUL_WIN", 2));
       outputw(r.x, 3, 0); outputw(r.y, 3, 48); outputw(r.z, 3, 96);
       outputw(r.z, 4, 0);
-      B.sched_window = env_int("NBLS_G1MUL_WINDOW", 200);   // scalar bits are extracted just in time instead of all 256 up front (they would pin 256 LDS slots)
-      return B.compile("g1_mul", G1MUL_W);
+      B.sched_window = w3 ? 300 : env_int("NBLS_G1MUL_WINDOW", 200);   // scalar bits are extracted just in time instead of all 256 up front (they would pin 256 LDS slots)
+      return B.compile(w3 ? "g1_mul_w3" : "g1_mul", G1MUL_W);
     }
-    case P_G2_MUL: {
+    case P_G2_MUL: case P_G2_MUL_W3: {
       SFp2 x = input_fp2(1, 0), y = input_fp2(1, 96);
       SFp k = input_raw(2, 0, 32);
-      Pt<SFp2> r = pt_mul_ladder(pt_affine(x, y), k, 256, env_int("NBLS_G2MUL_WIN", 2));
+      const bool w3 = id == P_G2_MUL_W3;
+      Pt<SFp2> r = pt_mul_ladder(pt_affine(x, y), k, 256, w3 ? 3 : env_int("NBLS_G2MUL_WIN", 2));
       outputw(r.x.c0, 3, 0); outputw(r.x.c1, 3, 48); outputw(r.y.c0, 3, 96); outputw(r.y.c1, 3, 144); outputw(r.z.c0, 3, 192); outputw(r.z.c1, 3, 240);
       outputw(sqr(r.z.c0) + sqr(r.z.c1), 4, 0);      // Fp2 norm, inverted by the inversion kernel (Fp2.invert, math.ts:522-526)
       B.sched_window = env_int("NBLS_MUL_WINDOW", 300);
-      return B.compile("g2_mul", G2MUL_W);
+      return B.compile(w3 ? "g2_mul_w3" : "g2_mul", G2MUL_W);
     }
     case P_G1_MSM_PREP: {
       // phi(x, y) = (beta x, y) acts on G1 as [-z^2] (the reference's subgroup check compares [-z^2]P with phi(P), index.ts:424-448)

@@ -140,9 +140,11 @@ def test_fp_inverse_edge_cases(sim):
         assert got % p == ((pow(x % p, -1, p) * R * R) % p if x % p else 0), hex(x)
 
 
-def test_scalar_mul_programs(sim, oracle, golden):
+@pytest.mark.parametrize('w3', [False, True])
+def test_scalar_mul_programs(sim, oracle, golden, w3):
     """the double-and-add-always ladders behind getPublicKey / sign (index.ts:738-752) against the oracle's scalar
-    multiplication: random and structured scalars (1, 2, r-1, r+1, 2^256-1, a value with a long zero run)"""
+    multiplication: random and structured scalars (1, 2, r-1, r+1, 2^256-1, a value with a long zero run); both forms: 2-bit windows (launches deeper than one
+    wavefront per SIMD) and 3-bit windows (the others)"""
     import random
     r = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
     rnd = random.Random(12381)
@@ -150,19 +152,19 @@ def test_scalar_mul_programs(sim, oracle, golden):
     g1 = oracle.g1_generator()
     p1 = hx(golden['g1pts'][0]) if isinstance(golden['g1pts'][0], str) else g1
     pts1 = b''.join([g1, p1] * 4)
-    out, st = vmsim_py.point_mul(sim, pts1, b''.join(k.to_bytes(32, 'big') for k in ks))
+    out, st = vmsim_py.point_mul(sim, pts1, b''.join(k.to_bytes(32, 'big') for k in ks), w3=w3)
     for i, k in enumerate(ks):
         assert st[i] == 0
         assert out[96 * i:96 * i + 96] == oracle.g1_mul(pts1[96 * i:96 * i + 96], k % r)[1], i
     g2 = oracle.g2_generator()
     q = oracle.g2_mul(g2, 0xabcdef123456789)[1]
     pts2 = b''.join([g2, q] * 4)
-    out, st = vmsim_py.point_mul(sim, pts2, b''.join(k.to_bytes(32, 'big') for k in ks), g2=True)
+    out, st = vmsim_py.point_mul(sim, pts2, b''.join(k.to_bytes(32, 'big') for k in ks), g2=True, w3=w3)
     for i, k in enumerate(ks):
         assert st[i] == 0
         assert out[192 * i:192 * i + 192] == oracle.g2_mul(pts2[192 * i:192 * i + 192], k % r)[1], i
     # k = r: the result is the zero point (status 1), which the host wrapper reports as an invalid key (status 5)
-    out, st = vmsim_py.point_mul(sim, g1, r.to_bytes(32, 'big'))
+    out, st = vmsim_py.point_mul(sim, g1, r.to_bytes(32, 'big'), w3=w3)
     assert st[0] == 1
 
 
