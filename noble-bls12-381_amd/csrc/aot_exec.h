@@ -190,8 +190,11 @@ NBLS_HD void aot_compress_columns(u64* acc) {
   }
 }
 
+// host only: what aot_acc_sum4 calls in place of the DPP stages (set by the simulator; null elsewhere)
+typedef void (*AotSimLsHook)(u64*);
+inline AotSimLsHook& aot_sim_ls_hook() { static AotSimLsHook h = nullptr; return h; }
 // Lane split: sum of the 28 column accumulators over the four adjacent lanes of a lane-op, result in the first of them.  Two DPP stages (lane i += lane i + 1, then
-// lane i += lane i + 2, inside rows of 16 lanes; groups of four never straddle a row).  Device only: the simulator runs lane-split programs on the interpreter's semantics.
+// lane i += lane i + 2, inside rows of 16 lanes; groups of four never straddle a row).  On the host the simulator's hook does the same sum.
 NBLS_HD void aot_acc_sum4(u64* acc) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -202,7 +205,7 @@ NBLS_HD void aot_acc_sum4(u64* acc) {
     acc[c] = v;
   }
 #else
-  (void)acc;
+  if (aot_sim_ls_hook()) aot_sim_ls_hook()(acc);   // the simulator supplies the cross-lane sum (vm_sim.cpp: lanes are visited from 63 down, so the partners' columns are there)
 #endif
 }
 

@@ -76,10 +76,25 @@ struct Pend { u32 dst; u32 v[NL]; };
   }
 #define SIM_ROW(ID, KIND, P0, FLAGS, T, SH0, SH1, CNT) {KIND, P0, FLAGS, T, SH0, SH1},
 NBLS_AOT_KERNELS(SIM_TABLE)
+// lane-split kernels (aot.h NBLS_AOT_LS_KERNELS): the same bodies with LS = 4.  The device sums the columns of the four sub-lanes of a lane-op with two DPP stages
+// (lane i <- v[i] + v[i+1] + v[i+2] + v[i+3] inside rows of 16 lanes); here the lanes of a step are visited from 63 down to 0, every lane leaves its columns in
+// g_ls_cols before it takes the sum, so the three partners of a sub-lane 0 are already there.
+static u64 g_ls_cols[64][2 * NL];
+static unsigned g_ls_lane = 0;
+static void sim_ls_sum(u64* acc) {
+  const unsigned i = g_ls_lane;
+  memcpy(g_ls_cols[i], acc, sizeof g_ls_cols[i]);
+  for (unsigned k = 1; k < 4; k++) if (i + k < 64 && (i + k) / 16 == i / 16) for (int c = 0; c < 2 * NL; c++) acc[c] += g_ls_cols[i + k][c];
+}
+#undef SIM_CASE
+#define SIM_CASE(ID, KIND, P0, FLAGS, T, SH0, SH1, CNT) \
+  case ID: aot_step<KIND, P0, FLAGS, T, SH0, SH1, 4>(d, lds, item, live, bufs, qp, [&](u32 dst, const u32* res) { Pend pd; pd.dst = dst; memcpy(pd.v, res, NL * 4); pend.push_back(pd); }); break;
+NBLS_AOT_LS_KERNELS(SIM_TABLE)
 typedef void (*SimStepFn)(u32, const HostDesc&, char*, u32, bool, const IOBuf*, const u32*, std::vector<Pend>&);
-struct SimKernel { int prog_id[4]; SimStepFn fn; const AotSig* sigs; unsigned nsigs; };
-#define SIM_ENTRY(PART, NAME, Q0, Q1, Q2, Q3) {{(int)Q0, (int)Q1, (int)Q2, (int)Q3}, sim_step_##NAME, sim_sigs_##NAME, (unsigned)(sizeof(sim_sigs_##NAME) / sizeof(AotSig))},
-static const SimKernel g_sim_kernels[] = {NBLS_AOT_KERNELS(SIM_ENTRY)};
+struct SimKernel { int prog_id[4]; SimStepFn fn; const AotSig* sigs; unsigned nsigs; bool ls; };
+#define SIM_ENTRY(PART, NAME, Q0, Q1, Q2, Q3) {{(int)Q0, (int)Q1, (int)Q2, (int)Q3}, sim_step_##NAME, sim_sigs_##NAME, (unsigned)(sizeof(sim_sigs_##NAME) / sizeof(AotSig)), false},
+#define SIM_ENTRY_LS(PART, NAME, Q0, Q1, Q2, Q3) {{(int)Q0, (int)Q1, (int)Q2, (int)Q3}, sim_step_##NAME, sim_sigs_##NAME, (unsigned)(sizeof(sim_sigs_##NAME) / sizeof(AotSig)), true},
+static const SimKernel g_sim_kernels[] = {NBLS_AOT_KERNELS(SIM_ENTRY) NBLS_AOT_LS_KERNELS(SIM_ENTRY_LS)};
 static int g_sim_aot = 0;
 // 0: ran; -2: the program has no ahead-of-time kernel; -3: its signatures are not in the kernel's table
 static int sim_run_aot(int prog, unsigned n_items, const IOBuf* bufs) {
@@ -100,9 +115,12 @@ static int sim_run_aot(int prog, unsigned n_items, const IOBuf* bufs) {
     for (unsigned g = 0; g < (p.shared_consts ? 1u : p.G); g++) for (unsigned c = 0; c < p.nconst; c++) memcpy(lds + g * p.inst_bytes() + c * p.slot_bytes, p.consts.data() + c * RAW_WORDS, NL * 4);
     for (size_t s = 0; s < ap.steps.size(); s++) {
       std::vector<Pend> pend;
-      for (unsigned lane = 0; lane < 64; lane++) {
+      aot_sim_ls_hook() = K->ls ? sim_ls_sum : nullptr;
+      for (unsigned v = 0; v < 64; v++) {
+        const unsigned lane = K->ls ? 63 - v : v;      // lane-split kernels: from the top down (sim_ls_sum)
         const unsigned inst = lane / p.W, item = blk * p.G + inst;
         HostDesc d; d.blk = ap.descs.data() + (size_t)ap.steps[s].y * 4; d.lane = lane;
+        g_ls_lane = lane;
         K->fn(map[ap.steps[s].x & 0xffu], d, lds, item, inst < p.G && item < n_items, bufs, qp_table, pend);
       }
       for (auto& pd : pend) st14(lds, pd.dst, pd.v);

@@ -19,7 +19,9 @@ def sim():
 def test_listed_programs_translate(sim):
     for name in ('EXPX', 'ACC_FE', 'ACC4_RAW', 'LINES_PQ'):
         assert sim.nbls_sim_has_aot(vmsim_py.P[name]) == 1, name
-    assert sim.nbls_sim_has_aot(vmsim_py.P['EXPX_LS']) == 0     # lane-split programs stay on the interpreter
+    for name in ('EXPX_LS', 'MILLER_FE_LS', 'MILLER_RAW_LS', 'MILLER_BYTES_LS'):     # the lane-split forms have kernels of their own (aot.h NBLS_AOT_LS_KERNELS)
+        assert sim.nbls_sim_has_aot(vmsim_py.P[name]) == 1, name
+    assert sim.nbls_sim_has_aot(vmsim_py.P['EXPC_SQ']) == 0     # the compressed-squaring experiment stays on the interpreter
 
 
 def test_final_exponentiation_through_translated_expx(sim, oracle, golden, testdata):
@@ -52,6 +54,12 @@ def test_translated_expx_on_extreme_elements(sim, oracle):
     a, b = elems(outs[0]), elems(outs[1])
     assert all((x - y) % p == 0 for x, y in zip(a, b))
     assert all(0 <= x < 8 * p for x in a)     # scratch elements are reloaded with bound 8 (trace.h outputw)
+
+
+def test_lane_split_programs_translated(sim, oracle, golden):
+    """the lane-split forms through aot_translate + aot_step<..., LS = 4>: every sub-lane's own round addresses, the columns of the four sub-lanes summed before the one
+    finish (on the device two DPP stages; the simulator visits the lanes from the top down and sums what the partners left), everything else on sub-lane 0"""
+    T.test_lane_split_programs(sim, oracle, golden)
 
 
 def test_decode_and_hash_programs_translated(sim, oracle, golden, testdata):
