@@ -6,6 +6,10 @@ A process that also uses PyTorch-ROCm must import torch BEFORE the first Engine 
 runtime, libnbls.so binds to whichever runtime is already loaded, and torch loaded second reports "No HIP GPUs are available"."""
 import ctypes as C
 import os
+try:
+    import numpy as _np
+except ImportError:      # the binding itself needs only ctypes
+    _np = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PROGRAMS = []   # names of the step programs in the library's numbering (filled by load_library from nbls_program_name)
@@ -212,6 +216,12 @@ class Engine:
 
     @staticmethod
     def _pack(msgs):
+        """messages -> (their bytes back to back, uint32 offsets with the end appended) as the C ABI takes them"""
+        n = len(msgs)
+        if _np is not None and n >= 256:      # 65,536 messages: 6 ms instead of 16 ms of Python loop
+            offs = _np.zeros(n + 1, dtype=_np.uint32)
+            _np.cumsum(_np.fromiter(map(len, msgs), dtype=_np.uint32, count=n), out=offs[1:])
+            return b''.join(msgs), (C.c_uint32 * (n + 1)).from_buffer(offs)
         offs = [0]
         for m in msgs:
             offs.append(offs[-1] + len(m))
