@@ -842,8 +842,8 @@ static int dev_decompress(nbls_ctx* ctx, bool g2, size_t n, const void* d_in, vo
 }
 // 256 uniform bytes per message (expand_message_xmd output) -> hash point, affine wire bytes (PointG2.hashToCurve, index.ts:481-490)
 // PointG2.clearCofactor (index.ts:659-672) on raw projective points: three programs: the t1-independent points, then one around each multiplication by x (programs.h P_H2C_C0 / C1 / C2).
-// in -> out (may alias in), norm of Z -> N; base and S are scratch of n * 6 raw elements each
-static int dev_clear_g2(nbls_ctx* ctx, size_t n, const void* in, uint8_t* base, uint8_t* S, void* out, void* N, hipStream_t s) {
+// in -> out (may alias in or base), norm of Z -> N; base and S are scratch of n * 6 raw elements each, and `in` is scratch too from the second program on (t1 is stored over P)
+static int dev_clear_g2(nbls_ctx* ctx, size_t n, void* in, uint8_t* base, uint8_t* S, void* out, void* N, hipStream_t s) {
   int r = run(ctx, P_H2C_C0, n, {B(3, in, 6 * RAW), B(6, base, 6 * RAW), B(5, S, 6 * RAW)}, s); if (r) return r;     // v = psi(P) -> base, u = psi^2(2P) - psi(P) - P -> S
   if ((r = run(ctx, P_H2C_C1, n, {B(3, in, 6 * RAW), B(6, base, 6 * RAW)}, s))) return r;                          // base = t1 + v over v, t1 = -[x]P over P
   return run(ctx, P_H2C_C2, n, {B(3, base, 6 * RAW), B(4, in, 6 * RAW), B(5, S, 6 * RAW), B(6, out, 6 * RAW), B(7, N, RAW)}, s);   // out may be in: every item reads its t1 before its result is stored
