@@ -341,6 +341,7 @@ def main():
             'valu_issue_busy': valu_busy,    # SQ_INSTS_VALU x 4 clocks / (kernel time x 2.4 GHz x 1024 SIMDs) from the PMC pass in profiles/ (same batch size, one batch at a time)
             'frac_at_value': round(value / world * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL / 1e12 / PEAK_TMAD, 4),
             'frac_note': 'achieved/frac: the kernels of ONE %d-pairing call running alone (sum of the HIP-event durations of its nbls_vm_kernel launches; profiles/ holds the rocprofv3 kernel trace of the same command); frac_at_value: the same algorithmic work at the rate of `value` (%d calls overlapping on %d streams; profiles/ holds a kernel trace taken with the same --inflight)' % (n, D, D),
+            'clock_note': 'peak is priced at 2.4 GHz; under saturated load (value, large_batch) this engine is power-limited: 2.21-2.22 GHz at 1330-1360 W of the 1400 W package limit (profiles/round4_clocks_under_load.txt), and a pure stream of its multiply-add sustains 30.6 T/s at 2.32 GHz (profiles/round4_ubench_mad_power.txt); one call at a time runs at 2.39 GHz',
             'kernel_ms': {k: round(v, 4) for k, v in per_step.items()},
             'miller_frac': round(n * FPMUL_MILLER * MAD_PER_FPMUL / (ms_miller * 1e-3) / 1e12 / PEAK_TMAD, 4),
             'final_exp_frac': round(n * FPMUL_FINALEXP * MAD_PER_FPMUL / (ms_hard * 1e-3) / 1e12 / PEAK_TMAD, 4),
