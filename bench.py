@@ -378,11 +378,30 @@ def main():
             for i in range(LF):
                 pipe.engines[i].pairing_batch_dev(nl, dl1.data_ptr(), dl2.data_ptr(), louts[i].data_ptr(), True, None)
             torch.cuda.synchronize()
+            # shader clock and package power while this leg keeps the chip saturated (rocm-smi from a side thread, two samples; None when the tool is missing): the saturated legs are
+            # power-limited, and the roofline peak is priced at 2.4 GHz
+            clk = {'sclk_mhz': [], 'power_w': []}
+            def _sample_clocks():
+                import re as _re, shutil as _sh, subprocess as _sp
+                if not _sh.which('rocm-smi'):
+                    return
+                for _ in range(2):
+                    time.sleep(0.25)
+                    try:
+                        o = _sp.run(['rocm-smi', '-d', str(local_rank), '--showclocks', '--showpower'], capture_output=True, text=True, timeout=10).stdout
+                    except Exception:   # noqa: BLE001
+                        return
+                    m = _re.search(r'sclk clock level: \S+ \((\d+)Mhz\)', o); w = _re.search(r'Power \(W\): ([0-9.]+)', o)
+                    if m: clk['sclk_mhz'].append(int(m.group(1)))
+                    if w: clk['power_w'].append(float(w.group(1)))
+            import threading as _th
+            smp = _th.Thread(target=_sample_clocks); smp.start()
             f0 = time.perf_counter()
             for k in range(LF * lreps):
                 pipe.engines[k % LF].pairing_batch_dev(nl, dl1.data_ptr(), dl2.data_ptr(), louts[k % LF].data_ptr(), True, None)
             torch.cuda.synchronize()
             ldt_f = (time.perf_counter() - f0) / (LF * lreps)
+            smp.join()
             assert bytes(louts[-1][:576 * 8].cpu().numpy().tobytes()) == ref, 'large-batch in-flight parity check failed'
             del louts
             # the call runs as two halves on two streams from 8192 pairs (csrc/nbls_api.cpp): its kernels overlap, so achieved / frac are over the WALL time of the call
@@ -391,7 +410,8 @@ def main():
                                    'frac': round(nl * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL / ldt / 1e12 / PEAK_TMAD, 4),
                                    'kernel_ms': {k: round(v[0], 4) for k, v in ltm.items()},
                                    'in_flight': {'calls_in_flight': LF, 'pairings_per_s': round(nl / ldt_f, 2), 'ms_per_call_amortised': round(ldt_f * 1e3, 3),
-                                                 'roofline_frac': round(nl * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL / ldt_f / 1e12 / PEAK_TMAD, 4)},
+                                                 'roofline_frac': round(nl * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL / ldt_f / 1e12 / PEAK_TMAD, 4),
+                                                 'sclk_mhz_under_load': clk['sclk_mhz'] or None, 'package_power_w_under_load': clk['power_w'] or None},
                                    'note': 'ONE call (the library runs it as two halves on two streams); achieved/frac over the wall time of the call; kernel_ms = HIP-event durations of its launches, which overlap pairwise (Miller loop as LINES + ACC)'}
             del dl1, dl2, dlo
         if world == 1 and not args.no_cpu_baseline:
