@@ -1,6 +1,7 @@
 // Microbenchmark: what clock and package power does a SATURATED stream of v_mad_u64_u32 sustain on gfx950 -- is the 2.4 GHz of the roofline peak reachable by the instruction the
 // engine is made of?  Runs one of three kernels back to back for a few seconds and prints the achieved multiply-add rate; tools/mad_power.sh samples rocm-smi beside it.
 //   mode 0: multiply-adds only, 32-bit random operands     mode 1: the same with 28-bit operands (the engine's limbs)     mode 2: 196 multiply-adds per 28 LDS dword reads + 14 writes
+//           (mode 2 is LDS-bound as written -- dword reads, 14.8 T multiply-adds/s at 880 W -- and says nothing about the engine, whose operand reads are 16-byte reads)
 //   mode 3: v_mad_i64_i32 on SIGNED 28-bit operands, half of them negative (what the engine's operands look like: sign-extended limbs)
 // Usage: mad_power <mode> <seconds> [waves per SIMD = 8]
 #include <hip/hip_runtime.h>
@@ -12,16 +13,18 @@ typedef unsigned int u32;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 #define ITERS 2048
 template <int MODE> __global__ void __launch_bounds__(64) k(u32* out, u32 seed) {
-  __shared__ u32 lds[64 * 32];
+  __shared__ u32 lds[64 * 40];      // two 80-byte slots per lane (the engine's stride where it fits: 16-byte reads without the 4-way conflicts of 64-byte slots)
   const u32 mask = MODE == 0 ? 0xffffffffu : 0x0fffffffu;      // (mode 3 sign-extends instead)
   u32 a[14], b[14];
-  for (int j = 0; j < 14; j++) { a[j] = (threadIdx.x * 2654435761u + seed * (j + 1)) & mask; b[j] = (a[j] * 40503u + j) & mask; lds[threadIdx.x * 32 + j] = a[j]; lds[threadIdx.x * 32 + 14 + j] = b[j]; }
+  for (int j = 0; j < 14; j++) { a[j] = (threadIdx.x * 2654435761u + seed * (j + 1)) & mask; b[j] = (a[j] * 40503u + j) & mask; lds[threadIdx.x * 40 + j] = a[j]; lds[threadIdx.x * 40 + 20 + j] = b[j]; }
   u64 acc[28];
   for (int j = 0; j < 28; j++) acc[j] = j;
   for (int i = 0; i < ITERS; i++) {
-    if (MODE == 2) {
+    if (MODE == 2) {      // operands come from LDS every iteration (a neighbour lane's slot, as in the engine: lane-ops read what other lanes wrote); the offset is opaque to the compiler
+      u32 off = ((threadIdx.x + 1 + (i & 3)) & 63) * 40;
+      asm volatile("" : "+v"(off));
 #pragma unroll
-      for (int j = 0; j < 14; j++) { a[j] = lds[threadIdx.x * 32 + j]; b[j] = lds[threadIdx.x * 32 + 14 + j]; }
+      for (int j = 0; j < 14; j++) { a[j] = lds[off + j]; b[j] = lds[off + 20 + j]; }
     }
     if (MODE == 3) {
 #pragma unroll
@@ -36,7 +39,7 @@ template <int MODE> __global__ void __launch_bounds__(64) k(u32* out, u32 seed) 
     }
     if (MODE == 2) {
 #pragma unroll
-      for (int j = 0; j < 14; j++) lds[threadIdx.x * 32 + j] = ((u32)acc[j] + i) & mask;
+      for (int j = 0; j < 14; j++) lds[threadIdx.x * 40 + j] = ((u32)acc[j] + i) & mask;
     } else if (MODE == 3) {
 #pragma unroll
       for (int j = 0; j < 14; j++) a[j] = (u32)((int)((a[j] + (u32)acc[j + 7]) << 4) >> 4);      // sign-extended 28-bit value: about half of them negative
@@ -47,7 +50,7 @@ template <int MODE> __global__ void __launch_bounds__(64) k(u32* out, u32 seed) 
 #pragma unroll
     for (int j = 0; j < 28; j++) acc[j] &= 0xffffffffffffull;
   }
-  u64 s = 0; for (int j = 0; j < 28; j++) s += acc[j];
+  u64 s = lds[(threadIdx.x * 40 + 5) % 2560]; for (int j = 0; j < 28; j++) s += acc[j];
   out[blockIdx.x * 64 + threadIdx.x] = (u32)s ^ (u32)(s >> 32);
 }
 int main(int argc, char** argv) {
