@@ -37,7 +37,7 @@
   X(1, fe_easy, P_FE_EASY, P_COUNT, P_COUNT, P_COUNT)                        \
   X(1, fe_final, P_FE_FINAL, P_COUNT, P_COUNT, P_COUNT)                      \
   X(1, miller_fe, P_MILLER_FE, P_MILLER_RAW, P_MILLER_BYTES, P_COUNT)        \
-  X(1, mul2, P_MUL2, P_COUNT, P_COUNT, P_COUNT)                              \
+  X(1, mul2, P_MUL2, P_MUL2S, P_COUNT, P_COUNT)                             \
   X(1, norm, P_NORM_RAW, P_NORM_BYTES, P_RAW_TO_BYTES, P_COUNT)              \
   X(2, h2c_a, P_H2C_A, P_COUNT, P_COUNT, P_COUNT)                            \
   X(2, h2c_b, P_H2C_B1, P_H2C_B2, P_COUNT, P_COUNT)                          \

@@ -11,6 +11,7 @@
 #include "programs.h"
 #include "consts_gen.h"
 #include "fp_inv.h"
+#include "pow_exec.h"
 #include "sha256.h"
 #include <thread>
 
@@ -20,7 +21,7 @@ extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, vo
 #include <tuple>
 extern "C" int nbls_fp_inv_launch(unsigned n, const void* in, void* out, void* stream);
 extern "C" int nbls_flag_compact_launch(unsigned n, const void* flags, void* list, void* count, void* stream);
-extern "C" int nbls_xmd_launch(unsigned n, const void* msgs, const void* offsets, const void* dst, unsigned dst_len, void* out, unsigned len_in_bytes, void* stream);
+extern "C" int nbls_xmd_launch(unsigned n, const void* msgs, const void* offsets, const void* dst, unsigned dst_len, void* out, unsigned len_in_bytes, void* bad_flag, void* stream);
 extern "C" int nbls_msm_keys_launch(unsigned n, unsigned nwin, const void* scalars, void* keys, void* vals, void* stream);
 extern "C" int nbls_msm_decompose_launch(unsigned n, unsigned dims, const void* scalars, void* out, void* stream);
 extern "C" int nbls_msm_sort_launch(void* temp, size_t* temp_bytes, const void* keys_in, void* keys_out, const void* vals_in, void* vals_out, size_t m, int key_bits, void* stream);
@@ -30,7 +31,7 @@ extern "C" int nbls_msm_pairs_launch(size_t m, unsigned d, const void* keys, con
 extern "C" int nbls_msm_fill_launch(size_t count, unsigned elem_bytes, const void* ident, void* dst, void* stream);
 extern "C" int nbls_msm_heads_launch(size_t m, unsigned elem_bytes, const void* keys, const void* P, void* buckets, void* stream);
 extern "C" int nbls_msm_bitsel_launch(unsigned nwin, unsigned elem_bytes, const void* buckets, void* G, void* stream);
-extern "C" int nbls_fp_pow_launch(unsigned n, const void* in, void* out, const void* nibbles, int nnib, void* scratch, int is_fp2, void* stream);
+extern "C" int nbls_fp_pow_launch(unsigned n, const void* in, void* out, const void* ops, int nops, void* scratch, int is_fp2, void* stream);
 
 using namespace nbls;
 static_assert(P_COUNT <= NBLS_N_PROGRAMS, "nbls_timing_read's arrays (NBLS_N_PROGRAMS + 1 entries) must cover every step program");
@@ -63,7 +64,7 @@ struct nbls_ctx {
   // general scratch pool for the codec / hash / sum pipelines (grown on demand)
   static const int NSB = 20;
   uint8_t* sb[NSB] = {nullptr}; size_t sb_cap[NSB] = {0};
-  uint8_t* nib[4] = {nullptr, nullptr, nullptr, nullptr}; int nnib[4] = {0, 0, 0, 0};   // exponent nibbles: (p+1)/4, (p^2+7)/16, (p^2-9)/16, (p-3)/4
+  uint8_t* nib[4] = {nullptr, nullptr, nullptr, nullptr}; int nnib[4] = {0, 0, 0, 0};   // op lists (pow_exec.h) of the exponents (p+1)/4, (p^2+7)/16, (p^2-9)/16, (p-3)/4 and their lengths in ops
   uint8_t* neg_g1 = nullptr;    // -G1 generator, affine wire bytes (verify: e(-G, S))
   uint8_t* gen_g1 = nullptr;    // G1 generator, affine wire bytes (getPublicKey)
   // side stream for the one-element chains of verifyBatch (signature decompression: a 758-bit Fp2 exponentiation on a single
@@ -72,6 +73,9 @@ struct nbls_ctx {
   // large pairing batches run as two halves on two streams (nbls_pairing_batch_dev): item offset applied to every per-item buffer of a launch, second stream, events
   size_t ioff = 0; hipStream_t half_stream = nullptr; hipEvent_t ev_half_fork = nullptr, ev_half_join = nullptr;
   size_t halves_min = env_long("NBLS_HALVES_MIN", 8192) > 0 ? (size_t)env_long("NBLS_HALVES_MIN", 8192) : (size_t)-1;   // NBLS_HALVES_MIN=0: never (profiles of kernels running alone)
+  // verifyBatch as a software pipeline (round 5, verify_pipeline): events of the chunks (two each), the "xmd met non-monotonic offsets" flag lives behind the statuses
+  std::vector<hipEvent_t> pipe_ev; hipEvent_t ev_pipe_done = nullptr;
+  long verify_chunks = env_long("NBLS_VERIFY_CHUNKS", 4), verify_last_pct = env_long("NBLS_VERIFY_LAST_PCT", 12), verify_pipe_min = env_long("NBLS_VERIFY_PIPE_MIN", 16384);   // nbls_set_tuning(NBLS_TUNE_VERIFY_*)
   hipStream_t side2 = nullptr; hipEvent_t ev_join2 = nullptr;   // verifyBatch: key decoding runs beside message hashing (their exponentiation kernels are latency-bound and leave issue slots free)
   uint8_t* ident_g1 = nullptr; uint8_t* ident_g2 = nullptr;   // projective identity (0 : 1 : 0), raw
   size_t cap_F = 0, cap_io = 0;
@@ -298,7 +302,7 @@ static int need(nbls_ctx* ctx, int i, size_t bytes, uint8_t** out) {
 }
 static int run_pow(nbls_ctx* ctx, int which, size_t n, const void* in, void* out, hipStream_t s, uint8_t* scratch = nullptr) {
   int is_fp2 = which == 1 || which == 2;
-  if (!scratch) { int r = need(ctx, 11, n * 16 * (is_fp2 ? 2 : 1) * RAW, &scratch); if (r) return r; }
+  if (!scratch) { int r = need(ctx, 11, n * POW_TAB * (is_fp2 ? 2 : 1) * RAW, &scratch); if (r) return r; }
   int e = nbls_fp_pow_launch((unsigned)n, in, out, ctx->nib[which], ctx->nnib[which], scratch, which == 1 ? 8 : which == 2 ? 7 : 0, s);   // Fp2: a^((p^2+7)/16) = b^K a^8, a^((p^2-9)/16) = b^K a^7
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
   return NBLS_OK;
@@ -341,14 +345,16 @@ static ProgId ls_variant(ProgId id, size_t n) {
   }
 }
 static int reduce_product(nbls_ctx* ctx, size_t n, uint8_t** result, hipStream_t s) {
-  uint8_t *src = ctx->F, *dst = ctx->F2;
-  size_t m = n;
-  while (m > 1) {
-    if (m & 1) { HIPCHK(hipMemcpyAsync(src + m * F12, ctx->one12, F12, hipMemcpyDeviceToDevice, s)); m++; }
-    int r = run(ctx, P_MUL2, m / 2, {B(3, src, 2 * F12), B(5, dst, F12)}, s); if (r) return r;
-    std::swap(src, dst); m /= 2;
+  // round 5: IN PLACE.  With spacing d the live elements are F[0], F[d], F[2d], ... below n; one launch multiplies F[2 i d] by F[2 i d + d] into the former for every
+  // complete pair, and an odd last element -- its index is a multiple of 2 d -- simply stays alive for the next level.  No level copies or pads anything (round 4: ping-pong
+  // between F and F2 with a copy of ONE behind every odd level: 15 launches + 15 copies for 16,385 values, 0.3 ms at the end of a verifyBatch with the GPU otherwise idle).
+  for (size_t d = 1; d < n; d *= 2) {
+    const size_t pairs = ((n + d - 1) / d) / 2;
+    if (!pairs) continue;
+    const int r = run(ctx, P_MUL2S, pairs, {B(3, ctx->F, 2 * d * F12), B(4, ctx->F + d * F12, 2 * d * F12), B(5, ctx->F, 2 * d * F12)}, s);
+    if (r) return r;
   }
-  *result = src;
+  *result = ctx->F;
   return NBLS_OK;
 }
 // out = conj(in^|x|) for n unitary raw Fp12 elements (cyclotomicExp + conjugate, math.ts:845-852, 862).  Default: ONE program, 63 Granger-Scott squarings
@@ -433,18 +439,17 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
     const uint64_t* exps[4] = {NBLS_EXP_P_PLUS_1_DIV_4, NBLS_EXP_P2_PLUS_7_DIV_16, NBLS_EXP_P2_MINUS_9_DIV_16, NBLS_EXP_P_MINUS_3_DIV_4};
     const int bits[4] = {NBLS_P_PLUS_1_DIV_4_BITS, NBLS_P2_PLUS_7_DIV_16_BITS, NBLS_P2_MINUS_9_DIV_16_BITS, NBLS_P_MINUS_3_DIV_4_BITS};
     for (int k = 0; k < 4; k++) {
-      int nn = (bits[k] + 3) / 4; std::vector<uint8_t> nb(nn);
-      for (int j = 0; j < nn; j++) { int lo = 4 * (nn - 1 - j); uint8_t d = 0; for (int b = 3; b >= 0; b--) { int bit = lo + b; d = (uint8_t)((d << 1) | (bit < bits[k] ? (exps[k][bit >> 6] >> (bit & 63)) & 1 : 0)); } nb[j] = d; }
-      // the two Fp2 exponents are (K p + 11 K + 8) and (K p + 11 K + 7) with K = (p - 11) / 16: the kernel raises conj(a) a^11 to K (pow_kernels.hip), so both get the nibbles of K
+      // op lists of the exponents (pow_exec.h: sliding windows).  The two Fp2 exponents are (K p + 11 K + 8) and (K p + 11 K + 7) with K = (p - 11) / 16: the kernel
+      // raises conj(a) a^11 to K (pow_kernels.hip), so both get the op list of K
+      std::vector<unsigned char> ops;
       if (k == 1 || k == 2) {
         uint64_t K[6]; for (int j = 0; j < 6; j++) K[j] = NBLS_EXP_P_MINUS_3_DIV_4[j];
         K[0] -= 2;                                                        // (p - 3) / 4 - 2 = (p - 11) / 4 (no borrow: the low word ends in ...aaaa)
         for (int j = 0; j < 6; j++) K[j] = (K[j] >> 2) | (j < 5 ? K[j + 1] << 62 : 0);   // / 4
-        const int kb = 377; nn = (kb + 3) / 4; nb.assign(nn, 0);
-        for (int j = 0; j < nn; j++) { int lo = 4 * (nn - 1 - j); uint8_t d = 0; for (int b = 3; b >= 0; b--) { int bit = lo + b; d = (uint8_t)((d << 1) | (bit < kb ? (K[bit >> 6] >> (bit & 63)) & 1 : 0)); } nb[j] = d; }
-      }
-      ctx->nnib[k] = nn;
-      if (hipMalloc(&ctx->nib[k], nn) != hipSuccess || hipMemcpy(ctx->nib[k], nb.data(), nn, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
+        ops = pow_make_ops(K, 377);
+      } else ops = pow_make_ops(exps[k], bits[k]);
+      ctx->nnib[k] = (int)(ops.size() / 2);
+      if (hipMalloc(&ctx->nib[k], ops.size()) != hipSuccess || hipMemcpy(ctx->nib[k], ops.data(), ops.size(), hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
     }
     // -G1 in wire form: x || (p - y)   (standard integers, big-endian)
     uint8_t ng[96];
@@ -479,7 +484,8 @@ EXPORT void nbls_destroy(nbls_ctx* ctx) {
   if (ctx->half_stream) hipStreamDestroy(ctx->half_stream);
   for (hipEvent_t e : {ctx->ev_half_fork, ctx->ev_half_join}) if (e) hipEventDestroy(e);
   if (ctx->side2) hipStreamDestroy(ctx->side2);
-  for (hipEvent_t e : {ctx->ev_fork, ctx->ev_join, ctx->ev_join2, ctx->ev_last}) if (e) hipEventDestroy(e);
+  for (hipEvent_t e : {ctx->ev_fork, ctx->ev_join, ctx->ev_join2, ctx->ev_last, ctx->ev_pipe_done}) if (e) hipEventDestroy(e);
+  for (hipEvent_t e : ctx->pipe_ev) hipEventDestroy(e);
   for (auto& t : ctx->tev) { hipEventDestroy(t.second.first); hipEventDestroy(t.second.second); }
   for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -588,17 +594,10 @@ EXPORT int nbls_pairing_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1, const 
   return NBLS_OK;
 }
 
-EXPORT int nbls_miller_product_dev(nbls_ctx* ctx, size_t n, const void* d_g1, const void* d_g2, int final_exp, void* d_out, void* stream) {
-  if (!ctx || !d_out || (n && (!d_g1 || !d_g2))) return NBLS_EINVAL;
-  std::lock_guard<std::recursive_mutex> g(ctx->mu);
-  HIPCHK(hipSetDevice(ctx->device));
-  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-  StreamOrder order_(ctx, s);
+// n >= 1 pairs -> *m_out raw Miller values (products of up to eight Miller loops each) in ctx->F[0 .. *m_out); the caller multiplies them (reduce_product)
+static int miller_values(nbls_ctx* ctx, size_t n, const void* d_g1, const void* d_g2, size_t* m_out, hipStream_t s) {
   int r;
-  if ((r = ensure_scratch(ctx, n ? n : 1))) return r;
-  uint8_t* res = ctx->F;
-  if (n == 0) { HIPCHK(hipMemcpyAsync(ctx->F, ctx->one12, F12, hipMemcpyDeviceToDevice, s)); }
-  else {
+  {
     // pairs are taken two at a time with a shared accumulator (one Fp12 squaring per bit for both); an odd last pair runs alone
     const size_t n2 = n / 2; size_t m = n2 + (n & 1);
     static const int fused_mode = (int)env_long("NBLS_FUSED_MILLER", -1);
@@ -639,6 +638,23 @@ EXPORT int nbls_miller_product_dev(nbls_ctx* ctx, size_t n, const void* d_g1, co
         m += cg;
       }
     }
+    *m_out = m;
+  }
+  return NBLS_OK;
+}
+EXPORT int nbls_miller_product_dev(nbls_ctx* ctx, size_t n, const void* d_g1, const void* d_g2, int final_exp, void* d_out, void* stream) {
+  if (!ctx || !d_out || (n && (!d_g1 || !d_g2))) return NBLS_EINVAL;
+  std::lock_guard<std::recursive_mutex> g(ctx->mu);
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  StreamOrder order_(ctx, s);
+  int r;
+  if ((r = ensure_scratch(ctx, n ? n : 1))) return r;
+  uint8_t* res = ctx->F;
+  if (n == 0) { HIPCHK(hipMemcpyAsync(ctx->F, ctx->one12, F12, hipMemcpyDeviceToDevice, s)); }
+  else {
+    size_t m = 0;
+    if ((r = miller_values(ctx, n, d_g1, d_g2, &m, s))) return r;
     if ((r = reduce_product(ctx, m, &res, s))) return r;
   }
   return finish_single(ctx, res, final_exp, d_out, s);
@@ -834,7 +850,7 @@ static int dev_validate(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, voi
 static int dev_decompress(nbls_ctx* ctx, bool g2, size_t n, const void* d_in, void* d_out, void* d_status, hipStream_t s, int slot0 = 0, int pow_slot = 11, int mode = 0) {
   const size_t e = g2 ? (mode == 1 ? 192 : 96) : 48, q = g2 ? 2 * RAW : RAW;
   uint8_t *X, *R, *Cd, *pw; int r;
-  if ((r = need(ctx, slot0, n * q, &X)) || (r = need(ctx, slot0 + 1, n * q, &R)) || (r = need(ctx, slot0 + 2, n * q, &Cd)) || (r = need(ctx, pow_slot, n * 16 * (g2 ? 2 : 1) * RAW, &pw))) return r;
+  if ((r = need(ctx, slot0, n * q, &X)) || (r = need(ctx, slot0 + 1, n * q, &R)) || (r = need(ctx, slot0 + 2, n * q, &Cd)) || (r = need(ctx, pow_slot, n * POW_TAB * (g2 ? 2 : 1) * RAW, &pw))) return r;
   const ProgId pa = !g2 ? P_G1_DEC_A : mode == 1 ? P_G2_DEC_A192 : P_G2_DEC_A, pb = !g2 ? P_G1_DEC_B : mode == 1 ? P_G2_DEC_B192 : mode == 2 ? P_G2_DEC_B_HEX : P_G2_DEC_B;
   if ((r = run(ctx, pa, n, {B(0, d_in, e), B(3, X, q), B(4, R, q)}, s))) return r;
   if ((r = run_pow(ctx, g2 ? 1 : 0, n, R, Cd, s, pw))) return r;
@@ -988,6 +1004,9 @@ EXPORT int nbls_set_tuning(nbls_ctx* ctx, int key, long long value) {
     case NBLS_TUNE_HALVES_MIN: if (value < 0) return NBLS_EINVAL; ctx->halves_min = value == 0 ? (size_t)-1 : (size_t)value; return NBLS_OK;
     case NBLS_TUNE_EXPC_MIN: if (value < 0) return NBLS_EINVAL; ctx->expc_min = (size_t)value; return NBLS_OK;
     case NBLS_TUNE_CHAIN_MAX: if (value < 0) return NBLS_EINVAL; ctx->chain_max = (size_t)value; return NBLS_OK;
+    case NBLS_TUNE_VERIFY_CHUNKS: if (value < 0 || value > 64) return NBLS_EINVAL; ctx->verify_chunks = (long)value; return NBLS_OK;
+    case NBLS_TUNE_VERIFY_LAST_PCT: if (value < 1 || value > 100) return NBLS_EINVAL; ctx->verify_last_pct = (long)value; return NBLS_OK;
+    case NBLS_TUNE_VERIFY_PIPE_MIN: if (value < 0) return NBLS_EINVAL; ctx->verify_pipe_min = (long)value; return NBLS_OK;
     default: return NBLS_EINVAL;
   }
 }
@@ -1038,7 +1057,7 @@ static int dev_expand(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32
   HIPCHK(hipMemcpyAsync(dofs, rel.data(), (n + 1) * 4, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(dd, dst, dst_len, hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));     // `rel` and a hashed DST live on this stack frame
-  int e = nbls_xmd_launch((unsigned)n, dm, dofs, dd, (unsigned)dst_len, du, len_in_bytes, s);
+  int e = nbls_xmd_launch((unsigned)n, dm, dofs, dd, (unsigned)dst_len, du, len_in_bytes, nullptr, s);
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
   *d_uniform = du;
   return NBLS_OK;
@@ -1347,6 +1366,146 @@ EXPORT int nbls_sign_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const u
   return NBLS_OK;
 }
 
+// ---- verifyBatch as a software pipeline (round 5) ------------------------------------------------------------------------------------------------------
+// Round 4 ran the call in two phases -- decode the keys and hash every message (12.5 ms at 65,536 signatures, most of it ONE chain of dependent launches), read the
+// statuses back, then the Miller product of all pairs (9.1 ms) -- and three such calls in flight took 18.4 ms each instead of 22.8: the phases leave issue slots
+// free (exponentiation kernels two wavefronts deep, the partly filled last round of every launch, a host round trip in the middle).  Now the signatures are cut into
+// K chunks of decreasing size; chunk c + 1 is decoded and hashed (caller's stream + the key stream) while the Miller loops of chunk c run on a third stream
+// (LINES_PQ -> ACC with four / two / one line tables per accumulator, by chunk size), every accumulator of every chunk lands in ONE array that the in-place product
+// tree reduces at the end, and the statuses are read back once, with the result: nothing is decided on the host before the end (an undecodable key only makes the
+// product meaningless, and the statuses say so).  index.ts:792-821.
+struct VerifyIn {
+  const void* d_sig96;      // 96-byte signature, or NULL (a shard without the signature pair)
+  const void* d_uniform;    // 256 B of expand_message_xmd output per message, or NULL when the messages themselves are given:
+  const void* d_msgs; const void* d_offsets; const uint8_t* dst_dev; unsigned dst_len;
+  const void* d_pk48;
+};
+static std::vector<size_t> verify_plan(nbls_ctx* ctx, size_t n) {
+  size_t K = (size_t)ctx->verify_chunks;
+  if (K < 2 || n < (size_t)ctx->verify_pipe_min || n < 64 * K) return {n};
+  // sizes fall linearly from the first chunk to the last (verify_last_pct per cent of n): the last chunk's Miller loops run with nothing beside them, so it is the small one;
+  // every size but the last is a multiple of 64 (whole groups of accumulators, whole wavefronts)
+  const double last = (double)n * (double)ctx->verify_last_pct / 100.0, first = 2.0 * (double)n / (double)K - last;
+  if (first <= last) { std::vector<size_t> v(K, (n / K) & ~(size_t)63); size_t sum = 0; for (size_t c = 0; c + 1 < K; c++) sum += v[c]; v[K - 1] = n - sum; return v; }
+  std::vector<size_t> v(K); size_t sum = 0;
+  for (size_t c = 0; c + 1 < K; c++) { v[c] = ((size_t)(first + (last - first) * (double)c / (double)(K - 1)) + 63) & ~(size_t)63; sum += v[c]; if (sum >= n) return {n}; }
+  v[K - 1] = n - sum;
+  return v;
+}
+static int pipe_event(nbls_ctx* ctx, size_t i, hipEvent_t* e) {
+  while (ctx->pipe_ev.size() <= i) { hipEvent_t ev = nullptr; HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); ctx->pipe_ev.push_back(ev); }
+  *e = ctx->pipe_ev[i];
+  return NBLS_OK;
+}
+static int ensure_half_stream(nbls_ctx* ctx) {
+  if (!ctx->half_stream && (hipStreamCreateWithFlags(&ctx->half_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_half_fork, hipEventDisableTiming) != hipSuccess ||
+                            hipEventCreateWithFlags(&ctx->ev_half_join, hipEventDisableTiming) != hipSuccess)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+  return NBLS_OK;
+}
+// final_exp = 1: the product's final exponentiation as 576 wire bytes in `out` (host); 0: the product itself as wire bytes at d_out (device; a shard's partial).
+// st: n statuses of the keys (+ 1 of the signature) as the decoders wrote them; *bad_offsets: the message offsets were not monotonic.
+static int verify_pipeline(nbls_ctx* ctx, size_t n, const VerifyIn& in, int final_exp, void* d_out, uint8_t* out, std::vector<int8_t>& st, int* bad_offsets, void* stream) {
+  const size_t np = n + (in.d_sig96 ? 1 : 0);
+  st.assign(np + 8, 0);
+  std::lock_guard<std::recursive_mutex> g_(ctx->mu); HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  StreamOrder order_(ctx, s);
+  int r;
+  uint8_t *G1, *G2, *ST, *O, *du = nullptr;
+  if ((r = need(ctx, 10, (n + 1) * (96 + 192) + (n + 1) + 576 + 64 + 16, &G1))) return r;
+  G2 = G1 + (n + 1) * 96; O = G2 + (n + 1) * 192; ST = O + 576;
+  uint32_t* d_bad = (uint32_t*)(ST + ((np + 3) & ~(size_t)3));   // one word behind the statuses
+  if (!in.d_uniform && (r = need(ctx, 8, n * 256, &du))) return r;
+  const std::vector<size_t> plan = verify_plan(ctx, n);
+  const size_t K = plan.size();
+  // streams: hash chain on the caller's stream, keys on side2, the signature on side, Miller loops of a chunked call on half_stream
+  if (!ctx->side2 && (hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming) != hipSuccess)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+  if (!ctx->ev_fork && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+  if (!ctx->ev_pipe_done && hipEventCreateWithFlags(&ctx->ev_pipe_done, hipEventDisableTiming) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+  if (K > 1 && (r = ensure_half_stream(ctx))) return r;
+  hipStream_t M = K > 1 ? ctx->half_stream : s;
+  HIPCHK(hipMemsetAsync(d_bad, 0, 4, s));
+  HIPCHK(hipEventRecord(ctx->ev_fork, s));
+  HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));
+  if (K > 1) HIPCHK(hipStreamWaitEvent(M, ctx->ev_fork, 0));
+  if (in.d_sig96) {
+    // normP2: PointG2.fromSignature for the ONE signature, on the side stream with its own scratch (its Fp2 exponentiation on two lanes is pure latency)
+    if (!ctx->side) {
+      if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+          hipMalloc(&ctx->side_scratch, (6 + 2 * POW_TAB) * RAW) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+    }
+    uint8_t *X = ctx->side_scratch, *Rr = X + 2 * RAW, *Cd = Rr + 2 * RAW, *pw = Cd + 2 * RAW;
+    HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    if ((r = run(ctx, P_G2_DEC_A, 1, {B(0, in.d_sig96, 96), B(3, X, 2 * RAW), B(4, Rr, 2 * RAW)}, ctx->side))) return r;
+    if ((r = run_pow(ctx, 1, 1, Rr, Cd, ctx->side, pw))) return r;
+    if ((r = run(ctx, P_G2_DEC_B, 1, {B(0, in.d_sig96, 96), B(3, X, 2 * RAW), B(4, Rr, 2 * RAW), B(5, Cd, 2 * RAW), B(6, G2 + n * 192, 192), B(7, ST + n, 1)}, ctx->side))) return r;
+    HIPCHK(hipEventRecord(ctx->ev_join, ctx->side));
+  }
+  if ((r = ensure_scratch(ctx, np))) return r;
+  size_t cmax = 0; for (size_t c : plan) cmax = std::max(cmax, c);
+  if (K > 1 && (r = ensure_lines(ctx, cmax + 8))) return r;
+  size_t o = 0, m_off = 0;
+  for (size_t c = 0; c < K; c++) {
+    const size_t nc = plan[c]; const bool last = c + 1 == K;
+    hipEvent_t evH, evD;
+    if ((r = pipe_event(ctx, 2 * c, &evH)) || (r = pipe_event(ctx, 2 * c + 1, &evD))) return r;
+    // normP1 (PointG1.fromHex of the keys) on the key stream: scratch slots 14..16 / 17
+    if ((r = dev_decompress(ctx, false, nc, (const uint8_t*)in.d_pk48 + o * 48, G1 + o * 96, ST + o, ctx->side2, 14, 17))) return r;
+    HIPCHK(hipEventRecord(evD, ctx->side2));
+    // normP2Hash (PointG2.hashToCurve of the messages) on the caller's stream: scratch slots 0..6 / 11 / 13 / 18 / 19
+    const uint8_t* uni = (const uint8_t*)in.d_uniform + o * 256;
+    if (!in.d_uniform) {
+      const int e = nbls_xmd_launch((unsigned)nc, in.d_msgs, (const uint32_t*)in.d_offsets + o, in.dst_dev, in.dst_len, du + o * 256, 256, d_bad, s);
+      if (e) { ctx->last_hip = e; return NBLS_EHIP; }
+      uni = du + o * 256;
+    }
+    if ((r = dev_hash_to_g2(ctx, nc, uni, G2 + o * 192, s))) return r;
+    if (K > 1) HIPCHK(hipEventRecord(evH, s));
+    // Miller loops of the chunk
+    if (K > 1) HIPCHK(hipStreamWaitEvent(M, evH, 0));
+    HIPCHK(hipStreamWaitEvent(M, evD, 0));
+    size_t cc = nc;
+    if (last && in.d_sig96) {
+      HIPCHK(hipMemcpyAsync(G1 + n * 96, ctx->neg_g1, 96, hipMemcpyDeviceToDevice, M));         // PointG1.BASE.negate()
+      HIPCHK(hipStreamWaitEvent(M, ctx->ev_join, 0));
+      cc++;
+    }
+    if (K == 1) {
+      if ((r = miller_values(ctx, cc, G1, G2, &m_off, M))) return r;
+    } else {
+      // line tables per accumulator: four where the chunk still fills the chip with a quarter of its pairs as items, fewer where only the length of one wavefront's instruction stream counts
+      const size_t GR = cc >= 14336 ? 4 : cc >= 6144 ? 2 : 1;
+      const ProgId acc = GR == 4 ? P_ACC4_RAW : GR == 2 ? P_ACC2_RAW : P_ACC_RAW;
+      const size_t gg = (cc + GR - 1) / GR;
+      if ((r = run(ctx, P_LINES_PQ, cc, {B(0, G1 + o * 96, 96), B(1, G2 + o * 192, 192), B(3, ctx->L, LINE_BYTES)}, M))) return r;
+      for (size_t k = cc; k < GR * gg; k++) HIPCHK(hipMemcpyAsync(ctx->L + k * LINE_BYTES, ctx->unit_lines, LINE_BYTES, hipMemcpyDeviceToDevice, M));
+      if ((r = run(ctx, acc, gg, {B(3, ctx->L, GR * LINE_BYTES), B(5, ctx->F + m_off * F12, F12)}, M))) return r;
+      m_off += gg;
+    }
+    o += nc;
+  }
+  uint8_t* res = ctx->F;
+  if ((r = reduce_product(ctx, m_off, &res, M))) return r;
+  if ((r = finish_single(ctx, res, final_exp, final_exp ? (void*)O : d_out, M))) return r;
+  HIPCHK(hipMemcpyAsync(st.data(), ST, ((np + 3) & ~(size_t)3) + 4, hipMemcpyDeviceToHost, M));
+  if (final_exp) HIPCHK(hipMemcpyAsync(out, O, 576, hipMemcpyDeviceToHost, M));
+  if (M != s) { HIPCHK(hipEventRecord(ctx->ev_pipe_done, M)); HIPCHK(hipStreamWaitEvent(s, ctx->ev_pipe_done, 0)); }
+  HIPCHK(hipStreamSynchronize(s));
+  uint32_t bad = 0; memcpy(&bad, st.data() + ((np + 3) & ~(size_t)3), 4);
+  if (bad_offsets) *bad_offsets = bad != 0;
+  st.resize(np);
+  return NBLS_OK;
+}
+static bool verify_pipe_enabled() { static const bool on = env_long("NBLS_VERIFY_PIPE", 1) != 0; return on; }
+static bool fp12_wire_is_one(const uint8_t* out) { bool one = out[47] == 1; for (int i = 0; i < 576 && one; i++) if (i != 47 && out[i]) one = false; return one; }   // exp.equals(Fp12.ONE)
+// the whole of verifyBatch behind the pipeline: decide from the statuses as the reference does (index.ts:792-821)
+static int verify_decide(const std::vector<int8_t>& st, size_t n, const uint8_t* out, int* ok, int8_t* pk_status) {
+  if (pk_status) memcpy(pk_status, st.data(), n);
+  for (int8_t v : st) if (v > 1) return NBLS_EDECODE;                  // the reference throws before its try block
+  for (int8_t v : st) if (v == 1) { *ok = 0; return NBLS_OK; }          // zero point -> pairing() throws -> false
+  *ok = fp12_wire_is_one(out) ? 1 : 0;
+  return NBLS_OK;
+}
 // verifyBatch(signature, messages, publicKeys) on wire inputs (index.ts:792-821): every message hashes to its own point
 // (hex inputs are distinct objects in the reference), n pairings e(pk_i, H(m_i)) times e(-G, sig), one final exponentiation.
 //   *ok = 1 / 0.  Return code: NBLS_OK, or NBLS_EDECODE when the reference would throw while decoding (before its try block):
@@ -1373,14 +1532,14 @@ EXPORT int nbls_verify_batch(nbls_ctx* ctx, size_t n, const uint8_t* sig96, cons
 // compressed keys.  SHA-256 expand_message_xmd (index.ts:207-231) runs first, on the same stream, then the call continues as nbls_verify_batch_dev_inputs.
 EXPORT int nbls_verify_batch_msgs_dev(nbls_ctx* ctx, size_t n, const void* d_sig96, const void* d_msgs, const void* d_offsets, const void* d_pk48, const uint8_t* dst, size_t dst_len, int* ok, void* stream) {
   std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);
-  if (!ctx || !ok || !n || !d_sig96 || !d_offsets || !d_pk48 || !dst || dst_len > 255) return NBLS_EINVAL;
-  uint8_t *dd, *du;
+  if (!ctx || !ok || !n || !d_sig96 || !d_offsets || !d_pk48 || !dst) return NBLS_EINVAL;
+  uint8_t* dd;
+  // a DST longer than 255 bytes is replaced by its SHA-256 digest (RFC 9380 5.3.3), as in dev_expand and the reference's expand_message_xmd (index.ts:207-231)
+  uint8_t dst_hash[32];
+  if (dst_len > 255) { Sha256 c; c.update((const uint8_t*)"H2C-OVERSIZE-DST-", 17); c.update(dst, dst_len); c.final(dst_hash); dst = dst_hash; dst_len = 32; }
   {
     std::lock_guard<std::recursive_mutex> g_(ctx->mu); HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    StreamOrder order_(ctx, s);
-    int r;
-    if ((r = need(ctx, 8, n * 256, &du))) return r;
     // the domain-separation tag is kept on the device between calls (a service verifies under one tag): no copy, no synchronisation in the steady state
     if (!ctx->dst_dev) HIPCHK(hipMalloc(&ctx->dst_dev, 256));
     if (ctx->dst_host.size() != dst_len || memcmp(ctx->dst_host.data(), dst, dst_len)) {
@@ -1389,8 +1548,27 @@ EXPORT int nbls_verify_batch_msgs_dev(nbls_ctx* ctx, size_t n, const void* d_sig
       ctx->dst_host.assign(dst, dst + dst_len);
     }
     dd = ctx->dst_dev;
-    const int e = nbls_xmd_launch((unsigned)n, (const uint8_t*)d_msgs, (const uint8_t*)d_offsets, dd, (unsigned)dst_len, du, 256, s);
+  }
+  if (verify_pipe_enabled()) {
+    VerifyIn in{d_sig96, nullptr, d_msgs, d_offsets, dd, (unsigned)dst_len, d_pk48};
+    std::vector<int8_t> st; uint8_t out[576]; int bad = 0;
+    int r = verify_pipeline(ctx, n, in, 1, nullptr, out, st, &bad, stream); if (r) return r;
+    if (bad) return NBLS_EINVAL;   // offsets[i + 1] < offsets[i] somewhere (the kernel hashed an empty message there instead of reading 4 GB)
+    return verify_decide(st, n, out, ok, nullptr);
+  }
+  uint8_t* du;
+  {
+    std::lock_guard<std::recursive_mutex> g_(ctx->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    StreamOrder order_(ctx, s);
+    int r;
+    if ((r = need(ctx, 8, n * 256 + 16, &du))) return r;
+    uint32_t* d_bad = (uint32_t*)(du + n * 256);
+    HIPCHK(hipMemsetAsync(d_bad, 0, 4, s));
+    const int e = nbls_xmd_launch((unsigned)n, (const uint8_t*)d_msgs, (const uint8_t*)d_offsets, dd, (unsigned)dst_len, du, 256, d_bad, s);
     if (e) { ctx->last_hip = e; return NBLS_EHIP; }
+    uint32_t bad = 0; HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+    if (bad) return NBLS_EINVAL;
   }
   return nbls_verify_batch_dev_inputs(ctx, n, d_sig96, du, d_pk48, ok, nullptr, stream);
 }
@@ -1412,7 +1590,7 @@ static int verify_stage(nbls_ctx* ctx, size_t n, const void* d_sig96, const void
     // that only run pairing batches (noble-bls12-381_amd/pipeline.py keeps several in flight) should each get a queue of their own.
     if (!ctx->side) {
       if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess || (!ctx->ev_fork && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) ||
-          hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess || hipMalloc(&ctx->side_scratch, (6 + 32) * RAW) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+          hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess || hipMalloc(&ctx->side_scratch, (6 + 2 * POW_TAB) * RAW) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
     }
     uint8_t *X = ctx->side_scratch, *Rr = X + 2 * RAW, *Cd = Rr + 2 * RAW, *pw = Cd + 2 * RAW;
     HIPCHK(hipEventRecord(ctx->ev_fork, s)); HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
@@ -1451,6 +1629,11 @@ EXPORT int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_s
   if (!ctx || !ok || !n || !d_sig96 || !d_uniform || !d_pk48) return NBLS_EINVAL;
   std::vector<int8_t> st;
   uint8_t out[576];
+  if (verify_pipe_enabled()) {
+    VerifyIn in{d_sig96, d_uniform, nullptr, nullptr, nullptr, 0, d_pk48};
+    int r = verify_pipeline(ctx, n, in, 1, nullptr, out, st, nullptr, stream); if (r) return r;
+    return verify_decide(st, n, out, ok, pk_status);
+  }
   int r = verify_stage(ctx, n, d_sig96, d_uniform, d_pk48, st, stream); if (r) return r;
   if (pk_status) memcpy(pk_status, st.data(), n);
   for (size_t i = 0; i <= n; i++) if (st[i] > 1) return NBLS_EDECODE;       // the reference throws before its try block
@@ -1464,8 +1647,7 @@ EXPORT int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_s
     HIPCHK(hipMemcpyAsync(out, base + (n + 1) * 288, 576, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
   }
-  bool one = out[47] == 1; for (int i = 0; i < 576 && one; i++) if (i != 47 && out[i]) one = false;   // exp.equals(Fp12.ONE)
-  *ok = one ? 1 : 0;
+  *ok = fp12_wire_is_one(out) ? 1 : 0;
   return NBLS_OK;
 }
 // One rank's share of a verifyBatch that is spread over several GPUs: the Miller product of this rank's n
@@ -1476,6 +1658,16 @@ EXPORT int nbls_verify_batch_partial_dev(nbls_ctx* ctx, size_t n, const void* d_
   std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);   // scratch and I/O staging buffers belong to this call until it returns
   if (!ctx || !zero_flag || !n || !d_uniform || !d_pk48 || !d_out_fp12) return NBLS_EINVAL;
   std::vector<int8_t> st;
+  if (verify_pipe_enabled()) {
+    // the pipeline decides nothing before its end: with an undecodable key or a zero point d_out_fp12 holds a meaningless product (round 4 left it unwritten); callers look at the return code and the flag first
+    VerifyIn in{d_sig96, d_uniform, nullptr, nullptr, nullptr, 0, d_pk48};
+    int r = verify_pipeline(ctx, n, in, 0, d_out_fp12, nullptr, st, nullptr, stream); if (r) return r;
+    if (pk_status) memcpy(pk_status, st.data(), n);
+    for (int8_t v : st) if (v > 1) return NBLS_EDECODE;
+    *zero_flag = 0;
+    for (int8_t v : st) if (v == 1) *zero_flag = 1;
+    return NBLS_OK;
+  }
   int r = verify_stage(ctx, n, d_sig96, d_uniform, d_pk48, st, stream); if (r) return r;
   if (pk_status) memcpy(pk_status, st.data(), n);
   for (int8_t v : st) if (v > 1) return NBLS_EDECODE;

@@ -401,6 +401,11 @@ static Program build(ProgId id) {
       outputw_fp12(mul(a, b), 5, 0);
       return B.compile("fp12_mul2", 16);
     }
+    case P_MUL2S: {
+      SFp12 a = inputw_fp12(3, 0), b = inputw_fp12(4, 0);
+      outputw_fp12(mul(a, b), 5, 0);
+      return B.compile("fp12_mul2s", 16);
+    }
     case P_RAW_TO_BYTES: {
       output_fp12(inputw_fp12(3, 0), 2, 0);
       return B.compile("raw_to_bytes", 16);

@@ -73,6 +73,8 @@ enum ProgId {
   P_H2C_B1,            // one SWU map per item (2 n items): t (buf 3: Fp2), its exponentiation (buf 5: Fp2) -> projective point on E2' (buf 6: 6 raw elements)
   P_H2C_B2,            // the two points of a message (buf 3: 12 raw elements) -> their sum mapped to E2 by the 3-isogeny (buf 6), index.ts:487-488
   P_G1_MUL_W3, P_G2_MUL_W3,     // the ladders with 3-bit windows (85 instead of 128 additions: a shorter instruction stream, but a table that limits the wavefronts per CU): launches of at most one wavefront per SIMD
+  P_MUL2S,             // A (buf 3) * B (buf 4) -> buf 5 (may alias buf 3): one level of the IN-PLACE product tree (round 5, reduce_product in nbls_api.cpp):
+                       // level k multiplies F[i 2^(k+1)] by F[i 2^(k+1) + 2^k] into the former, so no level copies or pads anything
   P_COUNT
 };
 // |x| = 2^63 + 2^62 + 2^60 + 2^57 + 2^48 + 2^16: the compressed chain runs to 2^57 and its values at the set bits 16, 48, 57 are decompressed; the powers

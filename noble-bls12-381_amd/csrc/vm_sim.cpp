@@ -9,6 +9,7 @@
 #include "vm_exec.h"
 #include "consts_gen.h"
 #include "fp_inv.h"
+#include "pow_exec.h"
 #include "aot_exec.h"
 #include "aot_sigs.inc"
 
@@ -157,7 +158,8 @@ static void fp2mulh(u32* r, const u32* a, const u32* b) {   // elements: c0 at [
   u32 one[NL]; memcpy(one, NBLS_R1, NL * 4); mmh(r0, r0, one); mmh(r1, r1, one);   // contract (keeps values far below the 16p subtraction bias)
   memset(r, 0, 32 * 4); memcpy(r, r0, NL * 4); memcpy(r + 16, r1, NL * 4);
 }
-__attribute__((visibility("default"))) void nbls_sim_fp_pow(unsigned n, const u32* in, u32* out, int which) {
+// plain square-and-multiply (what nbls_sim_fp_pow was until round 5): kept as the independent check of the chains below
+__attribute__((visibility("default"))) void nbls_sim_fp_pow_naive(unsigned n, const u32* in, u32* out, int which) {
   const uint64_t* e = which == 0 ? NBLS_EXP_P_PLUS_1_DIV_4 : which == 1 ? NBLS_EXP_P2_PLUS_7_DIV_16 : which == 2 ? NBLS_EXP_P2_MINUS_9_DIV_16 : NBLS_EXP_P_MINUS_3_DIV_4;
   int bits = which == 0 ? NBLS_P_PLUS_1_DIV_4_BITS : which == 1 ? NBLS_P2_PLUS_7_DIV_16_BITS : which == 2 ? NBLS_P2_MINUS_9_DIV_16_BITS : NBLS_P_MINUS_3_DIV_4_BITS;
   for (unsigned k = 0; k < n; k++) {
@@ -171,6 +173,62 @@ __attribute__((visibility("default"))) void nbls_sim_fp_pow(unsigned n, const u3
       memcpy(out + 32 * k, acc, 128);
     }
   }
+}
+// The chains of pow_exec.h on the host: the sequences (tables, sliding windows, the split of the Fp2 exponents) and the lane arithmetic the kernels of
+// pow_kernels.hip run; a lane pair of the Fp2 kernel is one value with both components here.
+struct FpHost {
+  struct V { u32 v[NL]; };
+  const u32* in; u32* out; u32 tab[POW_TAB][NL];
+  void sqr(V& r, const V& a) { u32 t[NL]; mont_sqr28(t, a.v); memcpy(r.v, t, sizeof t); }
+  void mul(V& r, const V& a, const V& b) { u32 t[NL]; mont_mul28(t, a.v, b.v); memcpy(r.v, t, sizeof t); }
+  void copy(V& r, const V& a) { r = a; }
+  void load(V& r) { memcpy(r.v, in, NL * 4); }
+  void store(const V& a) { memset(out, 0, 64); memcpy(out, a.v, NL * 4); }
+  void tab_put(int j, const V& a) { memcpy(tab[j], a.v, NL * 4); }
+  void tab_get(V& r, unsigned j) { memcpy(r.v, tab[j], NL * 4); }
+};
+struct Fp2Host {
+  struct V { u32 c[2][NL]; };
+  const u32* in; u32* out; V tab[POW_TAB];
+  void sqr(V& r, const V& a) { V t; fp2_sqr_c(t.c[0], a.c[0], a.c[1], false); fp2_sqr_c(t.c[1], a.c[1], a.c[0], true); r = t; }
+  void mul(V& r, const V& a, const V& b) { V t; fp2_mul_c(t.c[0], a.c[0], a.c[1], b.c[0], b.c[1], false); fp2_mul_c(t.c[1], a.c[1], a.c[0], b.c[1], b.c[0], true); r = t; }
+  void conj(V& r, const V& a) { const u32 BIAS[NL] = NBLS_BIAS16_28; V t = a; for (int k = 0; k < NL; k++) t.c[1][k] = BIAS[k] - a.c[1][k]; carry_norm(t.c[0]); carry_norm(t.c[1]); r = t; }
+  void copy(V& r, const V& a) { r = a; }
+  void load(V& r) { for (int h = 0; h < 2; h++) mont_mul28(r.c[h], in + 16 * h, NBLS_R1); }
+  void store(const V& a) { memset(out, 0, 128); memcpy(out, a.c[0], NL * 4); memcpy(out + 16, a.c[1], NL * 4); }
+  void tab_put(int j, const V& a) { tab[j] = a; }
+  void tab_get(V& r, unsigned j) { r = tab[j]; }
+};
+// out = in^e through the kernels' chains; which: 0 = (p+1)/4 on Fp, 1 = (p^2+7)/16 on Fp2, 2 = (p^2-9)/16 on Fp2, 3 = (p-3)/4 on Fp (raw elements of 16 words)
+__attribute__((visibility("default"))) void nbls_sim_fp_pow(unsigned n, const u32* in, u32* out, int which) {
+  std::vector<unsigned char> ops;
+  if (which == 1 || which == 2) {
+    uint64_t K[6]; for (int j = 0; j < 6; j++) K[j] = NBLS_EXP_P_MINUS_3_DIV_4[j];
+    K[0] -= 2;
+    for (int j = 0; j < 6; j++) K[j] = (K[j] >> 2) | (j < 5 ? K[j + 1] << 62 : 0);
+    ops = pow_make_ops(K, 377);
+  } else ops = which == 0 ? pow_make_ops(NBLS_EXP_P_PLUS_1_DIV_4, NBLS_P_PLUS_1_DIV_4_BITS) : pow_make_ops(NBLS_EXP_P_MINUS_3_DIV_4, NBLS_P_MINUS_3_DIV_4_BITS);
+  const int nops = (int)(ops.size() / 2);
+  for (unsigned k = 0; k < n; k++) {
+    if (which == 0 || which == 3) { FpHost o; o.in = in + 16 * k; o.out = out + 16 * k; fp_pow_seq(o, ops.data(), nops); }
+    else { Fp2Host o; o.in = in + 32 * k; o.out = out + 32 * k; fp2_pow_seq(o, ops.data(), nops, which == 1 ? 8 : 7); }
+  }
+}
+// op list statistics of an exponent (tests): squarings, multiplications
+__attribute__((visibility("default"))) void nbls_sim_pow_ops(int which, unsigned* out2) {
+  std::vector<unsigned char> ops;
+  if (which == 1 || which == 2) {
+    uint64_t K[6]; for (int j = 0; j < 6; j++) K[j] = NBLS_EXP_P_MINUS_3_DIV_4[j];
+    K[0] -= 2;
+    for (int j = 0; j < 6; j++) K[j] = (K[j] >> 2) | (j < 5 ? K[j + 1] << 62 : 0);
+    ops = pow_make_ops(K, 377);
+  } else ops = which == 0 ? pow_make_ops(NBLS_EXP_P_PLUS_1_DIV_4, NBLS_P_PLUS_1_DIV_4_BITS) : pow_make_ops(NBLS_EXP_P_MINUS_3_DIV_4, NBLS_P_MINUS_3_DIV_4_BITS);
+  out2[0] = out2[1] = 0;
+  for (size_t k = 0; k < ops.size() / 2; k++) { out2[0] += ops[2 * k]; if (k && ops[2 * k + 1] != 0xff) out2[1]++; }
+}
+// canonical representative of raw elements (tests compare results that may differ by multiples of p)
+__attribute__((visibility("default"))) void nbls_sim_fp_canon(unsigned n, const u32* in, u32* out) {
+  for (unsigned k = 0; k < n; k++) { u32 t[NL]; mont_mul28(t, in + 16 * k, NBLS_R1); csub_p(t); memset(out + 16 * k, 0, 64); memcpy(out + 16 * k, t, NL * 4); }
 }
 // static verification of a compiled program (trace.h verify_program): 0 = clean, else the first violation in msg
 __attribute__((visibility("default"))) int nbls_sim_verify(int prog, char* msg, unsigned cap) {

@@ -65,11 +65,13 @@ struct DevSha {
 // out[len * i ..] = expand_message_xmd(msg_i, DST, len), len = 64, 128 or 256 (hash_to_field for G1 encode / G1 hash, G2 encode / G2 hash);
 // dst_len <= 255 (longer DSTs are pre-hashed by the caller, RFC 9380 5.3.3)
 extern "C" __global__ void __launch_bounds__(64) nbls_xmd_kernel(unsigned n, const uint8_t* __restrict__ msgs, const u32* __restrict__ offsets,
-                                                                 const uint8_t* __restrict__ dst, unsigned dst_len, uint8_t* __restrict__ out, unsigned len) {
+                                                                 const uint8_t* __restrict__ dst, unsigned dst_len, uint8_t* __restrict__ out, unsigned len, u32* __restrict__ bad) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint8_t* m = msgs + offsets[i];
-  const u32 mlen = offsets[i + 1] - offsets[i];
+  u32 mlen = offsets[i + 1] - offsets[i];
+  // offsets that are not monotonic would make this a ~4 GB read: hash an empty message instead and tell the caller (device-resident offsets cannot be checked on the host)
+  if (offsets[i + 1] < offsets[i]) { mlen = 0; if (bad) atomicOr(bad, 1u); }
   DevSha c;
   u32 b0[8], bi[8];
   // b_0 = H(Z_pad || msg || l_i_b_str || 0 || DST_prime)
@@ -96,8 +98,8 @@ extern "C" __global__ void __launch_bounds__(64) nbls_xmd_kernel(unsigned n, con
 }
 }  // namespace nbls
 
-extern "C" int nbls_xmd_launch(unsigned n, const void* msgs, const void* offsets, const void* dst, unsigned dst_len, void* out, unsigned len_in_bytes, void* stream) {
+extern "C" int nbls_xmd_launch(unsigned n, const void* msgs, const void* offsets, const void* dst, unsigned dst_len, void* out, unsigned len_in_bytes, void* bad_flag, void* stream) {   // bad_flag: NULL, or a device word that is set when an offset pair is not monotonic
   if (n == 0) return 0;
-  hipLaunchKernelGGL(nbls::nbls_xmd_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, (const uint8_t*)msgs, (const nbls::u32*)offsets, (const uint8_t*)dst, dst_len, (uint8_t*)out, len_in_bytes);
+  hipLaunchKernelGGL(nbls::nbls_xmd_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, (const uint8_t*)msgs, (const nbls::u32*)offsets, (const uint8_t*)dst, dst_len, (uint8_t*)out, len_in_bytes, (nbls::u32*)bad_flag);
   return (int)hipGetLastError();
 }

@@ -55,6 +55,12 @@ def test_final_exp_and_product(sim, oracle, golden, testdata):
     vmsim_py.run(sim, 'MUL2', 1, {3: (F2, 2 * vmsim_py.F12), 5: (Fp, vmsim_py.F12)})
     vmsim_py.run(sim, 'RAW_TO_BYTES', 1, {3: (Fp, vmsim_py.F12), 2: (outb, 576)})
     assert outb.raw == hx(p['miller_product'])
+    # the in-place level of the product tree (round 5): A (buf 3) * B (buf 4) -> buf 5 aliasing buf 3
+    F2b = C.create_string_buffer(F2.raw, vmsim_py.F12 * 2)
+    second = (C.c_char * vmsim_py.F12).from_buffer(F2b, vmsim_py.F12)
+    vmsim_py.run(sim, 'MUL2S', 1, {3: (F2b, 2 * vmsim_py.F12), 4: (second, 2 * vmsim_py.F12), 5: (F2b, 2 * vmsim_py.F12)})
+    vmsim_py.run(sim, 'RAW_TO_BYTES', 1, {3: (F2b, 2 * vmsim_py.F12), 2: (outb, 576)})
+    assert outb.raw == hx(p['miller_product'])
     N1 = C.create_string_buffer(vmsim_py.RAW)
     vmsim_py.run(sim, 'NORM_RAW', 1, {3: (Fp, vmsim_py.F12), 4: (N1, vmsim_py.RAW)})
     vmsim_py.final_exp(sim, 1, Fp, N1, outb)
@@ -138,6 +144,61 @@ def test_fp_inverse_edge_cases(sim):
         got = sum(int.from_bytes(o[4 * i:4 * i + 4], 'little') << (28 * i) for i in range(14))
         assert got < 2 * p
         assert got % p == ((pow(x % p, -1, p) * R * R) % p if x % p else 0), hex(x)
+
+
+def _raw(xs):
+    return b''.join(b''.join(((x >> (28 * i)) & 0xfffffff).to_bytes(4, 'little') for i in range(14)) + bytes(8) for x in xs)
+
+
+def _unraw(buf, k):
+    o = buf[64 * k:64 * k + 64]
+    return sum(int.from_bytes(o[4 * i:4 * i + 4], 'little') << (28 * i) for i in range(14))
+
+
+def test_pow_chains(sim):
+    """the fixed-exponent chains of the per-lane kernels (pow_exec.h: sliding windows over odd powers, a dedicated Fp squaring, signed Fp2 operands, the
+    split a^e = (conj(a) a^11)^K a^tail of the two Fp2 exponents) executed on the host, against Python's pow() and against the plain square-and-multiply
+    stand-in: Fp.sqrt's a^((p+1)/4) (math.ts:251-264), the SWU exponent (p-3)/4, Fp2.sqrt's (p^2+7)/16 and sqrt_div_fp2's (p^2-9)/16 (math.ts:521-538, 1196-1198)"""
+    import random
+    p = vmsim_py.P_MOD
+    R = 1 << 392
+    rnd = random.Random(5381)
+    xs = [rnd.randrange(0, p) for _ in range(40)] + [0, 1, 2, p - 1, p - 2, (1 << 380), (1 << 381) - 1 - p, 3 * p + 5, 15 * p + 7, (p + 1) // 2]
+    for which, e in ((0, (p + 1) // 4), (3, (p - 3) // 4)):
+        src = C.create_string_buffer(_raw(xs), 64 * len(xs)); dst = C.create_string_buffer(64 * len(xs))
+        sim.nbls_sim_fp_pow(C.c_uint(len(xs)), src, dst, which)
+        for k, x in enumerate(xs):
+            got = _unraw(dst.raw, k)
+            a = (x * pow(R, -1, p)) % p                      # the element a raw value stands for
+            assert got < 4 * p and got % p == (pow(a, e, p) * R) % p, (which, hex(x))
+    # Fp2: elements (c0, c1), both components any representative below 16 p
+    def f2mul(a, b): return ((a[0] * b[0] - a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p)
+    def f2pow(a, e):
+        r = (1, 0)
+        for bit in bin(e)[2:]:
+            r = f2mul(r, r)
+            if bit == '1': r = f2mul(r, a)
+        return r
+    pairs = [(rnd.randrange(0, p), rnd.randrange(0, p)) for _ in range(12)] + [(0, 0), (1, 0), (0, 1), (p - 1, p - 1), (5, 0), (0, 7), (15 * p + 3, 14 * p + 9), (p - 1, 1)]
+    flat = [c for pr in pairs for c in pr]
+    for which, e in ((1, (p * p + 7) // 16), (2, (p * p - 9) // 16)):
+        src = C.create_string_buffer(_raw(flat), 64 * len(flat)); dst = C.create_string_buffer(64 * len(flat)); ref = C.create_string_buffer(64 * len(flat))
+        sim.nbls_sim_fp_pow(C.c_uint(len(pairs)), src, dst, which)
+        sim.nbls_sim_fp_pow_naive(C.c_uint(len(pairs)), src, ref, which)
+        cd = C.create_string_buffer(64 * len(flat)); cr = C.create_string_buffer(64 * len(flat))
+        sim.nbls_sim_fp_canon(C.c_uint(len(flat)), dst, cd); sim.nbls_sim_fp_canon(C.c_uint(len(flat)), ref, cr)
+        assert cd.raw == cr.raw, which
+        ri = pow(R, -1, p)
+        for k, (x0, x1) in enumerate(pairs):
+            want = f2pow(((x0 * ri) % p, (x1 * ri) % p), e)
+            got = (_unraw(dst.raw, 2 * k), _unraw(dst.raw, 2 * k + 1))
+            assert got[0] < 4 * p and got[1] < 4 * p
+            assert (got[0] % p, got[1] % p) == ((want[0] * R) % p, (want[1] * R) % p), (which, k)
+    # the chains are shorter than 4-bit fixed windows: squarings and multiplications of each op list
+    for which, nbits in ((0, 379), (1, 377), (2, 377), (3, 379)):
+        st = (C.c_uint * 2)()
+        sim.nbls_sim_pow_ops(which, st)
+        assert st[0] <= nbits and st[1] <= 70, (which, st[0], st[1])
 
 
 @pytest.mark.parametrize('w3', [False, True])
