@@ -212,7 +212,10 @@ int nbls_miller_product_partial_into(nbls_ctx* ctx, size_t n, const uint8_t* g1_
 int nbls_verify_batch_partial_into(nbls_ctx* ctx, size_t n, const uint8_t* sig96 /* or NULL */, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
                                    const uint8_t* dst, size_t dst_len, void* d_dst576, int* zero_flag, int8_t* pk_status /* n, may be NULL */);
 const char* nbls_config_describe(void);   /* "NBLS_X=value(env|default) ...": every environment switch the library has read so far and the value in force -- print it next to an A/B result */
-int nbls_abi_version(void);   /* 2: *_partial take *d_partial as OUT only, *_partial_into added, nbls_tower_op_batch, nbls_verify_batch_msgs_dev */
+/* 3 (round 5): nbls_program_kernel, nbls_pool_*, NBLS_TUNE_VERIFY_*; nbls_verify_batch_partial_dev writes d_out_fp12 even when it reports a zero point or a decode error
+   (contents then meaningless); 2: *_partial take *d_partial as OUT only, *_partial_into added, nbls_tower_op_batch, nbls_verify_batch_msgs_dev.  The bindings check it at load. */
+#define NBLS_ABI_VERSION 3
+int nbls_abi_version(void);
 int nbls_context_device(nbls_ctx* ctx);
 
 /* Several GPUs of one node behind one handle (one context, host thread and stream per device; contiguous shards).  n_devices = 0 takes every
@@ -253,6 +256,9 @@ int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks);
 int nbls_set_tuning(nbls_ctx* ctx, int key, long long value);
 int nbls_program_count(void);                 /* number of step programs; timing slot nbls_program_count() = the inversion kernel */
 const char* nbls_program_name(int prog);
+/* the kernel that executes program `prog` in this context: "nbls_aot_<name>" (ahead-of-time specialised, the product path) or "nbls_vm_kernel[_ls4]" (the interpreter:
+   NBLS_AOT=0, or the build-time and run-time compilations of the program disagree); NULL on a bad index.  The string is static. */
+const char* nbls_program_kernel(nbls_ctx* ctx, int prog);
 int nbls_timing_enable(nbls_ctx* ctx, int on);
 int nbls_timing_read(nbls_ctx* ctx, float* ms /*[NBLS_N_PROGRAMS+1]*/, uint32_t* counts /*[NBLS_N_PROGRAMS+1]*/);
 

@@ -117,6 +117,7 @@ std::string aot_translate(const Program& p, AotProgram& out);
 }  // namespace nbls
 
 // kernel side (aot_kernel.hip)
+extern "C" const char* nbls_aot_name(int k);   // "nbls_aot_<name>" of kernel k
 extern "C" int nbls_aot_index(int prog_id);   // index of the ahead-of-time kernel that serves a ProgId, or -1
 // remap the signature indices of a translated program to kernel k's table: 0, or -1 when a signature is not in the table
 extern "C" int nbls_aot_bind(int k, nbls::AotProgram* ap);

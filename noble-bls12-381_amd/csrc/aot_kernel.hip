@@ -98,8 +98,8 @@ namespace nbls {
 #define AOT_TABLE(PART, NAME, P0, P1, P2, P3) static const AotSig sigs_##NAME[] = {AOT_SIGS_##NAME(AOT_ROW)};
 NBLS_AOT_KERNELS(AOT_TABLE)
 NBLS_AOT_LS_KERNELS(AOT_TABLE)
-struct AotKernel { int prog_id[4]; const void* fn; const AotSig* sigs; unsigned nsigs; };
-#define AOT_ENTRY(PART, NAME, P0, P1, P2, P3) {{(int)P0, (int)P1, (int)P2, (int)P3}, (const void*)nbls_aot_##NAME, sigs_##NAME, (unsigned)(sizeof(sigs_##NAME) / sizeof(AotSig))},
+struct AotKernel { int prog_id[4]; const void* fn; const AotSig* sigs; unsigned nsigs; const char* name; };
+#define AOT_ENTRY(PART, NAME, P0, P1, P2, P3) {{(int)P0, (int)P1, (int)P2, (int)P3}, (const void*)nbls_aot_##NAME, sigs_##NAME, (unsigned)(sizeof(sigs_##NAME) / sizeof(AotSig)), "nbls_aot_" #NAME},
 static const AotKernel g_kernels[] = {NBLS_AOT_KERNELS(AOT_ENTRY) NBLS_AOT_LS_KERNELS(AOT_ENTRY)};
 static const int g_nkernels = (int)(sizeof(g_kernels) / sizeof(g_kernels[0]));
 
@@ -110,6 +110,7 @@ extern "C" int nbls_aot_index(int prog_id) {
   for (int k = 0; k < nbls::g_nkernels; k++) for (int j = 0; j < 4; j++) if (nbls::g_kernels[k].prog_id[j] == prog_id) return k;
   return -1;
 }
+extern "C" const char* nbls_aot_name(int k) { return k >= 0 && k < nbls::g_nkernels ? nbls::g_kernels[k].name : nullptr; }
 extern "C" int nbls_aot_bind(int k, nbls::AotProgram* ap) {
   using namespace nbls;
   if (k < 0 || k >= g_nkernels || !ap) return -1;

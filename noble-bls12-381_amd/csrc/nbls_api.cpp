@@ -74,7 +74,7 @@ struct nbls_ctx {
   size_t ioff = 0; hipStream_t half_stream = nullptr; hipEvent_t ev_half_fork = nullptr, ev_half_join = nullptr;
   size_t halves_min = env_long("NBLS_HALVES_MIN", 8192) > 0 ? (size_t)env_long("NBLS_HALVES_MIN", 8192) : (size_t)-1;   // NBLS_HALVES_MIN=0: never (profiles of kernels running alone)
   // verifyBatch as a software pipeline (round 5, verify_pipeline): events of the chunks (two each), the "xmd met non-monotonic offsets" flag lives behind the statuses
-  std::vector<hipEvent_t> pipe_ev; hipEvent_t ev_pipe_done = nullptr;
+  std::vector<hipEvent_t> pipe_ev; hipEvent_t ev_pipe_done = nullptr; std::vector<hipStream_t> pipe_streams;
   long verify_chunks = env_long("NBLS_VERIFY_CHUNKS", 4), verify_last_pct = env_long("NBLS_VERIFY_LAST_PCT", 12), verify_pipe_min = env_long("NBLS_VERIFY_PIPE_MIN", 16384);   // nbls_set_tuning(NBLS_TUNE_VERIFY_*)
   hipStream_t side2 = nullptr; hipEvent_t ev_join2 = nullptr;   // verifyBatch: key decoding runs beside message hashing (their exponentiation kernels are latency-bound and leave issue slots free)
   uint8_t* ident_g1 = nullptr; uint8_t* ident_g2 = nullptr;   // projective identity (0 : 1 : 0), raw
@@ -486,6 +486,7 @@ EXPORT void nbls_destroy(nbls_ctx* ctx) {
   if (ctx->side2) hipStreamDestroy(ctx->side2);
   for (hipEvent_t e : {ctx->ev_fork, ctx->ev_join, ctx->ev_join2, ctx->ev_last, ctx->ev_pipe_done}) if (e) hipEventDestroy(e);
   for (hipEvent_t e : ctx->pipe_ev) hipEventDestroy(e);
+  for (hipStream_t st : ctx->pipe_streams) hipStreamDestroy(st);
   for (auto& t : ctx->tev) { hipEventDestroy(t.second.first); hipEventDestroy(t.second.second); }
   for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -847,10 +848,13 @@ static int dev_validate(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, voi
 // slot0 / pow_slot: scratch-pool slots used (three from slot0, one for the exponentiation table), so that two chains can run on
 // different streams at the same time
 // mode (G2 only): 0 fromSignature 96 B, 1 fromSignature 192 B, 2 fromHex 96 B (no subgroup check, flag rules)
-static int dev_decompress(nbls_ctx* ctx, bool g2, size_t n, const void* d_in, void* d_out, void* d_status, hipStream_t s, int slot0 = 0, int pow_slot = 11, int mode = 0) {
-  const size_t e = g2 ? (mode == 1 ? 192 : 96) : 48, q = g2 ? 2 * RAW : RAW;
+// io / ntot: the call works on items [io, io + n) of scratch arrays sized for ntot items (verify_pipeline: sub-batches of one call run side by side on slices of the same arrays)
+static int dev_decompress(nbls_ctx* ctx, bool g2, size_t n, const void* d_in, void* d_out, void* d_status, hipStream_t s, int slot0 = 0, int pow_slot = 11, int mode = 0, size_t io = 0, size_t ntot = 0) {
+  const size_t e = g2 ? (mode == 1 ? 192 : 96) : 48, q = g2 ? 2 * RAW : RAW, pq = POW_TAB * (g2 ? 2 : 1) * RAW;
+  if (ntot < io + n) ntot = io + n;
   uint8_t *X, *R, *Cd, *pw; int r;
-  if ((r = need(ctx, slot0, n * q, &X)) || (r = need(ctx, slot0 + 1, n * q, &R)) || (r = need(ctx, slot0 + 2, n * q, &Cd)) || (r = need(ctx, pow_slot, n * POW_TAB * (g2 ? 2 : 1) * RAW, &pw))) return r;
+  if ((r = need(ctx, slot0, ntot * q, &X)) || (r = need(ctx, slot0 + 1, ntot * q, &R)) || (r = need(ctx, slot0 + 2, ntot * q, &Cd)) || (r = need(ctx, pow_slot, ntot * pq, &pw))) return r;
+  X += io * q; R += io * q; Cd += io * q; pw += io * pq;
   const ProgId pa = !g2 ? P_G1_DEC_A : mode == 1 ? P_G2_DEC_A192 : P_G2_DEC_A, pb = !g2 ? P_G1_DEC_B : mode == 1 ? P_G2_DEC_B192 : mode == 2 ? P_G2_DEC_B_HEX : P_G2_DEC_B;
   if ((r = run(ctx, pa, n, {B(0, d_in, e), B(3, X, q), B(4, R, q)}, s))) return r;
   if ((r = run_pow(ctx, g2 ? 1 : 0, n, R, Cd, s, pw))) return r;
@@ -864,17 +868,19 @@ static int dev_clear_g2(nbls_ctx* ctx, size_t n, void* in, uint8_t* base, uint8_
   if ((r = run(ctx, P_H2C_C1, n, {B(3, in, 6 * RAW), B(6, base, 6 * RAW)}, s))) return r;                          // base = t1 + v over v, t1 = -[x]P over P
   return run(ctx, P_H2C_C2, n, {B(3, base, 6 * RAW), B(4, in, 6 * RAW), B(5, S, 6 * RAW), B(6, out, 6 * RAW), B(7, N, RAW)}, s);   // out may be in: every item reads its t1 before its result is stored
 }
-static int dev_hash_to_g2(nbls_ctx* ctx, size_t n, const void* d_uniform, void* d_out, hipStream_t s) {
-  uint8_t *T, *E, *Pw, *Q, *N, *NI, *st, *St, *Pt2; int r;
-  if ((r = need(ctx, 0, n * 4 * RAW, &T)) || (r = need(ctx, 1, n * 6 * RAW, &E)) || (r = need(ctx, 2, n * 4 * RAW, &Pw)) || (r = need(ctx, 3, n * 6 * RAW, &Q)) ||
-      (r = need(ctx, 4, n * RAW, &N)) || (r = need(ctx, 5, n * RAW, &NI)) || (r = need(ctx, 6, n, &st)) || (r = need(ctx, 18, n * 24 * RAW, &St)) || (r = need(ctx, 19, n * 12 * RAW, &Pt2))) return r;
+static int dev_hash_to_g2(nbls_ctx* ctx, size_t n, const void* d_uniform, void* d_out, hipStream_t s, size_t io = 0, size_t ntot = 0) {   // io / ntot: see dev_decompress
+  if (ntot < io + n) ntot = io + n;
+  uint8_t *T, *E, *Pw, *Q, *N, *NI, *st, *St, *Pt2, *S, *tab; int r;
+  if ((r = need(ctx, 0, ntot * 4 * RAW, &T)) || (r = need(ctx, 1, ntot * 6 * RAW, &E)) || (r = need(ctx, 2, ntot * 4 * RAW, &Pw)) || (r = need(ctx, 3, ntot * 6 * RAW, &Q)) ||
+      (r = need(ctx, 4, ntot * RAW, &N)) || (r = need(ctx, 5, ntot * RAW, &NI)) || (r = need(ctx, 6, ntot, &st)) || (r = need(ctx, 18, ntot * 24 * RAW, &St)) || (r = need(ctx, 19, ntot * 12 * RAW, &Pt2)) ||
+      (r = need(ctx, 13, ntot * 6 * RAW, &S)) || (r = need(ctx, 11, ntot * 4 * POW_TAB * RAW, &tab))) return r;
+  T += io * 4 * RAW; E += io * 6 * RAW; Pw += io * 4 * RAW; Q += io * 6 * RAW; N += io * RAW; NI += io * RAW; st += io; St += io * 24 * RAW; Pt2 += io * 12 * RAW; S += io * 6 * RAW; tab += io * 4 * POW_TAB * RAW;
   // H2C_A: per message the two field elements t (T), the exponentiation inputs (E) and the rest of the SWU state (St: twelve raw elements per map)
   if ((r = run(ctx, P_H2C_A, n, {B(0, d_uniform, 256), B(3, T, 4 * RAW), B(4, E, 4 * RAW), B(5, St, 24 * RAW)}, s))) return r;
-  if ((r = run_pow(ctx, 2, 2 * n, E, Pw, s))) return r;
+  if ((r = run_pow(ctx, 2, 2 * n, E, Pw, s, tab))) return r;
   // H2C_B1: one map per item (2 n items) -> its point on E2'; H2C_B2: the two points of a message -> their sum on E2 (round 3: one program, 62 slots, four workgroups per CU)
   if ((r = run(ctx, P_H2C_B1, 2 * n, {B(3, T, 2 * RAW), B(5, Pw, 2 * RAW), B(4, St, 12 * RAW), B(6, Pt2, 6 * RAW)}, s))) return r;
   if ((r = run(ctx, P_H2C_B2, n, {B(3, Pt2, 12 * RAW), B(6, E, 6 * RAW)}, s))) return r;        // E is free again: reuse it for the E2 point
-  uint8_t* S; if ((r = need(ctx, 13, n * 6 * RAW, &S))) return r;
   if ((r = dev_clear_g2(ctx, n, E, Q, S, E, N, s))) return r;
   if ((r = run_inv_buf(ctx, n, N, NI, s))) return r;
   return run(ctx, P_G2_TO_AFFINE, n, {B(3, E, 6 * RAW), B(4, NI, RAW), B(2, d_out, 192), B(7, st, 1)}, s);
@@ -1004,11 +1010,21 @@ EXPORT int nbls_set_tuning(nbls_ctx* ctx, int key, long long value) {
     case NBLS_TUNE_HALVES_MIN: if (value < 0) return NBLS_EINVAL; ctx->halves_min = value == 0 ? (size_t)-1 : (size_t)value; return NBLS_OK;
     case NBLS_TUNE_EXPC_MIN: if (value < 0) return NBLS_EINVAL; ctx->expc_min = (size_t)value; return NBLS_OK;
     case NBLS_TUNE_CHAIN_MAX: if (value < 0) return NBLS_EINVAL; ctx->chain_max = (size_t)value; return NBLS_OK;
-    case NBLS_TUNE_VERIFY_CHUNKS: if (value < 0 || value > 64) return NBLS_EINVAL; ctx->verify_chunks = (long)value; return NBLS_OK;
+    case NBLS_TUNE_VERIFY_CHUNKS: if (value < 0 || value > 16) return NBLS_EINVAL; ctx->verify_chunks = (long)value; return NBLS_OK;
     case NBLS_TUNE_VERIFY_LAST_PCT: if (value < 1 || value > 100) return NBLS_EINVAL; ctx->verify_last_pct = (long)value; return NBLS_OK;
     case NBLS_TUNE_VERIFY_PIPE_MIN: if (value < 0) return NBLS_EINVAL; ctx->verify_pipe_min = (long)value; return NBLS_OK;
     default: return NBLS_EINVAL;
   }
+}
+// Which kernel executes a program in THIS context: "nbls_aot_<name>" when the program was translated and bound to its ahead-of-time kernel at upload, else the
+// interpreter ("nbls_vm_kernel": NBLS_AOT=0, a program without an ahead-of-time kernel, or step signatures that differ from the kernel's table -- a build mismatch).
+// Programs uploaded on first use (the scalar-multiplication ladders) are uploaded by the query.  tests/test_gpu_binding.py and bench.py (`aot_programs`) read it.
+EXPORT const char* nbls_program_kernel(nbls_ctx* ctx, int prog) {
+  if (!ctx || prog < 0 || prog >= P_COUNT) return nullptr;
+  std::lock_guard<std::recursive_mutex> g(ctx->mu);
+  if (hipSetDevice(ctx->device) != hipSuccess || upload(ctx, (ProgId)prog)) return nullptr;
+  const DevProgram& d = ctx->prog[prog];
+  return d.aot >= 0 ? nbls_aot_name(d.aot) : (d.p->lsplit ? "nbls_vm_kernel_ls4" : "nbls_vm_kernel");
 }
 EXPORT int nbls_program_count(void) { return (int)P_COUNT; }
 EXPORT const char* nbls_program_name(int prog) { return prog >= 0 && prog < P_COUNT ? get_program((ProgId)prog).name.c_str() : nullptr; }
@@ -1366,14 +1382,17 @@ EXPORT int nbls_sign_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const u
   return NBLS_OK;
 }
 
-// ---- verifyBatch as a software pipeline (round 5) ------------------------------------------------------------------------------------------------------
+// ---- verifyBatch as concurrent sub-batches (round 5) ------------------------------------------------------------------------------------------------------
 // Round 4 ran the call in two phases -- decode the keys and hash every message (12.5 ms at 65,536 signatures, most of it ONE chain of dependent launches), read the
-// statuses back, then the Miller product of all pairs (9.1 ms) -- and three such calls in flight took 18.4 ms each instead of 22.8: the phases leave issue slots
-// free (exponentiation kernels two wavefronts deep, the partly filled last round of every launch, a host round trip in the middle).  Now the signatures are cut into
-// K chunks of decreasing size; chunk c + 1 is decoded and hashed (caller's stream + the key stream) while the Miller loops of chunk c run on a third stream
-// (LINES_PQ -> ACC with four / two / one line tables per accumulator, by chunk size), every accumulator of every chunk lands in ONE array that the in-place product
-// tree reduces at the end, and the statuses are read back once, with the result: nothing is decided on the host before the end (an undecodable key only makes the
-// product meaningless, and the statuses say so).  index.ts:792-821.
+// statuses back, then the Miller product of all pairs (9.1 ms) -- and three such calls in flight took 18.4 ms each instead of 22.8: every launch of the chain leaves issue
+// slots free (the exponentiation kernels fill the chip 1.33 rounds deep, ACC4 1.07 rounds, every launch ends in a partly filled round, the host reads the statuses in the
+// middle).  First attempt of this round: chunks in SEQUENCE, the Miller loops of chunk c beside the hash chain of chunk c + 1 -- slower (24.5 ms with four chunks,
+// profiles/round5_verify_sweep_sequential.txt): the hash chain has a latency floor of ~3.7 ms whatever its size (a 377-squaring exponentiation per lane), four chains one after
+// the other are 15 ms of it, and sharing the SIMDs with Miller loops stretches them further.  What the in-flight figure really says is that INDEPENDENT chains fill each other's
+// holes.  So the signatures are cut into K sub-batches of decreasing size that all start at once, each on a stream of its own: keys -> hash chain (odd sub-batches the other
+// way round, so that equal kernels do not meet) -> LINES_PQ -> ACC over its own slice of the scratch arrays; every accumulator lands in ONE array that the in-place product tree
+// reduces at the end, and the statuses are read back once, with the result: nothing is decided on the host before the end (an undecodable key only makes the product
+// meaningless, and the statuses say so).  index.ts:792-821.
 struct VerifyIn {
   const void* d_sig96;      // 96-byte signature, or NULL (a shard without the signature pair)
   const void* d_uniform;    // 256 B of expand_message_xmd output per message, or NULL when the messages themselves are given:
@@ -1381,14 +1400,15 @@ struct VerifyIn {
   const void* d_pk48;
 };
 static std::vector<size_t> verify_plan(nbls_ctx* ctx, size_t n) {
-  size_t K = (size_t)ctx->verify_chunks;
-  if (K < 2 || n < (size_t)ctx->verify_pipe_min || n < 64 * K) return {n};
-  // sizes fall linearly from the first chunk to the last (verify_last_pct per cent of n): the last chunk's Miller loops run with nothing beside them, so it is the small one;
-  // every size but the last is a multiple of 64 (whole groups of accumulators, whole wavefronts)
-  const double last = (double)n * (double)ctx->verify_last_pct / 100.0, first = 2.0 * (double)n / (double)K - last;
-  if (first <= last) { std::vector<size_t> v(K, (n / K) & ~(size_t)63); size_t sum = 0; for (size_t c = 0; c + 1 < K; c++) sum += v[c]; v[K - 1] = n - sum; return v; }
+  const size_t K = (size_t)ctx->verify_chunks;
+  // every size but the last is a multiple of g: whole groups of accumulators (4), whole wavefronts where the batch is large (64)
+  const size_t g = n >= 4096 ? 64 : 4;
+  if (K < 2 || K > 16 || n < (size_t)ctx->verify_pipe_min || n < 2 * g * K || n + 128 > LINES_CHUNK) return {n};   // (a call's line tables are one allocation of at most LINES_CHUNK)
+  // sizes fall linearly from the first chunk to the last (verify_last_pct per cent of n): the last chunk's Miller loops run with nothing beside them, so it is the small one
+  double last = (double)n * (double)ctx->verify_last_pct / 100.0, first = 2.0 * (double)n / (double)K - last;
+  if (first < last) first = last = (double)n / (double)K;
   std::vector<size_t> v(K); size_t sum = 0;
-  for (size_t c = 0; c + 1 < K; c++) { v[c] = ((size_t)(first + (last - first) * (double)c / (double)(K - 1)) + 63) & ~(size_t)63; sum += v[c]; if (sum >= n) return {n}; }
+  for (size_t c = 0; c + 1 < K; c++) { v[c] = (((size_t)(first + (last - first) * (double)c / (double)(K - 1)) + g - 1) / g) * g; sum += v[c]; if (sum >= n) return {n}; }
   v[K - 1] = n - sum;
   return v;
 }
@@ -1404,6 +1424,11 @@ static int ensure_half_stream(nbls_ctx* ctx) {
 }
 // final_exp = 1: the product's final exponentiation as 576 wire bytes in `out` (host); 0: the product itself as wire bytes at d_out (device; a shard's partial).
 // st: n statuses of the keys (+ 1 of the signature) as the decoders wrote them; *bad_offsets: the message offsets were not monotonic.
+static int pipe_stream(nbls_ctx* ctx, size_t i, hipStream_t* st) {
+  while (ctx->pipe_streams.size() <= i) { hipStream_t x = nullptr; HIPCHK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking)); ctx->pipe_streams.push_back(x); }
+  *st = ctx->pipe_streams[i];
+  return NBLS_OK;
+}
 static int verify_pipeline(nbls_ctx* ctx, size_t n, const VerifyIn& in, int final_exp, void* d_out, uint8_t* out, std::vector<int8_t>& st, int* bad_offsets, void* stream) {
   const size_t np = n + (in.d_sig96 ? 1 : 0);
   st.assign(np + 8, 0);
@@ -1418,16 +1443,9 @@ static int verify_pipeline(nbls_ctx* ctx, size_t n, const VerifyIn& in, int fina
   if (!in.d_uniform && (r = need(ctx, 8, n * 256, &du))) return r;
   const std::vector<size_t> plan = verify_plan(ctx, n);
   const size_t K = plan.size();
-  // streams: hash chain on the caller's stream, keys on side2, the signature on side, Miller loops of a chunked call on half_stream
-  if (!ctx->side2 && (hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming) != hipSuccess)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
   if (!ctx->ev_fork && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
-  if (!ctx->ev_pipe_done && hipEventCreateWithFlags(&ctx->ev_pipe_done, hipEventDisableTiming) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
-  if (K > 1 && (r = ensure_half_stream(ctx))) return r;
-  hipStream_t M = K > 1 ? ctx->half_stream : s;
   HIPCHK(hipMemsetAsync(d_bad, 0, 4, s));
   HIPCHK(hipEventRecord(ctx->ev_fork, s));
-  HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));
-  if (K > 1) HIPCHK(hipStreamWaitEvent(M, ctx->ev_fork, 0));
   if (in.d_sig96) {
     // normP2: PointG2.fromSignature for the ONE signature, on the side stream with its own scratch (its Fp2 exponentiation on two lanes is pure latency)
     if (!ctx->side) {
@@ -1442,54 +1460,73 @@ static int verify_pipeline(nbls_ctx* ctx, size_t n, const VerifyIn& in, int fina
     HIPCHK(hipEventRecord(ctx->ev_join, ctx->side));
   }
   if ((r = ensure_scratch(ctx, np))) return r;
-  size_t cmax = 0; for (size_t c : plan) cmax = std::max(cmax, c);
-  if (K > 1 && (r = ensure_lines(ctx, cmax + 8))) return r;
-  size_t o = 0, m_off = 0;
-  for (size_t c = 0; c < K; c++) {
-    const size_t nc = plan[c]; const bool last = c + 1 == K;
-    hipEvent_t evH, evD;
-    if ((r = pipe_event(ctx, 2 * c, &evH)) || (r = pipe_event(ctx, 2 * c + 1, &evD))) return r;
-    // normP1 (PointG1.fromHex of the keys) on the key stream: scratch slots 14..16 / 17
-    if ((r = dev_decompress(ctx, false, nc, (const uint8_t*)in.d_pk48 + o * 48, G1 + o * 96, ST + o, ctx->side2, 14, 17))) return r;
-    HIPCHK(hipEventRecord(evD, ctx->side2));
-    // normP2Hash (PointG2.hashToCurve of the messages) on the caller's stream: scratch slots 0..6 / 11 / 13 / 18 / 19
-    const uint8_t* uni = (const uint8_t*)in.d_uniform + o * 256;
-    if (!in.d_uniform) {
-      const int e = nbls_xmd_launch((unsigned)nc, in.d_msgs, (const uint32_t*)in.d_offsets + o, in.dst_dev, in.dst_len, du + o * 256, 256, d_bad, s);
+  size_t m_off = 0;
+  if (K == 1) {
+    // one sub-batch: keys on a second stream beside the hash chain (both contain a per-lane exponentiation kernel that leaves issue slots free), then the Miller loops of all pairs
+    if (!ctx->side2 && (hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming) != hipSuccess)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+    HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));
+    if ((r = dev_decompress(ctx, false, n, in.d_pk48, G1, ST, ctx->side2, 14, 17))) return r;      // normP1: PointG1.fromHex; scratch slots 14..16 / 17
+    HIPCHK(hipEventRecord(ctx->ev_join2, ctx->side2));
+    const uint8_t* uni = (const uint8_t*)in.d_uniform;
+    if (!uni) {
+      const int e = nbls_xmd_launch((unsigned)n, in.d_msgs, in.d_offsets, in.dst_dev, in.dst_len, du, 256, d_bad, s);
       if (e) { ctx->last_hip = e; return NBLS_EHIP; }
-      uni = du + o * 256;
+      uni = du;
     }
-    if ((r = dev_hash_to_g2(ctx, nc, uni, G2 + o * 192, s))) return r;
-    if (K > 1) HIPCHK(hipEventRecord(evH, s));
-    // Miller loops of the chunk
-    if (K > 1) HIPCHK(hipStreamWaitEvent(M, evH, 0));
-    HIPCHK(hipStreamWaitEvent(M, evD, 0));
-    size_t cc = nc;
-    if (last && in.d_sig96) {
-      HIPCHK(hipMemcpyAsync(G1 + n * 96, ctx->neg_g1, 96, hipMemcpyDeviceToDevice, M));         // PointG1.BASE.negate()
-      HIPCHK(hipStreamWaitEvent(M, ctx->ev_join, 0));
-      cc++;
+    if ((r = dev_hash_to_g2(ctx, n, uni, G2, s))) return r;                                       // normP2Hash: PointG2.hashToCurve; slots 0..6 / 11 / 13 / 18 / 19
+    HIPCHK(hipStreamWaitEvent(s, ctx->ev_join2, 0));
+    if (in.d_sig96) {
+      HIPCHK(hipMemcpyAsync(G1 + n * 96, ctx->neg_g1, 96, hipMemcpyDeviceToDevice, s));            // PointG1.BASE.negate()
+      HIPCHK(hipStreamWaitEvent(s, ctx->ev_join, 0));
     }
-    if (K == 1) {
-      if ((r = miller_values(ctx, cc, G1, G2, &m_off, M))) return r;
-    } else {
-      // line tables per accumulator: four where the chunk still fills the chip with a quarter of its pairs as items, fewer where only the length of one wavefront's instruction stream counts
-      const size_t GR = cc >= 14336 ? 4 : cc >= 6144 ? 2 : 1;
+    if ((r = miller_values(ctx, np, G1, G2, &m_off, s))) return r;
+  } else {
+    // scratch is sized once for the whole call (the sub-batches work on slices of it): grow it before anything is in flight
+    if ((r = ensure_lines(ctx, np + 4 * K + 4))) return r;
+    if (np + 4 * K + 4 > ctx->cap_L) return NBLS_EINVAL;      // (more pairs than one allocation of line tables holds: verify_plan does not cut such calls)
+    size_t o = 0;
+    for (size_t c = 0; c < K; c++) {
+      const size_t nc = plan[c]; const bool last = c + 1 == K;
+      hipStream_t sc = s; hipEvent_t evc;
+      if (c && (r = pipe_stream(ctx, c - 1, &sc))) return r;
+      if ((r = pipe_event(ctx, c, &evc))) return r;
+      if (c) HIPCHK(hipStreamWaitEvent(sc, ctx->ev_fork, 0));
+      auto keys = [&]() { return dev_decompress(ctx, false, nc, (const uint8_t*)in.d_pk48 + o * 48, G1 + o * 96, ST + o, sc, 14, 17, 0, o, n); };   // normP1: PointG1.fromHex
+      auto hash = [&]() -> int {                                                                                                                  // normP2Hash: PointG2.hashToCurve
+        const uint8_t* uni = (const uint8_t*)in.d_uniform + o * 256;
+        if (!in.d_uniform) {
+          const int e = nbls_xmd_launch((unsigned)nc, in.d_msgs, (const uint32_t*)in.d_offsets + o, in.dst_dev, in.dst_len, du + o * 256, 256, d_bad, sc);
+          if (e) { ctx->last_hip = e; return NBLS_EHIP; }
+          uni = du + o * 256;
+        }
+        return dev_hash_to_g2(ctx, nc, uni, G2 + o * 192, sc, o, n);
+      };
+      if (c & 1) { if ((r = hash()) || (r = keys())) return r; }
+      else { if ((r = keys()) || (r = hash())) return r; }
+      size_t cc = nc;
+      if (last && in.d_sig96) {
+        HIPCHK(hipMemcpyAsync(G1 + n * 96, ctx->neg_g1, 96, hipMemcpyDeviceToDevice, sc));         // PointG1.BASE.negate()
+        HIPCHK(hipStreamWaitEvent(sc, ctx->ev_join, 0));
+        cc++;
+      }
+      // line tables per accumulator: four where a quarter of the sub-batch's pairs still are thousands of items, fewer where only the length of one wavefront's instruction stream counts
+      const size_t GR = cc >= 8192 ? 4 : cc >= 2048 ? 2 : 1;
       const ProgId acc = GR == 4 ? P_ACC4_RAW : GR == 2 ? P_ACC2_RAW : P_ACC_RAW;
       const size_t gg = (cc + GR - 1) / GR;
-      if ((r = run(ctx, P_LINES_PQ, cc, {B(0, G1 + o * 96, 96), B(1, G2 + o * 192, 192), B(3, ctx->L, LINE_BYTES)}, M))) return r;
-      for (size_t k = cc; k < GR * gg; k++) HIPCHK(hipMemcpyAsync(ctx->L + k * LINE_BYTES, ctx->unit_lines, LINE_BYTES, hipMemcpyDeviceToDevice, M));
-      if ((r = run(ctx, acc, gg, {B(3, ctx->L, GR * LINE_BYTES), B(5, ctx->F + m_off * F12, F12)}, M))) return r;
+      uint8_t* Lc = ctx->L + (o + 4 * c) * LINE_BYTES;      // its own line tables (+ up to three unit tables behind them)
+      if ((r = run(ctx, P_LINES_PQ, cc, {B(0, G1 + o * 96, 96), B(1, G2 + o * 192, 192), B(3, Lc, LINE_BYTES)}, sc))) return r;
+      for (size_t k = cc; k < GR * gg; k++) HIPCHK(hipMemcpyAsync(Lc + k * LINE_BYTES, ctx->unit_lines, LINE_BYTES, hipMemcpyDeviceToDevice, sc));
+      if ((r = run(ctx, acc, gg, {B(3, Lc, GR * LINE_BYTES), B(5, ctx->F + m_off * F12, F12)}, sc))) return r;
       m_off += gg;
+      if (c) { HIPCHK(hipEventRecord(evc, sc)); HIPCHK(hipStreamWaitEvent(s, evc, 0)); }      // (enqueued on s behind sub-batch 0's own work)
+      o += nc;
     }
-    o += nc;
   }
   uint8_t* res = ctx->F;
-  if ((r = reduce_product(ctx, m_off, &res, M))) return r;
-  if ((r = finish_single(ctx, res, final_exp, final_exp ? (void*)O : d_out, M))) return r;
-  HIPCHK(hipMemcpyAsync(st.data(), ST, ((np + 3) & ~(size_t)3) + 4, hipMemcpyDeviceToHost, M));
-  if (final_exp) HIPCHK(hipMemcpyAsync(out, O, 576, hipMemcpyDeviceToHost, M));
-  if (M != s) { HIPCHK(hipEventRecord(ctx->ev_pipe_done, M)); HIPCHK(hipStreamWaitEvent(s, ctx->ev_pipe_done, 0)); }
+  if ((r = reduce_product(ctx, m_off, &res, s))) return r;
+  if ((r = finish_single(ctx, res, final_exp, final_exp ? (void*)O : d_out, s))) return r;
+  HIPCHK(hipMemcpyAsync(st.data(), ST, ((np + 3) & ~(size_t)3) + 4, hipMemcpyDeviceToHost, s));
+  if (final_exp) HIPCHK(hipMemcpyAsync(out, O, 576, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   uint32_t bad = 0; memcpy(&bad, st.data() + ((np + 3) & ~(size_t)3), 4);
   if (bad_offsets) *bad_offsets = bad != 0;
@@ -1729,7 +1766,7 @@ EXPORT int nbls_miller_product_partial_into(nbls_ctx* ctx, size_t n, const uint8
   if (!d_dst) return NBLS_EINVAL;
   return miller_product_partial_core(ctx, n, g1, g2, validate, d_dst, nullptr, status);
 }
-EXPORT int nbls_abi_version(void) { return 2; }
+EXPORT int nbls_abi_version(void) { return NBLS_ABI_VERSION; }
 // every environment switch the library has read so far, with the value in force (config.h); the string lives until the next call on this thread
 EXPORT const char* nbls_config_describe(void) { static thread_local std::string s; s = env_describe(); return s.c_str(); }
 static int verify_batch_partial_core(nbls_ctx* ctx, size_t n, const uint8_t* sig96 /* or NULL */, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,

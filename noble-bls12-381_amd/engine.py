@@ -12,6 +12,7 @@ except ImportError:      # the binding itself needs only ctypes
     _np = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 3   # include/nbls.h NBLS_ABI_VERSION: checked at load (round 4's advisor: an ABI-1 caller of *_partial read stale bytes from an ABI-2 library with no error)
 PROGRAMS = []   # names of the step programs in the library's numbering (filled by load_library from nbls_program_name)
 DST_DEFAULT = b'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_'   # htfDefaults.DST, reference index.ts:64
 
@@ -89,6 +90,10 @@ def load_library():
     lib.nbls_multi_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, sz, C.POINTER(i32)]
     lib.nbls_program_name.restype = C.c_char_p
     lib.nbls_program_name.argtypes = [i32]
+    lib.nbls_program_kernel.restype = C.c_char_p
+    lib.nbls_program_kernel.argtypes = [vp, i32]
+    if lib.nbls_abi_version() != ABI_VERSION:
+        raise NblsError('libnbls.so has ABI %d, this binding is written for ABI %d (rebuild: make -C noble-bls12-381_amd/csrc)' % (lib.nbls_abi_version(), ABI_VERSION))
     if not PROGRAMS:
         PROGRAMS.extend(lib.nbls_program_name(k).decode() for k in range(lib.nbls_program_count()))
     lib.nbls_timing_enable.argtypes = [vp, i32]
@@ -392,6 +397,17 @@ class Engine:
         self._chk(self.lib.nbls_program_stats(self.h, PROGRAMS.index(name), o))
         keys = ['steps', 'dot_steps', 'lin_steps', 'dot_ops', 'products', 'lin_ops', 'slots', 'lds_bytes']
         return dict(zip(keys, list(o)))
+
+    def program_kernel(self, name):
+        """the kernel that executes step program `name` in this context: 'nbls_aot_<kernel>' or 'nbls_vm_kernel[_ls4]' (the interpreter)"""
+        k = self.lib.nbls_program_kernel(self.h, PROGRAMS.index(name))
+        if k is None:
+            raise NblsError('nbls_program_kernel(%s) failed' % name)
+        return k.decode()
+
+    def kernel_bindings(self):
+        """{program: kernel} over every step program"""
+        return {p: self.program_kernel(p) for p in PROGRAMS}
 
     def device_synchronize(self):
         self._chk(self.lib.nbls_device_synchronize(self.h))

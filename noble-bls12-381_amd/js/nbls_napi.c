@@ -294,6 +294,10 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
   LOAD(nbls_hash_to_g2_batch) LOAD(nbls_g1_sum) LOAD(nbls_g2_sum) LOAD(nbls_verify_batch) LOAD(nbls_g1_mul_batch) LOAD(nbls_g2_mul_batch) LOAD(nbls_sign_batch) LOAD(nbls_hash_to_g1_batch) LOAD(nbls_encode_to_g1_batch) LOAD(nbls_encode_to_g2_batch) LOAD(nbls_g1_msm) LOAD(nbls_g2_msm)
   LOAD(nbls_init_multi) LOAD(nbls_destroy_multi) LOAD(nbls_multi_device_count) LOAD(nbls_multi_context) LOAD(nbls_multi_pairing_batch) LOAD(nbls_multi_miller_product) LOAD(nbls_multi_verify_batch) LOAD(nbls_g2_prepare) LOAD(nbls_pairing_prepared)
   LOAD(nbls_g1_from_hex_batch) LOAD(nbls_g2_from_hex_batch) LOAD(nbls_g2_from_signature_batch) LOAD(nbls_g1_clear_cofactor_batch) LOAD(nbls_g2_clear_cofactor_batch)
+  {   /* the ABI the addon was written against (include/nbls.h NBLS_ABI_VERSION): an older or newer library is refused at load instead of misread at run time */
+    int (*abi)(void) = (int (*)(void))dlsym(lib, "nbls_abi_version");
+    if (!abi || abi() != NBLS_ABI_VERSION) { napi_throw_error(env, NULL, "libnbls.so: ABI version differs from the one this addon was built for (include/nbls.h NBLS_ABI_VERSION)"); return exports; }
+  }
   napi_property_descriptor d[] = {
     {"init", 0, Init, 0, 0, 0, napi_enumerable, 0}, {"pairingBatch", 0, PairingBatch, 0, 0, 0, napi_enumerable, 0}, {"millerProduct", 0, MillerProduct, 0, 0, 0, napi_enumerable, 0},
     {"finalExpBatch", 0, FinalExpBatch, 0, 0, 0, napi_enumerable, 0}, {"g1Decompress", 0, G1Decompress, 0, 0, 0, napi_enumerable, 0}, {"g2Decompress", 0, G2Decompress, 0, 0, 0, napi_enumerable, 0},
