@@ -250,9 +250,9 @@ int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks);
                                           (default: never -- 15 % fewer instructions but no faster as measured, see csrc/nbls_api.cpp expx; 0 = always) */
 #define NBLS_TUNE_CHAIN_MAX 4          /* items below which EXPX, FE_MID1, EXPX x 3, FE_MID2, EXPX of a final exponentiation are ONE launch (default 8192; 0 = seven launches:
                                           what a caller that keeps several calls in flight on other contexts wants, csrc/nbls_api.cpp run_chain) */
-#define NBLS_TUNE_VERIFY_CHUNKS 5      /* verifyBatch as a software pipeline (csrc/nbls_api.cpp verify_pipeline): number of chunks the signatures are cut into (default 4; 0 or 1 = one chunk) */
-#define NBLS_TUNE_VERIFY_LAST_PCT 6    /* ... size of the last chunk in per cent of the batch (default 12; the sizes fall linearly from the first chunk to the last) */
-#define NBLS_TUNE_VERIFY_PIPE_MIN 7    /* ... signatures from which a call is chunked at all (default 16384) */
+#define NBLS_TUNE_VERIFY_CHUNKS 5      /* verifyBatch as concurrent sub-batches (csrc/nbls_api.cpp verify_pipeline): number of sub-batches the signatures are cut into (default 2; 0 or 1 = one) */
+#define NBLS_TUNE_VERIFY_LAST_PCT 6    /* ... size of the last sub-batch in per cent of the batch (default 12; the sizes fall linearly from the first to the last) */
+#define NBLS_TUNE_VERIFY_PIPE_MIN 7    /* ... signatures from which a call is cut at all (default 32768) */
 int nbls_set_tuning(nbls_ctx* ctx, int key, long long value);
 int nbls_program_count(void);                 /* number of step programs; timing slot nbls_program_count() = the inversion kernel */
 const char* nbls_program_name(int prog);

@@ -112,7 +112,10 @@ struct AotArgs {
   const uint32_t* qp_table; const uint32_t* item_index; const uint32_t* n_items_dev;
 };
 // Translate a compiled program.  Returns an empty string, or why the program cannot run on an ahead-of-time kernel (lane split, a step kind the kernels do not implement).
+// aot_translate places the LDS slots as the generated table says (aot_layout.h; NBLS_LDS_LAYOUT=0: as compiled); aot_translate_with takes the placement (nullptr: as compiled).
+struct AotLayout;
 std::string aot_translate(const Program& p, AotProgram& out);
+std::string aot_translate_with(const Program& p, AotProgram& out, const AotLayout* layout);
 
 }  // namespace nbls
 

@@ -2,11 +2,17 @@
 // region) into the form the ahead-of-time kernels execute (aot.h): step signatures and per-PHYSICAL-lane descriptors with absolute LDS addresses.
 // Host code shared by aot_gen (build time: which signatures exist), libnbls.so (upload) and the test-only simulator.
 #include "aot.h"
+#include "aot_layout.h"
+#include "config.h"
 #include <map>
 
 namespace nbls {
 
 std::string aot_translate(const Program& p, AotProgram& out) {
+  static const bool placed = env_long("NBLS_LDS_LAYOUT", 1) != 0;
+  return aot_translate_with(p, out, placed ? aot_layout_for(p) : nullptr);
+}
+std::string aot_translate_with(const Program& p, AotProgram& out, const AotLayout* layout) {
   out = AotProgram();
   const u32 S = p.lsplit;   // lane split: a K_DOT lane-op has one descriptor per sub-lane (index = the physical lane), every other kind one per logical lane, executed by sub-lane 0
   if (S != 1 && S != 4) return p.name + ": lane split " + std::to_string(S) + " has no ahead-of-time body";
@@ -16,7 +22,12 @@ std::string aot_translate(const Program& p, AotProgram& out) {
   const u32 zero = 0;                         // constant 0 of instance 0 (replicated constants) or of the shared copy: the zero element (Builder::Builder)
   auto abs_addr = [&](u32 f, u32 g) -> u32 {  // vm_exec.h term_addr, resolved for instance g
     f &= 0xffffu;
-    if (p.shared_consts) return (f & 2u) ? p.inst_base(g) + (f - 2u) : f;
+    if (p.shared_consts) {
+      if (!(f & 2u)) return f;                       // a constant of the shared copy
+      f -= 2u;
+      if (layout) { const u32 sl = f / p.slot_bytes; f = (u32)layout->pos[g][sl] * p.slot_bytes + (f - sl * p.slot_bytes); }   // the slot's place inside its instance region (aot_layout.h)
+      return p.inst_base(g) + f;
+    }
     return p.inst_base(g) + f;
   };
   for (size_t s = 0; s < p.steps.size(); s++) {

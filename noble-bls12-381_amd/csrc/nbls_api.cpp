@@ -75,7 +75,7 @@ struct nbls_ctx {
   size_t halves_min = env_long("NBLS_HALVES_MIN", 8192) > 0 ? (size_t)env_long("NBLS_HALVES_MIN", 8192) : (size_t)-1;   // NBLS_HALVES_MIN=0: never (profiles of kernels running alone)
   // verifyBatch as a software pipeline (round 5, verify_pipeline): events of the chunks (two each), the "xmd met non-monotonic offsets" flag lives behind the statuses
   std::vector<hipEvent_t> pipe_ev; hipEvent_t ev_pipe_done = nullptr; std::vector<hipStream_t> pipe_streams;
-  long verify_chunks = env_long("NBLS_VERIFY_CHUNKS", 4), verify_last_pct = env_long("NBLS_VERIFY_LAST_PCT", 12), verify_pipe_min = env_long("NBLS_VERIFY_PIPE_MIN", 16384);   // nbls_set_tuning(NBLS_TUNE_VERIFY_*)
+  long verify_chunks = env_long("NBLS_VERIFY_CHUNKS", 2), verify_last_pct = env_long("NBLS_VERIFY_LAST_PCT", 12), verify_pipe_min = env_long("NBLS_VERIFY_PIPE_MIN", 32768);   // nbls_set_tuning(NBLS_TUNE_VERIFY_*)
   hipStream_t side2 = nullptr; hipEvent_t ev_join2 = nullptr;   // verifyBatch: key decoding runs beside message hashing (their exponentiation kernels are latency-bound and leave issue slots free)
   uint8_t* ident_g1 = nullptr; uint8_t* ident_g2 = nullptr;   // projective identity (0 : 1 : 0), raw
   size_t cap_F = 0, cap_io = 0;
@@ -1425,7 +1425,14 @@ static int ensure_half_stream(nbls_ctx* ctx) {
 // final_exp = 1: the product's final exponentiation as 576 wire bytes in `out` (host); 0: the product itself as wire bytes at d_out (device; a shard's partial).
 // st: n statuses of the keys (+ 1 of the signature) as the decoders wrote them; *bad_offsets: the message offsets were not monotonic.
 static int pipe_stream(nbls_ctx* ctx, size_t i, hipStream_t* st) {
-  while (ctx->pipe_streams.size() <= i) { hipStream_t x = nullptr; HIPCHK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking)); ctx->pipe_streams.push_back(x); }
+  // NBLS_VERIFY_PRIO=1: the streams of the later sub-batches get the lowest priority the device offers (experiment: does the first sub-batch then finish its hash chain early?)
+  static const long prio_mode = env_long("NBLS_VERIFY_PRIO", 0);
+  while (ctx->pipe_streams.size() <= i) {
+    hipStream_t x = nullptr;
+    if (prio_mode) { int lo = 0, hi = 0; HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi)); HIPCHK(hipStreamCreateWithPriority(&x, hipStreamNonBlocking, lo)); }
+    else HIPCHK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+    ctx->pipe_streams.push_back(x);
+  }
   *st = ctx->pipe_streams[i];
   return NBLS_OK;
 }

@@ -11,6 +11,7 @@
 #include "fp_inv.h"
 #include "pow_exec.h"
 #include "aot_exec.h"
+#include "aot_layout.h"
 #include "aot_sigs.inc"
 
 using namespace nbls;
@@ -247,6 +248,16 @@ __attribute__((visibility("default"))) int nbls_sim_verify_damaged(int prog, uns
   const std::string e = verify_program(p);
   if (msg && cap) snprintf(msg, cap, "%s", e.c_str());
   return e.empty() ? 0 : 1;
+}
+// slot placement of a program's translated form (aot_layout.h): out = {has a valid table row, LDS read cycles per wavefront as compiled, with the placement, without any conflict}
+__attribute__((visibility("default"))) int nbls_sim_layout_info(int prog, unsigned long* out4) {
+  if (prog < 0 || prog >= P_COUNT) return -1;
+  const Program& p = get_program((ProgId)prog);
+  const AotLayout* l = aot_layout_for(p);
+  const AotLdsCost c0 = aot_layout_cost(p, AotLayout());
+  const AotLdsCost c1 = l ? aot_layout_cost(p, *l) : c0;
+  out4[0] = l ? 1 : 0; out4[1] = c0.cycles; out4[2] = c1.cycles; out4[3] = c0.floor;
+  return 0;
 }
 __attribute__((visibility("default"))) int nbls_sim_program_count() { return (int)P_COUNT; }
 __attribute__((visibility("default"))) void nbls_sim_stats() { for (int i = 0; i < P_COUNT; i++) print_stats(get_program((ProgId)i)); }

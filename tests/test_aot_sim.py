@@ -68,3 +68,20 @@ def test_decode_and_hash_programs_translated(sim, oracle, golden, testdata):
         assert sim.nbls_sim_has_aot(vmsim_py.P[name]) == 1, name
     T.test_decompress_programs(sim, golden)
     T.test_hash_to_g2_program(sim, oracle, golden, testdata)
+
+
+def test_slot_placement_table_is_current_and_pays(sim):
+    """round 5 (csrc/aot_layout.h): the generated slot placements of the pairing path's programs belong to the programs as they compile NOW (a row whose hash no longer
+    matches is ignored at run time -- correct, but the kernels then run with round 4's bank conflicts: regenerate with `make -C noble-bls12-381_amd/csrc layout`), and under the
+    LDS bank model of the MI355X guide they remove at least a quarter of the conflict cycles of the three hot programs.  The pipelines above ran WITH these placements."""
+    for name, max_frac in (('EXPX', 0.36), ('ACC_FE', 0.42), ('LINES_PQ', 0.34), ('ACC4_RAW', 0.34), ('MILLER_FE', 0.40), ('ACC2_RAW', 0.40), ('ACC_RAW', 0.42)):
+        o = (C.c_ulong * 4)()
+        assert sim.nbls_sim_layout_info(vmsim_py.P[name], o) == 0
+        has, c0, c1, floor = list(o)
+        assert has == 1, '%s: aot_layout.inc is stale for this program' % name
+        assert c1 < c0 and (c1 - floor) / c1 <= max_frac and (c1 - floor) <= 0.78 * (c0 - floor), (name, c0, c1, floor)
+    # the compiled placement reproduces the measured conflict fractions of round 4 (profiles/round4_pmc_b65536.json: EXPX 0.50, ACC_FE 0.52, LINES_PQ 0.44)
+    for name, lo, hi in (('EXPX', 0.44, 0.54), ('ACC_FE', 0.47, 0.57), ('LINES_PQ', 0.34, 0.48)):
+        o = (C.c_ulong * 4)()
+        sim.nbls_sim_layout_info(vmsim_py.P[name], o)
+        assert lo <= (o[1] - o[3]) / o[1] <= hi, (name, list(o))
