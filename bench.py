@@ -39,9 +39,19 @@ PEAK_TMAD = 256 * 64 * 2.4e9 / 1e12   # T MAD32/s: 256 CU x 64 lanes/clk/CU x 2.
 HBM_PEAK_GBPS = 8000.0
 
 
+R_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+
+
+def bench_scalar(seed, k):
+    """s_k = SHA-256("nbls-bench-v1" || seed || u64be(k)) mod r, zero rejected (the next counter value in its place would be the survey's rule; SHA-256 never gave one)"""
+    s = int.from_bytes(hashlib.sha256(b'nbls-bench-v1' + seed.to_bytes(4, 'big') + k.to_bytes(8, 'big')).digest(), 'big') % R_ORDER
+    assert s != 0
+    return s
+
+
 def synth_points(oracle, n, seed=0x6e626c73):
-    """Deterministic valid (G1, G2) pairs.  64 distinct random multiples of the generators are produced by the oracle's
-    scalar multiplication (host, setup only) and combined into n distinct pairs (P_a, Q_b)."""
+    """Deterministic valid (G1, G2) pairs for the SECONDARY legs (product, aggregation): 64 distinct random multiples of the generators made by the oracle's
+    scalar multiplication (host, setup only) and combined into n distinct pairs (P_a, Q_b).  The pairing legs use synth_stream."""
     g1, g2 = oracle.g1_generator(), oracle.g2_generator()
     P, Q = [], []
     for i in range(64):
@@ -51,6 +61,22 @@ def synth_points(oracle, n, seed=0x6e626c73):
         Q.append(oracle.g2_mul(g2, b)[1])
     G1 = b''.join(P[i % 64] for i in range(n))
     G2 = b''.join(Q[(i // 64 + 3 * i) % 64] for i in range(n))
+    return G1, G2
+
+
+def synth_stream(eng, oracle, n, seed=0x6e626c73, first=0, check=(0, 1, -1)):
+    """SURVEY.md 8(d)'s per-item stream: pair i is (P_i, Q_i) = ([s_2i] G1, [s_2i+1] G2), every pair distinct and uniformly distributed over the subgroups.  The 2 n scalar
+    multiplications run on the GPU (the constant-time ladders of getPublicKey / sign: setup, never timed); the pairs at `check` are compared with the oracle's own
+    multiplications of the same scalars.  first: index of the first item (a rank's shard of a larger stream)."""
+    ks1 = [bench_scalar(seed, 2 * (first + i)).to_bytes(32, 'big') for i in range(n)]
+    ks2 = [bench_scalar(seed, 2 * (first + i) + 1).to_bytes(32, 'big') for i in range(n)]
+    G1, st1 = eng.point_mul_batch(ks1)
+    G2, st2 = eng.point_mul_batch(ks2, pts=oracle.g2_generator() * n, g2=True)
+    assert not any(st1) and not any(st2), 'a bench scalar gave the zero point'
+    for c in check:
+        i = c % n
+        assert G1[96 * i:96 * i + 96] == oracle.g1_mul(oracle.g1_generator(), int.from_bytes(ks1[i], 'big'))[1], 'bench input check (G1) against the oracle failed'
+        assert G2[192 * i:192 * i + 192] == oracle.g2_mul(oracle.g2_generator(), int.from_bytes(ks2[i], 'big'))[1], 'bench input check (G2) against the oracle failed'
     return G1, G2
 
 
@@ -72,6 +98,7 @@ def main():
     ap.add_argument('--product-terms', type=int, default=262144, help='terms of the sharded multi-pairing product leg (BASELINE configs[4]); 0 disables')
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'], help='torch.distributed backend of an N > 1 run: nccl (= RCCL, the real thing) or gloo, which lets several ranks share one GPU (rank r uses device r mod device count) so that the whole N-rank job -- launcher, sharded legs, barriers -- runs on a one-GPU box (RCCL refuses two ranks on one device); tests/test_gpu_rccl.py')
     ap.add_argument('--mark-timed-region', action='store_true', help='bracket the timed steps with two tiny torch fill kernels, so that a rocprofv3 kernel trace of the run shows where the timed region starts and ends (tools/profile_round3.sh)')
+    ap.add_argument('--config3-pairings', type=int, default=1 << 20, help='independent pairings of the BASELINE configs[3] leg, sharded over the ranks, ONE call per rank (1M over 8 GPUs = 131,072 per rank); 0 disables')
     ap.add_argument('--dry-launch', action='store_true', help='launch check without a GPU: the ranks of --gpus N rendezvous over gloo, all-reduce their ranks and rank 0 prints one JSON line (tests/test_bench_launch.py)')
     args = ap.parse_args()
 
@@ -95,8 +122,19 @@ def main():
         t = torch.tensor([rank + 1], dtype=torch.int64)
         dist.all_reduce(t)
         dist.barrier()
+        # rehearsal of the legs that shard BASELINE configs[3] / [2] over the ranks: the same shard arithmetic and the same order of barriers / reductions as the real run
+        par = importlib.import_module('noble-bls12-381_amd.parallel')
+        lo3, hi3 = par.shard_bounds(args.config3_pairings, world, rank)
+        shards = [None] * world
+        dist.all_gather_object(shards, (lo3, hi3))
+        dist.barrier()
+        t3 = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+        dist.barrier()
         if rank == 0:
-            print(json.dumps({'dry_launch': True, 'n_gpus': world, 'gpus_flag': args.gpus, 'rank_sum': int(t.item()), 'backend': 'gloo'}), flush=True)
+            print(json.dumps({'dry_launch': True, 'n_gpus': world, 'gpus_flag': args.gpus, 'rank_sum': int(t.item()), 'backend': 'gloo',
+                              'config3': {'pairings': args.config3_pairings, 'shards': shards, 'max_time_reduced': float(t3.item())},
+                              'legs': ['value', 'product', 'verify_batch_sharded', 'config3'] + (['multi_one_process'] if world > 1 else [])}), flush=True)
         dist.destroy_process_group()
         return
 
@@ -146,7 +184,7 @@ def main():
     eng = pipe.engines[0]
 
     n = args.batch
-    G1, G2 = synth_points(oracle, n, seed=0x6e626c73 + rank)
+    G1, G2 = synth_stream(eng, oracle, n, seed=0x6e626c73, first=rank * n)      # item i of rank r is pair r * n + i of the stream
     d_g1 = torch.frombuffer(bytearray(G1), dtype=torch.uint8).cuda()
     d_g2 = torch.frombuffer(bytearray(G2), dtype=torch.uint8).cuda()
     d_outs = [torch.empty(576 * n, dtype=torch.uint8, device='cuda') for _ in range(D)]
@@ -302,6 +340,70 @@ def main():
             raise     # see the product leg: collectives inside
         vshard = {'error': repr(e)}
 
+    # ---- BASELINE configs[3] as written (all N): --config3-pairings independent pairings sharded contiguously over the ranks, every rank ONE nbls_pairing_batch_dev call on its
+    # shard of SURVEY 8(d)'s item stream, barrier before and after, whole-node pairings/s over the slowest rank; no collective on the data path
+    config3 = None
+    try:
+        if args.config3_pairings > 0:
+            par = importlib.import_module('noble-bls12-381_amd.parallel')
+            lo3, hi3 = par.shard_bounds(args.config3_pairings, world, rank)
+            m3 = hi3 - lo3
+            C1, C2 = synth_stream(eng, oracle, m3, seed=0x6e626c73 + 3, first=lo3, check=(0, -1))
+            c1 = torch.frombuffer(bytearray(C1), dtype=torch.uint8).cuda(); c2 = torch.frombuffer(bytearray(C2), dtype=torch.uint8).cuda()
+            co = torch.empty(576 * m3, dtype=torch.uint8, device='cuda')
+            eng.pairing_batch_dev(m3, c1.data_ptr(), c2.data_ptr(), co.data_ptr(), True, stream)     # warm-up (scratch grows to this size)
+            torch.cuda.synchronize()
+            ref3, _ = oracle.pairing_batch(C1[:96 * 4] + C1[-96 * 4:], C2[:192 * 4] + C2[-192 * 4:], True, False, threads=8)
+            assert bytes(co[:576 * 4].cpu().numpy().tobytes()) + bytes(co[-576 * 4:].cpu().numpy().tobytes()) == ref3, 'configs[3] parity check failed'
+            # size-independent property over the whole shard: bilinearity of a random-looking pair of items is covered by tests; here a checksum of the outputs must not change between calls
+            if multi:
+                dist.barrier()
+            torch.cuda.synchronize()
+            q0 = time.perf_counter()
+            creps = 2
+            for _ in range(creps):
+                eng.pairing_batch_dev(m3, c1.data_ptr(), c2.data_ptr(), co.data_ptr(), True, stream)
+            torch.cuda.synchronize()
+            if multi:
+                dist.barrier()
+            qdt = (time.perf_counter() - q0) / creps
+            if multi:
+                t = torch.tensor([qdt], dtype=torch.float64, device='cuda')
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                qdt = float(t.item())
+            config3 = {'metric': 'pairings/sec, BASELINE configs[3]: %d independent pairings sharded over %d rank(s), one call per rank' % (args.config3_pairings, world),
+                       'pairings': args.config3_pairings, 'pairings_per_rank': m3, 'value': round(args.config3_pairings / qdt, 2), 'unit': 'pairings/s', 'ms': round(qdt * 1e3, 3),
+                       'roofline_frac_per_gpu': round(args.config3_pairings / world / qdt * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL / 1e12 / PEAK_TMAD, 4),
+                       'note': 'inputs: items [lo, hi) of the SURVEY 8(d) stream per rank, resident in HBM; outputs 576 B per pairing into HBM; time = max over ranks between two barriers'}
+            del c1, c2, co
+    except Exception as e:   # noqa: BLE001
+        if multi:
+            raise
+        config3 = {'error': repr(e)}
+
+    # ---- one PROCESS over every GPU of the node (rank 0 of an N > 1 job, the other ranks wait at the barrier): nbls_multi_pairing_batch / nbls_multi_verify_batch from host
+    # buffers -- the in-library form of the same sharding (csrc/nbls_multi.cpp: a context, a persistent host thread and a stream per device, partials gathered with hipMemcpyPeer)
+    multi1 = None
+    if world > 1:
+        try:
+            if rank == 0 and torch.cuda.device_count() >= world:
+                me = pkg.MultiEngine(list(range(world)))
+                nm1 = 16384 * world
+                M1, M2 = synth_stream(eng, oracle, nm1, seed=0x6e626c73 + 4, check=(0,))
+                outm, _ = me.pairing_batch(M1, M2, True, False)
+                refm, _ = oracle.pairing_batch(M1[:96 * 2] + M1[-96 * 2:], M2[:192 * 2] + M2[-192 * 2:], True, False, threads=4)
+                assert outm[:576 * 2] + outm[-576 * 2:] == refm, 'multi-device pairing parity check failed'
+                u0 = time.perf_counter(); me.pairing_batch(M1, M2, True, False); udt = time.perf_counter() - u0
+                prod, _ = me.miller_product(M1[:96 * 4096], M2[:192 * 4096], True, False)
+                assert prod == eng.miller_product(M1[:96 * 4096], M2[:192 * 4096], True, False)[0], 'multi-device product differs from one device'
+                multi1 = {'devices': world, 'pairings': nm1, 'pairings_per_s_host_buffers': round(nm1 / udt, 2), 'ms': round(udt * 1e3, 3),
+                          'peer_access': [me.lib.nbls_multi_peer_access(me.h, i) for i in range(world)],
+                          'note': 'nbls_multi_pairing_batch from HOST buffers (PCIe in and out included) in ONE process over all devices; product of 4096 pairs across the devices equals the one-device product'}
+                me.close()
+        except Exception as e:   # noqa: BLE001  -- no collective inside: rank 0 reaches the barrier either way
+            multi1 = {'error': repr(e)}
+        dist.barrier()
+
     # ---- roofline leg: per-kernel HIP-event durations of the same step (separate untimed passes)
     roof = None
     cpu = None
@@ -315,18 +417,20 @@ def main():
         tm = eng.timing_read()
         eng.timing_enable(False)
         per_step = {k: v[0] / reps for k, v in tm.items()}          # ms per bench step, summed over that program's launches
-        MILLER_PROGS = ('miller_fe', 'miller_fe_ls', 'lines_pq', 'acc_fe')   # one program below 49,152 pairings per call (its lane-split variant up to 1024), LINES + ACC from there on
+        MILLER_PROGS = ('miller_fe', 'miller_fe_ls', 'lines_pq', 'acc_fe')   # one fused program, or LINES_PQ -> ACC_FE through line tables in HBM (which one ran is read off the timing slots below)
         ms_miller = sum(v for k, v in per_step.items() if k in MILLER_PROGS)
         ms_inv = per_step['fp_inv']
         ms_hard = sum(v for k, v in per_step.items() if k not in MILLER_PROGS + ('fp_inv',))
         mads = n * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL
         vm_ms = ms_miller + ms_hard
-        achieved = mads / (vm_ms * 1e-3) / 1e12
-        # algorithmic HBM bytes per pairing: wire points in (288) and Fp12 out (576) + the raw scratch
-        # elements (768 B per Fp12, 64 B per Fp) every phase program reads and writes:
-        # miller_fe W 832 | fp_inv R 64 W 64 | fe_easy R 832 W 768 | 5 x expx R 768 W 768 | fe_mid1/2 R 1536 W 768 | fe_final R 5376
-        # (from 49,152 pairings per call -- SPLIT_MILLER_MIN in csrc/nbls_api.cpp -- the Miller loop runs as LINES + ACC and adds one 26,112-byte line table written and read per pairing)
-        hbm_bytes = n * (288 + 832 + 128 + 832 + 768 + 5 * 1536 + 2 * 2304 + 5376 + 576 + (2 * 26112 if n >= 49152 else 0))
+        call_ms = vm_ms + ms_inv            # every kernel of the call, the inversion kernel included (round 4 left it out of the denominator while naming it in the label)
+        achieved = mads / (call_ms * 1e-3) / 1e12
+        split_miller = per_step.get('lines_pq', 0) > 0      # the form that RAN (round 4 tested n >= 49152, a threshold the library no longer has)
+        chained = per_step.get('fe_mid1', 0) == 0           # the final exponentiation's middle as one chained launch: its time is booked on `expx`
+        # algorithmic HBM bytes per pairing: wire points in (288) and Fp12 out (576) + the raw scratch elements (768 B per Fp12, 64 B per Fp)
+        # every phase program reads and writes: Miller W 832 | fp_inv R 64 W 64 | fe_easy R 832 W 768 | 5 x expx R 768 W 768 | fe_mid1/2 R 1536 W 768 | fe_final R 5376
+        # -- and, with the two-program Miller loop, one 26,112-byte line table written by LINES_PQ and read by ACC_FE
+        hbm_bytes = n * (288 + 832 + 128 + 832 + 768 + 5 * 1536 + 2 * 2304 + 5376 + 576 + (2 * 26112 if split_miller else 0))
         traffic = None; valu_busy = None
         try:   # HBM bytes measured with rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, see profiles/README.md), same batch size only
             with open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')) as fh:
@@ -334,19 +438,27 @@ def main():
                 traffic = prof.get('bytes_per_step'); valu_busy = prof.get('valu_issue_busy')
         except OSError:
             pass
+        bind = eng.kernel_bindings()
+        ran = sorted({bind[k] for k in per_step if k in bind and per_step[k] > 0} | {'nbls_fp_inv_kernel'})
+        n_aot = sum(1 for k in bind.values() if k.startswith('nbls_aot_'))
         roof = {
-            'bound': 'valu-int32-mad', 'kernel': 'nbls_aot_* (the ahead-of-time kernels of the step programs of one pairing batch: lines_pq / acc_fe or miller_fe, fe_easy, expx chain, fe_final) + nbls_fp_inv_kernel',
+            'bound': 'valu-int32-mad', 'kernel': ' + '.join(ran), 'kernel_source': 'nbls_program_kernel() of the programs this call launched: the kernels that RAN (an interpreter binding would show as nbls_vm_kernel)',
+            'aot_programs': '%d/%d' % (n_aot, len(bind)),     # step programs bound to an ahead-of-time kernel in this process (tests/test_gpu_binding.py asserts the same on the box)
+            'miller_form': 'LINES_PQ -> ACC_FE (line tables through HBM)' if split_miller else 'one fused program', 'final_exp_middle': 'one chained launch' if chained else 'seven launches',
             'achieved': round(achieved, 4), 'peak': round(PEAK_TMAD, 3), 'unit': 'TMAD32/s', 'frac': round(achieved / PEAK_TMAD, 4),
             'traffic': traffic, 'traffic_source': 'profiles/hbm_traffic.json (rocprofv3 PMC passes of this batch size, FETCH_SIZE x 2 + WRITE_SIZE; a committed measurement, not taken in this run)' if traffic is not None else None,
             'valu_issue_busy': valu_busy,    # SQ_INSTS_VALU x 4 clocks / (kernel time x 2.4 GHz x 1024 SIMDs) from the PMC pass in profiles/ (same batch size, one batch at a time)
             'frac_at_value': round(value / world * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL / 1e12 / PEAK_TMAD, 4),
-            'frac_note': 'achieved/frac: the kernels of ONE %d-pairing call running alone (sum of the HIP-event durations of its nbls_vm_kernel launches; profiles/ holds the rocprofv3 kernel trace of the same command); frac_at_value: the same algorithmic work at the rate of `value` (%d calls overlapping on %d streams; profiles/ holds a kernel trace taken with the same --inflight)' % (n, D, D),
+            'frac_note': 'achieved/frac: the kernels of ONE %d-pairing call running alone (algorithmic multiply-adds over the sum of the HIP-event durations of ALL its launches, the inversion kernel included; profiles/ holds the rocprofv3 kernel trace of the same command); frac_at_value: the same algorithmic work at the rate of `value` (%d calls overlapping on %d streams; profiles/ holds a kernel trace taken with the same --inflight)' % (n, D, D),
             'clock_note': 'peak is priced at 2.4 GHz; under saturated load (value, large_batch) this engine is power-limited: 2.21-2.22 GHz at 1330-1360 W of the 1400 W package limit (profiles/round4_clocks_under_load.txt), and a pure stream of its multiply-add sustains 30.6 T/s at 2.32 GHz (profiles/round4_ubench_mad_power.txt); one call at a time runs at 2.39 GHz',
             'kernel_ms': {k: round(v, 4) for k, v in per_step.items()},
             'miller_frac': round(n * FPMUL_MILLER * MAD_PER_FPMUL / (ms_miller * 1e-3) / 1e12 / PEAK_TMAD, 4),
             'final_exp_frac': round(n * FPMUL_FINALEXP * MAD_PER_FPMUL / (ms_hard * 1e-3) / 1e12 / PEAK_TMAD, 4),
-            'hbm': {'algorithmic_bytes_per_launch': hbm_bytes, 'achieved_GBps': round(hbm_bytes / ((vm_ms + ms_inv) * 1e-3) / 1e9, 3),
-                    'peak_GBps': HBM_PEAK_GBPS, 'frac': round(hbm_bytes / ((vm_ms + ms_inv) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6)},
+            'hbm': {'algorithmic_bytes_per_launch': hbm_bytes, 'achieved_GBps': round(hbm_bytes / (call_ms * 1e-3) / 1e9, 3),
+                    'peak_GBps': HBM_PEAK_GBPS, 'frac': round(hbm_bytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
+                    'algorithmic_bytes_8d': 864 * n, 'traffic_ratio_vs_8d': round(traffic / (864.0 * n), 1) if traffic else None,
+                    'traffic_GBps': round(traffic / (call_ms * 1e-3) / 1e9, 1) if traffic else None,
+                    'note': 'algorithmic_bytes_per_launch: wire I/O + the raw scratch between the launches of the form that ran (line tables included when the Miller loop ran as two programs); algorithmic_bytes_8d: SURVEY 8(d)\'s 864 B per pairing (points in, Fp12 out); traffic_ratio_vs_8d: the PMC-measured bytes (roofline.traffic) over that -- the phase scratch and the line tables, never the bound (frac)'},
         }
         # the same batch through the host-buffer entry point (PCIe in and out included) -- reported, never `value`
         h0 = time.perf_counter()
@@ -356,13 +468,14 @@ def main():
         # the same pipeline as ONE call of --large-batch pairings: every SIMD holds three wavefronts (the VGPR limit), the issue slots are saturated
         if args.large_batch > 0:
             nl = args.large_batch
-            GL1, GL2 = (G1 * (nl // n + 1))[:96 * nl], (G2 * (nl // n + 1))[:192 * nl]
+            GL1, GL2 = synth_stream(eng, oracle, nl, seed=0x6e626c73, first=rank * n, check=(-1,))      # the same stream, nl items of it: every pair distinct
             dl1 = torch.frombuffer(bytearray(GL1), dtype=torch.uint8).cuda(); dl2 = torch.frombuffer(bytearray(GL2), dtype=torch.uint8).cuda()
             dlo = torch.empty(576 * nl, dtype=torch.uint8, device='cuda')
             for _ in range(2):
                 eng.pairing_batch_dev(nl, dl1.data_ptr(), dl2.data_ptr(), dlo.data_ptr(), True, stream)
             torch.cuda.synchronize()
-            assert bytes(dlo[:576 * 8].cpu().numpy().tobytes()) == ref and bytes(dlo[576 * n:576 * (n + 8)].cpu().numpy().tobytes()) == ref, 'large-batch parity check failed'
+            ref_tail, _ = oracle.pairing_batch(GL1[-96 * 8:], GL2[-192 * 8:], True, False, threads=8)
+            assert bytes(dlo[:576 * 8].cpu().numpy().tobytes()) == ref and bytes(dlo[-576 * 8:].cpu().numpy().tobytes()) == ref_tail, 'large-batch parity check failed'
             lreps = max(3, int(1.0 / (nl / 2.0e6)))      # about one second
             l0 = time.perf_counter()
             for _ in range(lreps):
@@ -603,7 +716,6 @@ def main():
         mleg = None
         if world == 1 and args.msm_points > 0:
             nm = args.msm_points
-            R_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
             gen1 = oracle.g1_generator()
             a64 = [int.from_bytes(hashlib.sha256(b'msm-a' + bytes([i])).digest(), 'big') % R_ORDER for i in range(64)]
             p64 = [oracle.g1_mul(gen1, a)[1] for a in a64]
@@ -641,6 +753,8 @@ def main():
             'single_stream': {'pairings_per_s': round(n * args.steps / dt_serial, 2), 'ms_per_batch': round(dt_serial / args.steps * 1e3, 4), 'note': 'alias of single_call (round-1 name)'},
             'rccl_ranks': ranks_seen if (multi and args.dist_backend == 'nccl') else None, 'ranks_in_all_gather': ranks_seen, 'dist_backend': args.dist_backend if multi else None,
             'roofline': roof, 'cpu_baseline': cpu, 'facade': facade, 'product': product, 'verify_batch': vbatch if vbatch is not None else vshard, 'verify_batch_sharded': vshard if vbatch is not None else None, 'sign': sleg, 'aggregate': aleg, 'msm': mleg,
+            'config3': config3, 'multi_one_process': multi1,
+            'pool': {'depth': D, 'entry_point': 'nbls_pool_pairing_batch_dev (include/nbls.h): `value` is measured through the C ABI pool; noble-bls12-381_amd/pipeline.py only forwards to it'},
         }
         out_line = json.dumps(line)
     else:

@@ -218,6 +218,20 @@ const char* nbls_config_describe(void);   /* "NBLS_X=value(env|default) ...": ev
 int nbls_abi_version(void);
 int nbls_context_device(nbls_ctx* ctx);
 
+/* ---- several calls in flight on ONE device (round 5): `depth` contexts, each with its own stream and scratch, fed round-robin (what noble-bls12-381_amd/pipeline.py does, for C
+ * callers).  A 4096-pairing call alone fills the chip one wavefront deep and runs at ~0.27 of the multiply-add roofline; twelve to twenty overlapping calls reach ~0.45.
+ * nbls_pool_pairing_batch_dev enqueues pairing(P_i, Q_i) (reference index.ts:715-722) for n device-resident pairs on the next context's stream and returns at once;
+ * *slot (may be NULL) = the context used -- keep one output buffer per slot; nbls_pool_next_slot tells it in advance.  Set GPU_MAX_HW_QUEUES >= depth (and <= 22) in the
+ * environment before the HIP runtime initialises: streams that share a hardware queue serialise. */
+typedef struct nbls_pool nbls_pool;
+int nbls_pool_init(int device_id, int depth /* 1 .. 64 */, nbls_pool** out);
+void nbls_pool_destroy(nbls_pool* p);
+int nbls_pool_depth(const nbls_pool* p);
+nbls_ctx* nbls_pool_context(nbls_pool* p, int i);
+int nbls_pool_next_slot(nbls_pool* p);
+int nbls_pool_pairing_batch_dev(nbls_pool* p, size_t n, const void* d_g1, const void* d_g2, int with_final_exp, void* d_out, int* slot);
+int nbls_pool_synchronize(nbls_pool* p);   /* everything submitted so far is complete (synchronises the device) */
+
 /* Several GPUs of one node behind one handle (one context, host thread and stream per device; contiguous shards).  n_devices = 0 takes every
  * visible device; device_ids = NULL means 0 .. n_devices-1.  Independent pairings need no exchange; the product paths reduce every shard
  * to a 576-byte Fp12 partial, gather the partials on the first device with hipMemcpyPeer (xGMI) and run ONE shared final exponentiation

@@ -4,13 +4,18 @@
 //   * Miller product / verifyBatch: every device reduces its shard to ONE Fp12 partial (576 bytes, no final exponentiation), the partials
 //     are copied device-to-device (hipMemcpyPeer over xGMI) into the first device's gather buffer, which multiplies them and runs the one
 //     shared final exponentiation.  The exchange is 576 bytes per device -- pure latency -- so no collective library is involved.
+// nbls_pool_* (the end of this file): several contexts of ONE device fed round-robin -- the in-flight form of bench.py's headline, for C callers.
 // This layer uses only the public single-device ABI (include/nbls.h) plus HIP for the peer copies.
 #include <hip/hip_runtime.h>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
 #include "nbls.h"
+#include "config.h"
 
 #define EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -22,7 +27,24 @@ struct CallBuffers {
   std::vector<uint8_t*> part;   // part[g] on dev[g]
   uint8_t* gather = nullptr;    // on dev[0]
 };
+// One host thread per device for the LIFETIME of the handle (round 5; round 4 created G - 1 std::threads per call, which shows in the latency of a single verify on
+// eight GPUs): a call posts its per-device work to the workers of devices 1 .. G-1, runs device 0's share itself and waits on a latch.  Calls racing on one handle
+// queue up per device in arrival order -- the contexts serialise their work anyway.
+struct Worker {
+  std::thread th; std::mutex mu; std::condition_variable cv; std::deque<std::function<void()>> q; bool stop = false;
+  void run() {
+    for (;;) {
+      std::function<void()> f;
+      { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return stop || !q.empty(); }); if (q.empty()) return; f = std::move(q.front()); q.pop_front(); }
+      f();
+    }
+  }
+  void post(std::function<void()> f) { { std::lock_guard<std::mutex> l(mu); q.push_back(std::move(f)); } cv.notify_one(); }
+  void start() { th = std::thread([this] { run(); }); }
+  void finish() { { std::lock_guard<std::mutex> l(mu); stop = true; } cv.notify_one(); if (th.joinable()) th.join(); }
+};
 struct nbls_multi {
+  std::vector<Worker*> workers;        // workers[g] serves device g of the handle (none for g = 0: the caller's thread)
   std::vector<nbls_ctx*> ctx;
   std::vector<int> dev;
   std::vector<int> peer;               // per device: 1 = peer access to / from the reducing device enabled (nbls_multi_peer_access)
@@ -62,6 +84,7 @@ struct SetLease {   // returns the set on every exit path
 
 EXPORT void nbls_destroy_multi(nbls_multi* m) {
   if (!m) return;
+  for (Worker* w : m->workers) if (w) { w->finish(); delete w; }
   for (CallBuffers* b : m->all_sets) free_set(m, b);
   for (nbls_ctx* c : m->ctx) nbls_destroy(c);
   delete m;
@@ -81,6 +104,8 @@ EXPORT int nbls_init_multi(int n_devices, const int* device_ids, nbls_multi** ou
     if (r) { nbls_destroy_multi(m); return r; }
     m->ctx.push_back(c); m->dev.push_back(d);
   }
+  m->workers.assign(m->ctx.size(), nullptr);
+  for (size_t g = 1; g < m->ctx.size(); g++) { m->workers[g] = new Worker(); m->workers[g]->start(); }
   { CallBuffers* b = take_set(m); if (!b) { nbls_destroy_multi(m); return NBLS_EHIP; } give_set(m, b); }   // the first call's buffers
   // peer access lets hipMemcpyPeer go straight over xGMI; without it the copy is staged, which is still correct
   // (round 4: both directions between the reducing device -- the FIRST listed one, whatever its id -- and every other device, and the outcome is kept for
@@ -110,12 +135,12 @@ EXPORT nbls_ctx* nbls_multi_context(nbls_multi* m, int i) { return m && i >= 0 &
 // contiguous shards [lo, hi) of n items over the devices (the first n % G devices take one item more)
 static void shard(size_t n, size_t G, size_t g, size_t* lo, size_t* hi) { const size_t q = n / G, r = n % G; *lo = g * q + (g < r ? g : r); *hi = *lo + q + (g < r ? 1 : 0); }
 
-template <class F> static int on_every_device(size_t G, F f) {
+template <class F> static int on_every_device(nbls_multi* m, size_t G, F f) {
   std::vector<int> rc(G, 0);
-  std::vector<std::thread> th;
-  for (size_t g = 1; g < G; g++) th.emplace_back([&, g] { rc[g] = f(g); });
+  std::mutex mu; std::condition_variable cv; size_t pending = G > 1 ? G - 1 : 0;
+  for (size_t g = 1; g < G; g++) m->workers[g]->post([&, g] { rc[g] = f(g); std::lock_guard<std::mutex> l(mu); if (--pending == 0) cv.notify_one(); });
   rc[0] = f(0);
-  for (auto& t : th) t.join();
+  { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return pending == 0; }); }
   for (size_t g = 0; g < G; g++) if (rc[g] && rc[g] != NBLS_EDECODE) return rc[g];
   for (size_t g = 0; g < G; g++) if (rc[g]) return rc[g];
   return NBLS_OK;
@@ -125,7 +150,7 @@ template <class F> static int on_every_device(size_t G, F f) {
 EXPORT int nbls_multi_pairing_batch(nbls_multi* m, size_t n, const uint8_t* g1, const uint8_t* g2, int with_final_exp, int validate, uint8_t* out, int8_t* status) {
   if (!m || m->ctx.empty() || (n && (!g1 || !g2 || !out))) return NBLS_EINVAL;
   const size_t G = m->ctx.size();
-  return on_every_device(G, [&](size_t g) {
+  return on_every_device(m, G, [&](size_t g) {
     size_t lo, hi; shard(n, G, g, &lo, &hi);
     if (hi == lo) return (int)NBLS_OK;
     return nbls_pairing_batch(m->ctx[g], hi - lo, g1 + lo * 96, g2 + lo * 192, with_final_exp, validate, out + lo * 576, status ? status + lo : nullptr);
@@ -153,7 +178,7 @@ EXPORT int nbls_multi_miller_product(nbls_multi* m, size_t n, const uint8_t* g1,
   SetLease lease(m);
   if (!lease.b) return NBLS_EHIP;
   CallBuffers* b = lease.b;
-  int r = on_every_device(G, [&](size_t g) {
+  int r = on_every_device(m, G, [&](size_t g) {
     size_t lo, hi; shard(n, G, g, &lo, &hi);   // an empty shard contributes the unit element
     void* p = b->part[g];
     return nbls_miller_product_partial_into(m->ctx[g], hi - lo, g1 + lo * 96, g2 + lo * 192, validate, p, status ? status + lo : nullptr);
@@ -173,7 +198,7 @@ EXPORT int nbls_multi_verify_batch(nbls_multi* m, size_t n, const uint8_t* sig96
   if (!lease.b) return NBLS_EHIP;
   CallBuffers* b = lease.b;
   std::vector<int> zero(G, 0);
-  int r = on_every_device(G, [&](size_t g) {
+  int r = on_every_device(m, G, [&](size_t g) {
     size_t lo, hi; shard(n, G, g, &lo, &hi);
     void* p = b->part[g];
     return nbls_verify_batch_partial_into(m->ctx[g], hi - lo, g == 0 ? sig96 : nullptr, msgs, offsets + lo, pk48 + lo * 48, dst, dst_len, p, &zero[g], nullptr);
@@ -187,3 +212,38 @@ EXPORT int nbls_multi_verify_batch(nbls_multi* m, size_t n, const uint8_t* sig96
   *ok = one ? 1 : 0;
   return NBLS_OK;
 }
+
+// ---- a pool of contexts on ONE device (round 5) --------------------------------------------------------------------------------------------------------
+// A 4096-pairing call fills the chip one wavefront deep, and a lone wavefront issues at little more than half rate: a service that has independent
+// batches keeps several calls in flight on contexts of their own.  Round 4 had this only as a Python helper (noble-bls12-381_amd/pipeline.py) and in the JS facade; the pool is
+// the same thing behind the C ABI: `depth` contexts, each with its own stream and scratch, tuned for overlapping calls (the two-program Miller loop at every size, the
+// final exponentiation's middle as seven launches: what counts with other calls' wavefronts on the SIMDs is the instruction count and fine launches), fed round-robin.
+// nbls_pool_pairing_batch_dev enqueues and returns; results are complete after nbls_pool_synchronize (or a synchronisation of the device by the caller).
+struct nbls_pool { std::vector<nbls_ctx*> ctx; std::mutex mu; size_t next = 0; int device = 0; };
+EXPORT void nbls_pool_destroy(nbls_pool* p) { if (!p) return; for (nbls_ctx* c : p->ctx) nbls_destroy(c); delete p; }
+EXPORT int nbls_pool_init(int device_id, int depth, nbls_pool** out) {
+  if (!out || depth < 1 || depth > 64) return NBLS_EINVAL;
+  nbls_pool* p = new nbls_pool(); p->device = device_id;
+  for (int i = 0; i < depth; i++) {
+    nbls_ctx* c = nullptr;
+    const int r = nbls_init(device_id, &c);
+    if (r) { nbls_pool_destroy(p); return r; }
+    p->ctx.push_back(c);
+    if (depth > 1) { nbls_set_tuning(c, NBLS_TUNE_SPLIT_MILLER_MIN, 0); if (nbls::env_long("NBLS_PIPELINE_CHAIN", 0) != 1) nbls_set_tuning(c, NBLS_TUNE_CHAIN_MAX, 0); }   // NBLS_PIPELINE_CHAIN=1: A/B switch (tools/ab_pipeline.sh)
+  }
+  *out = p;
+  return NBLS_OK;
+}
+EXPORT int nbls_pool_depth(const nbls_pool* p) { return p ? (int)p->ctx.size() : 0; }
+EXPORT nbls_ctx* nbls_pool_context(nbls_pool* p, int i) { return p && i >= 0 && i < (int)p->ctx.size() ? p->ctx[i] : nullptr; }
+// pairing(P_i, Q_i) for n device-resident pairs (index.ts:715-722) on the next context's own stream; returns at once.  *slot (optional) = index of the context used: a caller that
+// keeps calls in flight gives every slot its own output buffer (the pool does not order two calls that write the same memory).
+EXPORT int nbls_pool_pairing_batch_dev(nbls_pool* p, size_t n, const void* d_g1, const void* d_g2, int with_final_exp, void* d_out, int* slot) {
+  if (!p || p->ctx.empty()) return NBLS_EINVAL;
+  size_t k;
+  { std::lock_guard<std::mutex> l(p->mu); k = p->next++ % p->ctx.size(); }
+  if (slot) *slot = (int)k;
+  return nbls_pairing_batch_dev(p->ctx[k], n, d_g1, d_g2, with_final_exp, d_out, nullptr);
+}
+EXPORT int nbls_pool_next_slot(nbls_pool* p) { if (!p || p->ctx.empty()) return -1; std::lock_guard<std::mutex> l(p->mu); return (int)(p->next % p->ctx.size()); }
+EXPORT int nbls_pool_synchronize(nbls_pool* p) { return p && !p->ctx.empty() ? nbls_device_synchronize(p->ctx[0]) : NBLS_EINVAL; }

@@ -90,6 +90,15 @@ def load_library():
     lib.nbls_multi_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, sz, C.POINTER(i32)]
     lib.nbls_program_name.restype = C.c_char_p
     lib.nbls_program_name.argtypes = [i32]
+    lib.nbls_context_device.argtypes = [vp]
+    lib.nbls_pool_init.argtypes = [i32, i32, C.POINTER(vp)]
+    lib.nbls_pool_destroy.argtypes = [vp]
+    lib.nbls_pool_depth.argtypes = [vp]
+    lib.nbls_pool_context.restype = vp
+    lib.nbls_pool_context.argtypes = [vp, i32]
+    lib.nbls_pool_next_slot.argtypes = [vp]
+    lib.nbls_pool_pairing_batch_dev.argtypes = [vp, sz, vp, vp, i32, vp, C.POINTER(i32)]
+    lib.nbls_pool_synchronize.argtypes = [vp]
     lib.nbls_program_kernel.restype = C.c_char_p
     lib.nbls_program_kernel.argtypes = [vp, i32]
     if lib.nbls_abi_version() != ABI_VERSION:
@@ -104,8 +113,13 @@ def load_library():
 class Engine:
     """One engine context = one GPU."""
 
-    def __init__(self, device_id=0):
+    def __init__(self, device_id=0, _handle=None):
         self.lib = load_library()
+        self._owned = _handle is None
+        if _handle is not None:      # a context owned by a pool / multi handle (nbls_pool_context, nbls_multi_context): not destroyed by this object
+            self.h = C.c_void_p(_handle)
+            self.device_id = self.lib.nbls_context_device(self.h)
+            return
         h = C.c_void_p()
         r = self.lib.nbls_init(device_id, C.byref(h))
         if r != 0:
@@ -115,7 +129,8 @@ class Engine:
 
     def close(self):
         if getattr(self, 'h', None):
-            self.lib.nbls_destroy(self.h)
+            if self._owned:
+                self.lib.nbls_destroy(self.h)
             self.h = None
 
     def __del__(self):

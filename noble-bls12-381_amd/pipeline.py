@@ -11,39 +11,52 @@ surplus queues pays a queue switch (bench.py: 22; tools/ab_queues20.sh) -- in th
 kept in flight.  Round 4: 3.0-3.1 M pairings/s with twelve batches in flight; streams that carry several batches each run phase-locked (like that many large batches one after the other), so a short
 burst of k batches is fastest on k streams (20 batches: 2.86 M on twenty streams, 2.79 M on ten).
 """
-import os
+import ctypes as C
 
-from .engine import Engine
+from .engine import Engine, NblsError, load_library
 
 
 class PairingPipeline:
+    """Round 5: a thin view of the C ABI's pool (include/nbls.h nbls_pool_*: `depth` contexts, each with its own stream and scratch, tuned for overlapping calls --
+    the two-program Miller loop at every size, the final exponentiation's middle as seven launches -- and fed round-robin); `engines` wraps the pool's contexts."""
+
     def __init__(self, device_id=0, depth=12):
         assert depth >= 1
-        self.engines = [Engine(device_id) for _ in range(depth)]
+        self.lib = load_library()
+        h = C.c_void_p()
+        r = self.lib.nbls_pool_init(device_id, depth, C.byref(h))
+        if r != 0:
+            raise NblsError('nbls_pool_init failed: %s (code %d)' % (self.lib.nbls_strerror(r).decode(), r))
+        self.h = h
         self.depth = depth
-        # With several batches in flight the SIMDs are shared by wavefronts of different calls, so what counts is the instruction count per
-        # pairing, not the length of one call's longest instruction stream: the two-program Miller loop (15 % fewer instructions) is used
-        # whatever the batch size.  A single context keeps the library's latency-oriented default (one fused program below 8192 pairs).
-        # For the same reason the final exponentiation's middle runs as seven launches rather than one chain: a chained wavefront is 427 k instructions long, and with other calls'
-        # wavefronts on the SIMDs the finer launches pack better (twenty calls on twenty streams +1.2 %, 512 calls twelve deep +0.8 %; tools/ab_chain20.sh).
-        if depth > 1:
+        self.engines = [Engine(_handle=self.lib.nbls_pool_context(self.h, i)) for i in range(depth)]
+
+    def close(self):
+        if getattr(self, 'h', None):
             for e in self.engines:
-                e.set_split_miller_min(0)
-                if os.environ.get('NBLS_PIPELINE_CHAIN') != '1':     # A/B switch (tools/ab_pipeline.sh)
-                    e.set_chain_max(0)
-        self._next = 0
+                e.close()
+            self.lib.nbls_pool_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @property
     def slot(self):
         """index (0 .. depth-1) of the context the next submit() will use: callers keep one output buffer per slot"""
-        return self._next % self.depth
+        return self.lib.nbls_pool_next_slot(self.h)
 
     def submit(self, n, d_g1, d_g2, d_out, with_final_exp=True):
         """enqueue pairing(P_i, Q_i) for n device-resident pairs on the next context's own stream and return at once; the
         caller gives every batch in flight its own output buffer (one per `slot`) and calls synchronize() before reading"""
-        e = self.engines[self._next % self.depth]
-        self._next += 1
-        e.pairing_batch_dev(n, d_g1, d_g2, d_out, with_final_exp, None)
+        r = self.lib.nbls_pool_pairing_batch_dev(self.h, n, d_g1, d_g2, int(with_final_exp), d_out, None)
+        if r != 0:
+            raise NblsError('nbls_pool_pairing_batch_dev: %s (code %d)' % (self.lib.nbls_strerror(r).decode(), r))
 
     def synchronize(self):
-        self.engines[0].device_synchronize()
+        r = self.lib.nbls_pool_synchronize(self.h)
+        if r != 0:
+            raise NblsError('nbls_pool_synchronize: code %d' % r)

@@ -22,7 +22,8 @@ def _run(args, env_extra=None):
 
 def test_gpus_flag_spawns_ranks():
     d = _run(['--gpus', '2', '--dry-launch'])
-    assert d == {'dry_launch': True, 'n_gpus': 2, 'gpus_flag': 2, 'rank_sum': 3, 'backend': 'gloo'}
+    assert {k: d[k] for k in ('dry_launch', 'n_gpus', 'gpus_flag', 'rank_sum', 'backend')} == {'dry_launch': True, 'n_gpus': 2, 'gpus_flag': 2, 'rank_sum': 3, 'backend': 'gloo'}
+    assert d['config3']['shards'] == [[0, 1 << 19], [1 << 19, 1 << 20]]
 
 
 def test_gpus_flag_three_ranks():
@@ -39,6 +40,14 @@ def test_gpus_flag_eight_ranks():
     """the driver's scaling run: `python bench.py --gpus 8` -> eight ranks, one JSON line, every rank in the all-reduce (1 + 2 + ... + 8 = 36)"""
     d = _run(['--gpus', '8', '--dry-launch'])
     assert d['n_gpus'] == 8 and d['gpus_flag'] == 8 and d['rank_sum'] == 36
+    # round 5: the legs that shard BASELINE configs[3] (2^20 independent pairings, ONE call per rank) and the one-process multi-device leg are rehearsed with the same shard
+    # arithmetic, barriers and max-reduction as the real run: eight contiguous shards of 131,072 items cover the stream exactly
+    c3 = d['config3']
+    assert c3['pairings'] == 1 << 20 and len(c3['shards']) == 8
+    assert all(hi - lo == 131072 for lo, hi in c3['shards']) and c3['shards'][0][0] == 0 and c3['shards'][-1][1] == 1 << 20
+    assert all(c3['shards'][i][1] == c3['shards'][i + 1][0] for i in range(7))
+    assert abs(c3['max_time_reduced'] - 0.008) < 1e-9                     # the slowest rank's time is what every rank divides by
+    assert 'config3' in d['legs'] and 'multi_one_process' in d['legs']
 
 
 def test_driver_launcher_command_line():
