@@ -600,7 +600,8 @@ def main():
             aff, _ = eng.sign_batch_affine(msgs, sks)
             sig = eng.compress_g2(eng.point_sum(aff, g2=True)[0])
             ns_chk = min(nv, 32)
-            for i in range(0, ns_chk, 8):
+            # a strided sample across the whole range, the last index included (round 4 looked at the first 32 only): keys and signatures must be the oracle's
+            for i in sorted(set(list(range(0, nv, max(1, nv // 12))) + [nv - 1])):
                 assert pks[i] == oracle.get_public_key(sks[i]) and eng.compress_g2(aff[192 * i:192 * i + 192]) == oracle.sign(msgs[i], sks[i])[1], 'verifyBatch input check against the oracle failed'
             assert oracle.verify_batch_mt(eng.compress_g2(eng.point_sum(aff[:192 * ns_chk], g2=True)[0]), msgs[:ns_chk], pks[:ns_chk], threads=min(th, 32)), 'verifyBatch sample does not verify on the CPU'
             assert eng.verify_batch(sig, msgs, pks) is True, 'verifyBatch parity (true case) failed'

@@ -6,6 +6,7 @@
 // cases instead; the group elements produced are the same.
 #pragma once
 #include <cassert>
+#include <vector>
 #include "config.h"
 #include "tower.h"
 
@@ -156,6 +157,32 @@ template <class F> static inline Pt<F> pt_mul_ladder(const Pt<F>& p, const SFp& 
       v0 = pt_sel<F>(b2, v1, v0);
     }
     r = pt_add(r, v0);
+  }
+  return r;
+}
+// [k]G for the FIXED base point G1.BASE (getPublicKey, index.ts:738-740; PointG1.fromPrivateKey 350-353) with no doubling at all: k = sum_w d_w 2^(WIN w) over WIN-bit
+// digits, [k]G = sum_w [d_w 2^(WIN w)]G with the multiples [d 2^(WIN w)]G, d = 1 .. 2^WIN - 1, read from a table in HBM that every item shares (buffer `buf`, entry (2^WIN - 1) w + d - 1:
+// raw x, y, z = 1; built once per context on the device by the ladder above, nbls_api.cpp g1_fixed_table).  Per window: ALL entries are loaded and a binary tree of
+// masked selects on the four scalar bits picks one (digit 0: the identity (0 : 1 : 0)), then one complete addition -- the instruction stream, the LDS accesses and the global
+// addresses are the same for every key, as in the ladder.  With 3-bit windows (the default: seven entries per window keep the LDS image small enough for seven workgroups per CU; 4-bit windows hold 35+ slots per item) 86 additions where the 2-bit-window ladder spends 256 doublings and 128 additions.
+static const int G1_FIXED_WIN = (int)env_long("NBLS_G1FIXED_WIN", 3);   // bits per window of the fixed-base table (nbls_api.cpp builds the table for the same value)
+static inline int g1_fixed_windows() { return (256 + G1_FIXED_WIN - 1) / G1_FIXED_WIN; }
+static inline int g1_fixed_entries() { return (1 << G1_FIXED_WIN) - 1; }
+static inline Pt<SFp> pt_mul_fixed_g1(const SFp& k_raw, int buf) {
+  const int WIN = G1_FIXED_WIN, NW = g1_fixed_windows(), NE = g1_fixed_entries();
+  Pt<SFp> r = pt_mat(pt_identity<SFp>());
+  const SFp one = mat(fp_one()), zero = mat(SFp());
+  for (int w = 0; w < NW; w++) {
+    const int nb = std::min(WIN, 256 - WIN * w);           // the top window may be short
+    std::vector<SFp> b(nb); for (int i = 0; i < nb; i++) b[i] = bit_flag(k_raw, WIN * w + i);
+    const int m0 = 1 << nb;
+    std::vector<SFp> X(m0), Y(m0);
+    X[0] = zero; Y[0] = one;
+    for (int d = 1; d < m0; d++) { const int o = 144 * (NE * w + d - 1); X[d] = inputw(buf, o); Y[d] = inputw(buf, o + 48); }
+    for (int lvl = 0, m = m0; lvl < nb; lvl++, m /= 2)
+      for (int j = 0; j < m / 2; j++) { X[j] = select(b[lvl], X[2 * j + 1], X[2 * j]); Y[j] = select(b[lvl], Y[2 * j + 1], Y[2 * j]); }
+    SFp z = zero; for (int i = 0; i < nb; i++) z = select(b[i], one, z);   // digit 0: the identity (0 : 1 : 0)
+    r = pt_add(r, Pt<SFp>{X[0], Y[0], z});
   }
   return r;
 }

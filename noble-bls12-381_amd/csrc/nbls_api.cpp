@@ -13,6 +13,7 @@
 #include "fp_inv.h"
 #include "pow_exec.h"
 #include "sha256.h"
+#include "curve.h"   // G1_FIXED_WIN and the table geometry of pt_mul_fixed_g1
 #include <thread>
 
 extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream);
@@ -67,10 +68,12 @@ struct nbls_ctx {
   uint8_t* nib[4] = {nullptr, nullptr, nullptr, nullptr}; int nnib[4] = {0, 0, 0, 0};   // op lists (pow_exec.h) of the exponents (p+1)/4, (p^2+7)/16, (p^2-9)/16, (p-3)/4 and their lengths in ops
   uint8_t* neg_g1 = nullptr;    // -G1 generator, affine wire bytes (verify: e(-G, S))
   uint8_t* gen_g1 = nullptr;    // G1 generator, affine wire bytes (getPublicKey)
+  uint8_t* g1_fixed = nullptr;  // fixed-base table of the generator (curve.h pt_mul_fixed_g1): raw projective multiples [d 2^(WIN w)]G, built on first use by the ladder
   // side stream for the one-element chains of verifyBatch (signature decompression: a 758-bit Fp2 exponentiation on a single
   // lane is ~4 ms of pure latency) so that they overlap the batch-wide kernels instead of serialising with them
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; uint8_t* side_scratch = nullptr;
   // large pairing batches run as two halves on two streams (nbls_pairing_batch_dev): item offset applied to every per-item buffer of a launch, second stream, events
+  bool in_halves = false;   // the running pairing call is one of two halves on two streams: their launches fill each other's tails, so the final exponentiation's middle is NOT chained (run_chain)
   size_t ioff = 0; hipStream_t half_stream = nullptr; hipEvent_t ev_half_fork = nullptr, ev_half_join = nullptr;
   size_t halves_min = env_long("NBLS_HALVES_MIN", 8192) > 0 ? (size_t)env_long("NBLS_HALVES_MIN", 8192) : (size_t)-1;   // NBLS_HALVES_MIN=0: never (profiles of kernels running alone)
   // verifyBatch as a software pipeline (round 5, verify_pipeline): events of the chunks (two each), the "xmd met non-monotonic offsets" flag lives behind the statuses
@@ -120,23 +123,24 @@ static int upload(nbls_ctx* ctx, ProgId id) {
   return upload_program(ctx, d, get_program(id), aot_enabled() ? nbls_aot_index((int)id) : -1);
 }
 // k: index of the ahead-of-time kernel that serves the program, or -1
+static void free_program(DevProgram& d) {
+  for (void* p : {(void*)d.steps, (void*)d.descs, (void*)d.consts, (void*)d.aot_steps, (void*)d.aot_descs}) if (p) hipFree(p);
+  d = DevProgram();
+}
 static int upload_program(nbls_ctx* ctx, DevProgram& d, const Program& p, const int k) {
   if (checked_mode()) { const std::string e = verify_program(p); if (!e.empty()) { fprintf(stderr, "nbls (checked): %s\n", e.c_str()); return NBLS_EINVAL; } }
-  HIPCHK(hipMalloc(&d.steps, p.steps.size() * sizeof(Step)));
-  HIPCHK(hipMalloc(&d.descs, p.descs.size() * 4 + 64));
-  HIPCHK(hipMalloc(&d.consts, p.consts.size() * 4));
-  HIPCHK(hipMemcpy(d.steps, p.steps.data(), p.steps.size() * sizeof(Step), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(d.descs, p.descs.data(), p.descs.size() * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(d.consts, p.consts.data(), p.consts.size() * 4, hipMemcpyHostToDevice));
+  // a failure half way leaves nothing behind: d.p stays unset, so a retry uploads again, and would otherwise leak what the first attempt had allocated
+  auto fail = [&]() { ctx->last_hip = (int)hipGetLastError(); free_program(d); return NBLS_EHIP; };
+  if (hipMalloc(&d.steps, p.steps.size() * sizeof(Step)) != hipSuccess || hipMalloc(&d.descs, p.descs.size() * 4 + 64) != hipSuccess || hipMalloc(&d.consts, p.consts.size() * 4) != hipSuccess ||
+      hipMemcpy(d.steps, p.steps.data(), p.steps.size() * sizeof(Step), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d.descs, p.descs.data(), p.descs.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d.consts, p.consts.data(), p.consts.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail();
   // ahead-of-time kernel (aot.h): translate the program; one whose signatures are not all in the kernel's table (build / environment mismatch) stays on the interpreter
   if (k >= 0) {
     AotProgram ap;
     const std::string why = aot_translate(p, ap);
     if (why.empty() && nbls_aot_bind(k, &ap) == 0) {
-      HIPCHK(hipMalloc(&d.aot_steps, ap.steps.size() * sizeof(AotStep)));
-      HIPCHK(hipMalloc(&d.aot_descs, ap.descs.size() * 4));
-      HIPCHK(hipMemcpy(d.aot_steps, ap.steps.data(), ap.steps.size() * sizeof(AotStep), hipMemcpyHostToDevice));
-      HIPCHK(hipMemcpy(d.aot_descs, ap.descs.data(), ap.descs.size() * 4, hipMemcpyHostToDevice));
+      if (hipMalloc(&d.aot_steps, ap.steps.size() * sizeof(AotStep)) != hipSuccess || hipMalloc(&d.aot_descs, ap.descs.size() * 4) != hipSuccess ||
+          hipMemcpy(d.aot_steps, ap.steps.data(), ap.steps.size() * sizeof(AotStep), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d.aot_descs, ap.descs.data(), ap.descs.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail();
       d.aot = k; d.aot_lds = ap.lds_bytes;
     } else fprintf(stderr, "nbls: %s: %s; running on the interpreter\n", p.name.c_str(), why.empty() ? "step signatures differ from the ahead-of-time kernel's table" : why.c_str());
   }
@@ -258,13 +262,12 @@ static int ensure_scratch(nbls_ctx* ctx, size_t n) {
 }
 // scratch of the compressed-squaring exponentiation (2.8 KB per item): only a context that runs that path -- off by default, NBLS_TUNE_EXPC_MIN -- ever allocates it
 static int ensure_expc_scratch(nbls_ctx* ctx) {
-  if (ctx->KS) return NBLS_OK;     // sized with F / T (ensure_scratch frees it when they grow)
+  if (ctx->Kcount) return NBLS_OK;     // the LAST allocation below: a set that failed half way is not taken for complete (sized with F / T; ensure_scratch frees it when they grow)
   const size_t cap = ctx->cap_F;
-  HIPCHK(hipMalloc(&ctx->KS, cap * EXPC_SQ_ELEMS * RAW));
-  HIPCHK(hipMalloc(&ctx->KD, cap * EXPC_DEC_ELEMS * RAW));
-  HIPCHK(hipMalloc(&ctx->Kflag, cap));
-  HIPCHK(hipMalloc(&ctx->Klist, cap * 4));
-  HIPCHK(hipMalloc(&ctx->Kcount, 8));
+  auto fail = [&]() { for (void* p : {(void*)ctx->KS, (void*)ctx->KD, (void*)ctx->Kflag, (void*)ctx->Klist, (void*)ctx->Kcount}) if (p) hipFree(p); ctx->KS = ctx->KD = ctx->Kflag = nullptr; ctx->Klist = ctx->Kcount = nullptr; ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; };
+  if (ctx->KS) { hipFree(ctx->KS); ctx->KS = nullptr; } if (ctx->KD) { hipFree(ctx->KD); ctx->KD = nullptr; } if (ctx->Kflag) { hipFree(ctx->Kflag); ctx->Kflag = nullptr; } if (ctx->Klist) { hipFree(ctx->Klist); ctx->Klist = nullptr; }
+  if (hipMalloc(&ctx->KS, cap * EXPC_SQ_ELEMS * RAW) != hipSuccess || hipMalloc(&ctx->KD, cap * EXPC_DEC_ELEMS * RAW) != hipSuccess || hipMalloc(&ctx->Kflag, cap) != hipSuccess ||
+      hipMalloc(&ctx->Klist, cap * 4) != hipSuccess || hipMalloc(&ctx->Kcount, 8) != hipSuccess) return fail();
   return NBLS_OK;
 }
 static int ensure_io(nbls_ctx* ctx, size_t n) {
@@ -388,7 +391,7 @@ static int final_exp_pipeline(nbls_ctx* ctx, size_t n, uint8_t* f_raw, void* d_o
   uint8_t** T = ctx->T;
   if ((r = run_inv(ctx, n, s))) return r;
   if ((r = run(ctx, P_FE_EASY, n, {B(3, f_raw, F12), B(4, ctx->NI, RAW), B(5, T[0], F12)}, s))) return r;
-  if (n < ctx->expc_min && n < ctx->chain_max && ls_variant(P_EXPX, n) == P_EXPX) {
+  if (n < ctx->expc_min && n < ctx->chain_max && !ctx->in_halves && ls_variant(P_EXPX, n) == P_EXPX) {
     // the seven launches between the easy part and the final product as one chain (math.ts:862-867): t2 = t1^x, t3 = conj(t1^2) t2, t4 = t3^x, t5 = t4^x,
     // t6' = t5^x, t6 = t6' t2^2, t7 = t6^x
     if ((r = run_chain(ctx, n, {{P_EXPX, {B(3, T[0], F12), B(5, T[1], F12)}},
@@ -462,7 +465,7 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
         hipMalloc(&ctx->ident_g1, 3 * RAW) != hipSuccess || hipMemcpy(ctx->ident_g1, id1, 3 * RAW, hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc(&ctx->ident_g2, 6 * RAW) != hipSuccess || hipMemcpy(ctx->ident_g2, id2, 6 * RAW, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   }
-  for (int i = 0; i < P_COUNT; i++) { if (i == P_G1_MUL || i == P_G2_MUL || i == P_G1_MUL_W3 || i == P_G2_MUL_W3) continue;   // the scalar-multiplication ladders are uploaded on first use
+  for (int i = 0; i < P_COUNT; i++) { if (i == P_G1_MUL || i == P_G2_MUL || i == P_G1_MUL_W3 || i == P_G2_MUL_W3 || i == P_G1_MUL_FIXED) continue;   // the scalar-multiplication ladders are uploaded on first use
     int r = upload(ctx, (ProgId)i); if (r) { int e = ctx->last_hip; (void)e; nbls_destroy(ctx); return r; } }
   *out = ctx;
   return NBLS_OK;
@@ -472,9 +475,9 @@ EXPORT void nbls_destroy(nbls_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   if (ctx->dst_dev) hipFree(ctx->dst_dev);
-  for (auto& kv : ctx->tower) { DevProgram& d = kv.second; if (d.steps) hipFree(d.steps); if (d.descs) hipFree(d.descs); if (d.consts) hipFree(d.consts); }
-  for (auto& d : ctx->prog) { if (d.steps) hipFree(d.steps); if (d.descs) hipFree(d.descs); if (d.consts) hipFree(d.consts); if (d.aot_steps) hipFree(d.aot_steps); if (d.aot_descs) hipFree(d.aot_descs); }
-  for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->gen_g1, ctx->side_scratch, ctx->L, ctx->partial, ctx->unit_lines, ctx->KS, ctx->KD, ctx->Kflag, (uint8_t*)ctx->Klist, (uint8_t*)ctx->Kcount}) if (p) hipFree(p);
+  for (auto& kv : ctx->tower) free_program(kv.second);
+  for (auto& d : ctx->prog) free_program(d);
+  for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->gen_g1, ctx->g1_fixed, ctx->side_scratch, ctx->L, ctx->partial, ctx->unit_lines, ctx->KS, ctx->KD, ctx->Kflag, (uint8_t*)ctx->Klist, (uint8_t*)ctx->Kcount}) if (p) hipFree(p);
   for (uint8_t* p : ctx->T) if (p) hipFree(p);
   for (uint8_t* p : ctx->sb) if (p) hipFree(p);
   for (uint8_t* p : ctx->nib) if (p) hipFree(p);
@@ -529,8 +532,10 @@ EXPORT int nbls_pairing_batch_dev(nbls_ctx* ctx, size_t n, const void* d_g1, con
                               hipEventCreateWithFlags(&ctx->ev_half_join, hipEventDisableTiming) != hipSuccess)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
     const size_t h = (n / 2 + 63) & ~(size_t)63;
     HIPCHK(hipEventRecord(ctx->ev_half_fork, s)); HIPCHK(hipStreamWaitEvent(ctx->half_stream, ctx->ev_half_fork, 0));
+    ctx->in_halves = true;     // (round 4 compared each HALF with chain_max: calls of 8192..16383 pairs ran their halves chained, the configuration measured as slower)
     r = pairing_core(ctx, h, d_g1, d_g2, with_final_exp, d_out, s, true);
     if (!r) { ctx->ioff = h; r = pairing_core(ctx, n - h, d_g1, d_g2, with_final_exp, d_out, ctx->half_stream, true); ctx->ioff = 0; }
+    ctx->in_halves = false;
     HIPCHK(hipEventRecord(ctx->ev_half_join, ctx->half_stream)); HIPCHK(hipStreamWaitEvent(s, ctx->ev_half_join, 0));
     return r;
   }
@@ -540,9 +545,9 @@ static int pairing_core(nbls_ctx* ctx, size_t n, const void* d_g1, const void* d
   int r;
   // One program or two?  LINES + ACC execute ~12 % fewer instructions per pairing (no idle lanes in the Fp12 steps, 20 instead of 37 lane-ops
   // per bit in the point chain) but are two dependent chains of 307 + 173 steps where the fused program has 349: a launch that is only a few
-  // wavefronts per SIMD deep takes the time of its longest instruction stream, so batches below 49,152 pairs keep the fused program (measured:
-  // 4096 pairs 1.22 ms against 1.39 ms, 32,768 10.3 against 10.4 ms, 65,536 12.2 against 11.5 ms, 131,072 23.6 against 21.9 ms); with several
-  // calls in flight the instruction count is what matters (pipeline.py sets the threshold to 0).  NBLS_FUSED_MILLER = 1 / 0 forces one or the other.
+  // wavefronts per SIMD deep takes the time of its longest instruction stream: round 3 (the interpreter) kept the fused program below 49,152 pairs; with the
+  // ahead-of-time kernels the two programs win from split_min = 4096 pairs on (SPLIT_MILLER_MIN above, tools/sweep_modes.sh), and with several calls in flight
+  // the instruction count is what matters at every size (nbls_pool_init sets the threshold to 0).  NBLS_FUSED_MILLER = 1 / 0 forces one or the other.
   static const int fused_mode = (int)env_long("NBLS_FUSED_MILLER", -1);
   const bool fused = fused_mode >= 0 ? fused_mode != 0 : (!two_programs && n < ctx->split_min);
   if (fused) {
@@ -1214,15 +1219,51 @@ EXPORT int nbls_g1_clear_cofactor_batch(nbls_ctx* ctx, size_t n, const uint8_t* 
 EXPORT int nbls_g2_clear_cofactor_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, uint8_t* out192, int8_t* status) { return clear_host(ctx, true, n, g2_aff, out192, status); }
 
 // [k_i]P_i for per-item 256-bit big-endian scalars (pt_stride 0 = one point for all items): ladder -> inversion -> affine
-static int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, size_t pt_stride, const void* d_scalars, void* d_out, void* d_status, hipStream_t s) {
+static int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, size_t pt_stride, const void* d_scalars, void* d_out, void* d_status, hipStream_t s, bool allow_fixed = true);
+// the fixed-base table of G1.BASE (curve.h pt_mul_fixed_g1): for every window w and digit d = 1 .. 2^WIN - 1 the point [d 2^(WIN w)]G as a raw projective point (x, y, 1), computed
+// ONCE per context by the variable-base ladder itself (602 scalar multiplications with WIN = 3: a few hundred microseconds) -- no table of constants enters the source
+static int ensure_g1_fixed(nbls_ctx* ctx, hipStream_t s) {
+  if (ctx->g1_fixed) return NBLS_OK;
+  const int WIN = G1_FIXED_WIN, NW = g1_fixed_windows(), NE = g1_fixed_entries();
+  const size_t m = (size_t)NW * NE;
+  std::vector<uint8_t> ks(m * 32, 0);
+  for (int w = 0; w < NW; w++)
+    for (int d = 1; d <= NE; d++) {
+      uint8_t* k = &ks[((size_t)w * NE + d - 1) * 32];
+      const int sh = WIN * w;                                         // d << sh as a 256-bit big-endian integer; digits that would pass bit 255 (the short top window) are never read: [1]G stands in
+      if (sh + 32 - __builtin_clz((unsigned)d) > 256) { k[31] = 1; continue; }
+      for (int bit = 0; bit < WIN; bit++) if ((d >> bit) & 1) { const int pos = sh + bit; k[31 - pos / 8] |= (uint8_t)(1u << (pos % 8)); }
+    }
+  uint8_t *dk = nullptr, *aff = nullptr, *st = nullptr, *tab = nullptr;
+  auto fail = [&](int code) { for (uint8_t* p : {dk, aff, st, tab}) if (p) hipFree(p); return code; };
+  if (hipMalloc(&dk, m * 32) != hipSuccess || hipMalloc(&aff, m * 96) != hipSuccess || hipMalloc(&st, m) != hipSuccess || hipMalloc(&tab, m * 3 * RAW) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return fail(NBLS_EHIP); }
+  if (hipMemcpyAsync(dk, ks.data(), m * 32, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return fail(NBLS_EHIP); }
+  int r = dev_point_mul(ctx, false, m, ctx->gen_g1, 0, dk, aff, st, s, false);
+  if (!r) r = run(ctx, P_G1_TO_PROJ, m, {B(0, aff, 96), B(3, tab, 3 * RAW)}, s);
+  if (!r && hipStreamSynchronize(s) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); r = NBLS_EHIP; }
+  if (r) return fail(r);
+  hipFree(dk); hipFree(aff); hipFree(st);
+  ctx->g1_fixed = tab;
+  return NBLS_OK;
+}
+static int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, size_t pt_stride, const void* d_scalars, void* d_out, void* d_status, hipStream_t s, bool allow_fixed) {
   const size_t a = g2 ? 192 : 96, p = g2 ? 6 * RAW : 3 * RAW;
   uint8_t *Pj, *N, *NI; int r;
+  // getPublicKey (the base point is G1.BASE for every item): no doublings, the multiples of the generator come from a table (round 5: 86 additions instead of 256 doublings + 128
+  // additions; NBLS_G1_FIXED=0 keeps the ladder)
+  static const bool fixed_on = env_long("NBLS_G1_FIXED", 1) != 0;
+  const bool fixed = allow_fixed && fixed_on && !g2 && d_pts == ctx->gen_g1 && pt_stride == 0;
+  if (fixed && (r = ensure_g1_fixed(ctx, s))) return r;
   if ((r = need(ctx, 0, n * p, &Pj)) || (r = need(ctx, 4, n * RAW, &N)) || (r = need(ctx, 5, n * RAW, &NI))) return r;
+  if (fixed) {
+    if ((r = run(ctx, P_G1_MUL_FIXED, n, {B(2, d_scalars, 32), B(5, ctx->g1_fixed, 0), B(3, Pj, p), B(4, N, RAW)}, s))) return r;
+  } else {
   // up to one wavefront per SIMD (16 / 8 items per wavefront) the length of one wavefront's instruction stream counts: 3-bit windows (85 additions); above, wavefronts per CU
   // count: 2-bit windows, whose table of four leaves room for seven workgroups per CU instead of three / four (tools/mul_time.py)
   static const size_t w3_waves = (size_t)env_long("NBLS_MUL_W3_WAVES", 1024);
   const bool w3 = (n + (g2 ? 7 : 15)) / (g2 ? 8 : 16) <= w3_waves;
   if ((r = run(ctx, g2 ? (w3 ? P_G2_MUL_W3 : P_G2_MUL) : (w3 ? P_G1_MUL_W3 : P_G1_MUL), n, {B(g2 ? 1 : 0, d_pts, pt_stride), B(2, d_scalars, 32), B(3, Pj, p), B(4, N, RAW)}, s))) return r;
+  }
   if ((r = run_inv_buf(ctx, n, N, NI, s))) return r;
   return run(ctx, g2 ? P_G2_TO_AFFINE : P_G1_TO_AFFINE, n, {B(3, Pj, p), B(4, NI, RAW), B(2, d_out, a), B(7, d_status, 1)}, s);
 }
@@ -1734,6 +1775,8 @@ static int partial_buffer(nbls_ctx* ctx, void* d_dst, uint8_t** dst) {
   if (d_dst) {
     hipPointerAttribute_t at; memset(&at, 0, sizeof at);
     if (hipPointerGetAttributes(&at, d_dst) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != ctx->device) { (void)hipGetLastError(); return NBLS_EINVAL; }
+    hipDeviceptr_t base = nullptr; size_t size = 0;      // ... and 576 bytes must remain behind it inside its allocation
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)d_dst) != hipSuccess || (size_t)((uint8_t*)d_dst - (uint8_t*)base) + 576 > size) { (void)hipGetLastError(); return NBLS_EINVAL; }
     *dst = (uint8_t*)d_dst; return NBLS_OK;
   }
   if (!ctx->partial) HIPCHK(hipMalloc(&ctx->partial, 576));

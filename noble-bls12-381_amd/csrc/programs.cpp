@@ -565,6 +565,14 @@ static Program build(ProgId id) {
       B.sched_window = w3 ? 300 : env_int("NBLS_G1MUL_WINDOW", 200);   // scalar bits are extracted just in time instead of all 256 up front (they would pin 256 LDS slots)
       return B.compile(w3 ? "g1_mul_w3" : "g1_mul", G1MUL_W);
     }
+    case P_G1_MUL_FIXED: {
+      SFp k = input_raw(2, 0, 32);
+      Pt<SFp> r = pt_mul_fixed_g1(k, 5);
+      outputw(r.x, 3, 0); outputw(r.y, 3, 48); outputw(r.z, 3, 96);
+      outputw(r.z, 4, 0);
+      B.sched_window = env_int("NBLS_G1FIXED_WINDOW", 25);   // the table loads and bit extractions of a window are scheduled just ahead of its selects (they would otherwise pin 30 slots per window from the start)
+      return B.compile("g1_mul_fixed", G1MUL_W);
+    }
     case P_G2_MUL: case P_G2_MUL_W3: {
       SFp2 x = input_fp2(1, 0), y = input_fp2(1, 96);
       SFp k = input_raw(2, 0, 32);

@@ -85,3 +85,9 @@ def test_slot_placement_table_is_current_and_pays(sim):
         o = (C.c_ulong * 4)()
         sim.nbls_sim_layout_info(vmsim_py.P[name], o)
         assert lo <= (o[1] - o[3]) / o[1] <= hi, (name, list(o))
+
+
+def test_fixed_base_keys_translated(sim, oracle, testdata):
+    """getPublicKey's fixed-base program (round 5) through its ahead-of-time translation: a table shared by every item (buffer stride 0) and K_SEL / K_FLAG / K_BIT steps"""
+    assert sim.nbls_sim_has_aot(vmsim_py.P['G1_MUL_FIXED']) == 1
+    T.test_fixed_base_public_keys(sim, oracle, testdata)

@@ -229,6 +229,27 @@ def test_scalar_mul_programs(sim, oracle, golden, w3):
     assert st[0] == 1
 
 
+def test_fixed_base_public_keys(sim, oracle, testdata):
+    """getPublicKey without doublings (round 5, csrc/curve.h pt_mul_fixed_g1: [k]G1.BASE as a sum of table entries [d 2^(3 w)]G, all entries of a window read and one
+    picked by masked selects) against the oracle's scalar multiplication and the reference's own keys (the private keys of test/index.test.ts's sign vectors):
+    structured scalars -- single digits in the lowest, a middle and the short top window, all-ones, r - 1, r + 1, 2^255, 2^256 - 1 -- and random ones"""
+    import random
+    r = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    rnd = random.Random(4711)
+    ks = [1, 2, 7, 8, 1 << 3, 5 << 129, 1 << 255, (1 << 255) | 3, (1 << 256) - 1, r - 1, r + 1, int('49' * 32, 16)] + [rnd.randrange(1, r) for _ in range(4)]
+    ks += [int(p, 16) for p, _, _ in testdata['sign_vectors'][:4]]
+    tab = vmsim_py.g1_fixed_table(sim, oracle)
+    g1 = oracle.g1_generator()
+    out, st = vmsim_py.point_mul_fixed(sim, tab, b''.join(k.to_bytes(32, 'big') for k in ks))
+    for i, k in enumerate(ks):
+        assert st[i] == 0 and out[96 * i:96 * i + 96] == oracle.g1_mul(g1, k % r)[1], (i, hex(k))
+    for i, (p, _, _) in enumerate(testdata['sign_vectors'][:4]):
+        pk = oracle.get_public_key(bytes.fromhex(p.rjust(64, '0')))      # 48 bytes: x with the flag bits in the top three
+        assert out[96 * (16 + i) + 1:96 * (16 + i) + 48] == pk[1:] and (out[96 * (16 + i)] & 0x1f) == (pk[0] & 0x1f)
+    out, st = vmsim_py.point_mul_fixed(sim, tab, r.to_bytes(32, 'big') + (0).to_bytes(32, 'big'))      # k = r and k = 0: the zero point (status 1; the host wrapper reports status 5)
+    assert st[0] == 1 and st[1] == 1
+
+
 def test_msm_pipeline(sim, oracle):
     """the bucket-method multi-scalar multiplication (dev_msm in csrc/nbls_api.cpp: sort by window digit, segmented sums,
     bit-sliced bucket weighting, Horner over the windows) with its step programs on the simulator, against the oracle's
@@ -386,7 +407,7 @@ def test_split_miller(sim, oracle, golden):
     for i in range(g):
         k = min(4, n - 4 * i)
         assert out.raw[576 * i:576 * i + 576] == oracle.miller_product(g1[384 * i:384 * i + 96 * k], g2[768 * i:768 * i + 192 * k], final_exp=False), i
-    # eight tables per item (round 4: products of 32,768 pairs and more), the last group filled up the same way
+    # eight tables per item (round 4: Miller products of 131,072 pairs and more), the last group filled up the same way
     g8 = (n + 7) // 8
     L8 = C.create_string_buffer(L.raw[:LINE_BYTES * n] + unit * (8 * g8 - n), LINE_BYTES * 8 * g8)
     F8 = C.create_string_buffer(vmsim_py.F12 * g8)

@@ -17,7 +17,7 @@ def raw_elem(v):
 
 
 PROGS = ['MILLER_BYTES', 'MILLER_RAW', 'MILLER_FE', 'NORM_RAW', 'NORM_BYTES', 'FE_EASY', 'EXPX', 'FE_MID1', 'FE_MID2', 'FE_FINAL', 'MUL2', 'RAW_TO_BYTES', 'G1_VALIDATE', 'G2_VALIDATE', 'G1_DEC_A', 'G1_DEC_B', 'G2_DEC_A', 'G2_DEC_B', 'H2C_A', 'H2C_B',
-         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'G1_COMPRESS', 'G2_COMPRESS', 'H2C1_A', 'ENC1_A', 'H2C1_B', 'ENC1_B', 'G1_CLEAR', 'ENC2_A', 'ENC2_B', 'G1_MUL', 'G2_MUL', 'G1_ADD_AB', 'G2_ADD_AB', 'G1_HORNER', 'G2_HORNER', 'G1_SHIFTADD', 'G2_SHIFTADD', 'G1_MSM_PREP', 'G2_MSM_PREP', 'LINES_PQ', 'LINES_Q', 'LINES_BYTES', 'LINES_FROM_BYTES', 'ACC_BYTES', 'ACC_RAW', 'ACC_FE', 'ACC2_RAW', 'ACC_Q', 'G2_DEC_A192', 'G2_DEC_B192', 'G2_DEC_B_HEX', 'G1_FROM_RAW', 'G2_FROM_RAW', 'G2_SWAP', 'H2C_C1', 'H2C_C2', 'ACC4_RAW', 'MILLER_BYTES_LS', 'MILLER_RAW_LS', 'MILLER_FE_LS', 'EXPX_LS', 'EXPC_SQ', 'EXPC_DEC_A', 'EXPC_DEC_B', 'ACC8_RAW', 'H2C_C0', 'H2C_B1', 'H2C_B2', 'G1_MUL_W3', 'G2_MUL_W3', 'MUL2S']
+         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'G1_COMPRESS', 'G2_COMPRESS', 'H2C1_A', 'ENC1_A', 'H2C1_B', 'ENC1_B', 'G1_CLEAR', 'ENC2_A', 'ENC2_B', 'G1_MUL', 'G2_MUL', 'G1_ADD_AB', 'G2_ADD_AB', 'G1_HORNER', 'G2_HORNER', 'G1_SHIFTADD', 'G2_SHIFTADD', 'G1_MSM_PREP', 'G2_MSM_PREP', 'LINES_PQ', 'LINES_Q', 'LINES_BYTES', 'LINES_FROM_BYTES', 'ACC_BYTES', 'ACC_RAW', 'ACC_FE', 'ACC2_RAW', 'ACC_Q', 'G2_DEC_A192', 'G2_DEC_B192', 'G2_DEC_B_HEX', 'G1_FROM_RAW', 'G2_FROM_RAW', 'G2_SWAP', 'H2C_C1', 'H2C_C2', 'ACC4_RAW', 'MILLER_BYTES_LS', 'MILLER_RAW_LS', 'MILLER_FE_LS', 'EXPX_LS', 'EXPC_SQ', 'EXPC_DEC_A', 'EXPC_DEC_B', 'ACC8_RAW', 'H2C_C0', 'H2C_B1', 'H2C_B2', 'G1_MUL_W3', 'G2_MUL_W3', 'MUL2S', 'G1_MUL_FIXED']
 P = {n: i for i, n in enumerate(PROGS)}
 
 
@@ -164,6 +164,34 @@ def point_mul(lib, pts, scalars32, g2=False, w3=False):
     run(lib, pre + ('_MUL_W3' if w3 else '_MUL'), n, {(1 if g2 else 0): (buf(pts), sz), 2: (buf(scalars32), 32), 3: (Pj, psz), 4: (N, RAW)})
     lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
     run(lib, pre + '_TO_AFFINE', n, {3: (Pj, psz), 4: (NI, RAW), 2: (out, sz), 7: (st, 1)})
+    return out.raw, st.raw
+
+
+G1_FIXED_WIN = 3     # csrc/curve.h G1_FIXED_WIN (NBLS_G1FIXED_WIN)
+
+
+def g1_fixed_table(lib, oracle):
+    """ensure_g1_fixed() of csrc/nbls_api.cpp with the oracle in place of the device ladder: raw projective multiples [d 2^(WIN w)]G1, d = 1 .. 2^WIN - 1, per window"""
+    win = G1_FIXED_WIN; nw = (256 + win - 1) // win; ne = (1 << win) - 1
+    g = oracle.g1_generator()
+    aff = b''
+    for w in range(nw):
+        for d in range(1, ne + 1):
+            k = d << (win * w)
+            aff += oracle.g1_mul(g, k if k < (1 << 256) else 1)[1]
+    m = nw * ne
+    tab = buf(3 * RAW * m)
+    run(lib, 'G1_TO_PROJ', m, {0: (buf(aff), 96), 3: (tab, 3 * RAW)})
+    return tab
+
+
+def point_mul_fixed(lib, table, scalars32):
+    """dev_point_mul() for the fixed base G1.BASE (getPublicKey): table sums (no doublings) -> inversion -> affine"""
+    n = len(scalars32) // 32
+    Pj, N, NI, out, st = buf(3 * RAW * n), buf(RAW * n), buf(RAW * n), buf(96 * n), buf(n)
+    run(lib, 'G1_MUL_FIXED', n, {2: (buf(scalars32), 32), 5: (table, 0), 3: (Pj, 3 * RAW), 4: (N, RAW)})
+    lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
+    run(lib, 'G1_TO_AFFINE', n, {3: (Pj, 3 * RAW), 4: (NI, RAW), 2: (out, 96), 7: (st, 1)})
     return out.raw, st.raw
 
 
