@@ -281,6 +281,28 @@ static inline Pt<SFp> clear_cofactor_g1(const Pt<SFp>& P) { return pt_add(pt_mul
 
 static inline Pt<SFp2> psi_proj(const Pt<SFp2>& p) { return pt_mat<SFp2>({mul(conj(p.x), fp2_const(NBLS_PSI_X)), mul(conj(p.y), fp2_const(NBLS_PSI_Y)), conj(p.z)}); }
 static inline Pt<SFp2> psi2_proj(const Pt<SFp2>& p) { return pt_mat<SFp2>({mul_fp(p.x, fp_const(NBLS_PSI2_C1)), -p.y, p.z}); }
+// [k]Q for Q IN THE SUBGROUP G2 and a per-item scalar, with the scalar split along the endomorphism psi (round 5; sign, index.ts:744-752: Q = H(m) lies in G2 by construction):
+// psi acts on G2 as [z] = [-|z|] (the eigenvalue the reference's own subgroup check uses, index.ts:640-657), so with k = a0 + a1 |z| + a2 |z|^2 + a3 |z|^3 (four digits of at most
+// 65 bits, msm_kernels.hip msm_decompose_kernel)   [k]Q = [a0]Q - psi([a1]Q) + psi^2([a2]Q) - psi^3([a3]Q).
+// One accumulator, 2-bit windows over the FOUR digits at once: per window two doublings and four additions of psi^i(+-T[d_i]) with T = {0, Q, 2Q, 3Q} -- 33 windows, 66 doublings and
+// 132 additions where the plain ladder spends 256 and 128.  Constant time as the ladder: every table entry is read, selects are masked, psi is applied to whatever was selected.
+static inline Pt<SFp2> pt_mul_gls_g2(const Pt<SFp2>& q, const SFp a_raw[4]) {
+  Pt<SFp2> T[4];
+  T[0] = pt_mat(pt_identity<SFp2>()); T[1] = pt_mat(q); T[2] = pt_dbl(q); T[3] = pt_add(T[2], T[1]);
+  Pt<SFp2> r = T[0];
+  for (int w = 32; w >= 0; w--) {
+    if (w != 32) r = pt_dbl_n(r, 2);
+    for (int i = 0; i < 4; i++) {
+      const SFp b0 = bit_flag(a_raw[i], 2 * w), b1 = bit_flag(a_raw[i], 2 * w + 1);
+      Pt<SFp2> v = pt_sel<SFp2>(b1, pt_sel<SFp2>(b0, T[3], T[2]), pt_sel<SFp2>(b0, T[1], T[0]));
+      if (i == 1) v = pt_neg(psi_proj(v));
+      else if (i == 2) v = psi2_proj(v);
+      else if (i == 3) v = pt_neg(psi_proj(psi2_proj(v)));
+      r = pt_add(r, v);
+    }
+  }
+  return r;
+}
 // PointG2.clearCofactor (index.ts:659-672)
 // The same in two halves around the second multiplication by x, chained through HBM so that neither program keeps more than the ladder's base,
 // its running point and their temporaries live (26 slots instead of 38: twelve wavefronts per CU instead of six -- the one-program form ran at

@@ -41,9 +41,9 @@ __device__ inline u64 div_step(u64* limbs, int nl) {   // limbs (little-endian u
     for (int b = 63; b >= 0; b--) {
       const u64 carry = rem >> 63;
       rem = (rem << 1) | ((v >> b) & 1);
-      const bool ge = carry || rem >= Z;
-      if (ge) rem -= Z;
-      q = (q << 1) | (u64)ge;
+      const u64 ge = (u64)(carry | (u64)(rem >= Z));      // branch-free: sign's ladder feeds SECRET scalars through this division (round 5)
+      rem -= Z & (0 - ge);
+      q = (q << 1) | ge;
     }
     limbs[i] = q;
   }

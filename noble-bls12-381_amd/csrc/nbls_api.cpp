@@ -465,7 +465,7 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
         hipMalloc(&ctx->ident_g1, 3 * RAW) != hipSuccess || hipMemcpy(ctx->ident_g1, id1, 3 * RAW, hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc(&ctx->ident_g2, 6 * RAW) != hipSuccess || hipMemcpy(ctx->ident_g2, id2, 6 * RAW, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   }
-  for (int i = 0; i < P_COUNT; i++) { if (i == P_G1_MUL || i == P_G2_MUL || i == P_G1_MUL_W3 || i == P_G2_MUL_W3 || i == P_G1_MUL_FIXED) continue;   // the scalar-multiplication ladders are uploaded on first use
+  for (int i = 0; i < P_COUNT; i++) { if (i == P_G1_MUL || i == P_G2_MUL || i == P_G1_MUL_W3 || i == P_G2_MUL_W3 || i == P_G1_MUL_FIXED || i == P_G2_MUL_GLS) continue;   // the scalar-multiplication ladders are uploaded on first use
     int r = upload(ctx, (ProgId)i); if (r) { int e = ctx->last_hip; (void)e; nbls_destroy(ctx); return r; } }
   *out = ctx;
   return NBLS_OK;
@@ -1219,7 +1219,7 @@ EXPORT int nbls_g1_clear_cofactor_batch(nbls_ctx* ctx, size_t n, const uint8_t* 
 EXPORT int nbls_g2_clear_cofactor_batch(nbls_ctx* ctx, size_t n, const uint8_t* g2_aff, uint8_t* out192, int8_t* status) { return clear_host(ctx, true, n, g2_aff, out192, status); }
 
 // [k_i]P_i for per-item 256-bit big-endian scalars (pt_stride 0 = one point for all items): ladder -> inversion -> affine
-static int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, size_t pt_stride, const void* d_scalars, void* d_out, void* d_status, hipStream_t s, bool allow_fixed = true);
+static int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, size_t pt_stride, const void* d_scalars, void* d_out, void* d_status, hipStream_t s, bool allow_fixed = true, bool in_subgroup = false);
 // the fixed-base table of G1.BASE (curve.h pt_mul_fixed_g1): for every window w and digit d = 1 .. 2^WIN - 1 the point [d 2^(WIN w)]G as a raw projective point (x, y, 1), computed
 // ONCE per context by the variable-base ladder itself (602 scalar multiplications with WIN = 3: a few hundred microseconds) -- no table of constants enters the source
 static int ensure_g1_fixed(nbls_ctx* ctx, hipStream_t s) {
@@ -1246,7 +1246,7 @@ static int ensure_g1_fixed(nbls_ctx* ctx, hipStream_t s) {
   ctx->g1_fixed = tab;
   return NBLS_OK;
 }
-static int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, size_t pt_stride, const void* d_scalars, void* d_out, void* d_status, hipStream_t s, bool allow_fixed) {
+static int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, size_t pt_stride, const void* d_scalars, void* d_out, void* d_status, hipStream_t s, bool allow_fixed, bool in_subgroup) {
   const size_t a = g2 ? 192 : 96, p = g2 ? 6 * RAW : 3 * RAW;
   uint8_t *Pj, *N, *NI; int r;
   // getPublicKey (the base point is G1.BASE for every item): no doublings, the multiples of the generator come from a table (round 5: 86 additions instead of 256 doublings + 128
@@ -1255,6 +1255,15 @@ static int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, si
   const bool fixed = allow_fixed && fixed_on && !g2 && d_pts == ctx->gen_g1 && pt_stride == 0;
   if (fixed && (r = ensure_g1_fixed(ctx, s))) return r;
   if ((r = need(ctx, 0, n * p, &Pj)) || (r = need(ctx, 4, n * RAW, &N)) || (r = need(ctx, 5, n * RAW, &NI))) return r;
+  // sign (the base points are hash outputs: in G2 by construction): the scalar split along psi, four 65-bit digits on one accumulator (codec.h pt_mul_gls_g2: 66 doublings + 132 additions
+  // instead of 256 + 128; NBLS_G2_GLS=0 keeps the plain ladder).  The digits are made on the device by the MSM's decomposition kernel (branch-free long division by |z|).
+  static const bool gls_on = env_long("NBLS_G2_GLS", 1) != 0;
+  if (g2 && in_subgroup && gls_on) {
+    uint8_t* dig;
+    if ((r = need(ctx, 1, n * 128, &dig))) return r;
+    if (nbls_msm_decompose_launch((unsigned)n, 4, d_scalars, dig, s)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+    if ((r = run(ctx, P_G2_MUL_GLS, n, {B(1, d_pts, pt_stride), B(2, dig, 128), B(3, Pj, p), B(4, N, RAW)}, s))) return r;
+  } else
   if (fixed) {
     if ((r = run(ctx, P_G1_MUL_FIXED, n, {B(2, d_scalars, 32), B(5, ctx->g1_fixed, 0), B(3, Pj, p), B(4, N, RAW)}, s))) return r;
   } else {
@@ -1415,7 +1424,7 @@ EXPORT int nbls_sign_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const u
   uint8_t* d; int r = dev_expand(ctx, n, msgs, offsets, dst, dst_len, &d, s); if (r) return r;
   HIPCHK(hipMemcpyAsync(dk, keys32, n * 32, hipMemcpyHostToDevice, s));
   if ((r = dev_hash_to_g2(ctx, n, d, h, s))) return r;
-  if ((r = dev_point_mul(ctx, true, n, h, 192, dk, o, st, s))) return r;
+  if ((r = dev_point_mul(ctx, true, n, h, 192, dk, o, st, s, true, true))) return r;      // H(m) is in G2: the ladder may split the key along psi
   std::vector<int8_t> tmp(n);
   HIPCHK(hipMemcpyAsync(out192, o, n * 192, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(tmp.data(), st, n, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
   for (size_t i = 0; i < n; i++) if (scalar_is_zero_mod_r(keys32 + 32 * i)) tmp[i] = 5;

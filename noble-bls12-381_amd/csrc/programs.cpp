@@ -565,6 +565,15 @@ static Program build(ProgId id) {
       B.sched_window = w3 ? 300 : env_int("NBLS_G1MUL_WINDOW", 200);   // scalar bits are extracted just in time instead of all 256 up front (they would pin 256 LDS slots)
       return B.compile(w3 ? "g1_mul_w3" : "g1_mul", G1MUL_W);
     }
+    case P_G2_MUL_GLS: {
+      SFp2 x = input_fp2(1, 0), y = input_fp2(1, 96);
+      SFp a[4]; for (int i = 0; i < 4; i++) a[i] = input_raw(2, 32 * i, 32);
+      Pt<SFp2> r = pt_mul_gls_g2(pt_affine(x, y), a);
+      outputw(r.x.c0, 3, 0); outputw(r.x.c1, 3, 48); outputw(r.y.c0, 3, 96); outputw(r.y.c1, 3, 144); outputw(r.z.c0, 3, 192); outputw(r.z.c1, 3, 240);
+      outputw(sqr(r.z.c0) + sqr(r.z.c1), 4, 0);
+      B.sched_window = env_int("NBLS_G2GLS_WINDOW", 300);
+      return B.compile("g2_mul_gls", G2MUL_W);
+    }
     case P_G1_MUL_FIXED: {
       SFp k = input_raw(2, 0, 32);
       Pt<SFp> r = pt_mul_fixed_g1(k, 5);

@@ -91,3 +91,9 @@ def test_fixed_base_keys_translated(sim, oracle, testdata):
     """getPublicKey's fixed-base program (round 5) through its ahead-of-time translation: a table shared by every item (buffer stride 0) and K_SEL / K_FLAG / K_BIT steps"""
     assert sim.nbls_sim_has_aot(vmsim_py.P['G1_MUL_FIXED']) == 1
     T.test_fixed_base_public_keys(sim, oracle, testdata)
+
+
+def test_gls_ladder_translated(sim, oracle):
+    """sign's psi-split ladder (round 5) through its ahead-of-time translation"""
+    assert sim.nbls_sim_has_aot(vmsim_py.P['G2_MUL_GLS']) == 1
+    T.test_gls_ladder_for_subgroup_points(sim, oracle)

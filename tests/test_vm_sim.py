@@ -250,6 +250,24 @@ def test_fixed_base_public_keys(sim, oracle, testdata):
     assert st[0] == 1 and st[1] == 1
 
 
+def test_gls_ladder_for_subgroup_points(sim, oracle):
+    """sign's ladder with the key split along psi (round 5, csrc/codec.h pt_mul_gls_g2: k = a0 + a1 |z| + a2 |z|^2 + a3 |z|^3, one accumulator over the four digits) against the
+    oracle's scalar multiplication on points of G2: structured keys (1, |z|, |z|^2, |z|^3 and their neighbours -- a digit rolling over --, r - 1, r + 1, 2^256 - 1: a3 of 65 bits) and random ones"""
+    import random
+    r = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    Z = 0xd201000000010000
+    rnd = random.Random(777)
+    ks = [1, 2, 3, Z - 1, Z, Z + 1, Z * Z - 1, Z * Z, Z ** 3, Z ** 3 - 1, r - 1, r + 1, (1 << 256) - 1, (1 << 255) + 12345] + [rnd.randrange(1, r) for _ in range(2)]
+    g2 = oracle.g2_generator()
+    q = oracle.g2_mul(g2, 0x1234567890abcdef1234567)[1]
+    pts = b''.join([g2, q] * (len(ks) // 2))
+    out, st = vmsim_py.point_mul_gls(sim, pts, b''.join(k.to_bytes(32, 'big') for k in ks))
+    for i, k in enumerate(ks):
+        assert st[i] == 0 and out[192 * i:192 * i + 192] == oracle.g2_mul(pts[192 * i:192 * i + 192], k % r)[1], (i, hex(k))
+    out, st = vmsim_py.point_mul_gls(sim, g2, r.to_bytes(32, 'big'))       # k = r: the zero point
+    assert st[0] == 1
+
+
 def test_msm_pipeline(sim, oracle):
     """the bucket-method multi-scalar multiplication (dev_msm in csrc/nbls_api.cpp: sort by window digit, segmented sums,
     bit-sliced bucket weighting, Horner over the windows) with its step programs on the simulator, against the oracle's

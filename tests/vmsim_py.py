@@ -17,7 +17,7 @@ def raw_elem(v):
 
 
 PROGS = ['MILLER_BYTES', 'MILLER_RAW', 'MILLER_FE', 'NORM_RAW', 'NORM_BYTES', 'FE_EASY', 'EXPX', 'FE_MID1', 'FE_MID2', 'FE_FINAL', 'MUL2', 'RAW_TO_BYTES', 'G1_VALIDATE', 'G2_VALIDATE', 'G1_DEC_A', 'G1_DEC_B', 'G2_DEC_A', 'G2_DEC_B', 'H2C_A', 'H2C_B',
-         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'G1_COMPRESS', 'G2_COMPRESS', 'H2C1_A', 'ENC1_A', 'H2C1_B', 'ENC1_B', 'G1_CLEAR', 'ENC2_A', 'ENC2_B', 'G1_MUL', 'G2_MUL', 'G1_ADD_AB', 'G2_ADD_AB', 'G1_HORNER', 'G2_HORNER', 'G1_SHIFTADD', 'G2_SHIFTADD', 'G1_MSM_PREP', 'G2_MSM_PREP', 'LINES_PQ', 'LINES_Q', 'LINES_BYTES', 'LINES_FROM_BYTES', 'ACC_BYTES', 'ACC_RAW', 'ACC_FE', 'ACC2_RAW', 'ACC_Q', 'G2_DEC_A192', 'G2_DEC_B192', 'G2_DEC_B_HEX', 'G1_FROM_RAW', 'G2_FROM_RAW', 'G2_SWAP', 'H2C_C1', 'H2C_C2', 'ACC4_RAW', 'MILLER_BYTES_LS', 'MILLER_RAW_LS', 'MILLER_FE_LS', 'EXPX_LS', 'EXPC_SQ', 'EXPC_DEC_A', 'EXPC_DEC_B', 'ACC8_RAW', 'H2C_C0', 'H2C_B1', 'H2C_B2', 'G1_MUL_W3', 'G2_MUL_W3', 'MUL2S', 'G1_MUL_FIXED']
+         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'G1_COMPRESS', 'G2_COMPRESS', 'H2C1_A', 'ENC1_A', 'H2C1_B', 'ENC1_B', 'G1_CLEAR', 'ENC2_A', 'ENC2_B', 'G1_MUL', 'G2_MUL', 'G1_ADD_AB', 'G2_ADD_AB', 'G1_HORNER', 'G2_HORNER', 'G1_SHIFTADD', 'G2_SHIFTADD', 'G1_MSM_PREP', 'G2_MSM_PREP', 'LINES_PQ', 'LINES_Q', 'LINES_BYTES', 'LINES_FROM_BYTES', 'ACC_BYTES', 'ACC_RAW', 'ACC_FE', 'ACC2_RAW', 'ACC_Q', 'G2_DEC_A192', 'G2_DEC_B192', 'G2_DEC_B_HEX', 'G1_FROM_RAW', 'G2_FROM_RAW', 'G2_SWAP', 'H2C_C1', 'H2C_C2', 'ACC4_RAW', 'MILLER_BYTES_LS', 'MILLER_RAW_LS', 'MILLER_FE_LS', 'EXPX_LS', 'EXPC_SQ', 'EXPC_DEC_A', 'EXPC_DEC_B', 'ACC8_RAW', 'H2C_C0', 'H2C_B1', 'H2C_B2', 'G1_MUL_W3', 'G2_MUL_W3', 'MUL2S', 'G1_MUL_FIXED', 'G2_MUL_GLS']
 P = {n: i for i, n in enumerate(PROGS)}
 
 
@@ -192,6 +192,26 @@ def point_mul_fixed(lib, table, scalars32):
     run(lib, 'G1_MUL_FIXED', n, {2: (buf(scalars32), 32), 5: (table, 0), 3: (Pj, 3 * RAW), 4: (N, RAW)})
     lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
     run(lib, 'G1_TO_AFFINE', n, {3: (Pj, 3 * RAW), 4: (NI, RAW), 2: (out, 96), 7: (st, 1)})
+    return out.raw, st.raw
+
+
+def point_mul_gls(lib, pts192, scalars32):
+    """dev_point_mul() for points known to lie in G2 (sign): base-|z| digits of the scalar (msm_decompose_kernel, here in Python) -> GLS ladder -> inversion -> affine"""
+    Z = 0xd201000000010000
+    n = len(scalars32) // 32
+    dig = b''
+    for i in range(n):
+        k = int.from_bytes(scalars32[32 * i:32 * i + 32], 'big')
+        a = []
+        for _ in range(3):
+            a.append(k % Z); k //= Z
+        a.append(k)
+        dig += b''.join(x.to_bytes(32, 'big') for x in a)
+    psz = 6 * RAW
+    Pj, N, NI, out, st = buf(psz * n), buf(RAW * n), buf(RAW * n), buf(192 * n), buf(n)
+    run(lib, 'G2_MUL_GLS', n, {1: (buf(pts192), 192), 2: (buf(dig), 128), 3: (Pj, psz), 4: (N, RAW)})
+    lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
+    run(lib, 'G2_TO_AFFINE', n, {3: (Pj, psz), 4: (NI, RAW), 2: (out, 192), 7: (st, 1)})
     return out.raw, st.raw
 
 
