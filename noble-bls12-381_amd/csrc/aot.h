@@ -67,6 +67,12 @@
   X(7, expx_ls, P_EXPX_LS, P_COUNT, P_COUNT, P_COUNT)                                      \
   X(3, miller_ls, P_MILLER_FE_LS, P_MILLER_RAW_LS, P_MILLER_BYTES_LS, P_COUNT)
 
+// Two-lane split (round 5): launches of 1025 .. 2048 items -- at most one wavefront per SIMD with TWO items per wavefront --, every K_DOT lane-op on two adjacent lanes, ONE DPP
+// stage.  Round 3 costed this form from the interpreter's numbers and left it; on the specialised kernels 2048 pairings take 1.9 instead of 2.17 ms (profiles/round5_ab_ls2.txt).
+#define NBLS_AOT_LS2_KERNELS(X)                                                             \
+  X(4, expx_ls2, P_EXPX_LS2, P_COUNT, P_COUNT, P_COUNT)                                    \
+  X(5, miller_ls2, P_MILLER_FE_LS2, P_MILLER_RAW_LS2, P_MILLER_BYTES_LS2, P_COUNT)
+
 namespace nbls {
 
 // K_DOT flags of a signature

@@ -193,22 +193,22 @@ NBLS_HD void aot_compress_columns(u64* acc) {
 // host only: what aot_acc_sum4 calls in place of the DPP stages (set by the simulator; null elsewhere)
 typedef void (*AotSimLsHook)(u64*);
 inline AotSimLsHook& aot_sim_ls_hook() { static AotSimLsHook h = nullptr; return h; }
-// Lane split: sum of the 28 column accumulators over the four adjacent lanes of a lane-op, result in the first of them.  Two DPP stages (lane i += lane i + 1, then
-// lane i += lane i + 2, inside rows of 16 lanes; groups of four never straddle a row).  On the host the simulator's hook does the same sum.
-NBLS_HD void aot_acc_sum4(u64* acc) {
+// Lane split: sum of the 28 column accumulators over the LS = 4 (2) adjacent lanes of a lane-op, result in the first of them.  Two DPP stages (lane i += lane i + 1, then
+// lane i += lane i + 2, inside rows of 16 lanes; groups of four never straddle a row) -- one stage for LS = 2.  On the host the simulator's hook does the same sum.
+template <u32 LS>
+NBLS_HD void aot_acc_sum(u64* acc) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
   for (int c = 0; c < 2 * NL - 1; c++) {
     u64 v = acc[c];
     v += ((u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x101, 0xf, 0xf, true) << 32) | (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x101, 0xf, 0xf, true);   // row_shl:1
-    v += ((u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x102, 0xf, 0xf, true) << 32) | (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x102, 0xf, 0xf, true);   // row_shl:2
+    if (LS == 4) v += ((u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x102, 0xf, 0xf, true) << 32) | (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x102, 0xf, 0xf, true);   // row_shl:2
     acc[c] = v;
   }
 #else
   if (aot_sim_ls_hook()) aot_sim_ls_hook()(acc);   // the simulator supplies the cross-lane sum (vm_sim.cpp: lanes are visited from 63 down, so the partners' columns are there)
 #endif
 }
-
 // The columns are made opaque between product rounds: the optimiser would otherwise re-associate every column's sum over ALL rounds of an unrolled body
 // (every round's operands live at once: 330-480 registers); the scheduling barrier keeps the LDS reads of later rounds from being hoisted to the top.
 NBLS_HD void aot_round_fence(u64* acc) {
@@ -269,7 +269,7 @@ NBLS_HD void aot_step(const D& desc, LDSP lds, const u32 item, const bool live, 
     if constexpr (P0 > 5) do_round(std::integral_constant<u32, 5>{});
     if constexpr (P0 > 6) do_round(std::integral_constant<u32, 6>{});
     if constexpr (P0 > 7) do_round(std::integral_constant<u32, 7>{});
-    if constexpr (LS > 1) aot_acc_sum4(acc);   // lane split: the columns of the four sub-lanes land in the first one (the others finish into the junk slot)
+    if constexpr (LS > 1) aot_acc_sum<LS>(acc);   // lane split: the columns of the four sub-lanes land in the first one (the others finish into the junk slot)
     u32 res[NL];
     aot_dot_finish<FLAGS, T>(res, acc, h0.x, post, lds);
     commit(h0.x & 0xffffu, res);

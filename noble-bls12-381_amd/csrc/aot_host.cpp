@@ -15,7 +15,7 @@ std::string aot_translate(const Program& p, AotProgram& out) {
 std::string aot_translate_with(const Program& p, AotProgram& out, const AotLayout* layout) {
   out = AotProgram();
   const u32 S = p.lsplit;   // lane split: a K_DOT lane-op has one descriptor per sub-lane (index = the physical lane), every other kind one per logical lane, executed by sub-lane 0
-  if (S != 1 && S != 4) return p.name + ": lane split " + std::to_string(S) + " has no ahead-of-time body";
+  if (S != 1 && S != 2 && S != 4) return p.name + ": lane split " + std::to_string(S) + " has no ahead-of-time body";
   if (p.lds_bytes() + 64 > 65536) return p.name + ": LDS image above 64 KB (16-bit address fields)";
   const u32 junk = p.lds_bytes();             // one slot behind the image: destination of idle lanes
   out.lds_bytes = p.lds_bytes() + 64;

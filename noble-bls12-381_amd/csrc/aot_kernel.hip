@@ -71,6 +71,8 @@ __device__ __forceinline__ void aot_body(const AotArgs& ka, Dispatch&& dispatch)
   case ID: aot_step<KIND, P0, FLAGS, T, SH0, SH1>(d, lds, item, live, bufs, ka.qp_table, [&](u32 dst, const u32* res) __attribute__((always_inline)) { st14(lds, dst, res); }); break;
 #define AOT_CASE_LS(ID, KIND, P0, FLAGS, T, SH0, SH1, CNT) \
   case ID: aot_step<KIND, P0, FLAGS, T, SH0, SH1, 4>(d, lds, item, live, bufs, ka.qp_table, [&](u32 dst, const u32* res) __attribute__((always_inline)) { st14(lds, dst, res); }); break;
+#define AOT_CASE_LS2(ID, KIND, P0, FLAGS, T, SH0, SH1, CNT) \
+  case ID: aot_step<KIND, P0, FLAGS, T, SH0, SH1, 2>(d, lds, item, live, bufs, ka.qp_table, [&](u32 dst, const u32* res) __attribute__((always_inline)) { st14(lds, dst, res); }); break;
 // this translation unit is compiled NBLS_AOT_PARTS times (Makefile: -DNBLS_AOT_PART=i); every part declares all kernels and defines its own
 #if !defined(NBLS_AOT_PART)
 #define NBLS_AOT_PART 0
@@ -78,9 +80,11 @@ __device__ __forceinline__ void aot_body(const AotArgs& ka, Dispatch&& dispatch)
 #define AOT_DECL(PART, NAME, P0, P1, P2, P3) extern "C" __global__ void nbls_aot_##NAME(AotArgs ka);
 NBLS_AOT_KERNELS(AOT_DECL)
 NBLS_AOT_LS_KERNELS(AOT_DECL)
+NBLS_AOT_LS2_KERNELS(AOT_DECL)
 #define AOT_KERNEL_BODY(NAME) AOT_KERNEL_BODY_(NAME, AOT_CASE, NBLS_AOT_OCC)
 // (launched at one wavefront per SIMD at most, so no register budget to keep)
 #define AOT_KERNEL_BODY_LS(NAME) AOT_KERNEL_BODY_(NAME, AOT_CASE_LS, __attribute__((amdgpu_waves_per_eu(1, 2))))   // lane-split programs: the columns of four adjacent lanes are summed before the reduction
+#define AOT_KERNEL_BODY_LS2(NAME) AOT_KERNEL_BODY_(NAME, AOT_CASE_LS2, __attribute__((amdgpu_waves_per_eu(1, 2))))   // two-lane split (1025 .. 2048 items: one wavefront per SIMD at most)
 #define AOT_KERNEL_BODY_(NAME, CASE, OCC)                                                                                                 \
   extern "C" __global__ void __launch_bounds__(64) OCC nbls_aot_##NAME(AotArgs ka) {                                           \
     aot_body(ka, [&](u32 sig, const DevDesc& d, char* lds, u32 item, bool live, const IOBuf* bufs) __attribute__((always_inline)) { \
@@ -98,9 +102,10 @@ namespace nbls {
 #define AOT_TABLE(PART, NAME, P0, P1, P2, P3) static const AotSig sigs_##NAME[] = {AOT_SIGS_##NAME(AOT_ROW)};
 NBLS_AOT_KERNELS(AOT_TABLE)
 NBLS_AOT_LS_KERNELS(AOT_TABLE)
+NBLS_AOT_LS2_KERNELS(AOT_TABLE)
 struct AotKernel { int prog_id[4]; const void* fn; const AotSig* sigs; unsigned nsigs; const char* name; };
 #define AOT_ENTRY(PART, NAME, P0, P1, P2, P3) {{(int)P0, (int)P1, (int)P2, (int)P3}, (const void*)nbls_aot_##NAME, sigs_##NAME, (unsigned)(sizeof(sigs_##NAME) / sizeof(AotSig)), "nbls_aot_" #NAME},
-static const AotKernel g_kernels[] = {NBLS_AOT_KERNELS(AOT_ENTRY) NBLS_AOT_LS_KERNELS(AOT_ENTRY)};
+static const AotKernel g_kernels[] = {NBLS_AOT_KERNELS(AOT_ENTRY) NBLS_AOT_LS_KERNELS(AOT_ENTRY) NBLS_AOT_LS2_KERNELS(AOT_ENTRY)};
 static const int g_nkernels = (int)(sizeof(g_kernels) / sizeof(g_kernels[0]));
 
 }  // namespace nbls

@@ -337,15 +337,31 @@ static inline BufArg B(int idx, const void* p, size_t stride) { return {idx, {p,
 // reduction (ahead-of-time kernels nbls_aot_miller_ls / nbls_aot_expx_ls, aot.h NBLS_AOT_LS_KERNELS; on the interpreter nbls_vm_kernel_ls4).  Measured
 // (tools/ab_ls.sh): one pairing 1.72 against 2.09 ms, 1024 pairings 1.79 against 2.12 ms.  NBLS_LS_MAX overrides (0 = the throughput forms at every size).
 static size_t ls_max() { static const size_t v = (size_t)env_long("NBLS_LS_MAX", 1024); return v; }
-static ProgId ls_variant(ProgId id, size_t n) {
-  if (n > ls_max()) return id;
-  switch (id) {
-    case P_MILLER_BYTES: return P_MILLER_BYTES_LS;
-    case P_MILLER_RAW: return P_MILLER_RAW_LS;
-    case P_MILLER_FE: return P_MILLER_FE_LS;
-    case P_EXPX: return P_EXPX_LS;
-    default: return id;
+// round 5: from LS_MAX + 1 to LS2_MAX items (two items per wavefront on 1024 SIMDs) the TWO-lane forms (nbls_aot_miller_ls2 / nbls_aot_expx_ls2; no interpreter form exists, so they are
+// used only where the program is bound to its ahead-of-time kernel).  Measured (tools/ab_ls2.sh): 2048 pairings 1.9 against 2.17 ms.  NBLS_LS2_MAX = 0 switches them off.
+static size_t ls2_max() { static const size_t v = (size_t)env_long("NBLS_LS2_MAX", 2048); return v; }
+static ProgId ls_variant(nbls_ctx* ctx, ProgId id, size_t n) {
+  if (n <= ls_max()) {
+    switch (id) {
+      case P_MILLER_BYTES: return P_MILLER_BYTES_LS;
+      case P_MILLER_RAW: return P_MILLER_RAW_LS;
+      case P_MILLER_FE: return P_MILLER_FE_LS;
+      case P_EXPX: return P_EXPX_LS;
+      default: return id;
+    }
   }
+  if (n <= ls2_max()) {
+    ProgId v = id;
+    switch (id) {
+      case P_MILLER_BYTES: v = P_MILLER_BYTES_LS2; break;
+      case P_MILLER_RAW: v = P_MILLER_RAW_LS2; break;
+      case P_MILLER_FE: v = P_MILLER_FE_LS2; break;
+      case P_EXPX: v = P_EXPX_LS2; break;
+      default: return id;
+    }
+    if (upload(ctx, v) == NBLS_OK && ctx->prog[v].aot >= 0) return v;
+  }
+  return id;
 }
 static int reduce_product(nbls_ctx* ctx, size_t n, uint8_t** result, hipStream_t s) {
   // round 5: IN PLACE.  With spacing d the live elements are F[0], F[d], F[2d], ... below n; one launch multiplies F[2 i d] by F[2 i d + d] into the former for every
@@ -373,7 +389,7 @@ static int reduce_product(nbls_ctx* ctx, size_t n, uint8_t** result, hipStream_t
 // input) is flagged by DEC_B and recomputed by the plain program over an index list kept on the device, so the result is the reference's for every input.
 static int expx(nbls_ctx* ctx, size_t n, uint8_t* in, uint8_t* out, hipStream_t s) {
   int r;
-  if (n < ctx->expc_min) return run(ctx, ls_variant(P_EXPX, n), n, {B(3, in, F12), B(5, out, F12)}, s);
+  if (n < ctx->expc_min) return run(ctx, ls_variant(ctx, P_EXPX, n), n, {B(3, in, F12), B(5, out, F12)}, s);
   const size_t KSB = (size_t)EXPC_SQ_ELEMS * RAW, KDB = (size_t)EXPC_DEC_ELEMS * RAW;
   if ((r = ensure_expc_scratch(ctx))) return r;
   if ((r = run(ctx, P_EXPC_SQ, n, {B(3, in, F12), B(5, ctx->KS, KSB)}, s))) return r;
@@ -391,7 +407,7 @@ static int final_exp_pipeline(nbls_ctx* ctx, size_t n, uint8_t* f_raw, void* d_o
   uint8_t** T = ctx->T;
   if ((r = run_inv(ctx, n, s))) return r;
   if ((r = run(ctx, P_FE_EASY, n, {B(3, f_raw, F12), B(4, ctx->NI, RAW), B(5, T[0], F12)}, s))) return r;
-  if (n < ctx->expc_min && n < ctx->chain_max && !ctx->in_halves && ls_variant(P_EXPX, n) == P_EXPX) {
+  if (n < ctx->expc_min && n < ctx->chain_max && !ctx->in_halves && ls_variant(ctx, P_EXPX, n) == P_EXPX) {
     // the seven launches between the easy part and the final product as one chain (math.ts:862-867): t2 = t1^x, t3 = conj(t1^2) t2, t4 = t3^x, t5 = t4^x,
     // t6' = t5^x, t6 = t6' t2^2, t7 = t6^x
     if ((r = run_chain(ctx, n, {{P_EXPX, {B(3, T[0], F12), B(5, T[1], F12)}},
@@ -551,9 +567,9 @@ static int pairing_core(nbls_ctx* ctx, size_t n, const void* d_g1, const void* d
   static const int fused_mode = (int)env_long("NBLS_FUSED_MILLER", -1);
   const bool fused = fused_mode >= 0 ? fused_mode != 0 : (!two_programs && n < ctx->split_min);
   if (fused) {
-    if (!with_final_exp) return run(ctx, ls_variant(P_MILLER_BYTES, n), n, {B(0, d_g1, 96), B(1, d_g2, 192), B(2, d_out, 576)}, s);
+    if (!with_final_exp) return run(ctx, ls_variant(ctx, P_MILLER_BYTES, n), n, {B(0, d_g1, 96), B(1, d_g2, 192), B(2, d_out, 576)}, s);
     if ((r = ensure_scratch(ctx, n))) return r;
-    if ((r = run(ctx, ls_variant(P_MILLER_FE, n), n, {B(0, d_g1, 96), B(1, d_g2, 192), B(3, ctx->F, F12), B(4, ctx->N, RAW)}, s))) return r;
+    if ((r = run(ctx, ls_variant(ctx, P_MILLER_FE, n), n, {B(0, d_g1, 96), B(1, d_g2, 192), B(3, ctx->F, F12), B(4, ctx->N, RAW)}, s))) return r;
     return final_exp_pipeline(ctx, n, ctx->F, d_out, s);
   }
   // calcPairingPrecomputes + millerLoop (math.ts:1331-1388) as two programs: line tables through HBM (LINE_BYTES per pair)
@@ -612,7 +628,7 @@ static int miller_values(nbls_ctx* ctx, size_t n, const void* d_g1, const void* 
       // up to one wavefront per SIMD (4 pairs per wavefront): the call takes the time of ONE wavefront's instruction stream whatever it computes, so every
       // pair gets an item of its own (420 k instructions) rather than sharing an accumulator with a second one (630 k): a single verify 6.1 -> 5.5 ms
       m = n;
-      if ((r = run(ctx, ls_variant(P_MILLER_RAW, n), n, {B(0, d_g1, 96), B(1, d_g2, 192), B(3, ctx->F, F12)}, s))) return r;
+      if ((r = run(ctx, ls_variant(ctx, P_MILLER_RAW, n), n, {B(0, d_g1, 96), B(1, d_g2, 192), B(3, ctx->F, F12)}, s))) return r;
     } else if (fused) {
       if (n2 && (r = run(ctx, P_MILLER_RAW2, n2, {B(0, d_g1, 192), B(1, d_g2, 384), B(3, ctx->F, F12)}, s))) return r;
       if ((n & 1) && (r = run(ctx, P_MILLER_RAW, 1, {B(0, (const uint8_t*)d_g1 + (n - 1) * 96, 96), B(1, (const uint8_t*)d_g2 + (n - 1) * 192, 192), B(3, ctx->F + n2 * F12, F12)}, s))) return r;
@@ -1029,7 +1045,7 @@ EXPORT const char* nbls_program_kernel(nbls_ctx* ctx, int prog) {
   std::lock_guard<std::recursive_mutex> g(ctx->mu);
   if (hipSetDevice(ctx->device) != hipSuccess || upload(ctx, (ProgId)prog)) return nullptr;
   const DevProgram& d = ctx->prog[prog];
-  return d.aot >= 0 ? nbls_aot_name(d.aot) : (d.p->lsplit ? "nbls_vm_kernel_ls4" : "nbls_vm_kernel");
+  return d.aot >= 0 ? nbls_aot_name(d.aot) : (d.p->lsplit > 1 ? "nbls_vm_kernel_ls4" : "nbls_vm_kernel");
 }
 EXPORT int nbls_program_count(void) { return (int)P_COUNT; }
 EXPORT const char* nbls_program_name(int prog) { return prog >= 0 && prog < P_COUNT ? get_program((ProgId)prog).name.c_str() : nullptr; }

@@ -247,18 +247,19 @@ static Program build(ProgId id) {
   // step that has free lanes (-4 % instructions); with two point chains per item (MILLER_RAW2) those steps are full, so no cap there
   if (id == P_MILLER_BYTES || id == P_MILLER_RAW || id == P_MILLER_FE) B.max_dot = env_int("NBLS_MILLER_MAXDOT", 6);
   if (id == P_EXPX) B.max_dot = env_int("NBLS_EXPX_MAXDOT", 8);
-  const bool ls = id == P_MILLER_BYTES_LS || id == P_MILLER_RAW_LS || id == P_MILLER_FE_LS || id == P_EXPX_LS;
-  if (ls) { B.lane_split = 4; B.max_dot = env_int("NBLS_LS_MAXDOT", 8); }   // four sub-lanes share a lane-op's products: eight of them are two rounds
+  const bool ls2 = id == P_MILLER_BYTES_LS2 || id == P_MILLER_RAW_LS2 || id == P_MILLER_FE_LS2 || id == P_EXPX_LS2;
+  const bool ls = ls2 || id == P_MILLER_BYTES_LS || id == P_MILLER_RAW_LS || id == P_MILLER_FE_LS || id == P_EXPX_LS;
+  if (ls) { B.lane_split = ls2 ? 2 : 4; B.max_dot = env_int("NBLS_LS_MAXDOT", 8); }   // four (two) sub-lanes share a lane-op's products: eight of them are two (four) rounds
   switch (id) {
-    case P_MILLER_BYTES: case P_MILLER_BYTES_LS: {
+    case P_MILLER_BYTES: case P_MILLER_BYTES_LS: case P_MILLER_BYTES_LS2: {
       SFp Px, Py; SFp2 Qx, Qy; load_points(Px, Py, Qx, Qy);
       output_fp12(trace_miller(Px, Py, Qx, Qy), 2, 0);
-      return B.compile(ls ? "miller_bytes_ls" : "miller_bytes", ls ? 16 : MILLER_W);
+      return B.compile(ls2 ? "miller_bytes_ls2" : ls ? "miller_bytes_ls" : "miller_bytes", ls ? 16 : MILLER_W);
     }
-    case P_MILLER_RAW: case P_MILLER_RAW_LS: {
+    case P_MILLER_RAW: case P_MILLER_RAW_LS: case P_MILLER_RAW_LS2: {
       SFp Px, Py; SFp2 Qx, Qy; load_points(Px, Py, Qx, Qy);
       outputw_fp12(trace_miller(Px, Py, Qx, Qy), 3, 0);
-      return B.compile(ls ? "miller_raw_ls" : "miller_raw", ls ? 16 : MILLER_W);
+      return B.compile(ls2 ? "miller_raw_ls2" : ls ? "miller_raw_ls" : "miller_raw", ls ? 16 : MILLER_W);
     }
     case P_MILLER_RAW2: {   // two pairs per item: g1 (buf 0, 2 x 96 B), g2 (buf 1, 2 x 192 B) -> raw Fp12 of the product (buf 3)
       std::vector<SFp> Px, Py; std::vector<SFp2> Qx, Qy;
@@ -267,12 +268,12 @@ static Program build(ProgId id) {
       B.sched_window = env_int("NBLS_MILLER2_WINDOW", 450);   // keeps the two point-update chains within ~1.5 iterations of the accumulator chain
       return B.compile("miller_raw2", MILLER_W);
     }
-    case P_MILLER_FE: case P_MILLER_FE_LS: {
+    case P_MILLER_FE: case P_MILLER_FE_LS: case P_MILLER_FE_LS2: {
       SFp Px, Py; SFp2 Qx, Qy; load_points(Px, Py, Qx, Qy);
       SFp12 f = mat(trace_miller(Px, Py, Qx, Qy));
       outputw_fp12(f, 3, 0);
       outputw(inv_chain(f).n, 4, 0);
-      return B.compile(ls ? "miller_fe_ls" : "miller_fe", ls ? 16 : MILLER_W);
+      return B.compile(ls2 ? "miller_fe_ls2" : ls ? "miller_fe_ls" : "miller_fe", ls ? 16 : MILLER_W);
     }
     case P_NORM_RAW: {
       SFp12 f = inputw_fp12(3, 0);
@@ -293,12 +294,12 @@ static Program build(ProgId id) {
       outputw_fp12(trace_fe_easy(f, finv), 5, 0);
       return B.compile("fe_easy", env_int("NBLS_FE_EASY_W", 16));
     }
-    case P_EXPX: case P_EXPX_LS: {
+    case P_EXPX: case P_EXPX_LS: case P_EXPX_LS2: {
       if (env_int("NBLS_EXPX_RELOAD", 1)) {
         B.sched_window = env_int("NBLS_EXPX_WINDOW", 150);   // the reloads of the base are scheduled about one squaring ahead of the multiplication that needs them
         outputw_fp12(conj(cyclotomic_exp_x(inputw_fp12(3, 0), [&]() { return inputw_fp12(3, 0); })), 5, 0);
       } else outputw_fp12(conj(cyclotomic_exp_x(inputw_fp12(3, 0))), 5, 0);
-      return B.compile(ls ? "expx_ls" : "expx", ls ? 12 : EXPX_W);
+      return B.compile(ls2 ? "expx_ls2" : ls ? "expx_ls" : "expx", ls ? 12 : EXPX_W);
     }
     case P_EXPC_SQ: {
       // raw Fp12 element order: c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2 (two raw elements each)

@@ -82,21 +82,26 @@ NBLS_AOT_KERNELS(SIM_TABLE)
 // (lane i <- v[i] + v[i+1] + v[i+2] + v[i+3] inside rows of 16 lanes); here the lanes of a step are visited from 63 down to 0, every lane leaves its columns in
 // g_ls_cols before it takes the sum, so the three partners of a sub-lane 0 are already there.
 static u64 g_ls_cols[64][2 * NL];
-static unsigned g_ls_lane = 0;
+static unsigned g_ls_lane = 0, g_ls_width = 4;
 static void sim_ls_sum(u64* acc) {
   const unsigned i = g_ls_lane;
   memcpy(g_ls_cols[i], acc, sizeof g_ls_cols[i]);
-  for (unsigned k = 1; k < 4; k++) if (i + k < 64 && (i + k) / 16 == i / 16) for (int c = 0; c < 2 * NL; c++) acc[c] += g_ls_cols[i + k][c];
+  for (unsigned k = 1; k < g_ls_width; k++) if (i + k < 64 && (i + k) / 16 == i / 16) for (int c = 0; c < 2 * NL; c++) acc[c] += g_ls_cols[i + k][c];
 }
 #undef SIM_CASE
 #define SIM_CASE(ID, KIND, P0, FLAGS, T, SH0, SH1, CNT) \
   case ID: aot_step<KIND, P0, FLAGS, T, SH0, SH1, 4>(d, lds, item, live, bufs, qp, [&](u32 dst, const u32* res) { Pend pd; pd.dst = dst; memcpy(pd.v, res, NL * 4); pend.push_back(pd); }); break;
 NBLS_AOT_LS_KERNELS(SIM_TABLE)
+#undef SIM_CASE
+#define SIM_CASE(ID, KIND, P0, FLAGS, T, SH0, SH1, CNT) \
+  case ID: aot_step<KIND, P0, FLAGS, T, SH0, SH1, 2>(d, lds, item, live, bufs, qp, [&](u32 dst, const u32* res) { Pend pd; pd.dst = dst; memcpy(pd.v, res, NL * 4); pend.push_back(pd); }); break;
+NBLS_AOT_LS2_KERNELS(SIM_TABLE)
 typedef void (*SimStepFn)(u32, const HostDesc&, char*, u32, bool, const IOBuf*, const u32*, std::vector<Pend>&);
-struct SimKernel { int prog_id[4]; SimStepFn fn; const AotSig* sigs; unsigned nsigs; bool ls; };
-#define SIM_ENTRY(PART, NAME, Q0, Q1, Q2, Q3) {{(int)Q0, (int)Q1, (int)Q2, (int)Q3}, sim_step_##NAME, sim_sigs_##NAME, (unsigned)(sizeof(sim_sigs_##NAME) / sizeof(AotSig)), false},
-#define SIM_ENTRY_LS(PART, NAME, Q0, Q1, Q2, Q3) {{(int)Q0, (int)Q1, (int)Q2, (int)Q3}, sim_step_##NAME, sim_sigs_##NAME, (unsigned)(sizeof(sim_sigs_##NAME) / sizeof(AotSig)), true},
-static const SimKernel g_sim_kernels[] = {NBLS_AOT_KERNELS(SIM_ENTRY) NBLS_AOT_LS_KERNELS(SIM_ENTRY_LS)};
+struct SimKernel { int prog_id[4]; SimStepFn fn; const AotSig* sigs; unsigned nsigs; unsigned ls; };   // ls: sub-lanes per lane-op (0: none)
+#define SIM_ENTRY(PART, NAME, Q0, Q1, Q2, Q3) {{(int)Q0, (int)Q1, (int)Q2, (int)Q3}, sim_step_##NAME, sim_sigs_##NAME, (unsigned)(sizeof(sim_sigs_##NAME) / sizeof(AotSig)), 0},
+#define SIM_ENTRY_LS(PART, NAME, Q0, Q1, Q2, Q3) {{(int)Q0, (int)Q1, (int)Q2, (int)Q3}, sim_step_##NAME, sim_sigs_##NAME, (unsigned)(sizeof(sim_sigs_##NAME) / sizeof(AotSig)), 4},
+#define SIM_ENTRY_LS2(PART, NAME, Q0, Q1, Q2, Q3) {{(int)Q0, (int)Q1, (int)Q2, (int)Q3}, sim_step_##NAME, sim_sigs_##NAME, (unsigned)(sizeof(sim_sigs_##NAME) / sizeof(AotSig)), 2},
+static const SimKernel g_sim_kernels[] = {NBLS_AOT_KERNELS(SIM_ENTRY) NBLS_AOT_LS_KERNELS(SIM_ENTRY_LS) NBLS_AOT_LS2_KERNELS(SIM_ENTRY_LS2)};
 static int g_sim_aot = 0;
 // 0: ran; -2: the program has no ahead-of-time kernel; -3: its signatures are not in the kernel's table
 static int sim_run_aot(int prog, unsigned n_items, const IOBuf* bufs) {
@@ -117,7 +122,7 @@ static int sim_run_aot(int prog, unsigned n_items, const IOBuf* bufs) {
     for (unsigned g = 0; g < (p.shared_consts ? 1u : p.G); g++) for (unsigned c = 0; c < p.nconst; c++) memcpy(lds + g * p.inst_bytes() + c * p.slot_bytes, p.consts.data() + c * RAW_WORDS, NL * 4);
     for (size_t s = 0; s < ap.steps.size(); s++) {
       std::vector<Pend> pend;
-      aot_sim_ls_hook() = K->ls ? sim_ls_sum : nullptr;
+      aot_sim_ls_hook() = K->ls ? sim_ls_sum : nullptr; g_ls_width = K->ls ? K->ls : 4;
       for (unsigned v = 0; v < 64; v++) {
         const unsigned lane = K->ls ? 63 - v : v;      // lane-split kernels: from the top down (sim_ls_sum)
         const unsigned inst = lane / p.W, item = blk * p.G + inst;

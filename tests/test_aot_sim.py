@@ -59,7 +59,10 @@ def test_translated_expx_on_extreme_elements(sim, oracle):
 def test_lane_split_programs_translated(sim, oracle, golden):
     """the lane-split forms through aot_translate + aot_step<..., LS = 4>: every sub-lane's own round addresses, the columns of the four sub-lanes summed before the one
     finish (on the device two DPP stages; the simulator visits the lanes from the top down and sums what the partners left), everything else on sub-lane 0"""
-    T.test_lane_split_programs(sim, oracle, golden)
+    T.test_lane_split_programs.__wrapped__(sim, oracle, golden, '_LS') if hasattr(T.test_lane_split_programs, '__wrapped__') else T.test_lane_split_programs(sim, oracle, golden, '_LS')
+    for name in ('EXPX_LS2', 'MILLER_FE_LS2', 'MILLER_RAW_LS2', 'MILLER_BYTES_LS2'):       # round 5: the two-lane forms (one DPP stage) have kernels of their own
+        assert sim.nbls_sim_has_aot(vmsim_py.P[name]) == 1, name
+    T.test_lane_split_programs(sim, oracle, golden, '_LS2')
 
 
 def test_decode_and_hash_programs_translated(sim, oracle, golden, testdata):

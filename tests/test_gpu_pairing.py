@@ -226,11 +226,11 @@ def test_two_halves_execution(oracle, golden):
 
 def test_chained_and_separate_final_exponentiation(oracle, golden):
     """The middle of the final exponentiation (EXPX, FE_MID1, EXPX x 3, FE_MID2, EXPX; math.ts:862-867) is one chained launch below NBLS_TUNE_CHAIN_MAX items and seven launches
-    otherwise (what PairingPipeline's contexts use): same bytes either way, equal to the oracle's; sizes above the lane-split range (1024), with a partly filled last wavefront."""
+    otherwise (what PairingPipeline's contexts use): same bytes either way, equal to the oracle's; sizes above the lane-split ranges (1024 / 2048: those forms run unchained), with a partly filled last wavefront."""
     pkg = importlib.import_module('noble-bls12-381_amd')
     eng = pkg.Engine(0)
     pairs = golden['pairs']
-    for n in (1027, 2050):
+    for n in (2051, 3077):
         g1 = b''.join(hx(pairs[(5 * i + 2) % len(pairs)]['g1']) for i in range(n)); g2 = b''.join(hx(pairs[(3 * i + n) % len(pairs)]['g2']) for i in range(n))
         eng.set_chain_max(8192)
         eng.timing_enable(True)
@@ -261,3 +261,25 @@ def test_default_dispatch_thresholds(oracle, golden):
         got, _ = eng.pairing_batch(g1, g2, True, False)
         exp, _ = oracle.pairing_batch(g1, g2, True, False, threads=os.cpu_count() or 16)
         assert got == exp, n
+
+
+@pytest.mark.parametrize('n', [1025, 1530, 2048])
+def test_two_lane_split_range(oracle, golden, n):
+    """round 5: calls of 1025 .. 2048 pairs run the two-lane forms (nbls_aot_miller_ls2 / nbls_aot_expx_ls2: two items per wavefront, every K_DOT lane-op on two adjacent lanes,
+    one DPP stage) -- pairings, raw Miller values and a Miller product against the oracle at both ends of the range and inside it, and the same bytes as the plain forms"""
+    pkg = importlib.import_module('noble-bls12-381_amd')
+    eng = pkg.Engine(0)
+    b = eng.kernel_bindings()
+    assert b['miller_fe_ls2'] == 'nbls_aot_miller_ls2' and b['expx_ls2'] == 'nbls_aot_expx_ls2' and b['miller_raw_ls2'] == 'nbls_aot_miller_ls2'
+    pairs = golden['pairs']
+    g1 = b''.join(hx(pairs[(7 * i + 1) % len(pairs)]['g1']) for i in range(n)); g2 = b''.join(hx(pairs[(3 * i + 2 * n) % len(pairs)]['g2']) for i in range(n))
+    eng.timing_enable(True)
+    out, _ = eng.pairing_batch(g1, g2, True, False)
+    tm = eng.timing_read(); eng.timing_enable(False)
+    assert 'miller_fe_ls2' in tm and 'expx_ls2' in tm and 'miller_fe' not in tm and 'expx' not in tm, sorted(tm)      # the two-lane forms are what ran
+    ref, _ = oracle.pairing_batch(g1, g2, True, False, threads=32)
+    assert out == ref
+    ml, _ = eng.pairing_batch(g1, g2, False, False)
+    refm, _ = oracle.pairing_batch(g1, g2, False, False, threads=32)
+    assert ml == refm
+    assert eng.miller_product(g1, g2, True)[0] == oracle.miller_product(g1, g2, True)

@@ -494,20 +494,26 @@ def test_uncompressed_flag_bits(sim, golden3):
     assert {v['result'] for v in golden3['g2_raw192_flags']} >= {'ok', 'zero', 'Invalid encoding flag: 32', 'Invalid encoding flag: 96', 'Invalid encoding flag: 224', 'Invalid point G2, expected 96/192 bytes'}
 
 
-def test_lane_split_programs(sim, oracle, golden):
-    """The latency variants (every K_DOT lane-op spread over four adjacent lanes, one item per wavefront): same results as the golden pairs --
-    Miller value, and the whole pairing with the lane-split Miller and exponentiation programs."""
+@pytest.mark.parametrize('suffix', ['_LS', '_LS2'])
+def test_lane_split_programs(sim, oracle, golden, suffix):
+    """The latency variants (every K_DOT lane-op spread over four adjacent lanes, one item per wavefront; round 5: over TWO lanes, two items per wavefront -- launches of
+    1025 .. 2048 items): same results as the golden pairs -- Miller value, and the whole pairing with the lane-split Miller and exponentiation programs."""
     n = 3
     g1, g2 = _points(golden, n)
     out = C.create_string_buffer(576 * n)
-    vmsim_py.run(sim, 'MILLER_BYTES_LS', n, {0: (C.create_string_buffer(g1, len(g1)), 96), 1: (C.create_string_buffer(g2, len(g2)), 192), 2: (out, 576)})
+    vmsim_py.run(sim, 'MILLER_BYTES' + suffix, n, {0: (C.create_string_buffer(g1, len(g1)), 96), 1: (C.create_string_buffer(g2, len(g2)), 192), 2: (out, 576)})
     for i in range(n):
         assert out.raw[576 * i:576 * (i + 1)] == hx(golden['pairs'][i]['miller']), i
     F = C.create_string_buffer(vmsim_py.F12 * n); N = C.create_string_buffer(vmsim_py.RAW * n)
-    vmsim_py.run(sim, 'MILLER_FE_LS', n, {0: (C.create_string_buffer(g1, len(g1)), 96), 1: (C.create_string_buffer(g2, len(g2)), 192), 3: (F, vmsim_py.F12), 4: (N, vmsim_py.RAW)})
-    vmsim_py.final_exp(sim, n, F, N, out, expx='EXPX_LS')
+    vmsim_py.run(sim, 'MILLER_FE' + suffix, n, {0: (C.create_string_buffer(g1, len(g1)), 96), 1: (C.create_string_buffer(g2, len(g2)), 192), 3: (F, vmsim_py.F12), 4: (N, vmsim_py.RAW)})
+    vmsim_py.final_exp(sim, n, F, N, out, expx='EXPX' + suffix)
     for i in range(n):
         assert out.raw[576 * i:576 * (i + 1)] == hx(golden['pairs'][i]['pairing']), i
+    Fr = C.create_string_buffer(vmsim_py.F12 * n); outr = C.create_string_buffer(576 * n)
+    vmsim_py.run(sim, 'MILLER_RAW' + suffix, n, {0: (C.create_string_buffer(g1, len(g1)), 96), 1: (C.create_string_buffer(g2, len(g2)), 192), 3: (Fr, vmsim_py.F12)})
+    vmsim_py.run(sim, 'RAW_TO_BYTES', n, {3: (Fr, vmsim_py.F12), 2: (outr, 576)})
+    for i in range(n):
+        assert outr.raw[576 * i:576 * (i + 1)] == hx(golden['pairs'][i]['miller']), i
 
 
 def test_compressed_exponentiation(sim, golden, testdata):

@@ -17,7 +17,7 @@ def raw_elem(v):
 
 
 PROGS = ['MILLER_BYTES', 'MILLER_RAW', 'MILLER_FE', 'NORM_RAW', 'NORM_BYTES', 'FE_EASY', 'EXPX', 'FE_MID1', 'FE_MID2', 'FE_FINAL', 'MUL2', 'RAW_TO_BYTES', 'G1_VALIDATE', 'G2_VALIDATE', 'G1_DEC_A', 'G1_DEC_B', 'G2_DEC_A', 'G2_DEC_B', 'H2C_A', 'H2C_B',
-         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'G1_COMPRESS', 'G2_COMPRESS', 'H2C1_A', 'ENC1_A', 'H2C1_B', 'ENC1_B', 'G1_CLEAR', 'ENC2_A', 'ENC2_B', 'G1_MUL', 'G2_MUL', 'G1_ADD_AB', 'G2_ADD_AB', 'G1_HORNER', 'G2_HORNER', 'G1_SHIFTADD', 'G2_SHIFTADD', 'G1_MSM_PREP', 'G2_MSM_PREP', 'LINES_PQ', 'LINES_Q', 'LINES_BYTES', 'LINES_FROM_BYTES', 'ACC_BYTES', 'ACC_RAW', 'ACC_FE', 'ACC2_RAW', 'ACC_Q', 'G2_DEC_A192', 'G2_DEC_B192', 'G2_DEC_B_HEX', 'G1_FROM_RAW', 'G2_FROM_RAW', 'G2_SWAP', 'H2C_C1', 'H2C_C2', 'ACC4_RAW', 'MILLER_BYTES_LS', 'MILLER_RAW_LS', 'MILLER_FE_LS', 'EXPX_LS', 'EXPC_SQ', 'EXPC_DEC_A', 'EXPC_DEC_B', 'ACC8_RAW', 'H2C_C0', 'H2C_B1', 'H2C_B2', 'G1_MUL_W3', 'G2_MUL_W3', 'MUL2S', 'G1_MUL_FIXED', 'G2_MUL_GLS']
+         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'G1_COMPRESS', 'G2_COMPRESS', 'H2C1_A', 'ENC1_A', 'H2C1_B', 'ENC1_B', 'G1_CLEAR', 'ENC2_A', 'ENC2_B', 'G1_MUL', 'G2_MUL', 'G1_ADD_AB', 'G2_ADD_AB', 'G1_HORNER', 'G2_HORNER', 'G1_SHIFTADD', 'G2_SHIFTADD', 'G1_MSM_PREP', 'G2_MSM_PREP', 'LINES_PQ', 'LINES_Q', 'LINES_BYTES', 'LINES_FROM_BYTES', 'ACC_BYTES', 'ACC_RAW', 'ACC_FE', 'ACC2_RAW', 'ACC_Q', 'G2_DEC_A192', 'G2_DEC_B192', 'G2_DEC_B_HEX', 'G1_FROM_RAW', 'G2_FROM_RAW', 'G2_SWAP', 'H2C_C1', 'H2C_C2', 'ACC4_RAW', 'MILLER_BYTES_LS', 'MILLER_RAW_LS', 'MILLER_FE_LS', 'EXPX_LS', 'EXPC_SQ', 'EXPC_DEC_A', 'EXPC_DEC_B', 'ACC8_RAW', 'H2C_C0', 'H2C_B1', 'H2C_B2', 'G1_MUL_W3', 'G2_MUL_W3', 'MUL2S', 'G1_MUL_FIXED', 'G2_MUL_GLS', 'MILLER_BYTES_LS2', 'MILLER_RAW_LS2', 'MILLER_FE_LS2', 'EXPX_LS2']
 P = {n: i for i, n in enumerate(PROGS)}
 
 
