@@ -195,7 +195,8 @@ int nbls_verify_batch_dev_inputs(nbls_ctx* ctx, size_t n, const void* d_sig96, c
  * (key, message) pairs, times millerLoop(-G, S) on the ONE rank that passes the signature (d_sig96 = NULL elsewhere), WITHOUT the
  * final exponentiation, as 576 wire bytes in device memory.  Ranks all-gather their partials and finish with
  * nbls_fp12_product_final_dev (product + shared finalExponentiate, index.ts:811-817), then compare with Fp12.ONE.
- * *zero_flag = 1: a zero point was met (verifyBatch answers false, d_out_fp12 not written).  NBLS_EDECODE as nbls_verify_batch. */
+ * *zero_flag = 1: a zero point was met (verifyBatch answers false).  NBLS_EDECODE as nbls_verify_batch.  ABI 3: the call decides nothing on the host before its end, so d_out_fp12 IS
+ * written in both cases -- with a meaningless product; look at the return code and the flag first. */
 int nbls_verify_batch_partial_dev(nbls_ctx* ctx, size_t n, const void* d_sig96 /* or NULL */, const void* d_uniform256, const void* d_pk48,
                                   void* d_out_fp12, int* zero_flag, int8_t* pk_status /* n, may be NULL */, void* stream);
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Markdown rows of DESIGN.md section 6 from the committed bench JSON lines (profiles/roundN_bench_default.json, ..._bench_driver_args.json).  Usage: tools/design_numbers.py [round]"""
 import json, sys
-r = sys.argv[1] if len(sys.argv) > 1 else '4'
+r = sys.argv[1] if len(sys.argv) > 1 else '5'
 d = json.load(open('profiles/round%s_bench_default.json' % r)); a = json.load(open('profiles/round%s_bench_driver_args.json' % r))
 v = d['verify_batch']; f = d.get('facade') or {}; c = d['cpu_baseline']; j = c['js_bigint']
 print('| `value`: 4096-pairing batches, %d in flight (%d steps) | **%.3f M pairings/s** (%.3f ms per batch) | %.3f (`roofline.frac_at_value`) |' % (d['config']['batches_in_flight'], d['steps'], d['value'] / 1e6, d['ms_per_step'], d['roofline']['frac_at_value']))
@@ -13,6 +13,7 @@ print('| `verify_batch`: 65,536 signatures, one call at a time, messages / keys 
 print('| one `verify` from host buffers (C ABI) / `await bls.verify(...)` from JavaScript / `await bls.sign(...)` | %.2f ms / %s ms / %s ms | critical path, section 4 |' % (v['single_verify_ms'], f.get('verify_ms'), f.get('sign_ms')))
 print('| `product`: 2^18-term Miller product + one final exponentiation | %.1f ms (%.2f M terms/s) | |' % (d['product']['ms_per_product'], d['product']['value'] / 1e6))
 print('| `sign` 8192 / `getPublicKey` | %.2f M sigs/s / %.2f M keys/s | |' % (d['sign']['value'] / 1e6, d['sign']['get_public_key_keys_per_s'] / 1e6))
+if d.get('config3'): print('| `config3`: BASELINE configs[3], %d independent pairings in ONE call per rank (1 rank) | %.1f ms (%.2f M pairings/s) | %.3f |' % (d['config3']['pairings'], d['config3']['ms'], d['config3']['value'] / 1e6, d['config3']['roofline_frac_per_gpu']))
 print('| MSM G1, 65,536 points, 255-bit scalars | %.1f M points/s | |' % (d['msm']['value'] / 1e6))
 print('| hash-to-G2 / hash-to-G1, 16,384 messages from host buffers | %.2f / %.2f M msgs/s | |' % (d['aggregate']['hash_to_g2_msgs_per_s'] / 1e6, d['aggregate']['hash_to_g1_msgs_per_s'] / 1e6))
 print()
