@@ -1574,7 +1574,19 @@ static int verify_pipeline(nbls_ctx* ctx, size_t n, const VerifyIn& in, int fina
         }
         return dev_hash_to_g2(ctx, nc, uni, G2 + o * 192, sc, o, n);
       };
-      if (c & 1) { if ((r = hash()) || (r = keys())) return r; }
+      // experiment: the first (large) sub-batch decodes its keys on a stream of its own beside its hash chain, as round 4 did for the whole call: both contain an exponentiation kernel that leaves
+      // issue slots free, and in sequence they put 3 ms in front of the longest chain of the call -- measured no better either (profiles/round5_ab_verify2.txt), off by default: NBLS_VERIFY_KEYS_SIDE=1
+      static const bool keys_side = env_long("NBLS_VERIFY_KEYS_SIDE", 0) != 0;
+      if (c == 0 && keys_side) {
+        if (!ctx->side2 && (hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming) != hipSuccess)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+        HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));
+        hipStream_t keep = sc; sc = ctx->side2;
+        if ((r = keys())) return r;
+        sc = keep;
+        HIPCHK(hipEventRecord(ctx->ev_join2, ctx->side2));
+        if ((r = hash())) return r;
+        HIPCHK(hipStreamWaitEvent(sc, ctx->ev_join2, 0));
+      } else if (c & 1) { if ((r = hash()) || (r = keys())) return r; }
       else { if ((r = keys()) || (r = hash())) return r; }
       size_t cc = nc;
       if (last && in.d_sig96) {
@@ -1587,9 +1599,24 @@ static int verify_pipeline(nbls_ctx* ctx, size_t n, const VerifyIn& in, int fina
       const ProgId acc = GR == 4 ? P_ACC4_RAW : GR == 2 ? P_ACC2_RAW : P_ACC_RAW;
       const size_t gg = (cc + GR - 1) / GR;
       uint8_t* Lc = ctx->L + (o + 4 * c) * LINE_BYTES;      // its own line tables (+ up to three unit tables behind them)
-      if ((r = run(ctx, P_LINES_PQ, cc, {B(0, G1 + o * 96, 96), B(1, G2 + o * 192, 192), B(3, Lc, LINE_BYTES)}, sc))) return r;
-      for (size_t k = cc; k < GR * gg; k++) HIPCHK(hipMemcpyAsync(Lc + k * LINE_BYTES, ctx->unit_lines, LINE_BYTES, hipMemcpyDeviceToDevice, sc));
-      if ((r = run(ctx, acc, gg, {B(3, Lc, GR * LINE_BYTES), B(5, ctx->F + m_off * F12, F12)}, sc))) return r;
+      // experiment: the FIRST (large) sub-batch's Miller loops run alone once the small ones are done; as two halves on two streams, like nbls_pairing_batch_dev, so that the partly filled
+      // last round of LINES / ACC of one half runs under the other -- measured NO better (profiles/round5_ab_verify2.txt: 12 % worse with the default split, even with a 75 / 25 split),
+      // so the switch NBLS_VERIFY_HALVES=1 is off by default
+      static const bool halves_on = env_long("NBLS_VERIFY_HALVES", 0) != 0;
+      const size_t h = (c == 0 && halves_on && cc >= 2 * ctx->halves_min) ? (((cc / 2) + GR * 64 - 1) / (GR * 64)) * (GR * 64) : cc;   // whole groups, whole wavefronts
+      if (h < cc) {
+        if ((r = ensure_half_stream(ctx))) return r;
+        HIPCHK(hipEventRecord(ctx->ev_half_fork, sc)); HIPCHK(hipStreamWaitEvent(ctx->half_stream, ctx->ev_half_fork, 0));
+      }
+      for (size_t lo = 0; lo < cc; lo += h) {
+        const size_t part = lo ? cc - lo : h, pg = (part + GR - 1) / GR;
+        hipStream_t sh = lo ? ctx->half_stream : sc;
+        if ((r = run(ctx, P_LINES_PQ, part, {B(0, G1 + (o + lo) * 96, 96), B(1, G2 + (o + lo) * 192, 192), B(3, Lc + lo * LINE_BYTES, LINE_BYTES)}, sh))) return r;
+        for (size_t k = part; k < GR * pg; k++) HIPCHK(hipMemcpyAsync(Lc + (lo + k) * LINE_BYTES, ctx->unit_lines, LINE_BYTES, hipMemcpyDeviceToDevice, sh));
+        if ((r = run(ctx, acc, pg, {B(3, Lc + lo * LINE_BYTES, GR * LINE_BYTES), B(5, ctx->F + (m_off + lo / GR) * F12, F12)}, sh))) return r;
+        if (lo) break;
+      }
+      if (h < cc) { HIPCHK(hipEventRecord(ctx->ev_half_join, ctx->half_stream)); HIPCHK(hipStreamWaitEvent(sc, ctx->ev_half_join, 0)); }
       m_off += gg;
       if (c) { HIPCHK(hipEventRecord(evc, sc)); HIPCHK(hipStreamWaitEvent(s, evc, 0)); }      // (enqueued on s behind sub-batch 0's own work)
       o += nc;
