@@ -76,10 +76,12 @@ NBLS_HD void aot_dot_finish(u32* r, u64* acc, const u32 w0, const u32* post, LDS
     const u32 q = (u32)(((u64)(u32)e * 2642610142u) >> 48);
 #endif
     f = boffs - (i32)q;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(f));   // one multiply-add pass with the coefficient offs - q (the optimiser otherwise splits it into offs * P[k] and - q * P[k])
-#endif
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  // one multiply-add per limb with an opaque coefficient: with the weak reduction the optimiser otherwise splits the pass into offs * P[k] and - q * P[k]; without it (round 5) it knows
+  // offs < 16, computes offs * P[k] with a 32-bit multiply and adds it in 64 bits -- two instructions per limb where one v_mad_i64_i32 does (-14 per lane-op with a bias)
+  asm volatile("" : "+v"(f));
+#endif
   if (((FLAGS & AF_OFFS) && !(FLAGS & (AF_MULTSH | AF_MULT3))) || (FLAGS & AF_WRED)) {
 #pragma unroll
     for (int k = 0; k < NL; k++) c[k] = (u64)((i64)c[k] + (i64)f * (i64)(i32)P[k]);
