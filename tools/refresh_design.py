@@ -13,7 +13,7 @@ s = s[:a] + '\n| leg | round 5 | fraction of the MAD32 roofline |\n|---|---|---|
 c = s.index('<!-- r5-cpu-begin -->') + len('<!-- r5-cpu-begin -->'); d = s.index('<!-- r5-cpu-end -->')
 s = s[:c] + '\n' + cpu + '\n' + s[d:]
 rows = run('design_table.py').strip()
-a = s.index('| 4096 | nbls_aot_lines_pq |'); b = s.index('\n\n**173.8 k VALU wave-instructions per pairing**')
+a = s.index('| 4096 | nbls_aot_lines_pq |'); b = s.index('\n\n**172.9 k VALU wave-instructions per pairing**')
 s = s[:a] + rows + s[b:]
 open(p, 'w').write(s)
 print('DESIGN.md refreshed')
