@@ -546,7 +546,8 @@ EXPORT int nbls_pairing_batch_dev(nbls_ctx* ctx, size_t n, const void* d_g1, con
     if (with_final_exp && (r = ensure_scratch(ctx, n))) return r;
     if (!ctx->half_stream && (hipStreamCreateWithFlags(&ctx->half_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_half_fork, hipEventDisableTiming) != hipSuccess ||
                               hipEventCreateWithFlags(&ctx->ev_half_join, hipEventDisableTiming) != hipSuccess)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
-    const size_t h = (n / 2 + 63) & ~(size_t)63;
+    static const size_t split_pct = (size_t)env_long("NBLS_HALVES_SPLIT_PCT", 55);      // size of the first half in per cent: slightly unequal halves do not run phase-locked (profiles/round5_ab_split.txt: 16,384 pairs 6.25 -> 6.14 ms, 65,536 within noise)
+    const size_t h = ((n * split_pct / 100) + 63) & ~(size_t)63;
     HIPCHK(hipEventRecord(ctx->ev_half_fork, s)); HIPCHK(hipStreamWaitEvent(ctx->half_stream, ctx->ev_half_fork, 0));
     ctx->in_halves = true;     // (round 4 compared each HALF with chain_max: calls of 8192..16383 pairs ran their halves chained, the configuration measured as slower)
     r = pairing_core(ctx, h, d_g1, d_g2, with_final_exp, d_out, s, true);
