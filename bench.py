@@ -174,12 +174,10 @@ def main():
         dist.all_gather_into_tensor(everyone, mine)
         ranks_seen = len(set(everyone.cpu().tolist()))
     oracle = oracle_py.load(rebuild=not os.path.exists(os.path.join(ROOT, 'oracle', 'libnbls_oracle.so')))
+    # calls in flight: twelve contexts, whatever the number of steps (an explicit --inflight is taken as given).  Round 4 gave the driver's 20 steps twenty streams (one batch each:
+    # 2.86 against 2.79 M pairings/s for 10 x 2 then); with this round's build the order is the other way round -- 20 steps on 10 / 12 / 14 / 20 contexts: 2.95 / 2.97 / 2.97 / 2.93 M
+    # (medians of two interleaved sweeps, tools/burst_ab.py, profiles/round5_burst_depth.txt): streams that carry two batches are no longer phase-locked with their neighbours
     D = max(1, args.inflight if args.inflight is not None else 12)
-    if args.inflight is None and args.steps < 4 * D and D > 8:   # an explicit --inflight is taken as given
-        # few timed steps (the driver's --steps 20): every stream should carry the same number of batches, or the streams with one batch more finish alone -- and streams
-        # that carry several batches run phase-locked, i.e. like that many large batches one after the other with every phase's tail exposed: take the depth in 8..20 that
-        # leaves the smallest remainder, the larger the better (20 steps: 20 streams x 1 batch, 2.86 M/s against 2.79 M/s for 10 x 2; tools/ab_depth.sh)
-        D = min(range(8, 21), key=lambda d: ((-args.steps) % d, -d))
     pipe = pkg.PairingPipeline(local_rank, D)     # D engine contexts, each with its own stream and scratch (noble-bls12-381_amd/pipeline.py)
     eng = pipe.engines[0]
 
