@@ -45,6 +45,14 @@ if len(sys.argv) > 2 and sys.argv[2] == 'depth':
     for D in (8, 10, 12, 16, 20):
         run('pool default, 240 steps', D, 240, lambda p: None)
     sys.exit(0)
+if len(sys.argv) > 2 and sys.argv[2] == 'd12':
+    for rep in range(3):
+        run('pool default', 12, 20, lambda p: None)
+        run('all chained', 12, 20, lambda p: some(p, 1.0, lambda e: e.set_chain_max(8192)))
+        run('fused Miller below 4096', 12, 20, lambda p: some(p, 1.0, lambda e: e.set_split_miller_min(4097)))
+        run('pool default', 13, 20, lambda p: None)
+        run('pool default', 11, 20, lambda p: None)
+    sys.exit(0)
 for rep in range(2):
     run('pool default (split Miller, unchained)', 20, 20, lambda p: None)
     run('all chained', 20, 20, lambda p: some(p, 1.0, lambda e: e.set_chain_max(8192)))
