@@ -140,7 +140,7 @@ def main():
 
     # the HIP runtime maps streams onto this many hardware queues (default 4): with fewer queues than batches in flight two
     # streams share a queue and their kernels serialise (must be set before the runtime initialises)
-    # One hardware queue per stream in flight (up to twenty, see D below) and no more than 22 in all: from ~24 user queues the process oversubscribes the device's hardware queue
+    # One hardware queue per stream in flight (twelve pool contexts + the streams of the other legs) and no more than 22 in all: from ~24 user queues the process oversubscribes the device's hardware queue
     # slots, and the legs that create further streams after the in-flight contexts (verifyBatch, sign) then pay a queue switch per launch -- with 32: verifyBatch 29.6 instead of
     # 23.4 ms, one verify 7.7 instead of 3.7 ms, sign 17.4 instead of 6.3 ms; with 20 the twenty streams share with the default stream and lose 4 % (tools/ab_queues20.sh,
     # profiles/round4_ab_queues20.txt).

@@ -8,8 +8,8 @@ flight (bench.py; 2.15 M with four, 2.31 M with five, 2.42 M with six, 2.47 M wi
 multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue serialise (eight batches on eight queues: 2.22 M, on
 sixteen queues: 2.50 M), so set GPU_MAX_HW_QUEUES to at least the number of streams -- and to no more than 22: from ~24 user queues a process oversubscribes the hardware queue slots and every launch on the
 surplus queues pays a queue switch (bench.py: 22; tools/ab_queues20.sh) -- in the environment before the runtime initialises when more than three batches are
-kept in flight.  Round 4: 3.0-3.1 M pairings/s with twelve batches in flight; streams that carry several batches each run phase-locked (like that many large batches one after the other), so a short
-burst of k batches is fastest on k streams (20 batches: 2.86 M on twenty streams, 2.79 M on ten).
+kept in flight.  Round 4: 3.0-3.1 M pairings/s with twelve batches in flight.  Round 5: a short burst of 20 batches is as fast on ten to fourteen contexts as on twenty (2.95-2.97 against 2.93 M;
+round 4's build had it the other way round), and any burst that starts on an idle chip loses 3-6 % to the clock ramp (tools/burst_ab.py, bench.py `cold_start`).
 """
 import ctypes as C
 
