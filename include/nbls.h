@@ -220,7 +220,7 @@ int nbls_abi_version(void);
 int nbls_context_device(nbls_ctx* ctx);
 
 /* ---- several calls in flight on ONE device (round 5): `depth` contexts, each with its own stream and scratch, fed round-robin (what noble-bls12-381_amd/pipeline.py does, for C
- * callers).  A 4096-pairing call alone fills the chip one wavefront deep and runs at ~0.27 of the multiply-add roofline; twelve to twenty overlapping calls reach ~0.45.
+ * callers).  A 4096-pairing call alone fills the chip one wavefront deep and runs at ~0.27 of the multiply-add roofline; twelve overlapping calls (nbls_pool_*) reach ~0.45.
  * nbls_pool_pairing_batch_dev enqueues pairing(P_i, Q_i) (reference index.ts:715-722) for n device-resident pairs on the next context's stream and returns at once;
  * *slot (may be NULL) = the context used -- keep one output buffer per slot; nbls_pool_next_slot tells it in advance.  Set GPU_MAX_HW_QUEUES >= depth (and <= 22) in the
  * environment before the HIP runtime initialises: streams that share a hardware queue serialise. */

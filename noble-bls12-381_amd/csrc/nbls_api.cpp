@@ -218,8 +218,8 @@ struct ChainLink { ProgId id; BufList bufs; };
 // ctx->chain_max: items up to which the middle of the final exponentiation runs as one chain (default 8192, NBLS_CHAIN_MAX / NBLS_TUNE_CHAIN_MAX): measured equal to seven
 // launches up to 4096 pairings per call (2.371 against 2.374 ms), slower where a call runs as two halves on two streams (16,384: 6.53 against 6.28 ms), whose launches fill each
 // other's tails -- and slower with calls in flight on other streams for the same reason: a chained wavefront is 427 k instructions long, so the rounds of wavefronts at the end of a
-// burst are coarse (twenty 4096-pairing calls on twenty streams 2.82 against 2.85 M pairings/s, 512 calls twelve deep 3.05 against 3.08 M; tools/ab_chain20.sh).  PairingPipeline
-// (pipeline.py) therefore sets it to 0 for its contexts.
+// burst are coarse (twenty 4096-pairing calls on twenty streams 2.82 against 2.85 M pairings/s, 512 calls twelve deep 3.05 against 3.08 M; tools/ab_chain20.sh).  The pool
+// (nbls_pool_init, nbls_multi.cpp) therefore sets it to 0 for its contexts.
 static bool chains_enabled() { static const bool on = env_long("NBLS_CHAIN", 1) != 0; return on; }
 static int run_chain(nbls_ctx* ctx, size_t n, std::initializer_list<ChainLink> links, hipStream_t s) {
   int r;

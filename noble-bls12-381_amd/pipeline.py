@@ -1,15 +1,13 @@
-"""Batches in flight: D engine contexts on one GPU, each with its own HIP stream and scratch, fed round-robin.
+"""Batches in flight: D engine contexts on one GPU, each with its own HIP stream and scratch, fed round-robin (a thin wrapper over the C-ABI pool, nbls_pool_*).
 
-A call of 4096 pairings fills the chip exactly one wavefront deep (1024 workgroups on 1024 SIMDs), and a lone wavefront
-reaches well under half of a SIMD's issue rate, so one batch at a time leaves most of the machine
-idle.  Consecutive batches are independent, so a service keeps several of them in flight: the kernels of batch i+1 run
-beside those of batch i on other streams.  Throughput at 4096-pairing batches rises from 1.3 M (one call at a time, 3.1 ms each) to 2.5 M pairings/s with seven to twenty batches in
-flight (bench.py; 2.15 M with four, 2.31 M with five, 2.42 M with six, 2.47 M with seven, 2.52 M with ten or twelve, 2.55 M with fourteen).  The HIP runtime
-multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue serialise (eight batches on eight queues: 2.22 M, on
-sixteen queues: 2.50 M), so set GPU_MAX_HW_QUEUES to at least the number of streams -- and to no more than 22: from ~24 user queues a process oversubscribes the hardware queue slots and every launch on the
-surplus queues pays a queue switch (bench.py: 22; tools/ab_queues20.sh) -- in the environment before the runtime initialises when more than three batches are
-kept in flight.  Round 4: 3.0-3.1 M pairings/s with twelve batches in flight.  Round 5: a short burst of 20 batches is as fast on ten to fourteen contexts as on twenty (2.95-2.97 against 2.93 M;
-round 4's build had it the other way round), and any burst that starts on an idle chip loses 3-6 % to the clock ramp (tools/burst_ab.py, bench.py `cold_start`).
+A call of 4096 pairings fills the chip exactly one wavefront deep (1024 workgroups on 1024 SIMDs), and a lone wavefront reaches well under half of a SIMD's
+issue rate, so one batch at a time leaves most of the machine idle.  Consecutive batches are independent, so a service keeps several of
+them in flight: the kernels of batch i+1 run beside those of batch i on other streams.  Round 5, 4096-pairing batches: 1.77 M pairings/s one call at a time
+(2.32 ms each), 3.0-3.1 M with twelve in flight (more contexts add nothing; fewer than seven lose).  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES
+hardware queues (default 4); streams that share a queue serialise, so set GPU_MAX_HW_QUEUES to at least the number of streams -- and to no more than 22: from
+~24 user queues a process oversubscribes the hardware queue slots and every launch on the surplus queues pays a queue switch (bench.py: 22;
+tools/ab_queues20.sh) -- in the environment before the runtime initialises.  A short burst of 20 batches is as fast on ten to fourteen contexts as on twenty
+(2.95-2.97 against 2.93 M), and any burst that starts on an idle chip loses 3-6 % to the clock ramp (tools/burst_ab.py, bench.py `cold_start`).
 """
 import ctypes as C
 
