@@ -696,20 +696,44 @@ def main():
             sg = eng.sign_batch(msgs_, sks_)
             for i in (0, 1, ns_ // 2, ns_ - 1):       # parity spot check against the oracle
                 assert sg[i] == oracle.sign(msgs_[i], sks_[i])[1], 'sign parity check failed'
-            eng.timing_enable(True)
+            # `value`: the C-ABI call from host buffers by itself -- inputs packed and outputs allocated beforehand (round 4 timed the Python marshalling with it, and ONE call with the per-kernel
+            # instrumentation on: 5.9 ms where the call takes 4.9), mean of four calls; `resident`: nbls_sign_batch_dev, messages / keys / signatures in HBM (the verifyBatch leg's convention)
+            import ctypes as C_
+            import numpy as np
+            blob_ = b''.join(msgs_); kblob_ = b''.join(sks_)
+            offs_np = np.zeros(ns_ + 1, dtype=np.uint32); offs_np[1:] = np.cumsum([len(m) for m in msgs_])
+            offs_ = (C_.c_uint32 * (ns_ + 1)).from_buffer(offs_np)
+            out_ = C_.create_string_buffer(192 * ns_); st_ = C_.create_string_buffer(ns_)
+            eng.sign_packed(ns_, blob_, offs_, kblob_, out_, st_)
+            assert eng.compress_batch(out_.raw[:192 * 4], g2=True) == b''.join(sg[:4]) and st_.raw == bytes(ns_), 'sign (packed buffers) differs'
+            sreps = 4
             s0 = time.perf_counter()
-            eng.sign_batch_affine(msgs_, sks_)
-            sdt = time.perf_counter() - s0
+            for _ in range(sreps):
+                eng.sign_packed(ns_, blob_, offs_, kblob_, out_, st_)
+            sdt = (time.perf_counter() - s0) / sreps
+            d_m = torch.frombuffer(bytearray(blob_), dtype=torch.uint8).cuda(); d_o = torch.from_numpy(offs_np.view(np.int32)).cuda(); d_k = torch.frombuffer(bytearray(kblob_), dtype=torch.uint8).cuda()
+            d_so = torch.empty(192 * ns_, dtype=torch.uint8, device='cuda'); d_ss = torch.empty(ns_, dtype=torch.uint8, device='cuda')
+            eng.sign_batch_dev(ns_, d_m.data_ptr(), d_o.data_ptr(), d_k.data_ptr(), d_so.data_ptr(), d_ss.data_ptr())
+            assert bytes(d_so[:192 * 4].cpu().numpy().tobytes()) == out_.raw[:192 * 4] and bytes(d_so[-192:].cpu().numpy().tobytes()) == out_.raw[-192:], 'sign (resident) differs from the host-buffer call'
+            r0 = time.perf_counter()
+            for _ in range(sreps):
+                eng.sign_batch_dev(ns_, d_m.data_ptr(), d_o.data_ptr(), d_k.data_ptr(), d_so.data_ptr(), d_ss.data_ptr())
+            rdt = (time.perf_counter() - r0) / sreps
+            eng.timing_enable(True)
+            eng.sign_batch_dev(ns_, d_m.data_ptr(), d_o.data_ptr(), d_k.data_ptr(), d_so.data_ptr(), d_ss.data_ptr())
             stm = eng.timing_read(); eng.timing_enable(False)
             eng.point_mul_batch(sks_[:64])     # program upload outside the timed call (the verifyBatch leg, when it runs, has done it already)
             k0 = time.perf_counter()
-            eng.point_mul_batch(sks_)
-            kdt = time.perf_counter() - k0
+            for _ in range(sreps):
+                eng.point_mul_batch(sks_)
+            kdt = (time.perf_counter() - k0) / sreps
             c0 = time.perf_counter()
             for i in range(16):
                 oracle.sign(msgs_[i], sks_[i])
             csdt = (time.perf_counter() - c0) / 16
             sleg = {'metric': 'sign sigs/sec: nbls_sign_batch from host buffers (device SHA-256 expand_message_xmd + hash-to-G2 + constant-time G2 ladder + affine), compression not included', 'n': ns_, 'value': round(ns_ / sdt, 2), 'ms': round(sdt * 1e3, 3),
+                    'resident': {'sigs_per_s': round(ns_ / rdt, 2), 'ms': round(rdt * 1e3, 3), 'kernels_ms': round(sum(v_[0] for v_ in stm.values()), 3),
+                                 'note': 'nbls_sign_batch_dev: message bytes, offsets, keys and the affine signatures resident in HBM (as the verify_batch leg); kernels_ms = sum of the HIP-event durations of its launches (separate instrumented call)'},
                     'g2_ladder_kernel_ms': round(sum(stm.get(k_, (0, 0))[0] for k_ in ('g2_mul', 'g2_mul_w3', 'g2_mul_gls')), 3), 'get_public_key_keys_per_s': round(ns_ / kdt, 2),
                     'cpu_baseline': {'value': round(1 / csdt, 2), 'unit': 'sigs/s', 'cores': 1, 'kind': 'port', 'sample': '16 signatures on one host thread (oracle/)'}}
         aleg = None

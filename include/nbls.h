@@ -178,6 +178,12 @@ int nbls_msm_dev(nbls_ctx* ctx, int g2, size_t n, const void* d_pts, const void*
  * Messages as in nbls_hash_to_g2_batch. */
 int nbls_sign_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len,
                     const uint8_t* keys32, uint8_t* out192, int8_t* status);
+/* Same with everything resident in device memory (round 5): message bytes, n + 1 uint32 offsets into them, 32-byte big-endian keys -> n affine points (192 B) and n status
+ * bytes in device memory; SHA-256 expand_message_xmd, hash-to-G2 and the ladder run as one chain on `stream` (NULL = the context's).  status: 0 ok, 1 the result is the zero
+ * point, i.e. the key is 0 mod r (the host-buffer call reports 5 there, as normalizePrivKey's message demands; keys >= r are reduced, index.ts:269-279).  Synchronises;
+ * NBLS_EINVAL if the offsets decrease somewhere. */
+int nbls_sign_batch_dev(nbls_ctx* ctx, size_t n, const void* d_msgs, const void* d_offsets, const uint8_t* dst, size_t dst_len,
+                        const void* d_keys32, void* d_out192, void* d_status, void* stream);
 
 /* verifyBatch(signature, messages, publicKeys) on wire inputs -- reference index.ts:792-821 with every message distinct.
  * *ok = 1/0; returns NBLS_EDECODE where the reference throws while decoding its arguments. */

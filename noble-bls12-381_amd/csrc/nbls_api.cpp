@@ -65,6 +65,8 @@ struct nbls_ctx {
   // general scratch pool for the codec / hash / sum pipelines (grown on demand)
   static const int NSB = 20;
   uint8_t* sb[NSB] = {nullptr}; size_t sb_cap[NSB] = {0};
+  // staging buffers of the host-buffer entry points (HostIO): kept between calls -- a hipMalloc / hipFree pair per buffer and call cost more than the copies at small batches
+  struct IoBlock { void* p; size_t cap; bool busy; }; std::vector<IoBlock> io_pool; size_t io_pool_bytes = 0;
   uint8_t* nib[4] = {nullptr, nullptr, nullptr, nullptr}; int nnib[4] = {0, 0, 0, 0};   // op lists (pow_exec.h) of the exponents (p+1)/4, (p^2+7)/16, (p^2-9)/16, (p-3)/4 and their lengths in ops
   uint8_t* neg_g1 = nullptr;    // -G1 generator, affine wire bytes (verify: e(-G, S))
   uint8_t* gen_g1 = nullptr;    // G1 generator, affine wire bytes (getPublicKey)
@@ -496,6 +498,7 @@ EXPORT void nbls_destroy(nbls_ctx* ctx) {
   for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->gen_g1, ctx->g1_fixed, ctx->side_scratch, ctx->L, ctx->partial, ctx->unit_lines, ctx->KS, ctx->KD, ctx->Kflag, (uint8_t*)ctx->Klist, (uint8_t*)ctx->Kcount}) if (p) hipFree(p);
   for (uint8_t* p : ctx->T) if (p) hipFree(p);
   for (uint8_t* p : ctx->sb) if (p) hipFree(p);
+  for (auto& b : ctx->io_pool) if (b.p) hipFree(b.p);
   for (uint8_t* p : ctx->nib) if (p) hipFree(p);
   if (ctx->qp_table) hipFree(ctx->qp_table);
   for (uint8_t* p : {ctx->neg_g1, ctx->ident_g1, ctx->ident_g2}) if (p) hipFree(p);
@@ -927,10 +930,33 @@ static int dev_point_sum(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, vo
 }
 
 // ---- host-buffer wrappers ------------------------------------------------------------------------------------
-struct HostIO {   // staging buffers on the device for one call
-  nbls_ctx* ctx; std::vector<void*> bufs;
-  ~HostIO() { for (void* p : bufs) hipFree(p); }
-  void* alloc(size_t n) { void* p = nullptr; if (hipMalloc(&p, n ? n : 1) != hipSuccess) return nullptr; bufs.push_back(p); return p; }
+// Staging buffers on the device for one host-buffer call.  Round 5: taken from a pool the context keeps (best fit among the free blocks of at most four times the size; a miss
+// allocates) and handed back when the call returns -- every such call ends with a stream synchronisation and holds the context's mutex throughout, so a block is never reused while
+// the device still works on it.  The pool is capped (NBLS_IO_POOL_MB, default 1024): free blocks are released oldest first when it would grow past the cap.
+struct HostIO {
+  nbls_ctx* ctx; std::vector<size_t> mine;
+  ~HostIO() { for (size_t i : mine) ctx->io_pool[i].busy = false; }
+  void* alloc(size_t n) {
+    if (!n) n = 1;
+    auto& pool = ctx->io_pool;
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < pool.size(); i++)
+      if (!pool[i].busy && pool[i].p && pool[i].cap >= n && pool[i].cap / 4 <= n && (best == (size_t)-1 || pool[i].cap < pool[best].cap)) best = i;
+    if (best != (size_t)-1) { pool[best].busy = true; mine.push_back(best); return pool[best].p; }
+    static const size_t cap_bytes = (size_t)env_long("NBLS_IO_POOL_MB", 1024) << 20;
+    const size_t cap = n + n / 8 + 256;
+    for (size_t i = 0; i < pool.size() && ctx->io_pool_bytes + cap > cap_bytes; i++)
+      if (!pool[i].busy && pool[i].p) { hipFree(pool[i].p); ctx->io_pool_bytes -= pool[i].cap; pool[i].p = nullptr; pool[i].cap = 0; }
+    void* p = nullptr;
+    if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    ctx->io_pool_bytes += cap;
+    size_t slot = (size_t)-1;
+    for (size_t i = 0; i < pool.size(); i++) if (!pool[i].p) { slot = i; break; }
+    if (slot == (size_t)-1) { pool.push_back({nullptr, 0, false}); slot = pool.size() - 1; }
+    pool[slot] = {p, cap, true};
+    mine.push_back(slot);
+    return p;
+  }
 };
 #define LOCKED(ctx) std::lock_guard<std::recursive_mutex> g_((ctx)->mu); HIPCHK(hipSetDevice((ctx)->device)); hipStream_t s = (ctx)->stream
 
@@ -1449,6 +1475,45 @@ EXPORT int nbls_sign_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const u
   return NBLS_OK;
 }
 
+// The domain-separation tag of the device-resident hash entry points, kept on the device between calls (a service works under one tag): no copy, no synchronisation in the steady
+// state.  A DST longer than 255 bytes is replaced by its SHA-256 digest (RFC 9380 5.3.3), as in dev_expand and the reference's expand_message_xmd (index.ts:207-231).
+static int dst_on_device(nbls_ctx* ctx, const uint8_t* dst, size_t* dst_len, hipStream_t s, uint8_t** dd) {
+  uint8_t dst_hash[32];
+  if (*dst_len > 255) { Sha256 c; c.update((const uint8_t*)"H2C-OVERSIZE-DST-", 17); c.update(dst, *dst_len); c.final(dst_hash); dst = dst_hash; *dst_len = 32; }
+  std::lock_guard<std::recursive_mutex> g_(ctx->mu); HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->dst_dev) HIPCHK(hipMalloc(&ctx->dst_dev, 256));
+  if (ctx->dst_host.size() != *dst_len || memcmp(ctx->dst_host.data(), dst, *dst_len)) {
+    HIPCHK(hipStreamSynchronize(s));   // an earlier call may still read the old tag
+    HIPCHK(hipMemcpy(ctx->dst_dev, dst, *dst_len, hipMemcpyHostToDevice));
+    ctx->dst_host.assign(dst, dst + *dst_len);
+  }
+  *dd = ctx->dst_dev;
+  return NBLS_OK;
+}
+// sign with everything resident in HBM (round 5): message bytes + offsets, 32-byte keys -> affine signature points and status bytes; SHA-256 expand_message_xmd, hash-to-G2 and
+// the constant-time ladder in one chain on `stream`.  Synchronises (the offsets are validated by the hashing kernel and the verdict is read back).  index.ts:744-752.
+EXPORT int nbls_sign_batch_dev(nbls_ctx* ctx, size_t n, const void* d_msgs, const void* d_offsets, const uint8_t* dst, size_t dst_len, const void* d_keys32, void* d_out192, void* d_status, void* stream) {
+  std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);
+  if (!ctx || (n && (!d_offsets || !d_keys32 || !d_out192 || !d_status || !dst))) return NBLS_EINVAL;
+  if (!n) return NBLS_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  uint8_t* dd; int r;
+  if ((r = dst_on_device(ctx, dst, &dst_len, s, &dd))) return r;
+  StreamOrder order_(ctx, s);
+  HostIO io{ctx}; void* h = io.alloc(n * 192); if (!h) return NBLS_EHIP;
+  uint8_t* du;
+  if ((r = need(ctx, 8, n * 256 + 16, &du))) return r;
+  uint32_t* d_bad = (uint32_t*)(du + n * 256);
+  HIPCHK(hipMemsetAsync(d_bad, 0, 4, s));
+  const int e = nbls_xmd_launch((unsigned)n, (const uint8_t*)d_msgs, (const uint8_t*)d_offsets, dd, (unsigned)dst_len, du, 256, d_bad, s);
+  if (e) { ctx->last_hip = e; return NBLS_EHIP; }
+  if ((r = dev_hash_to_g2(ctx, n, du, h, s))) return r;
+  if ((r = dev_point_mul(ctx, true, n, h, 192, d_keys32, d_out192, d_status, s, true, true))) return r;      // H(m) is in G2: the ladder may split the key along psi
+  uint32_t bad = 0; HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+  return bad ? NBLS_EINVAL : NBLS_OK;     // offsets[i + 1] < offsets[i] somewhere
+}
+
 // ---- verifyBatch as concurrent sub-batches (round 5) ------------------------------------------------------------------------------------------------------
 // Round 4 ran the call in two phases -- decode the keys and hash every message (12.5 ms at 65,536 signatures, most of it ONE chain of dependent launches), read the
 // statuses back, then the Miller product of all pairs (9.1 ms) -- and three such calls in flight took 18.4 ms each instead of 22.8: every launch of the chain leaves issue
@@ -1672,21 +1737,7 @@ EXPORT int nbls_verify_batch_msgs_dev(nbls_ctx* ctx, size_t n, const void* d_sig
   std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);
   if (!ctx || !ok || !n || !d_sig96 || !d_offsets || !d_pk48 || !dst) return NBLS_EINVAL;
   uint8_t* dd;
-  // a DST longer than 255 bytes is replaced by its SHA-256 digest (RFC 9380 5.3.3), as in dev_expand and the reference's expand_message_xmd (index.ts:207-231)
-  uint8_t dst_hash[32];
-  if (dst_len > 255) { Sha256 c; c.update((const uint8_t*)"H2C-OVERSIZE-DST-", 17); c.update(dst, dst_len); c.final(dst_hash); dst = dst_hash; dst_len = 32; }
-  {
-    std::lock_guard<std::recursive_mutex> g_(ctx->mu); HIPCHK(hipSetDevice(ctx->device));
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    // the domain-separation tag is kept on the device between calls (a service verifies under one tag): no copy, no synchronisation in the steady state
-    if (!ctx->dst_dev) HIPCHK(hipMalloc(&ctx->dst_dev, 256));
-    if (ctx->dst_host.size() != dst_len || memcmp(ctx->dst_host.data(), dst, dst_len)) {
-      HIPCHK(hipStreamSynchronize(s));   // an earlier call may still read the old tag
-      HIPCHK(hipMemcpy(ctx->dst_dev, dst, dst_len, hipMemcpyHostToDevice));
-      ctx->dst_host.assign(dst, dst + dst_len);
-    }
-    dd = ctx->dst_dev;
-  }
+  { const int r = dst_on_device(ctx, dst, &dst_len, stream ? (hipStream_t)stream : ctx->stream, &dd); if (r) return r; }
   if (verify_pipe_enabled()) {
     VerifyIn in{d_sig96, nullptr, d_msgs, d_offsets, dd, (unsigned)dst_len, d_pk48};
     std::vector<int8_t> st; uint8_t out[576]; int bad = 0;

@@ -63,6 +63,7 @@ def load_library():
     lib.nbls_g2_msm.argtypes = [vp, sz, vp, vp, vp, vp]
     lib.nbls_msm_dev.argtypes = [vp, i32, sz, vp, vp, C.c_uint32, vp, vp, vp]
     lib.nbls_sign_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, vp]
+    lib.nbls_sign_batch_dev.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, vp, vp]
     lib.nbls_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, sz, C.POINTER(i32)]
     lib.nbls_verify_batch_dev_inputs.argtypes = [vp, sz, vp, vp, vp, C.POINTER(i32), vp, vp]
     lib.nbls_verify_batch_msgs_dev.argtypes = [vp, sz, vp, vp, vp, vp, vp, sz, C.POINTER(i32), vp]
@@ -334,6 +335,14 @@ class Engine:
         out = C.create_string_buffer(max(192 * n, 1)); st = C.create_string_buffer(max(n, 1))
         self._chk(self.lib.nbls_sign_batch(self.h, n, blob, offs, dst, len(dst), b''.join(keys), out, st))
         return out.raw[:192 * n], st.raw[:n]
+
+    def sign_batch_dev(self, n, d_msgs, d_offsets, d_keys32, d_out192, d_status, dst=DST_DEFAULT, stream=None):
+        """nbls_sign_batch_dev: everything resident in device memory (pointers as integers); synchronises"""
+        self._chk(self.lib.nbls_sign_batch_dev(self.h, n, C.c_void_p(d_msgs), C.c_void_p(d_offsets), dst, len(dst), C.c_void_p(d_keys32), C.c_void_p(d_out192), C.c_void_p(d_status), stream))
+
+    def sign_packed(self, n, blob, offs, keys_blob, out, st, dst=DST_DEFAULT):
+        """nbls_sign_batch on buffers the caller has already packed (message bytes, ctypes uint32 offsets, n * 32 key bytes) into preallocated ctypes outputs: the C-ABI call by itself"""
+        self._chk(self.lib.nbls_sign_batch(self.h, n, blob, offs, dst, len(dst), keys_blob, out, st))
 
     def sign_batch(self, msgs, keys, dst=DST_DEFAULT):
         """sign(msg_i, key_i) -> list of 96-byte compressed signatures"""

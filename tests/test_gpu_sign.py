@@ -78,3 +78,42 @@ def test_sign_then_verify_batch(eng):
     assert z == 0
     assert eng.verify_batch(eng.compress_g2(agg), msgs, pks) is True
     assert eng.verify_batch(eng.compress_g2(agg), msgs[::-1], pks) is False
+
+
+def test_sign_with_everything_resident_in_hbm(eng, testdata):
+    """nbls_sign_batch_dev (round 5): messages, offsets and keys in device memory -> affine points and status bytes in device memory, against the reference's 559 sign vectors
+    (ragged message lengths, the empty message among them); a key that is 0 mod r gives the zero point and status 1; decreasing offsets are refused; staging buffers are reused
+    between host-buffer calls of different sizes (the pooled HostIO) without mixing results up"""
+    import numpy as np
+    import torch
+    pkg = importlib.import_module('noble-bls12-381_amd')
+    vs = testdata['sign_vectors']
+    msgs = [hx(v[1]) for v in vs] + [b'', b'zero-key']
+    keys = [hx(v[0]) for v in vs] + [(7).to_bytes(32, 'big'), R.to_bytes(32, 'big')]
+    n = len(msgs)
+    offs = np.zeros(n + 1, dtype=np.uint32); offs[1:] = np.cumsum([len(m) for m in msgs])
+    d_msgs = torch.frombuffer(bytearray(b''.join(msgs) + b'\0'), dtype=torch.uint8).cuda()
+    d_offs = torch.from_numpy(offs.view(np.int32)).cuda()
+    d_keys = torch.frombuffer(bytearray(b''.join(keys)), dtype=torch.uint8).cuda()
+    d_out = torch.empty(192 * n, dtype=torch.uint8, device='cuda'); d_st = torch.full((n,), 77, dtype=torch.uint8, device='cuda')
+    eng.sign_batch_dev(n, d_msgs.data_ptr(), d_offs.data_ptr(), d_keys.data_ptr(), d_out.data_ptr(), d_st.data_ptr())
+    out = bytes(d_out.cpu().numpy().tobytes()); st = bytes(d_st.cpu().numpy().tobytes())
+    assert st == bytes(n - 1) + bytes([1])
+    sigs = eng.compress_batch(out[:192 * (n - 1)], g2=True)
+    for i, v in enumerate(vs):
+        assert sigs[96 * i:96 * i + 96] == hx(v[2]), i
+    assert sigs[96 * (n - 2):96 * (n - 1)] == eng.sign_batch([b''], [(7).to_bytes(32, 'big')])[0]
+    # a second stream, and a sub-range of the same buffers
+    s2 = torch.cuda.Stream()
+    d_out2 = torch.empty(192 * 100, dtype=torch.uint8, device='cuda'); d_st2 = torch.empty(100, dtype=torch.uint8, device='cuda')
+    eng.sign_batch_dev(100, d_msgs.data_ptr(), d_offs.data_ptr(), d_keys.data_ptr(), d_out2.data_ptr(), d_st2.data_ptr(), stream=s2.cuda_stream)
+    assert bytes(d_out2.cpu().numpy().tobytes()) == out[:192 * 100]
+    bad = offs.copy(); bad[5] = bad[6] + 3
+    d_bad = torch.from_numpy(bad.view(np.int32)).cuda()
+    with pytest.raises(pkg.NblsError):
+        eng.sign_batch_dev(n, d_msgs.data_ptr(), d_bad.data_ptr(), d_keys.data_ptr(), d_out.data_ptr(), d_st.data_ptr())
+    # pooled staging buffers: host-buffer calls of changing sizes interleaved, every result as before
+    ref = [hx(v[2]) for v in vs]
+    for k in (3, 200, 17, 559, 64, 1):
+        assert eng.sign_batch([hx(v[1]) for v in vs[:k]], [hx(v[0]) for v in vs[:k]]) == ref[:k]
+        assert eng.get_public_keys([hx(v[0]) for v in vs[:k]])[0] == eng.get_public_keys([hx(vs[0][0])])[0]
