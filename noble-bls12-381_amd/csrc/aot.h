@@ -46,7 +46,7 @@
   X(2, g1_dec, P_G1_DEC_A, P_G1_DEC_B, P_COUNT, P_COUNT)                     \
   X(2, g2_dec, P_G2_DEC_A, P_G2_DEC_B, P_COUNT, P_COUNT)                     \
   X(2, g2_to_affine, P_G2_TO_AFFINE, P_G2_NORM, P_G2_TO_PROJ, P_G2_ADD2)     \
-  X(3, g2_mul, P_G2_MUL, P_G2_MUL_W3, P_G2_MUL_GLS, P_COUNT)              \
+  X(3, g2_mul, P_G2_MUL, P_G2_MUL_W3, P_G2_MUL_GLS, P_G2_MUL_SAC)         \
   X(3, g1_mul, P_G1_MUL, P_G1_MUL_W3, P_G1_MUL_FIXED, P_COUNT)               \
   X(4, g1_validate, P_G1_VALIDATE, P_COUNT, P_COUNT, P_COUNT)                \
   X(4, g2_validate, P_G2_VALIDATE, P_COUNT, P_COUNT, P_COUNT)                \

@@ -303,6 +303,31 @@ static inline Pt<SFp2> pt_mul_gls_g2(const Pt<SFp2>& q, const SFp a_raw[4]) {
   }
   return r;
 }
+// The same multiplication with ONE addition per bit (round 5, launches of at most one wavefront per SIMD, where the length of the instruction stream is the time): the four digits are
+// recoded SIGN-ALIGNED (Faz-Hernandez, Longa, Sanchez 2013, "GLV-SAC"; msm_kernels.hip sac_recode_kernel): with a0 odd, a0 = sum_i s_i 2^i over 66 digits s_i = +-1 (s_65 = +1), and
+// a_j = sum_i s_i e_ji 2^i with e_ji in {0, 1} for j = 1 .. 3, so   [k]Q = sum_i 2^i s_i (Q0 + e_1i Q1 + e_2i Q2 + e_3i Q3),  Q0 = Q, Q1 = -psi(Q), Q2 = psi^2(Q), Q3 = -psi^3(Q):
+// a table of the eight sums Q0 + ..., per bit one doubling, one entry picked by masked selects on (e_3i, e_2i, e_1i), its y negated under the mask of s_i, one complete addition --
+// 65 doublings + 66 additions + 7 for the table where the windowed form spends 66 + 132.  An even a0 is recoded as a0 + 1 and Q0 is subtracted at the end (both results are computed,
+// one is selected).  rc[0]: bits 0 .. 65 = (s_i == +1), bit 66 = "a0 was even"; rc[j]: bit i = e_ji.  The table costs 48 slots (101 with the working set: three workgroups per CU): the form for launches whose wavefronts are all resident at once (6144 keys), the wrong one for dense launches.
+static inline Pt<SFp2> pt_mul_sac_g2(const Pt<SFp2>& q, const SFp rc[4]) {
+  const Pt<SFp2> Q0 = pt_mat(q), Q1 = pt_mat(pt_neg(psi_proj(Q0))), Q2 = pt_mat(psi2_proj(Q0)), Q3 = pt_mat(pt_neg(psi_proj(Q2)));
+  Pt<SFp2> T[8];
+  T[0] = Q0; T[1] = pt_add(Q0, Q1); T[2] = pt_add(Q0, Q2); T[3] = pt_add(T[1], Q2);
+  for (int j = 0; j < 4; j++) T[4 + j] = pt_add(T[j], Q3);
+  auto pick = [&](int i) {
+    const SFp e1 = bit_flag(rc[1], i), e2 = bit_flag(rc[2], i), e3 = bit_flag(rc[3], i);
+    Pt<SFp2> lo = pt_sel<SFp2>(e2, pt_sel<SFp2>(e1, T[3], T[2]), pt_sel<SFp2>(e1, T[1], T[0]));
+    Pt<SFp2> hi = pt_sel<SFp2>(e2, pt_sel<SFp2>(e1, T[7], T[6]), pt_sel<SFp2>(e1, T[5], T[4]));
+    return pt_sel<SFp2>(e3, hi, lo);
+  };
+  Pt<SFp2> r = pick(65);
+  for (int i = 64; i >= 0; i--) {
+    Pt<SFp2> v = pick(i);
+    v.y = sel<SFp2>(bit_flag(rc[0], i), v.y, -v.y);
+    r = pt_add(pt_dbl(r), v);
+  }
+  return pt_sel<SFp2>(bit_flag(rc[0], 66), pt_add(r, pt_neg(Q0)), r);
+}
 // PointG2.clearCofactor (index.ts:659-672)
 // The same in two halves around the second multiplication by x, chained through HBM so that neither program keeps more than the ladder's base,
 // its running point and their temporaries live (26 slots instead of 38: twelve wavefronts per CU instead of six -- the one-program form ran at

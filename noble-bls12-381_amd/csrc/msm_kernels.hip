@@ -76,6 +76,40 @@ __global__ void msm_decompose_kernel(u32 n, u32 dims, const uint8_t* __restrict_
   }
 }
 
+// The four digits recoded SIGN-ALIGNED for the one-addition-per-bit ladder of sign (codec.h pt_mul_sac_g2; Faz-Hernandez, Longa, Sanchez 2013): with a0 made odd (a0 + 1 when even:
+// the ladder subtracts Q again), a0 = sum_i s_i 2^i over 66 digits s_i = +-1 with s_i = 2 bit_(i+1)(a0) - 1 and s_65 = +1; every other digit is rewritten over the same signs,
+// a_j = sum_i s_i e_ji 2^i with e_ji = a_j mod 2 and a_j <- (a_j >> 1) + (e_ji and s_i = -1).  Output per scalar, 4 x 32 bytes big-endian: [bits 0..65: s_i = +1, bit 66: a0 was even],
+// then the bits e_1i, e_2i, e_3i.  Branch-free: the scalars are secret keys.
+__global__ void msm_sac_kernel(u32 n, const uint8_t* __restrict__ scalars, uint8_t* __restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32* k = (const u32*)(scalars + 32ull * i);
+  u64 l[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) l[j] = ((u64)__builtin_bswap32(k[6 - 2 * j]) << 32) | __builtin_bswap32(k[7 - 2 * j]);
+  u64 alo[4], ahi[4];
+  alo[0] = div_step(l, 4); alo[1] = div_step(l, 4); alo[2] = div_step(l, 3); alo[3] = l[0];
+  ahi[0] = ahi[1] = ahi[2] = 0; ahi[3] = l[1];
+  const u64 even = (alo[0] & 1) ^ 1;
+  alo[0] |= 1;
+  // signs: bit i of (slo, shi) set <=> s_i = +1
+  const u64 slo = alo[0] >> 1, shi = 2;          // bits 63, 64 clear (a0 < 2^64), bit 65 set
+  uint8_t* o = out + 128ull * i;
+  store_be(o, slo, shi | (even << 2), 0);
+  for (int j = 1; j < 4; j++) {
+    u64 lo = alo[j], hi = ahi[j], elo = 0, ehi = 0;
+    for (int b = 0; b < 66; b++) {
+      const u64 e = lo & 1;
+      const u64 sp = b < 64 ? (slo >> b) & 1 : (shi >> (b - 64)) & 1;
+      if (b < 64) elo |= e << b; else ehi |= e << (b - 64);
+      lo = (lo >> 1) | (hi << 63); hi >>= 1;
+      const u64 inc = e & (sp ^ 1);
+      lo += inc; hi += (u64)(lo < inc);
+    }
+    store_be(o + 32 * j, elo, ehi, 0);
+  }
+}
+
 // dst[j] = src[idx[j]]   (q = 16-byte vectors per element)
 __global__ void msm_gather_kernel(u64 m, u32 q, const u32* __restrict__ idx, const uint4* __restrict__ src, uint4* __restrict__ dst) {
   const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -174,6 +208,10 @@ int nbls_msm_keys_launch(unsigned n, unsigned nwin, const void* scalars, void* k
 }
 int nbls_msm_decompose_launch(unsigned n, unsigned dims, const void* scalars, void* out, void* stream) {
   hipLaunchKernelGGL(msm_decompose_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, n, dims, (const uint8_t*)scalars, (uint8_t*)out);
+  return (int)hipGetLastError();
+}
+int nbls_msm_sac_launch(unsigned n, const void* scalars, void* out, void* stream) {
+  hipLaunchKernelGGL(msm_sac_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, n, (const uint8_t*)scalars, (uint8_t*)out);
   return (int)hipGetLastError();
 }
 // temp == NULL: returns the scratch size in *temp_bytes

@@ -575,6 +575,15 @@ static Program build(ProgId id) {
       B.sched_window = env_int("NBLS_G2GLS_WINDOW", 300);
       return B.compile("g2_mul_gls", G2MUL_W);
     }
+    case P_G2_MUL_SAC: {
+      SFp2 x = input_fp2(1, 0), y = input_fp2(1, 96);
+      SFp rc[4]; for (int i = 0; i < 4; i++) rc[i] = input_raw(2, 32 * i, 32);
+      Pt<SFp2> r = pt_mul_sac_g2(pt_affine(x, y), rc);
+      outputw(r.x.c0, 3, 0); outputw(r.x.c1, 3, 48); outputw(r.y.c0, 3, 96); outputw(r.y.c1, 3, 144); outputw(r.z.c0, 3, 192); outputw(r.z.c1, 3, 240);
+      outputw(sqr(r.z.c0) + sqr(r.z.c1), 4, 0);
+      B.sched_window = env_int("NBLS_G2SAC_WINDOW", 300);
+      return B.compile("g2_mul_sac", G2MUL_W);
+    }
     case P_G1_MUL_FIXED: {
       SFp k = input_raw(2, 0, 32);
       Pt<SFp> r = pt_mul_fixed_g1(k, 5);

@@ -483,6 +483,7 @@ Program Builder::compile(const std::string& name, int W) {
       if (free_slots.empty()) nodes[c].slot = nslots++; else { nodes[c].slot = free_slots.back(); free_slots.pop_back(); }
       if (nodes[c].last_use < 0) free_slots.push_back(nodes[c].slot);   // defensive: result never read
     }
+    if (env_set("NBLS_DUMP_LIVE")) fprintf(stderr, "%s live step %zu kind=%d slots_in_use=%d\n", name.c_str(), s, step_nodes[s].empty() ? -1 : (int)nodes[step_nodes[s][0]].kind, nslots - (int)free_slots.size());
   }
   P.slots = nslots;
   P.nconst = (u32)const_words.size() / SLOT_WORDS;

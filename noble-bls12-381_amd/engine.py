@@ -406,6 +406,10 @@ class Engine:
         """items below which the middle of the final exponentiation is one chained launch (NBLS_TUNE_CHAIN_MAX; default 8192, 0: one launch per program)"""
         self._chk(self.lib.nbls_set_tuning(self.h, 4, n))
 
+    def set_sac_max(self, n):
+        """keys up to which sign's ladder is the sign-aligned one-addition-per-bit form (NBLS_TUNE_SAC_MAX; default 6144, 0: the windowed psi-split ladder at every size)"""
+        self._chk(self.lib.nbls_set_tuning(self.h, 8, n))
+
     def set_verify_pipeline(self, chunks=None, last_pct=None, pipe_min=None):
         """verifyBatch as a software pipeline (NBLS_TUNE_VERIFY_CHUNKS / _LAST_PCT / _PIPE_MIN): number of chunks (0 / 1: one), size of the last chunk in
         per cent of the batch, signatures from which a call is chunked at all"""

@@ -100,3 +100,9 @@ def test_gls_ladder_translated(sim, oracle):
     """sign's psi-split ladder (round 5) through its ahead-of-time translation"""
     assert sim.nbls_sim_has_aot(vmsim_py.P['G2_MUL_GLS']) == 1
     T.test_gls_ladder_for_subgroup_points(sim, oracle)
+
+
+def test_sign_aligned_ladder_translated(sim, oracle):
+    """sign's one-addition-per-bit ladder (round 5, pt_mul_sac_g2) through its ahead-of-time translation"""
+    assert sim.nbls_sim_has_aot(vmsim_py.P['G2_MUL_SAC']) == 1
+    T.test_sign_aligned_ladder_for_subgroup_points(sim, oracle)

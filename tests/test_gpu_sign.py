@@ -117,3 +117,21 @@ def test_sign_with_everything_resident_in_hbm(eng, testdata):
     for k in (3, 200, 17, 559, 64, 1):
         assert eng.sign_batch([hx(v[1]) for v in vs[:k]], [hx(v[0]) for v in vs[:k]]) == ref[:k]
         assert eng.get_public_keys([hx(v[0]) for v in vs[:k]])[0] == eng.get_public_keys([hx(vs[0][0])])[0]
+
+
+def test_both_ladders_of_sign(eng, testdata, oracle):
+    """sign's two ladders for points of G2 (csrc/nbls_api.cpp dev_point_mul): the sign-aligned one-addition-per-bit form (up to 6144 keys) and the windowed psi-split form (above) on the
+    reference's 559 sign vectors and on structured keys -- even / odd low digit, digits rolling over at powers of |z|, r - 1, r + 1, 2^256 - 1 -- against the oracle"""
+    vs = testdata['sign_vectors']
+    Z = 0xd201000000010000
+    ks = [1, 2, 3, 4, Z - 1, Z, Z + 1, Z * Z - 1, Z * Z, Z ** 3, Z ** 3 - 1, R - 1, R + 1, (1 << 256) - 1, (1 << 256) - 2, (1 << 255) + 12345]
+    msgs = [b'structured-%d' % i for i in range(len(ks))]
+    want = [oracle.sign(m, (k % R).to_bytes(32, 'big'))[1] for m, k in zip(msgs, ks)]
+    try:
+        for sac_max in (0, 6144):
+            eng.set_sac_max(sac_max)
+            sigs = eng.sign_batch([hx(v[1]) for v in vs], [hx(v[0]) for v in vs])
+            assert sigs == [hx(v[2]) for v in vs], sac_max
+            assert eng.sign_batch(msgs, [k.to_bytes(32, 'big') for k in ks]) == want, sac_max
+    finally:
+        eng.set_sac_max(6144)

@@ -268,6 +268,24 @@ def test_gls_ladder_for_subgroup_points(sim, oracle):
     assert st[0] == 1
 
 
+def test_sign_aligned_ladder_for_subgroup_points(sim, oracle):
+    """sign's ladder for launches of at most one wavefront per SIMD (round 5, csrc/codec.h pt_mul_sac_g2: the digits recoded sign-aligned, one addition per bit from a table of eight)
+    against the oracle: keys whose a0 is even / odd, digits rolling over, extreme digits (a3 of 65 bits), r - 1, r + 1, r (the zero point), random ones"""
+    import random
+    r = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    Z = 0xd201000000010000
+    rnd = random.Random(778)
+    ks = [1, 2, 3, 4, Z - 1, Z, Z + 1, Z * Z - 1, Z * Z, Z ** 3, Z ** 3 - 1, r - 1, r + 1, (1 << 256) - 1, (1 << 256) - 2, (1 << 255) + 12345, (Z - 1) * (1 + Z + Z * Z) + (Z ** 3) * ((1 << 64) - 1)] + [rnd.randrange(1, r) for _ in range(3)]
+    g2 = oracle.g2_generator()
+    q = oracle.g2_mul(g2, 0x1234567890abcdef1234567)[1]
+    pts = b''.join([g2, q] * (len(ks) // 2))
+    out, st = vmsim_py.point_mul_sac(sim, pts, b''.join(k.to_bytes(32, 'big') for k in ks))
+    for i, k in enumerate(ks):
+        assert st[i] == 0 and out[192 * i:192 * i + 192] == oracle.g2_mul(pts[192 * i:192 * i + 192], k % r)[1], (i, hex(k))
+    out, st = vmsim_py.point_mul_sac(sim, g2 + g2, r.to_bytes(32, 'big') + (2 * r).to_bytes(32, 'big'))       # k = r, 2r: the zero point
+    assert st[0] == 1 and st[1] == 1
+
+
 def test_msm_pipeline(sim, oracle):
     """the bucket-method multi-scalar multiplication (dev_msm in csrc/nbls_api.cpp: sort by window digit, segmented sums,
     bit-sliced bucket weighting, Horner over the windows) with its step programs on the simulator, against the oracle's

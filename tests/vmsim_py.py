@@ -17,7 +17,7 @@ def raw_elem(v):
 
 
 PROGS = ['MILLER_BYTES', 'MILLER_RAW', 'MILLER_FE', 'NORM_RAW', 'NORM_BYTES', 'FE_EASY', 'EXPX', 'FE_MID1', 'FE_MID2', 'FE_FINAL', 'MUL2', 'RAW_TO_BYTES', 'G1_VALIDATE', 'G2_VALIDATE', 'G1_DEC_A', 'G1_DEC_B', 'G2_DEC_A', 'G2_DEC_B', 'H2C_A', 'H2C_B',
-         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'G1_COMPRESS', 'G2_COMPRESS', 'H2C1_A', 'ENC1_A', 'H2C1_B', 'ENC1_B', 'G1_CLEAR', 'ENC2_A', 'ENC2_B', 'G1_MUL', 'G2_MUL', 'G1_ADD_AB', 'G2_ADD_AB', 'G1_HORNER', 'G2_HORNER', 'G1_SHIFTADD', 'G2_SHIFTADD', 'G1_MSM_PREP', 'G2_MSM_PREP', 'LINES_PQ', 'LINES_Q', 'LINES_BYTES', 'LINES_FROM_BYTES', 'ACC_BYTES', 'ACC_RAW', 'ACC_FE', 'ACC2_RAW', 'ACC_Q', 'G2_DEC_A192', 'G2_DEC_B192', 'G2_DEC_B_HEX', 'G1_FROM_RAW', 'G2_FROM_RAW', 'G2_SWAP', 'H2C_C1', 'H2C_C2', 'ACC4_RAW', 'MILLER_BYTES_LS', 'MILLER_RAW_LS', 'MILLER_FE_LS', 'EXPX_LS', 'EXPC_SQ', 'EXPC_DEC_A', 'EXPC_DEC_B', 'ACC8_RAW', 'H2C_C0', 'H2C_B1', 'H2C_B2', 'G1_MUL_W3', 'G2_MUL_W3', 'MUL2S', 'G1_MUL_FIXED', 'G2_MUL_GLS', 'MILLER_BYTES_LS2', 'MILLER_RAW_LS2', 'MILLER_FE_LS2', 'EXPX_LS2']
+         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'G1_COMPRESS', 'G2_COMPRESS', 'H2C1_A', 'ENC1_A', 'H2C1_B', 'ENC1_B', 'G1_CLEAR', 'ENC2_A', 'ENC2_B', 'G1_MUL', 'G2_MUL', 'G1_ADD_AB', 'G2_ADD_AB', 'G1_HORNER', 'G2_HORNER', 'G1_SHIFTADD', 'G2_SHIFTADD', 'G1_MSM_PREP', 'G2_MSM_PREP', 'LINES_PQ', 'LINES_Q', 'LINES_BYTES', 'LINES_FROM_BYTES', 'ACC_BYTES', 'ACC_RAW', 'ACC_FE', 'ACC2_RAW', 'ACC_Q', 'G2_DEC_A192', 'G2_DEC_B192', 'G2_DEC_B_HEX', 'G1_FROM_RAW', 'G2_FROM_RAW', 'G2_SWAP', 'H2C_C1', 'H2C_C2', 'ACC4_RAW', 'MILLER_BYTES_LS', 'MILLER_RAW_LS', 'MILLER_FE_LS', 'EXPX_LS', 'EXPC_SQ', 'EXPC_DEC_A', 'EXPC_DEC_B', 'ACC8_RAW', 'H2C_C0', 'H2C_B1', 'H2C_B2', 'G1_MUL_W3', 'G2_MUL_W3', 'MUL2S', 'G1_MUL_FIXED', 'G2_MUL_GLS', 'MILLER_BYTES_LS2', 'MILLER_RAW_LS2', 'MILLER_FE_LS2', 'EXPX_LS2', 'G2_MUL_SAC']
 P = {n: i for i, n in enumerate(PROGS)}
 
 
@@ -210,6 +210,45 @@ def point_mul_gls(lib, pts192, scalars32):
     psz = 6 * RAW
     Pj, N, NI, out, st = buf(psz * n), buf(RAW * n), buf(RAW * n), buf(192 * n), buf(n)
     run(lib, 'G2_MUL_GLS', n, {1: (buf(pts192), 192), 2: (buf(dig), 128), 3: (Pj, psz), 4: (N, RAW)})
+    lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
+    run(lib, 'G2_TO_AFFINE', n, {3: (Pj, psz), 4: (NI, RAW), 2: (out, 192), 7: (st, 1)})
+    return out.raw, st.raw
+
+
+def sac_recode(k):
+    """msm_sac_kernel of csrc/msm_kernels.hip restated: the four base-|z| digits of k recoded sign-aligned -> (S with the 'a0 was even' flag at bit 66, e1, e2, e3)"""
+    Z = 0xd201000000010000
+    a = []
+    for _ in range(3):
+        a.append(k % Z); k //= Z
+    a.append(k)
+    even = 1 - (a[0] & 1)
+    a0 = a[0] | 1
+    S = (a0 >> 1) | (1 << 65)
+    out = [S | (even << 66)]
+    for j in range(1, 4):
+        v, e = a[j], 0
+        for b in range(66):
+            bit = v & 1
+            e |= bit << b
+            v = (v >> 1) + (bit & (1 - ((S >> b) & 1)))
+        assert v == 0
+        out.append(e)
+    # the recoding represents the digits: a_j = sum_i s_i e_ji 2^i
+    sgn = lambda i: 1 if (S >> i) & 1 else -1
+    assert sum(sgn(i) << i for i in range(66)) == a0
+    for j in range(1, 4):
+        assert sum(sgn(i) * ((out[j] >> i) & 1) << i for i in range(66)) == a[j]
+    return out
+
+
+def point_mul_sac(lib, pts192, scalars32):
+    """dev_point_mul() for at most 8192 points known to lie in G2 (sign): sign-aligned recoding of the digits -> one-addition-per-bit ladder -> inversion -> affine"""
+    n = len(scalars32) // 32
+    rc = b''.join(b''.join(x.to_bytes(32, 'big') for x in sac_recode(int.from_bytes(scalars32[32 * i:32 * i + 32], 'big'))) for i in range(n))
+    psz = 6 * RAW
+    Pj, N, NI, out, st = buf(psz * n), buf(RAW * n), buf(RAW * n), buf(192 * n), buf(n)
+    run(lib, 'G2_MUL_SAC', n, {1: (buf(pts192), 192), 2: (buf(rc), 128), 3: (Pj, psz), 4: (N, RAW)})
     lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
     run(lib, 'G2_TO_AFFINE', n, {3: (Pj, psz), 4: (NI, RAW), 2: (out, 192), 7: (st, 1)})
     return out.raw, st.raw

@@ -13,7 +13,7 @@ print('| `roofline.large_batch`: one 65,536-pairing call | %.2f ms (%.2f M pairi
 print('| `verify_batch`: 65,536 signatures, one call at a time, messages / keys / signature resident in HBM, `expand_message_xmd` inside | %.2f ms (%.2f M sigs/s) | %.3f on the reference\'s count, **%.3f on the executed algorithm**; three calls in flight %.2f ms per call (%.2f M sigs/s) |' % (v['ms'], v['value'] / 1e6, v['roofline']['frac'], v['roofline']['frac_executed'], v['in_flight']['ms_per_call_amortised'], v['in_flight']['sigs_per_s'] / 1e6))
 print('| one `verify` from host buffers (C ABI) / `await bls.verify(...)` from JavaScript / `await bls.sign(...)` | %.2f ms / %s ms / %s ms | critical path, section 4 |' % (v['single_verify_ms'], f.get('verify_ms'), f.get('sign_ms')))
 print('| `product`: 2^18-term Miller product + one final exponentiation | %.1f ms (%.2f M terms/s) | |' % (d['product']['ms_per_product'], d['product']['value'] / 1e6))
-print('| `sign` 8192 / `getPublicKey` | %.2f M sigs/s / %.2f M keys/s | |' % (d['sign']['value'] / 1e6, d['sign']['get_public_key_keys_per_s'] / 1e6))
+print('| `sign` 8192 keys from host buffers / resident in HBM (`nbls_sign_batch_dev`) / `getPublicKey` | %.2f M / %s M sigs/s / %.2f M keys/s | |' % (d['sign']['value'] / 1e6, ('%.2f' % (d['sign']['resident']['sigs_per_s'] / 1e6)) if d['sign'].get('resident') else '–', d['sign']['get_public_key_keys_per_s'] / 1e6))
 if d.get('config3'): print('| `config3`: BASELINE configs[3], %d independent pairings in ONE call per rank (1 rank) | %.1f ms (%.2f M pairings/s) | %.3f |' % (d['config3']['pairings'], d['config3']['ms'], d['config3']['value'] / 1e6, d['config3']['roofline_frac_per_gpu']))
 print('| MSM G1, 65,536 points, 255-bit scalars | %.1f M points/s | |' % (d['msm']['value'] / 1e6))
 print('| hash-to-G2 / hash-to-G1, 16,384 messages from host buffers | %.2f / %.2f M msgs/s | |' % (d['aggregate']['hash_to_g2_msgs_per_s'] / 1e6, d['aggregate']['hash_to_g1_msgs_per_s'] / 1e6))
