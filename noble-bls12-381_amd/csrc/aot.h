@@ -71,7 +71,8 @@
 // stage.  Round 3 costed this form from the interpreter's numbers and left it; on the specialised kernels 2048 pairings take 1.9 instead of 2.17 ms (profiles/round5_ab_ls2.txt).
 #define NBLS_AOT_LS2_KERNELS(X)                                                             \
   X(4, expx_ls2, P_EXPX_LS2, P_COUNT, P_COUNT, P_COUNT)                                    \
-  X(5, miller_ls2, P_MILLER_FE_LS2, P_MILLER_RAW_LS2, P_MILLER_BYTES_LS2, P_COUNT)
+  X(5, miller_ls2, P_MILLER_FE_LS2, P_MILLER_RAW_LS2, P_MILLER_BYTES_LS2, P_COUNT)                    \
+  X(6, g2pt_ls2, P_H2C_C1_LS2, P_H2C_C2_LS2, P_G2_MUL_SAC_LS2, P_COUNT)
 
 namespace nbls {
 

@@ -90,6 +90,7 @@ struct nbls_ctx {
   // cyclotomic exponentiation with compressed squarings (expx): scratch per item -- compressed powers, decompression scratch, redo flags and list -- and two redo counters (one per half)
   uint8_t *KS = nullptr, *KD = nullptr, *Kflag = nullptr; uint32_t *Klist = nullptr, *Kcount = nullptr;
   size_t expc_min = (size_t)env_long("NBLS_EXPC_MIN", (long)EXPC_MIN_DEFAULT);   // nbls_set_tuning(NBLS_TUNE_EXPC_MIN)
+  size_t pt_ls2_max = (size_t)env_long("NBLS_PT_LS2_MAX", 4096);                // nbls_set_tuning(NBLS_TUNE_PT_LS2_MAX): items up to which the G2 point chains run in their two-lane forms (pt_ls2_variant)
   size_t sac_max = (size_t)env_long("NBLS_G2_SAC_MAX", 6144);                   // nbls_set_tuning(NBLS_TUNE_SAC_MAX): keys up to which sign's ladder is the sign-aligned form (dev_point_mul)
   size_t chain_max = (size_t)env_long("NBLS_CHAIN_MAX", 8192);                  // nbls_set_tuning(NBLS_TUNE_CHAIN_MAX); see run_chain
   u32* qp_table = nullptr;      // multiples of p for the weak reduction (vm_exec.h weak_reduce), device copy
@@ -367,6 +368,14 @@ static ProgId ls_variant(nbls_ctx* ctx, ProgId id, size_t n) {
   }
   return id;
 }
+// The G2 point chains of a single verify / sign (the two ladders of clearCofactor, sign's own ladder) in their two-lane forms (round 5; nbls_aot_g2pt_ls2): four items per wavefront,
+// launches of at most 4096 items -- one wavefront per SIMD at most, where a shorter instruction stream is the whole gain.  NBLS_PT_LS2_MAX / NBLS_TUNE_PT_LS2_MAX (0 = never).
+static ProgId pt_ls2_variant(nbls_ctx* ctx, ProgId id, size_t n) {
+  if (n > ctx->pt_ls2_max) return id;
+  const ProgId v = id == P_H2C_C1 ? P_H2C_C1_LS2 : id == P_H2C_C2 ? P_H2C_C2_LS2 : id == P_G2_MUL_SAC ? P_G2_MUL_SAC_LS2 : id;
+  if (v != id && upload(ctx, v) == NBLS_OK && ctx->prog[v].aot >= 0) return v;   // (no interpreter form of the two-lane split exists)
+  return id;
+}
 static int reduce_product(nbls_ctx* ctx, size_t n, uint8_t** result, hipStream_t s) {
   // round 5: IN PLACE.  With spacing d the live elements are F[0], F[d], F[2d], ... below n; one launch multiplies F[2 i d] by F[2 i d + d] into the former for every
   // complete pair, and an odd last element -- its index is a multiple of 2 d -- simply stays alive for the next level.  No level copies or pads anything (round 4: ping-pong
@@ -485,7 +494,7 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
         hipMalloc(&ctx->ident_g1, 3 * RAW) != hipSuccess || hipMemcpy(ctx->ident_g1, id1, 3 * RAW, hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc(&ctx->ident_g2, 6 * RAW) != hipSuccess || hipMemcpy(ctx->ident_g2, id2, 6 * RAW, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   }
-  for (int i = 0; i < P_COUNT; i++) { if (i == P_G1_MUL || i == P_G2_MUL || i == P_G1_MUL_W3 || i == P_G2_MUL_W3 || i == P_G1_MUL_FIXED || i == P_G2_MUL_GLS || i == P_G2_MUL_SAC) continue;   // the scalar-multiplication ladders are uploaded on first use
+  for (int i = 0; i < P_COUNT; i++) { if (i == P_G1_MUL || i == P_G2_MUL || i == P_G1_MUL_W3 || i == P_G2_MUL_W3 || i == P_G1_MUL_FIXED || i == P_G2_MUL_GLS || i == P_G2_MUL_SAC || i == P_G2_MUL_SAC_LS2) continue;   // the scalar-multiplication ladders are uploaded on first use
     int r = upload(ctx, (ProgId)i); if (r) { int e = ctx->last_hip; (void)e; nbls_destroy(ctx); return r; } }
   *out = ctx;
   return NBLS_OK;
@@ -892,8 +901,8 @@ static int dev_decompress(nbls_ctx* ctx, bool g2, size_t n, const void* d_in, vo
 // in -> out (may alias in or base), norm of Z -> N; base and S are scratch of n * 6 raw elements each, and `in` is scratch too from the second program on (t1 is stored over P)
 static int dev_clear_g2(nbls_ctx* ctx, size_t n, void* in, uint8_t* base, uint8_t* S, void* out, void* N, hipStream_t s) {
   int r = run(ctx, P_H2C_C0, n, {B(3, in, 6 * RAW), B(6, base, 6 * RAW), B(5, S, 6 * RAW)}, s); if (r) return r;     // v = psi(P) -> base, u = psi^2(2P) - psi(P) - P -> S
-  if ((r = run(ctx, P_H2C_C1, n, {B(3, in, 6 * RAW), B(6, base, 6 * RAW)}, s))) return r;                          // base = t1 + v over v, t1 = -[x]P over P
-  return run(ctx, P_H2C_C2, n, {B(3, base, 6 * RAW), B(4, in, 6 * RAW), B(5, S, 6 * RAW), B(6, out, 6 * RAW), B(7, N, RAW)}, s);   // out may be in: every item reads its t1 before its result is stored
+  if ((r = run(ctx, pt_ls2_variant(ctx, P_H2C_C1, n), n, {B(3, in, 6 * RAW), B(6, base, 6 * RAW)}, s))) return r;                          // base = t1 + v over v, t1 = -[x]P over P
+  return run(ctx, pt_ls2_variant(ctx, P_H2C_C2, n), n, {B(3, base, 6 * RAW), B(4, in, 6 * RAW), B(5, S, 6 * RAW), B(6, out, 6 * RAW), B(7, N, RAW)}, s);   // out may be in: every item reads its t1 before its result is stored
 }
 static int dev_hash_to_g2(nbls_ctx* ctx, size_t n, const void* d_uniform, void* d_out, hipStream_t s, size_t io = 0, size_t ntot = 0) {   // io / ntot: see dev_decompress
   if (ntot < io + n) ntot = io + n;
@@ -1061,6 +1070,7 @@ EXPORT int nbls_set_tuning(nbls_ctx* ctx, int key, long long value) {
     case NBLS_TUNE_EXPC_MIN: if (value < 0) return NBLS_EINVAL; ctx->expc_min = (size_t)value; return NBLS_OK;
     case NBLS_TUNE_CHAIN_MAX: if (value < 0) return NBLS_EINVAL; ctx->chain_max = (size_t)value; return NBLS_OK;
     case NBLS_TUNE_SAC_MAX: if (value < 0) return NBLS_EINVAL; ctx->sac_max = (size_t)value; return NBLS_OK;
+    case NBLS_TUNE_PT_LS2_MAX: if (value < 0) return NBLS_EINVAL; ctx->pt_ls2_max = (size_t)value; return NBLS_OK;
     case NBLS_TUNE_VERIFY_CHUNKS: if (value < 0 || value > 16) return NBLS_EINVAL; ctx->verify_chunks = (long)value; return NBLS_OK;
     case NBLS_TUNE_VERIFY_LAST_PCT: if (value < 1 || value > 100) return NBLS_EINVAL; ctx->verify_last_pct = (long)value; return NBLS_OK;
     case NBLS_TUNE_VERIFY_PIPE_MIN: if (value < 0) return NBLS_EINVAL; ctx->verify_pipe_min = (long)value; return NBLS_OK;
@@ -1312,7 +1322,7 @@ static int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, si
     // windowed form, whose table of four leaves room for six workgroups per CU (NBLS_G2_SAC_MAX / NBLS_TUNE_SAC_MAX; 0 = never)
     if (n <= ctx->sac_max) {
       if (nbls_msm_sac_launch((unsigned)n, d_scalars, dig, s)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
-      if ((r = run(ctx, P_G2_MUL_SAC, n, {B(1, d_pts, pt_stride), B(2, dig, 128), B(3, Pj, p), B(4, N, RAW)}, s))) return r;
+      if ((r = run(ctx, pt_ls2_variant(ctx, P_G2_MUL_SAC, n), n, {B(1, d_pts, pt_stride), B(2, dig, 128), B(3, Pj, p), B(4, N, RAW)}, s))) return r;
     } else {
     if (nbls_msm_decompose_launch((unsigned)n, 4, d_scalars, dig, s)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
     if ((r = run(ctx, P_G2_MUL_GLS, n, {B(1, d_pts, pt_stride), B(2, dig, 128), B(3, Pj, p), B(4, N, RAW)}, s))) return r;

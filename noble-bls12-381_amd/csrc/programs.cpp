@@ -247,7 +247,7 @@ static Program build(ProgId id) {
   // step that has free lanes (-4 % instructions); with two point chains per item (MILLER_RAW2) those steps are full, so no cap there
   if (id == P_MILLER_BYTES || id == P_MILLER_RAW || id == P_MILLER_FE) B.max_dot = env_int("NBLS_MILLER_MAXDOT", 6);
   if (id == P_EXPX) B.max_dot = env_int("NBLS_EXPX_MAXDOT", 8);
-  const bool ls2 = id == P_MILLER_BYTES_LS2 || id == P_MILLER_RAW_LS2 || id == P_MILLER_FE_LS2 || id == P_EXPX_LS2;
+  const bool ls2 = id == P_MILLER_BYTES_LS2 || id == P_MILLER_RAW_LS2 || id == P_MILLER_FE_LS2 || id == P_EXPX_LS2 || id == P_H2C_C1_LS2 || id == P_H2C_C2_LS2 || id == P_G2_MUL_SAC_LS2;
   const bool ls = ls2 || id == P_MILLER_BYTES_LS || id == P_MILLER_RAW_LS || id == P_MILLER_FE_LS || id == P_EXPX_LS;
   if (ls) { B.lane_split = ls2 ? 2 : 4; B.max_dot = env_int("NBLS_LS_MAXDOT", 8); }   // four (two) sub-lanes share a lane-op's products: eight of them are two (four) rounds
   switch (id) {
@@ -575,14 +575,14 @@ static Program build(ProgId id) {
       B.sched_window = env_int("NBLS_G2GLS_WINDOW", 300);
       return B.compile("g2_mul_gls", G2MUL_W);
     }
-    case P_G2_MUL_SAC: {
+    case P_G2_MUL_SAC: case P_G2_MUL_SAC_LS2: {
       SFp2 x = input_fp2(1, 0), y = input_fp2(1, 96);
       SFp rc[4]; for (int i = 0; i < 4; i++) rc[i] = input_raw(2, 32 * i, 32);
       Pt<SFp2> r = pt_mul_sac_g2(pt_affine(x, y), rc);
       outputw(r.x.c0, 3, 0); outputw(r.x.c1, 3, 48); outputw(r.y.c0, 3, 96); outputw(r.y.c1, 3, 144); outputw(r.z.c0, 3, 192); outputw(r.z.c1, 3, 240);
       outputw(sqr(r.z.c0) + sqr(r.z.c1), 4, 0);
       B.sched_window = env_int("NBLS_G2SAC_WINDOW", 300);
-      return B.compile("g2_mul_sac", G2MUL_W);
+      return B.compile(ls2 ? "g2_mul_sac_ls2" : "g2_mul_sac", G2MUL_W);
     }
     case P_G1_MUL_FIXED: {
       SFp k = input_raw(2, 0, 32);
@@ -645,22 +645,22 @@ static Program build(ProgId id) {
       for (int k = 0; k < 2; k++) { const Pt<SFp2>& q = *o[k]; const int b = k ? 5 : 6; outputw(q.x.c0, b, 0); outputw(q.x.c1, b, 48); outputw(q.y.c0, b, 96); outputw(q.y.c1, b, 144); outputw(q.z.c0, b, 192); outputw(q.z.c1, b, 240); }
       return B.compile("h2c_c0", G2_W);
     }
-    case P_H2C_C1: {
+    case P_H2C_C1: case P_H2C_C1_LS2: {
       auto ld = [&](int buf) { return Pt<SFp2>{{inputw(buf, 0), inputw(buf, 48)}, {inputw(buf, 96), inputw(buf, 144)}, {inputw(buf, 192), inputw(buf, 240)}}; };
       Pt<SFp2> p = ld(3), base, t1;
       clear_cofactor_g2_first(p, ld(6), base, t1);
       const Pt<SFp2>* o[2] = {&base, &t1};
       for (int k = 0; k < 2; k++) { const Pt<SFp2>& q = *o[k]; const int b = k ? 3 : 6; outputw(q.x.c0, b, 0); outputw(q.x.c1, b, 48); outputw(q.y.c0, b, 96); outputw(q.y.c1, b, 144); outputw(q.z.c0, b, 192); outputw(q.z.c1, b, 240); }
       B.sched_window = env_int("NBLS_CLEAR_WINDOW", 100);   // psi(P) is only needed after the ladder: its load must not occupy slots throughout
-      return B.compile("h2c_c1", G2_W);
+      return B.compile(ls2 ? "h2c_c1_ls2" : "h2c_c1", G2_W);
     }
-    case P_H2C_C2: {
+    case P_H2C_C2: case P_H2C_C2_LS2: {
       auto ld = [&](int buf) { return Pt<SFp2>{{inputw(buf, 0), inputw(buf, 48)}, {inputw(buf, 96), inputw(buf, 144)}, {inputw(buf, 192), inputw(buf, 240)}}; };
       Pt<SFp2> q = clear_cofactor_g2_second(ld(3), ld(4), ld(5));
       outputw(q.x.c0, 6, 0); outputw(q.x.c1, 6, 48); outputw(q.y.c0, 6, 96); outputw(q.y.c1, 6, 144); outputw(q.z.c0, 6, 192); outputw(q.z.c1, 6, 240);
       outputw(sqr(q.z.c0) + sqr(q.z.c1), 7, 0);
       B.sched_window = env_int("NBLS_CLEAR_WINDOW", 100);   // t1 and u likewise
-      return B.compile("h2c_c2", G2_W);
+      return B.compile(ls2 ? "h2c_c2_ls2" : "h2c_c2", G2_W);
     }
     case P_G2_DEC_A192: g2_decompress_A(0, 3, 4, true); return B.compile("g2_dec_a192", 4);
     case P_G2_DEC_B192: g2_decompress_B(0, 3, 4, 5, 6, 7, 1); return B.compile("g2_dec_b192", G2_W);

@@ -81,6 +81,9 @@ enum ProgId {
   P_MILLER_BYTES_LS2, P_MILLER_RAW_LS2, P_MILLER_FE_LS2, P_EXPX_LS2,
   P_G2_MUL_SAC,        // [k]Q for Q in G2 with the four digits recoded sign-aligned (msm_kernels.hip sac_recode_kernel): affine Q (buf 1), 4 x 32 B big-endian (signs + correction flag, index bits 0..2)
                        // (buf 2) -> projective (3), norm of Z (4): ONE addition per bit from a table of eight (round 5, codec.h pt_mul_sac_g2): launches of at most 6144 keys (three workgroups per CU)
+  // two-lane split of the G2 point chains (round 5): launches of at most 4096 items (four items per wavefront): the two ladders of clearCofactor and sign's ladder -- a single verify / sign is
+  // a chain of one-item launches whose time is the length of their instruction streams
+  P_H2C_C1_LS2, P_H2C_C2_LS2, P_G2_MUL_SAC_LS2,
   P_COUNT
 };
 // |x| = 2^63 + 2^62 + 2^60 + 2^57 + 2^48 + 2^16: the compressed chain runs to 2^57 and its values at the set bits 16, 48, 57 are decompressed; the powers

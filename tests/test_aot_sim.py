@@ -106,3 +106,12 @@ def test_sign_aligned_ladder_translated(sim, oracle):
     """sign's one-addition-per-bit ladder (round 5, pt_mul_sac_g2) through its ahead-of-time translation"""
     assert sim.nbls_sim_has_aot(vmsim_py.P['G2_MUL_SAC']) == 1
     T.test_sign_aligned_ladder_for_subgroup_points(sim, oracle)
+
+
+def test_two_lane_point_chains(sim, oracle, golden, testdata):
+    """round 5: the G2 point chains of a single verify / sign in their two-lane forms (nbls_aot_g2pt_ls2: clearCofactor's two ladders, sign's sign-aligned ladder; launches of at
+    most 4096 items) -- the reference-generated hash vectors, the RFC 9380 suite and the structured keys of the ladder test through them"""
+    for name in ('H2C_C1_LS2', 'H2C_C2_LS2', 'G2_MUL_SAC_LS2'):
+        assert sim.nbls_sim_has_aot(vmsim_py.P[name]) == 1, name
+    T.test_hash_to_g2_program(sim, oracle, golden, testdata, True)
+    T.test_sign_aligned_ladder_for_subgroup_points(sim, oracle, 'G2_MUL_SAC_LS2')

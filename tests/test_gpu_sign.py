@@ -127,11 +127,13 @@ def test_both_ladders_of_sign(eng, testdata, oracle):
     ks = [1, 2, 3, 4, Z - 1, Z, Z + 1, Z * Z - 1, Z * Z, Z ** 3, Z ** 3 - 1, R - 1, R + 1, (1 << 256) - 1, (1 << 256) - 2, (1 << 255) + 12345]
     msgs = [b'structured-%d' % i for i in range(len(ks))]
     want = [oracle.sign(m, (k % R).to_bytes(32, 'big'))[1] for m, k in zip(msgs, ks)]
+    hv = [oracle.hash_to_g2(m)[1] for m in msgs]
     try:
-        for sac_max in (0, 6144):
-            eng.set_sac_max(sac_max)
+        for sac_max, ls2_max in ((0, 0), (6144, 0), (6144, 4096), (0, 4096)):     # the two-lane forms of the point chains (clearCofactor's ladders, the sign-aligned ladder) on and off
+            eng.set_sac_max(sac_max); eng.set_pt_ls2_max(ls2_max)
             sigs = eng.sign_batch([hx(v[1]) for v in vs], [hx(v[0]) for v in vs])
-            assert sigs == [hx(v[2]) for v in vs], sac_max
-            assert eng.sign_batch(msgs, [k.to_bytes(32, 'big') for k in ks]) == want, sac_max
+            assert sigs == [hx(v[2]) for v in vs], (sac_max, ls2_max)
+            assert eng.sign_batch(msgs, [k.to_bytes(32, 'big') for k in ks]) == want, (sac_max, ls2_max)
+            assert eng.hash_to_g2_batch(msgs) == b''.join(hv), (sac_max, ls2_max)
     finally:
-        eng.set_sac_max(6144)
+        eng.set_sac_max(6144); eng.set_pt_ls2_max(4096)

@@ -101,15 +101,15 @@ def test_decompress_programs(sim, golden):
             assert out[192 * i:192 * (i + 1)] == hx(v['aff'])
 
 
-def test_hash_to_g2_program(sim, oracle, golden, testdata):
+def test_hash_to_g2_program(sim, oracle, golden, testdata, ls2=False):
     vs = golden['h2c']
     uni = b''.join(oracle.expand_message_xmd(hx(v['msg']), v['dst'].encode(), 256) for v in vs)
-    out = vmsim_py.hash_to_g2(sim, uni)
+    out = vmsim_py.hash_to_g2(sim, uni, ls2)
     for i, v in enumerate(vs):
         assert out[192 * i:192 * (i + 1)] == hx(v['aff']), i
     suite = testdata['h2c_g2_ro']          # RFC 9380 vectors held by test/hashToCurve.test.ts
     uni = b''.join(oracle.expand_message_xmd(hx(v['msg']), suite['dst'].encode(), 256) for v in suite['vectors'])
-    out = vmsim_py.hash_to_g2(sim, uni)
+    out = vmsim_py.hash_to_g2(sim, uni, ls2)
     for i, v in enumerate(suite['vectors']):
         e = hx(v['x1x0y1y0'])
         assert out[192 * i:192 * (i + 1)] == e[48:96] + e[0:48] + e[144:192] + e[96:144], i
@@ -268,7 +268,7 @@ def test_gls_ladder_for_subgroup_points(sim, oracle):
     assert st[0] == 1
 
 
-def test_sign_aligned_ladder_for_subgroup_points(sim, oracle):
+def test_sign_aligned_ladder_for_subgroup_points(sim, oracle, prog='G2_MUL_SAC'):
     """sign's ladder for launches of at most one wavefront per SIMD (round 5, csrc/codec.h pt_mul_sac_g2: the digits recoded sign-aligned, one addition per bit from a table of eight)
     against the oracle: keys whose a0 is even / odd, digits rolling over, extreme digits (a3 of 65 bits), r - 1, r + 1, r (the zero point), random ones"""
     import random
@@ -279,10 +279,10 @@ def test_sign_aligned_ladder_for_subgroup_points(sim, oracle):
     g2 = oracle.g2_generator()
     q = oracle.g2_mul(g2, 0x1234567890abcdef1234567)[1]
     pts = b''.join([g2, q] * (len(ks) // 2))
-    out, st = vmsim_py.point_mul_sac(sim, pts, b''.join(k.to_bytes(32, 'big') for k in ks))
+    out, st = vmsim_py.point_mul_sac(sim, pts, b''.join(k.to_bytes(32, 'big') for k in ks), prog)
     for i, k in enumerate(ks):
         assert st[i] == 0 and out[192 * i:192 * i + 192] == oracle.g2_mul(pts[192 * i:192 * i + 192], k % r)[1], (i, hex(k))
-    out, st = vmsim_py.point_mul_sac(sim, g2 + g2, r.to_bytes(32, 'big') + (2 * r).to_bytes(32, 'big'))       # k = r, 2r: the zero point
+    out, st = vmsim_py.point_mul_sac(sim, g2 + g2, r.to_bytes(32, 'big') + (2 * r).to_bytes(32, 'big'), prog)       # k = r, 2r: the zero point
     assert st[0] == 1 and st[1] == 1
 
 

@@ -17,7 +17,7 @@ def raw_elem(v):
 
 
 PROGS = ['MILLER_BYTES', 'MILLER_RAW', 'MILLER_FE', 'NORM_RAW', 'NORM_BYTES', 'FE_EASY', 'EXPX', 'FE_MID1', 'FE_MID2', 'FE_FINAL', 'MUL2', 'RAW_TO_BYTES', 'G1_VALIDATE', 'G2_VALIDATE', 'G1_DEC_A', 'G1_DEC_B', 'G2_DEC_A', 'G2_DEC_B', 'H2C_A', 'H2C_B',
-         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'G1_COMPRESS', 'G2_COMPRESS', 'H2C1_A', 'ENC1_A', 'H2C1_B', 'ENC1_B', 'G1_CLEAR', 'ENC2_A', 'ENC2_B', 'G1_MUL', 'G2_MUL', 'G1_ADD_AB', 'G2_ADD_AB', 'G1_HORNER', 'G2_HORNER', 'G1_SHIFTADD', 'G2_SHIFTADD', 'G1_MSM_PREP', 'G2_MSM_PREP', 'LINES_PQ', 'LINES_Q', 'LINES_BYTES', 'LINES_FROM_BYTES', 'ACC_BYTES', 'ACC_RAW', 'ACC_FE', 'ACC2_RAW', 'ACC_Q', 'G2_DEC_A192', 'G2_DEC_B192', 'G2_DEC_B_HEX', 'G1_FROM_RAW', 'G2_FROM_RAW', 'G2_SWAP', 'H2C_C1', 'H2C_C2', 'ACC4_RAW', 'MILLER_BYTES_LS', 'MILLER_RAW_LS', 'MILLER_FE_LS', 'EXPX_LS', 'EXPC_SQ', 'EXPC_DEC_A', 'EXPC_DEC_B', 'ACC8_RAW', 'H2C_C0', 'H2C_B1', 'H2C_B2', 'G1_MUL_W3', 'G2_MUL_W3', 'MUL2S', 'G1_MUL_FIXED', 'G2_MUL_GLS', 'MILLER_BYTES_LS2', 'MILLER_RAW_LS2', 'MILLER_FE_LS2', 'EXPX_LS2', 'G2_MUL_SAC']
+         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'G1_COMPRESS', 'G2_COMPRESS', 'H2C1_A', 'ENC1_A', 'H2C1_B', 'ENC1_B', 'G1_CLEAR', 'ENC2_A', 'ENC2_B', 'G1_MUL', 'G2_MUL', 'G1_ADD_AB', 'G2_ADD_AB', 'G1_HORNER', 'G2_HORNER', 'G1_SHIFTADD', 'G2_SHIFTADD', 'G1_MSM_PREP', 'G2_MSM_PREP', 'LINES_PQ', 'LINES_Q', 'LINES_BYTES', 'LINES_FROM_BYTES', 'ACC_BYTES', 'ACC_RAW', 'ACC_FE', 'ACC2_RAW', 'ACC_Q', 'G2_DEC_A192', 'G2_DEC_B192', 'G2_DEC_B_HEX', 'G1_FROM_RAW', 'G2_FROM_RAW', 'G2_SWAP', 'H2C_C1', 'H2C_C2', 'ACC4_RAW', 'MILLER_BYTES_LS', 'MILLER_RAW_LS', 'MILLER_FE_LS', 'EXPX_LS', 'EXPC_SQ', 'EXPC_DEC_A', 'EXPC_DEC_B', 'ACC8_RAW', 'H2C_C0', 'H2C_B1', 'H2C_B2', 'G1_MUL_W3', 'G2_MUL_W3', 'MUL2S', 'G1_MUL_FIXED', 'G2_MUL_GLS', 'MILLER_BYTES_LS2', 'MILLER_RAW_LS2', 'MILLER_FE_LS2', 'EXPX_LS2', 'G2_MUL_SAC', 'H2C_C1_LS2', 'H2C_C2_LS2', 'G2_MUL_SAC_LS2']
 P = {n: i for i, n in enumerate(PROGS)}
 
 
@@ -108,8 +108,8 @@ def g2_decompress(lib, comp, mode='sig'):
     return out.raw, list(st.raw)
 
 
-def hash_to_g2(lib, uniform):
-    """uniform: n * 256 bytes of expand_message_xmd output"""
+def hash_to_g2(lib, uniform, ls2=False):
+    """uniform: n * 256 bytes of expand_message_xmd output; ls2: the two ladders of clearCofactor in their two-lane forms (launches of at most 4096 messages)"""
     n = len(uniform) // 256
     T, E, Pw, Q, N, NI, out, st = buf(4 * RAW * n), buf(4 * RAW * n), buf(4 * RAW * n), buf(6 * RAW * n), buf(RAW * n), buf(RAW * n), buf(192 * n), buf(n)
     St, Pt2 = buf(24 * RAW * n), buf(12 * RAW * n)
@@ -123,8 +123,8 @@ def hash_to_g2(lib, uniform):
     # in csrc/nbls_api.cpp, in place like there: C1 overwrites P with t1, C2 writes the result over t1)
     S = buf(6 * RAW * n)
     run(lib, 'H2C_C0', n, {3: (E2, 6 * RAW), 6: (Q, 6 * RAW), 5: (S, 6 * RAW)})
-    run(lib, 'H2C_C1', n, {3: (E2, 6 * RAW), 6: (Q, 6 * RAW)})
-    run(lib, 'H2C_C2', n, {3: (Q, 6 * RAW), 4: (E2, 6 * RAW), 5: (S, 6 * RAW), 6: (E2, 6 * RAW), 7: (N, RAW)})
+    run(lib, 'H2C_C1_LS2' if ls2 else 'H2C_C1', n, {3: (E2, 6 * RAW), 6: (Q, 6 * RAW)})
+    run(lib, 'H2C_C2_LS2' if ls2 else 'H2C_C2', n, {3: (Q, 6 * RAW), 4: (E2, 6 * RAW), 5: (S, 6 * RAW), 6: (E2, 6 * RAW), 7: (N, RAW)})
     lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
     run(lib, 'G2_TO_AFFINE', n, {3: (E2, 6 * RAW), 4: (NI, RAW), 2: (out, 192), 7: (st, 1)})
     return out.raw
@@ -242,13 +242,13 @@ def sac_recode(k):
     return out
 
 
-def point_mul_sac(lib, pts192, scalars32):
-    """dev_point_mul() for at most 8192 points known to lie in G2 (sign): sign-aligned recoding of the digits -> one-addition-per-bit ladder -> inversion -> affine"""
+def point_mul_sac(lib, pts192, scalars32, prog='G2_MUL_SAC'):
+    """dev_point_mul() for at most 6144 points known to lie in G2 (sign): sign-aligned recoding of the digits -> one-addition-per-bit ladder (prog: its two-lane form up to 4096) -> inversion -> affine"""
     n = len(scalars32) // 32
     rc = b''.join(b''.join(x.to_bytes(32, 'big') for x in sac_recode(int.from_bytes(scalars32[32 * i:32 * i + 32], 'big'))) for i in range(n))
     psz = 6 * RAW
     Pj, N, NI, out, st = buf(psz * n), buf(RAW * n), buf(RAW * n), buf(192 * n), buf(n)
-    run(lib, 'G2_MUL_SAC', n, {1: (buf(pts192), 192), 2: (buf(rc), 128), 3: (Pj, psz), 4: (N, RAW)})
+    run(lib, prog, n, {1: (buf(pts192), 192), 2: (buf(rc), 128), 3: (Pj, psz), 4: (N, RAW)})
     lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
     run(lib, 'G2_TO_AFFINE', n, {3: (Pj, psz), 4: (NI, RAW), 2: (out, 192), 7: (st, 1)})
     return out.raw, st.raw
