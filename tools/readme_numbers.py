@@ -21,8 +21,7 @@ saturated at %.2f GHz / %d W; the boxes of the pool differ by ±4 %% on saturate
 | a single `verify` (C ABI) / `await bls.verify()` / `await bls.sign()` from JavaScript | %.2f / %.2f / %.2f ms | [3.71 / 3.93 / –] |
 | `getPublicKey` / `sign`, 8192 keys from host buffers; `sign` with everything resident in HBM | %.2f M keys/s / %.2f M sigs/s; %.2f M sigs/s | [3.08 M / 1.38 M] |
 
-With 512 steps (`python bench.py`, the steady state): %.2f M pairings/s (%d %%; 3.02–3.11 M over the boxes of the round; the fastest of them gave 21.5 ms per 65,536-pairing call and 20.2–20.5 ms per
-verifyBatch: `EXPERIMENTS.md`). The same box's host: the C restatement of the reference 8–9 k pairings/s on 128 threads; the
+With 512 steps (`python bench.py`, the steady state): %.2f M pairings/s (%d %%; over the boxes the final build ran on: 3.02–3.09 M, 21.3–22.1 ms per 65,536-pairing call, 19.9–20.9 ms per verifyBatch, `value` at the driver's arguments 2.85–2.99 M). The same box's host: the C restatement of the reference 8–9 k pairings/s on 128 threads; the
 reference's algorithm in JavaScript BigInt %d pairings/s on one core, 1.3 k on all 256.
 
 """ % (sum(cl['sclk_mhz_under_load']) / 2 / 1000, round(sum(cl['package_power_w_under_load']) / 2), d['value'] / 1e6, round(100 * d['roofline']['frac_at_value']), d['cold_start']['pairings_per_s'] / 1e6,
