@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
+#include "scalar_split.h"
 
 namespace {
 typedef uint32_t u32;
@@ -30,84 +31,16 @@ __global__ void msm_keys_kernel(u32 n, u32 nwin, const uint8_t* __restrict__ sca
   }
 }
 
-// Scalar decomposition for the endomorphism split: k = a0 + a1 |z| + a2 |z|^2 + a3 |z|^3 in base |z| = 0xd201000000010000 (the
-// BLS parameter; a0..a2 < 2^64, a3 < 2^65 for k < 2^256).  dims = 4 (G2): the four digits; dims = 2 (G1): k mod z^2 = a0 + a1 |z|
-// and k div z^2 = a2 + a3 |z|.  Output: dims scalars per input scalar, 32 bytes big-endian each (the format msm_keys_kernel reads).
-__device__ inline u64 div_step(u64* limbs, int nl) {   // limbs (little-endian u64) /= |z|, returns the remainder; bitwise, |z| has its top bit set
-  const u64 Z = 0xd201000000010000ull;
-  u64 rem = 0;
-  for (int i = nl - 1; i >= 0; i--) {
-    u64 q = 0; const u64 v = limbs[i];
-    for (int b = 63; b >= 0; b--) {
-      const u64 carry = rem >> 63;
-      rem = (rem << 1) | ((v >> b) & 1);
-      const u64 ge = (u64)(carry | (u64)(rem >= Z));      // branch-free: sign's ladder feeds SECRET scalars through this division (round 5)
-      rem -= Z & (0 - ge);
-      q = (q << 1) | ge;
-    }
-    limbs[i] = q;
-  }
-  return rem;
-}
-__device__ inline void store_be(uint8_t* out, u64 l0, u64 l1, u64 l2) {   // 32-byte big-endian of l0 + l1 2^64 + l2 2^128
-  u32* o = (u32*)out;
-  o[0] = 0; o[1] = 0; o[2] = __builtin_bswap32((u32)(l2 >> 32)); o[3] = __builtin_bswap32((u32)l2);
-  o[4] = __builtin_bswap32((u32)(l1 >> 32)); o[5] = __builtin_bswap32((u32)l1); o[6] = __builtin_bswap32((u32)(l0 >> 32)); o[7] = __builtin_bswap32((u32)l0);
-}
+// Scalar decomposition for the endomorphism split and its sign-aligned recoding: scalar_split.h (written once, compiled here and into the test-only simulator).
 __global__ void msm_decompose_kernel(u32 n, u32 dims, const uint8_t* __restrict__ scalars, uint8_t* __restrict__ out) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const u32* k = (const u32*)(scalars + 32ull * i);
-  u64 l[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) l[j] = ((u64)__builtin_bswap32(k[6 - 2 * j]) << 32) | __builtin_bswap32(k[7 - 2 * j]);
-  const u64 a0 = div_step(l, 4);
-  const u64 a1 = div_step(l, 4);          // l = k div z^2 (< 2^129)
-  uint8_t* o = out + 32ull * dims * i;
-  if (dims == 2) {
-    const u64 Z = 0xd201000000010000ull;
-    const u64 lo = a1 * Z, hi = __umul64hi(a1, Z);
-    const u64 s0 = lo + a0, s1 = hi + (s0 < lo);
-    store_be(o, s0, s1, 0);
-    store_be(o + 32, l[0], l[1], l[2]);
-  } else {
-    const u64 a2 = div_step(l, 3);          // l = a3 (< 2^65)
-    store_be(o, a0, 0, 0); store_be(o + 32, a1, 0, 0); store_be(o + 64, a2, 0, 0); store_be(o + 96, l[0], l[1], 0);
-  }
+  nbls::scalar_decompose(scalars + 32ull * i, dims, out + 32ull * dims * i);
 }
-
-// The four digits recoded SIGN-ALIGNED for the one-addition-per-bit ladder of sign (codec.h pt_mul_sac_g2; Faz-Hernandez, Longa, Sanchez 2013): with a0 made odd (a0 + 1 when even:
-// the ladder subtracts Q again), a0 = sum_i s_i 2^i over 66 digits s_i = +-1 with s_i = 2 bit_(i+1)(a0) - 1 and s_65 = +1; every other digit is rewritten over the same signs,
-// a_j = sum_i s_i e_ji 2^i with e_ji = a_j mod 2 and a_j <- (a_j >> 1) + (e_ji and s_i = -1).  Output per scalar, 4 x 32 bytes big-endian: [bits 0..65: s_i = +1, bit 66: a0 was even],
-// then the bits e_1i, e_2i, e_3i.  Branch-free: the scalars are secret keys.
 __global__ void msm_sac_kernel(u32 n, const uint8_t* __restrict__ scalars, uint8_t* __restrict__ out) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const u32* k = (const u32*)(scalars + 32ull * i);
-  u64 l[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) l[j] = ((u64)__builtin_bswap32(k[6 - 2 * j]) << 32) | __builtin_bswap32(k[7 - 2 * j]);
-  u64 alo[4], ahi[4];
-  alo[0] = div_step(l, 4); alo[1] = div_step(l, 4); alo[2] = div_step(l, 3); alo[3] = l[0];
-  ahi[0] = ahi[1] = ahi[2] = 0; ahi[3] = l[1];
-  const u64 even = (alo[0] & 1) ^ 1;
-  alo[0] |= 1;
-  // signs: bit i of (slo, shi) set <=> s_i = +1
-  const u64 slo = alo[0] >> 1, shi = 2;          // bits 63, 64 clear (a0 < 2^64), bit 65 set
-  uint8_t* o = out + 128ull * i;
-  store_be(o, slo, shi | (even << 2), 0);
-  for (int j = 1; j < 4; j++) {
-    u64 lo = alo[j], hi = ahi[j], elo = 0, ehi = 0;
-    for (int b = 0; b < 66; b++) {
-      const u64 e = lo & 1;
-      const u64 sp = b < 64 ? (slo >> b) & 1 : (shi >> (b - 64)) & 1;
-      if (b < 64) elo |= e << b; else ehi |= e << (b - 64);
-      lo = (lo >> 1) | (hi << 63); hi >>= 1;
-      const u64 inc = e & (sp ^ 1);
-      lo += inc; hi += (u64)(lo < inc);
-    }
-    store_be(o + 32 * j, elo, ehi, 0);
-  }
+  nbls::scalar_sac_recode(scalars + 32ull * i, out + 128ull * i);
 }
 
 // dst[j] = src[idx[j]]   (q = 16-byte vectors per element)

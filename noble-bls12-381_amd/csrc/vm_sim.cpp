@@ -10,6 +10,7 @@
 #include "consts_gen.h"
 #include "fp_inv.h"
 #include "pow_exec.h"
+#include "scalar_split.h"
 #include "aot_exec.h"
 #include "aot_layout.h"
 #include "aot_sigs.inc"
@@ -263,6 +264,10 @@ __attribute__((visibility("default"))) int nbls_sim_layout_info(int prog, unsign
   const AotLdsCost c1 = l ? aot_layout_cost(p, *l) : c0;
   out4[0] = l ? 1 : 0; out4[1] = c0.cycles; out4[2] = c1.cycles; out4[3] = c0.floor;
   return 0;
+}
+// the scalar side of the endomorphism splits as the device runs it (scalar_split.h): dims = 2 / 4: base-|z| digits; dims = 0: the sign-aligned recoding (4 x 32 bytes per scalar)
+__attribute__((visibility("default"))) void nbls_sim_scalar_split(unsigned n, unsigned dims, const uint8_t* scalars, uint8_t* out) {
+  for (unsigned i = 0; i < n; i++) { if (dims) scalar_decompose(scalars + 32ull * i, dims, out + 32ull * dims * i); else scalar_sac_recode(scalars + 32ull * i, out + 128ull * i); }
 }
 __attribute__((visibility("default"))) int nbls_sim_program_count() { return (int)P_COUNT; }
 __attribute__((visibility("default"))) void nbls_sim_stats() { for (int i = 0; i < P_COUNT; i++) print_stats(get_program((ProgId)i)); }

@@ -572,3 +572,34 @@ def test_plain_formula_switches():
     r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-p', 'no:cacheprovider', os.path.abspath(__file__), '-k', sel], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'passed' in r.stdout
+
+
+def test_scalar_splits_as_the_device_runs_them(sim):
+    """csrc/scalar_split.h (compiled into msm_kernels.hip and into the simulator): the base-|z| digits of a scalar in both layouts (G2: four digits; G1: k mod z^2, k div z^2)
+    and the sign-aligned recoding of sign's ladder against Python integers -- structured scalars (digits rolling over, extreme digits, 0, 2^256 - 1) and random ones"""
+    import random
+    Z = 0xd201000000010000
+    r = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    rnd = random.Random(4242)
+    ks = [0, 1, 2, Z - 1, Z, Z + 1, Z * Z - 1, Z * Z, Z * Z + 1, Z ** 3 - 1, Z ** 3, r - 1, r, r + 1, (1 << 256) - 1, (1 << 256) - 2, 1 << 255, (Z - 1) * (1 + Z + Z * Z) + (Z ** 3) * ((1 << 64) - 1)]
+    ks += [rnd.randrange(1 << 256) for _ in range(200)] + [rnd.randrange(r) for _ in range(200)]
+    n = len(ks)
+    blob = b''.join(k.to_bytes(32, 'big') for k in ks)
+    for dims in (4, 2, 0):
+        out = C.create_string_buffer(n * (128 if dims == 0 else 32 * dims))
+        sim.nbls_sim_scalar_split(C.c_uint(n), C.c_uint(dims), blob, out)
+        for i, k in enumerate(ks):
+            if dims == 4:
+                a, kk = [], k
+                for _ in range(3):
+                    a.append(kk % Z); kk //= Z
+                a.append(kk)
+                want = b''.join(x.to_bytes(32, 'big') for x in a)
+                got = out.raw[128 * i:128 * i + 128]
+            elif dims == 2:
+                want = (k % (Z * Z)).to_bytes(32, 'big') + (k // (Z * Z)).to_bytes(32, 'big')
+                got = out.raw[64 * i:64 * i + 64]
+            else:
+                want = b''.join(x.to_bytes(32, 'big') for x in vmsim_py.sac_recode(k))
+                got = out.raw[128 * i:128 * i + 128]
+            assert got == want, (dims, hex(k))
