@@ -904,7 +904,7 @@ static int dev_clear_g2(nbls_ctx* ctx, size_t n, void* in, uint8_t* base, uint8_
   if ((r = run(ctx, pt_ls2_variant(ctx, P_H2C_C1, n), n, {B(3, in, 6 * RAW), B(6, base, 6 * RAW)}, s))) return r;                          // base = t1 + v over v, t1 = -[x]P over P
   return run(ctx, pt_ls2_variant(ctx, P_H2C_C2, n), n, {B(3, base, 6 * RAW), B(4, in, 6 * RAW), B(5, S, 6 * RAW), B(6, out, 6 * RAW), B(7, N, RAW)}, s);   // out may be in: every item reads its t1 before its result is stored
 }
-static int dev_hash_to_g2(nbls_ctx* ctx, size_t n, const void* d_uniform, void* d_out, hipStream_t s, size_t io = 0, size_t ntot = 0) {   // io / ntot: see dev_decompress
+static int dev_hash_to_g2(nbls_ctx* ctx, size_t n, const void* d_uniform, void* d_out, hipStream_t s, size_t io = 0, size_t ntot = 0, uint8_t** proj = nullptr) {   // io / ntot: see dev_decompress; proj: stop at the raw projective points (scratch slot 1) -- the caller multiplies them (sign) and normalises once, at the end
   if (ntot < io + n) ntot = io + n;
   uint8_t *T, *E, *Pw, *Q, *N, *NI, *st, *St, *Pt2, *S, *tab; int r;
   if ((r = need(ctx, 0, ntot * 4 * RAW, &T)) || (r = need(ctx, 1, ntot * 6 * RAW, &E)) || (r = need(ctx, 2, ntot * 4 * RAW, &Pw)) || (r = need(ctx, 3, ntot * 6 * RAW, &Q)) ||
@@ -918,6 +918,7 @@ static int dev_hash_to_g2(nbls_ctx* ctx, size_t n, const void* d_uniform, void* 
   if ((r = run(ctx, P_H2C_B1, 2 * n, {B(3, T, 2 * RAW), B(5, Pw, 2 * RAW), B(4, St, 12 * RAW), B(6, Pt2, 6 * RAW)}, s))) return r;
   if ((r = run(ctx, P_H2C_B2, n, {B(3, Pt2, 12 * RAW), B(6, E, 6 * RAW)}, s))) return r;        // E is free again: reuse it for the E2 point
   if ((r = dev_clear_g2(ctx, n, E, Q, S, E, N, s))) return r;
+  if (proj) { *proj = E; return NBLS_OK; }
   if ((r = run_inv_buf(ctx, n, N, NI, s))) return r;
   return run(ctx, P_G2_TO_AFFINE, n, {B(3, E, 6 * RAW), B(4, NI, RAW), B(2, d_out, 192), B(7, st, 1)}, s);
 }
@@ -1315,8 +1316,10 @@ static int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, si
   // instead of 256 + 128; NBLS_G2_GLS=0 keeps the plain ladder).  The digits are made on the device by the MSM's decomposition kernel (branch-free long division by |z|).
   static const bool gls_on = env_long("NBLS_G2_GLS", 1) != 0;
   if (g2 && in_subgroup && gls_on) {
+    // up to sac_max keys d_pts are RAW PROJECTIVE points (six raw elements each, pt_stride = 6 * RAW: sign_points() below) -- the hash points as cofactor clearing leaves them in
+    // scratch slot 1, so the digits go to slot 2; above, affine wire points as everywhere else
     uint8_t* dig;
-    if ((r = need(ctx, 1, n * 128, &dig))) return r;
+    if ((r = need(ctx, n <= ctx->sac_max ? 2 : 1, n * 128, &dig))) return r;
     // while every wavefront of the launch is resident at once the length of ONE wavefront's instruction stream is the time: the sign-aligned recoding with one addition per bit
     // (codec.h pt_mul_sac_g2: 65 doublings + 73 additions; its table of eight points takes 101 slots = three workgroups per CU = 768 wavefronts of 8 keys); above 6144 keys the
     // windowed form, whose table of four leaves room for six workgroups per CU (NBLS_G2_SAC_MAX / NBLS_TUNE_SAC_MAX; 0 = never)
@@ -1339,6 +1342,20 @@ static int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, si
   }
   if ((r = run_inv_buf(ctx, n, N, NI, s))) return r;
   return run(ctx, g2 ? P_G2_TO_AFFINE : P_G1_TO_AFFINE, n, {B(3, Pj, p), B(4, NI, RAW), B(2, d_out, a), B(7, d_status, 1)}, s);
+}
+// sign's two halves: hash-to-G2, then the key ladder on the hash points.  Up to sac_max keys the points stay projective in between (no inversion, no affine program: the
+// sign-aligned ladder reads raw projective points); above, they are normalised first (the windowed ladder's affine input keeps it at six workgroups per CU).  `h`: n * 192 bytes of
+// device scratch for the affine points of the second form
+static int sign_points(nbls_ctx* ctx, size_t n, const void* d_uniform, void* h, const void* d_keys32, void* d_out192, void* d_status, hipStream_t s) {
+  int r;
+  static const bool gls_on = env_long("NBLS_G2_GLS", 1) != 0;
+  if (gls_on && n <= ctx->sac_max) {
+    uint8_t* pj;
+    if ((r = dev_hash_to_g2(ctx, n, d_uniform, nullptr, s, 0, 0, &pj))) return r;
+    return dev_point_mul(ctx, true, n, pj, 6 * RAW, d_keys32, d_out192, d_status, s, true, true);
+  }
+  if ((r = dev_hash_to_g2(ctx, n, d_uniform, h, s))) return r;
+  return dev_point_mul(ctx, true, n, h, 192, d_keys32, d_out192, d_status, s, true, true);      // H(m) is in G2: the ladder may split the key along psi
 }
 // scalar k is acceptable iff k mod r != 0 (normalizePrivKey, index.ts:269-279, reduces mod r and rejects zero); the ladder
 // itself takes any 256-bit value since the points are in the order-r subgroup
@@ -1487,8 +1504,7 @@ EXPORT int nbls_sign_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const u
   if (!h || !dk || !o || !st) return NBLS_EHIP;
   uint8_t* d; int r = dev_expand(ctx, n, msgs, offsets, dst, dst_len, &d, s); if (r) return r;
   HIPCHK(hipMemcpyAsync(dk, keys32, n * 32, hipMemcpyHostToDevice, s));
-  if ((r = dev_hash_to_g2(ctx, n, d, h, s))) return r;
-  if ((r = dev_point_mul(ctx, true, n, h, 192, dk, o, st, s, true, true))) return r;      // H(m) is in G2: the ladder may split the key along psi
+  if ((r = sign_points(ctx, n, d, h, dk, o, st, s))) return r;
   std::vector<int8_t> tmp(n);
   HIPCHK(hipMemcpyAsync(out192, o, n * 192, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(tmp.data(), st, n, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
   for (size_t i = 0; i < n; i++) if (scalar_is_zero_mod_r(keys32 + 32 * i)) tmp[i] = 5;
@@ -1529,8 +1545,7 @@ EXPORT int nbls_sign_batch_dev(nbls_ctx* ctx, size_t n, const void* d_msgs, cons
   HIPCHK(hipMemsetAsync(d_bad, 0, 4, s));
   const int e = nbls_xmd_launch((unsigned)n, (const uint8_t*)d_msgs, (const uint8_t*)d_offsets, dd, (unsigned)dst_len, du, 256, d_bad, s);
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
-  if ((r = dev_hash_to_g2(ctx, n, du, h, s))) return r;
-  if ((r = dev_point_mul(ctx, true, n, h, 192, d_keys32, d_out192, d_status, s, true, true))) return r;      // H(m) is in G2: the ladder may split the key along psi
+  if ((r = sign_points(ctx, n, du, h, d_keys32, d_out192, d_status, s))) return r;
   uint32_t bad = 0; HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
   return bad ? NBLS_EINVAL : NBLS_OK;     // offsets[i + 1] < offsets[i] somewhere
 }

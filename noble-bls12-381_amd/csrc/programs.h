@@ -79,7 +79,7 @@ enum ProgId {
   P_G2_MUL_GLS,        // [k]Q for Q in G2: affine Q (buf 1), the four base-|z| digits of k as 4 x 32 B big-endian (buf 2) -> projective (3), norm of Z (4): sign's ladder with the scalar split along psi (round 5, codec.h pt_mul_gls_g2)
   // two-lane split (round 5): launches of 1025 .. 2048 items, TWO items per wavefront, every K_DOT lane-op on two adjacent lanes (one DPP stage sums the columns)
   P_MILLER_BYTES_LS2, P_MILLER_RAW_LS2, P_MILLER_FE_LS2, P_EXPX_LS2,
-  P_G2_MUL_SAC,        // [k]Q for Q in G2 with the four digits recoded sign-aligned (msm_kernels.hip sac_recode_kernel): affine Q (buf 1), 4 x 32 B big-endian (signs + correction flag, index bits 0..2)
+  P_G2_MUL_SAC,        // [k]Q for Q in G2 with the four digits recoded sign-aligned (scalar_split.h): raw projective Q (buf 1), 4 x 32 B big-endian (signs + correction flag, index bits 0..2)
                        // (buf 2) -> projective (3), norm of Z (4): ONE addition per bit from a table of eight (round 5, codec.h pt_mul_sac_g2): launches of at most 6144 keys (three workgroups per CU)
   // two-lane split of the G2 point chains (round 5): launches of at most 4096 items (four items per wavefront): the two ladders of clearCofactor and sign's ladder -- a single verify / sign is
   // a chain of one-item launches whose time is the length of their instruction streams

@@ -195,6 +195,23 @@ def point_mul_fixed(lib, table, scalars32):
     return out.raw, st.raw
 
 
+def g2_affine_to_raw_projective(pts192, scale_seed=None):
+    """n affine G2 wire points (x.c0 x.c1 y.c0 y.c1, 48 bytes big-endian each) -> raw projective points (six raw Montgomery elements each), the form sign's ladders take;
+    scale_seed: multiply every point through by a pseudo-random z in Fp2 (another representative of the same point)"""
+    import random
+    rnd = random.Random(scale_seed)
+    mul2 = lambda a, b: ((a[0] * b[0] - a[1] * b[1]) % P_MOD, (a[0] * b[1] + a[1] * b[0]) % P_MOD)
+    out = b''
+    for i in range(len(pts192) // 192):
+        w = [int.from_bytes(pts192[192 * i + 48 * k:192 * i + 48 * k + 48], 'big') for k in range(4)]
+        x, y, z = (w[0], w[1]), (w[2], w[3]), (1, 0)
+        if scale_seed is not None:
+            z = (rnd.randrange(1, P_MOD), rnd.randrange(P_MOD))
+            x, y = mul2(x, z), mul2(y, z)
+        out += b''.join(raw_elem(v) for v in (x[0], x[1], y[0], y[1], z[0], z[1]))
+    return out
+
+
 def point_mul_gls(lib, pts192, scalars32):
     """dev_point_mul() for points known to lie in G2 (sign): base-|z| digits of the scalar (msm_decompose_kernel, here in Python) -> GLS ladder -> inversion -> affine"""
     Z = 0xd201000000010000
@@ -243,12 +260,13 @@ def sac_recode(k):
 
 
 def point_mul_sac(lib, pts192, scalars32, prog='G2_MUL_SAC'):
-    """dev_point_mul() for at most 6144 points known to lie in G2 (sign): sign-aligned recoding of the digits -> one-addition-per-bit ladder (prog: its two-lane form up to 4096) -> inversion -> affine"""
+    """dev_point_mul() for at most 6144 points known to lie in G2 (sign): sign-aligned recoding of the digits -> one-addition-per-bit ladder on raw PROJECTIVE base points (scaled representatives here;
+    prog: its two-lane form up to 4096) -> inversion -> affine"""
     n = len(scalars32) // 32
     rc = b''.join(b''.join(x.to_bytes(32, 'big') for x in sac_recode(int.from_bytes(scalars32[32 * i:32 * i + 32], 'big'))) for i in range(n))
     psz = 6 * RAW
     Pj, N, NI, out, st = buf(psz * n), buf(RAW * n), buf(RAW * n), buf(192 * n), buf(n)
-    run(lib, prog, n, {1: (buf(pts192), 192), 2: (buf(rc), 128), 3: (Pj, psz), 4: (N, RAW)})
+    run(lib, prog, n, {1: (buf(g2_affine_to_raw_projective(pts192, 98)), psz), 2: (buf(rc), 128), 3: (Pj, psz), 4: (N, RAW)})
     lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
     run(lib, 'G2_TO_AFFINE', n, {3: (Pj, psz), 4: (NI, RAW), 2: (out, 192), 7: (st, 1)})
     return out.raw, st.raw
