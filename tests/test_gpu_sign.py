@@ -137,3 +137,19 @@ def test_both_ladders_of_sign(eng, testdata, oracle):
             assert eng.hash_to_g2_batch(msgs) == b''.join(hv), (sac_max, ls2_max)
     finally:
         eng.set_sac_max(6144); eng.set_pt_ls2_max(4096)
+
+
+def test_sign_dispatch_thresholds(eng, oracle):
+    """batch sizes on both sides of the two dispatch thresholds of sign (two-lane point chains up to 4096 items, sign-aligned ladder with a projective hand-over up to 6144 keys,
+    windowed ladder on affine points above): every size gives the signatures of the small-batch path, which is pinned on the reference's vectors above; spot checks against the oracle"""
+    import hashlib
+    n = 6146
+    sks = [(int.from_bytes(hashlib.sha256(b'thr-sk%d' % i).digest(), 'big') % (R - 1) + 1).to_bytes(32, 'big') for i in range(n)]
+    msgs = [hashlib.sha256(b'thr-m%d' % i).digest()[:1 + i % 32] for i in range(n)]
+    ref = []
+    for i in range(0, n, 512):
+        ref += eng.sign_batch(msgs[i:i + 512], sks[i:i + 512])
+    for i in (0, 4095, 4096, 6143, 6144, 6145):
+        assert ref[i] == oracle.sign(msgs[i], sks[i])[1], i
+    for m in (4096, 4097, 6144, 6145, 6146):
+        assert eng.sign_batch(msgs[:m], sks[:m]) == ref[:m], m
