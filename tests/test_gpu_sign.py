@@ -153,3 +153,16 @@ def test_sign_dispatch_thresholds(eng, oracle):
         assert ref[i] == oracle.sign(msgs[i], sks[i])[1], i
     for m in (4096, 4097, 6144, 6145, 6146):
         assert eng.sign_batch(msgs[:m], sks[:m]) == ref[:m], m
+
+
+def test_hash_to_g2_dispatch_threshold(eng, oracle):
+    """hash-to-G2 on both sides of the size up to which clearCofactor's ladders run in their two-lane forms (4096 messages): equal to the chunked small-batch results, which the
+    RFC 9380 / reference vectors pin (tests/test_gpu_reference_vectors.py); spot checks against the oracle"""
+    import hashlib
+    n = 4098
+    msgs = [hashlib.sha256(b'thr-h%d' % i).digest()[:1 + i % 32] for i in range(n)]
+    ref = b''.join(eng.hash_to_g2_batch(msgs[i:i + 600]) for i in range(0, n, 600))
+    for i in (0, 4095, 4096, 4097):
+        assert ref[192 * i:192 * i + 192] == oracle.hash_to_g2(msgs[i])[1], i
+    for m in (4096, 4097, 4098):
+        assert eng.hash_to_g2_batch(msgs[:m]) == ref[:192 * m], m
