@@ -235,21 +235,22 @@ def main():
             d_ = float(t.item())
         return d_
 
-    # The chip drops to its idle power state while the host checks the parity bytes, and W = 5 warm-up steps (7 ms of work) do not lift it back: a burst of 20 calls timed right
-    # there measures the DVFS ramp -- 2.77 M pairings/s against 2.94 M for the same burst on a chip that has been busy for a tenth of a second (six interleaved pairs, +6.1 %,
-    # profiles/round5_ab_bench_prewarm.txt).  So the line carries both: `cold_start` = W warm-up + K timed steps exactly as they come after the idle phase, and `value` = the same
-    # W + K after PREWARM untimed steps that put the device into the state a service runs in.  NBLS_BENCH_PREWARM=0 makes `value` the cold-start figure.
+    # `value` = the driver's protocol as it comes: W untimed warm-up steps, then exactly K timed steps (rounds 1-4; round 5 had put 8 D untimed "pre-warm" steps in front of it, which the
+    # round-5 review and ADVICE.md rightly called a change of method: +6.1 % for the same burst, profiles/round5_ab_bench_prewarm.txt).  The chip drops to its idle power state while the
+    # host checks the parity bytes and W = 5 steps (7 ms of work) do not lift it back, so at the driver's 20 steps `value` includes the clock ramp.  The figure on a chip that has been
+    # busy for a tenth of a second -- what a service sees -- is reported separately as `steady_state` (PREWARM untimed steps, then the same W + K); with hundreds of timed steps the
+    # ramp is noise and the second region is skipped.  NBLS_BENCH_PREWARM=0 switches the second region off.
     PREWARM = int(os.environ.get('NBLS_BENCH_PREWARM', str(8 * D)))
-    dt_cold = None
-    if PREWARM > 0 and args.steps <= 64:      # (with hundreds of timed steps the ramp is noise, and a second region would double the run)
-        dt_cold = timed_region(False)
-    for i in range(PREWARM):
-        step(i)
     dt = timed_region(args.mark_timed_region)
+    dt_steady = None
+    if PREWARM > 0 and args.steps <= 64:
+        for i in range(PREWARM):
+            step(i)
+        dt_steady = timed_region(False)
     # strictly serial figure (one batch at a time on one stream) = per-batch latency, this rank
     torch.cuda.synchronize()
     eng.set_chain_max(8192)             # ... and the chained final exponentiation (6 launches per call; the in-flight contexts run it as seven launches, pipeline.py)
-    eng.set_split_miller_min(4096)      # the single-call legs use the library's default choice of Miller programs (SPLIT_MILLER_MIN in csrc/nbls_api.cpp; the in-flight contexts were set to 0)
+    eng.set_split_miller_min(4097)      # the single-call legs use the library's default choice of Miller programs (SPLIT_MILLER_MIN in csrc/nbls_api.cpp: the fused program up to 4096 pairs; the in-flight contexts were set to 0)
     serial_steps = max(8, min(args.steps, 320))
     s0 = time.perf_counter()
     for _ in range(serial_steps):
@@ -734,7 +735,7 @@ def main():
             sleg = {'metric': 'sign sigs/sec: nbls_sign_batch from host buffers (device SHA-256 expand_message_xmd + hash-to-G2 + constant-time G2 ladder + affine), compression not included', 'n': ns_, 'value': round(ns_ / sdt, 2), 'ms': round(sdt * 1e3, 3),
                     'resident': {'sigs_per_s': round(ns_ / rdt, 2), 'ms': round(rdt * 1e3, 3), 'kernels_ms': round(sum(v_[0] for v_ in stm.values()), 3),
                                  'note': 'nbls_sign_batch_dev: message bytes, offsets, keys and the affine signatures resident in HBM (as the verify_batch leg); kernels_ms = sum of the HIP-event durations of its launches (separate instrumented call)'},
-                    'g2_ladder_kernel_ms': round(sum(stm.get(k_, (0, 0))[0] for k_ in ('g2_mul', 'g2_mul_w3', 'g2_mul_gls')), 3), 'get_public_key_keys_per_s': round(ns_ / kdt, 2),
+                    'g2_ladder_kernel_ms': round(sum(stm.get(k_, (0, 0))[0] for k_ in ('g2_mul', 'g2_mul_w3', 'g2_mul_gls', 'g2_mul_sac', 'g2_mul_sac_ls2')), 3), 'get_public_key_keys_per_s': round(ns_ / kdt, 2),
                     'cpu_baseline': {'value': round(1 / csdt, 2), 'unit': 'sigs/s', 'cores': 1, 'kind': 'port', 'sample': '16 signatures on one host thread (oracle/)'}}
         aleg = None
         if world == 1 and args.sign_batch > 0:
@@ -788,9 +789,18 @@ def main():
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'int64', 'dtype_detail': 'signed 64-bit column accumulators over 14 x 28-bit limbs (v_mad_i64_i32), 381-bit Fp in Montgomery form R = 2^392; results bit-exact', 'data': 'synthetic',
             'config': {'workload': 'batch of %d independent BLS12-381 pairings per GPU (Miller loop + final exponentiation, inputs pre-validated, bit-exact vs reference), inputs/outputs resident in HBM' % n,
-                       'batch_per_gpu': n, 'sharding': 'independent batches per rank, no collective', 'batches_in_flight': D},
-            'prewarm_steps': PREWARM, 'cold_start': {'pairings_per_s': round(n * args.steps * world / dt_cold, 2), 'ms_per_step': round(dt_cold / args.steps * 1e3, 4),
-                                                     'note': 'the same W warm-up + K timed steps WITHOUT the %d untimed pre-warm steps: the burst right after the idle phase of the parity check (the chip is on its clock ramp); `value` is measured after them' % PREWARM} if dt_cold else None,
+                       'batch_per_gpu': n, 'sharding': 'independent batches per rank, no collective', 'batches_in_flight': D,
+                       'protocol': '`value` = exactly W warm-up + K timed steps with no other untimed steps in front of them (the round 1-4 protocol); the figure after %d further untimed steps is `steady_state`' % PREWARM},
+            # the scalars a reader of a truncated line needs, before the large nested objects (round-5 review item 4)
+            'summary': {'value_pairings_per_s': round(value, 2), 'steady_state_pairings_per_s': round(n * args.steps * world / dt_steady, 2) if dt_steady else None, 'prewarm_steps_of_steady_state': PREWARM if dt_steady else 0,
+                        'single_call_ms': round(dt_serial / args.steps * 1e3, 4), 'single_call_roofline_frac': roof['frac'] if roof else None,
+                        'large_batch_ms': (roof or {}).get('large_batch', {}).get('ms_per_call') if roof else None,
+                        'verify_batch_ms': (vbatch or {}).get('ms'), 'verify_batch_in_flight_ms': ((vbatch or {}).get('in_flight') or {}).get('ms_per_call_amortised'), 'single_verify_ms': (vbatch or {}).get('single_verify_ms'),
+                        'facade_verify_ms': (facade or {}).get('verify_ms') if isinstance(facade, dict) else None, 'facade_sign_ms': (facade or {}).get('sign_ms') if isinstance(facade, dict) else None,
+                        'sign_sigs_per_s': (sleg or {}).get('value'), 'msm_points_per_s': (mleg or {}).get('value'), 'gpu_max_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES')},
+            'steady_state': {'pairings_per_s': round(n * args.steps * world / dt_steady, 2), 'ms_per_step': round(dt_steady / args.steps * 1e3, 4), 'prewarm_steps': PREWARM,
+                             'note': 'the same W warm-up + K timed steps after %d further untimed steps (a chip that has been busy for ~0.1 s: no clock ramp inside the region); NOT `value`' % PREWARM} if dt_steady else None,
+            'cold_start': {'pairings_per_s': round(value, 2), 'ms_per_step': round(dt / args.steps * 1e3, 4), 'note': 'alias of `value` (round-5 name): W warm-up + K timed steps with nothing in front of them'},
             'in_flight': {'pairings_per_s': round(value, 2), 'batches_in_flight': D, 'ms_per_batch_amortised': round(dt / args.steps * 1e3, 4), 'timed_s': round(dt, 3),
                           'roofline_frac': round(value / world * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL / 1e12 / PEAK_TMAD, 4),
                           'note': '`value`: %d independent calls of %d pairings overlapping on %d streams / engine contexts per GPU' % (D, n, D)},

@@ -37,10 +37,11 @@ static const i32 AOT_P_TOP = 106513;      // floor(p / 2^364)
 static const i32 AOT_Q_MARGIN = 330;      // the estimate below is off by less than 130 (columns 11 and lower: |c| < 2^63 -> |c / 2^56| < 128); twice that and a bit
 // Finish of a K_DOT lane-op in the columns.  acc: the 28 columns after the product rounds (no bias inside).  Semantics as vm_exec.h dot_finish:
 //   dst = m * (REDC(sum) + offs p) + sum_t coef_t X_t  [weakly reduced]  [halved]
-template <u32 FLAGS, u32 T, typename LDSP>
+// REDUCED (round 6, the lane-split forms): the rows of the reduction have run already -- on every sub-lane, before the cross-lane sum -- and acc[NL ..] holds the summed upper columns.
+template <u32 FLAGS, u32 T, bool REDUCED = false, typename LDSP = char*>
 NBLS_HD void aot_dot_finish(u32* r, u64* acc, const u32 w0, const u32* post, LDSP lds) {
   const u32 P[NL] = NBLS_P28;
-  redc28_rows(acc);
+  if (!REDUCED) redc28_rows(acc);
   u64* c = acc + NL;
   i32 boffs = (FLAGS & AF_OFFS) ? (i32)((w0 >> 20) & 0xfu) : 0;
   if (FLAGS & (AF_MULTSH | AF_MULT3)) {
@@ -192,24 +193,53 @@ NBLS_HD void aot_compress_columns(u64* acc) {
   }
 }
 
-// host only: what aot_acc_sum4 calls in place of the DPP stages (set by the simulator; null elsewhere)
-typedef void (*AotSimLsHook)(u64*);
+// host only: what aot_acc_sum calls in place of the DPP stages (set by the simulator; null elsewhere): (columns, how many)
+typedef void (*AotSimLsHook)(u64*, int);
 inline AotSimLsHook& aot_sim_ls_hook() { static AotSimLsHook h = nullptr; return h; }
-// Lane split: sum of the 28 column accumulators over the LS = 4 (2) adjacent lanes of a lane-op, result in the first of them.  Two DPP stages (lane i += lane i + 1, then
+// Lane split: sum of NC 64-bit columns over the LS = 4 (2) adjacent lanes of a lane-op, result in the first of them.  Two DPP stages (lane i += lane i + 1, then
 // lane i += lane i + 2, inside rows of 16 lanes; groups of four never straddle a row) -- one stage for LS = 2.  On the host the simulator's hook does the same sum.
-template <u32 LS>
+template <u32 LS, int NC>
 NBLS_HD void aot_acc_sum(u64* acc) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-  for (int c = 0; c < 2 * NL - 1; c++) {
+  for (int c = 0; c < NC; c++) {
     u64 v = acc[c];
     v += ((u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x101, 0xf, 0xf, true) << 32) | (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x101, 0xf, 0xf, true);   // row_shl:1
     if (LS == 4) v += ((u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x102, 0xf, 0xf, true) << 32) | (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x102, 0xf, 0xf, true);   // row_shl:2
     acc[c] = v;
   }
 #else
-  if (aot_sim_ls_hook()) aot_sim_ls_hook()(acc);   // the simulator supplies the cross-lane sum (vm_sim.cpp: lanes are visited from 63 down, so the partners' columns are there)
+  if (aot_sim_ls_hook()) aot_sim_ls_hook()(acc, NC);   // the simulator supplies the cross-lane sum (vm_sim.cpp: lanes are visited from 63 down, so the partners' columns are there)
 #endif
+}
+// Reduce first, then sum (round 6).  Until round 5 the 27 product columns of the S sub-lanes were summed (27 x 4 instructions per DPP stage: 216 for S = 4, 108 for S = 2) and the first sub-lane
+// reduced the sum while the others computed junk.  But every lane of a wavefront executes the reduction anyway, and the reduction is linear modulo p: each sub-lane reduces ITS OWN columns
+// (REDC(a) + REDC(b) = (a + b) / R mod p, each term adding less than p -- the host compiler books S p instead of p for these programs, trace.cpp emit_dot) and only the 14 upper columns
+// cross the lanes: 112 / 56 instructions.  The sum of S columns must stay inside 63 bits: a column that could pass 127 units of 2^56 over the S sub-lanes is compressed first
+// (aot_compress_columns), as the product rounds do under the column budget.  Returns the mask (bit k: upper column k) for a signature; S = 1: nothing to do.
+constexpr u32 aot_ls_presum_mask(u32 P0, u32 SH0, u32 SH1, u32 S) {
+  if (S <= 1) return 0;
+  u32 B[2 * NL + 1] = {};
+  const bool budget = aot_has_norm(SH0, SH1);
+  const u32 LIMIT = 113;
+  for (u32 r = 0; r < P0 && r < (u32)MAX_DOT_PRODUCTS; r++) {
+    const u32 shape = ((r < 4 ? SH0 : SH1) >> (8 * (r & 3))) & 0xffu;
+    const u32 add = aot_shape_units(shape & 3u) * aot_shape_units((shape >> SH_B_SHIFT) & 3u);
+    if (budget) {   // the sub-lane's own compression plan (aot_compress_plan with S = 1)
+      u32 mask = 0;
+      for (u32 k = 0; k < 2 * NL - 1; k++) { const u32 terms = k < (u32)NL ? k + 1 : 2 * NL - 1 - k; if (B[k] + terms * add > LIMIT) mask |= 1u << k; }
+      for (u32 k = 0; k < 2 * NL - 1; k++) if (mask & (1u << k)) { B[k + 1] += 1; B[k] = 1; }
+    }
+    for (u32 k = 0; k < 2 * NL - 1; k++) { const u32 terms = k < (u32)NL ? k + 1 : 2 * NL - 1 - k; B[k] += terms * add; }
+  }
+  // the reduction's rows: row i adds m P[j] (one unit each) to column i + j and the carry of column i (less than a unit) to column i + 1
+  u32 mask = 0;
+  for (u32 k = NL; k < 2 * NL; k++) {
+    const u32 rows = k < 2 * NL - 1 ? 2 * NL - 1 - k : 0;
+    const u32 U = B[k] + rows + 1;
+    if (S * U > 127 && k < 2 * NL - 1) { mask |= 1u << (k - NL); B[k + 1] += 1; }
+  }
+  return mask;
 }
 // The columns are made opaque between product rounds: the optimiser would otherwise re-associate every column's sum over ALL rounds of an unrolled body
 // (every round's operands live at once: 330-480 registers); the scheduling barrier keeps the LDS reads of later rounds from being hoisted to the top.
@@ -243,7 +273,7 @@ NBLS_HD void aot_step(const D& desc, LDSP lds, const u32 item, const bool live, 
     auto do_round = [&](auto RC) __attribute__((always_inline)) {
       constexpr u32 r = decltype(RC)::value;
       constexpr bool budget = aot_has_norm(SH0, SH1);   // signatures without normalised operands keep the host compiler's own budget (sum of ca * cb <= 8)
-      constexpr u32 cmask = budget ? aot_compress_plan(P0, SH0, SH1, LS).before[r] : 0u;
+      constexpr u32 cmask = budget ? aot_compress_plan(P0, SH0, SH1, 1).before[r] : 0u;   // (lane split: every sub-lane reduces its own columns, so a round counts once)
       V4 nx = cur;
       if (r + 1 < P0) nx = desc.quad(HQ + r + 1);
       constexpr u32 shape = ((r < 4 ? SH0 : SH1) >> (8 * (r & 3))) & 0xffu;
@@ -271,9 +301,15 @@ NBLS_HD void aot_step(const D& desc, LDSP lds, const u32 item, const bool live, 
     if constexpr (P0 > 5) do_round(std::integral_constant<u32, 5>{});
     if constexpr (P0 > 6) do_round(std::integral_constant<u32, 6>{});
     if constexpr (P0 > 7) do_round(std::integral_constant<u32, 7>{});
-    if constexpr (LS > 1) aot_acc_sum<LS>(acc);   // lane split: the columns of the four sub-lanes land in the first one (the others finish into the junk slot)
     u32 res[NL];
-    aot_dot_finish<FLAGS, T>(res, acc, h0.x, post, lds);
+    if constexpr (LS > 1) {
+      // lane split: every sub-lane reduces its own columns, the 14 upper columns are summed across the sub-lanes and land in the first one (the others finish into the junk slot)
+      redc28_rows(acc);
+      constexpr u32 smask = aot_ls_presum_mask(P0, SH0, SH1, LS);
+      if (smask) aot_compress_columns<(smask << NL)>(acc);
+      aot_acc_sum<LS, NL>(acc + NL);
+      aot_dot_finish<FLAGS, T, true>(res, acc, h0.x, post, lds);
+    } else aot_dot_finish<FLAGS, T>(res, acc, h0.x, post, lds);
     commit(h0.x & 0xffffu, res);
   } else if constexpr (KIND == K_LIN) {
     u32 res[NL];

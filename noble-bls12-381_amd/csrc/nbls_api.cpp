@@ -40,7 +40,7 @@ static_assert(P_COUNT <= NBLS_N_PROGRAMS, "nbls_timing_read's arrays (NBLS_N_PRO
 static const size_t RAW = RAW_FP_BYTES;     // one raw field element in HBM scratch (14 limbs + padding)
 static const size_t F12 = 12 * RAW;        // raw Fp12
 static const size_t LINE_BYTES = (size_t)LINE_ELEMS * RAW;   // one line table: 68 triples of Fp2 as raw elements (26,112 B)
-static const size_t SPLIT_MILLER_MIN = 4096;   // pairs from which the Miller loop runs as LINES + ACC (see nbls_pairing_batch_dev; round 4: with the ahead-of-time kernels the two programs win from 4096 pairs, tools/sweep_modes.sh)
+static const size_t SPLIT_MILLER_MIN = 4097;   // pairs from which the Miller loop runs as LINES + ACC (see nbls_pairing_batch_dev).  Round 4 measured the two programs ahead from 4096 pairs on; on the round-5 / 6 build a 4096-pair call -- exactly one wavefront of the fused program (four items) on each of the 1024 SIMDs -- takes 2.19 ms fused against 2.32 ms split, 3072 pairs likewise, and from 4608 pairs on the split form wins (tools/ab_split_min.py, profiles/round6_ab_split_min.txt)
 static const size_t LINES_CHUNK = 131072;   // pairs whose line tables are in HBM at a time (3.4 GB of the 288); larger batches run chunk by chunk on the same stream
 
 #define EXPORT extern "C" __attribute__((visibility("default")))
@@ -61,7 +61,7 @@ struct nbls_ctx {
   std::vector<uint8_t> dst_host; uint8_t* dst_dev = nullptr;   // hash-to-curve domain-separation tag last used by nbls_verify_batch_msgs_dev, and its device copy
   std::map<std::tuple<int, int, int, int>, DevProgram> tower;   // single tower operations (nbls_tower_op_batch), uploaded on first use
   // scratch (device)
-  uint8_t *F = nullptr, *F2 = nullptr, *N = nullptr, *NI = nullptr, *io_g1 = nullptr, *io_g2 = nullptr, *io_f12 = nullptr, *one12 = nullptr;
+  uint8_t *F = nullptr, *N = nullptr, *NI = nullptr, *io_g1 = nullptr, *io_g2 = nullptr, *io_f12 = nullptr, *one12 = nullptr;
   uint8_t* T[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // t1..t7 of the final exponentiation, raw Fp12
   // general scratch pool for the codec / hash / sum pipelines (grown on demand)
   static const int NSB = 20;
@@ -255,10 +255,9 @@ static int run_chain(nbls_ctx* ctx, size_t n, std::initializer_list<ChainLink> l
 static int ensure_scratch(nbls_ctx* ctx, size_t n) {
   if (n <= ctx->cap_F) return NBLS_OK;
   size_t cap = n + n / 8 + 64;
-  if (ctx->F) { hipFree(ctx->F); hipFree(ctx->F2); hipFree(ctx->N); hipFree(ctx->NI); for (auto& t : ctx->T) { hipFree(t); t = nullptr; } hipFree(ctx->KS); hipFree(ctx->KD); hipFree(ctx->Kflag); hipFree(ctx->Klist); hipFree(ctx->Kcount); }
-  ctx->F = ctx->F2 = ctx->N = ctx->NI = ctx->KS = ctx->KD = ctx->Kflag = nullptr; ctx->Klist = ctx->Kcount = nullptr; ctx->cap_F = 0;
+  if (ctx->F) { hipFree(ctx->F); hipFree(ctx->N); hipFree(ctx->NI); for (auto& t : ctx->T) { hipFree(t); t = nullptr; } hipFree(ctx->KS); hipFree(ctx->KD); hipFree(ctx->Kflag); hipFree(ctx->Klist); hipFree(ctx->Kcount); }
+  ctx->F = ctx->N = ctx->NI = ctx->KS = ctx->KD = ctx->Kflag = nullptr; ctx->Klist = ctx->Kcount = nullptr; ctx->cap_F = 0;
   HIPCHK(hipMalloc(&ctx->F, (cap + 2) * F12));
-  HIPCHK(hipMalloc(&ctx->F2, (cap / 2 + 2) * F12));
   HIPCHK(hipMalloc(&ctx->N, cap * RAW));
   HIPCHK(hipMalloc(&ctx->NI, cap * RAW));
   for (auto& t : ctx->T) HIPCHK(hipMalloc(&t, cap * F12));
@@ -333,10 +332,17 @@ struct StreamOrder {
   ~StreamOrder() { if (ctx->ev_last && hipEventRecord(ctx->ev_last, s) == hipSuccess) { ctx->ev_last_set = true; ctx->last_stream = s; } }
 };
 
+// A call that has forked work onto other streams of the context (the side streams of verifyBatch, the second half of a large pairing call) and then fails must not return while
+// those streams still run: StreamOrder records the call's end on `s` only, and the next call would free, regrow or overwrite scratch the orphaned kernels use.
+// Armed right after the fork; every error return in between synchronises the device, the success path disarms it.
+struct ForkGuard {
+  bool armed = true;
+  ~ForkGuard() { if (armed) (void)hipDeviceSynchronize(); }
+};
 typedef std::pair<int, std::pair<const void*, size_t>> BufArg;
 static inline BufArg B(int idx, const void* p, size_t stride) { return {idx, {p, stride}}; }
 
-// F (n raw Fp12) -> one element in F[0] (or F2[0]); returns pointer to the buffer holding the product
+// F (n raw Fp12) -> one element in F[0]; returns pointer to the buffer holding the product
 // Launches of at most one wavefront per SIMD take the time of one wavefront's instruction stream, so up to LS_MAX items (one item per wavefront
 // on 1024 SIMDs) the lane-split variants run: the same formulas with every lane-op's products shared by four lanes, the columns summed across them before the one
 // reduction (ahead-of-time kernels nbls_aot_miller_ls / nbls_aot_expx_ls, aot.h NBLS_AOT_LS_KERNELS; on the interpreter nbls_vm_kernel_ls4).  Measured
@@ -506,7 +512,7 @@ EXPORT void nbls_destroy(nbls_ctx* ctx) {
   if (ctx->dst_dev) hipFree(ctx->dst_dev);
   for (auto& kv : ctx->tower) free_program(kv.second);
   for (auto& d : ctx->prog) free_program(d);
-  for (uint8_t* p : {ctx->F, ctx->F2, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->gen_g1, ctx->g1_fixed, ctx->side_scratch, ctx->L, ctx->partial, ctx->unit_lines, ctx->KS, ctx->KD, ctx->Kflag, (uint8_t*)ctx->Klist, (uint8_t*)ctx->Kcount}) if (p) hipFree(p);
+  for (uint8_t* p : {ctx->F, ctx->N, ctx->NI, ctx->io_g1, ctx->io_g2, ctx->io_f12, ctx->one12, ctx->gen_g1, ctx->g1_fixed, ctx->side_scratch, ctx->L, ctx->partial, ctx->unit_lines, ctx->KS, ctx->KD, ctx->Kflag, (uint8_t*)ctx->Klist, (uint8_t*)ctx->Kcount}) if (p) hipFree(p);
   for (uint8_t* p : ctx->T) if (p) hipFree(p);
   for (uint8_t* p : ctx->sb) if (p) hipFree(p);
   for (auto& b : ctx->io_pool) if (b.p) hipFree(b.p);
@@ -560,15 +566,19 @@ EXPORT int nbls_pairing_batch_dev(nbls_ctx* ctx, size_t n, const void* d_g1, con
     if (with_final_exp && (r = ensure_scratch(ctx, n))) return r;
     if (!ctx->half_stream && (hipStreamCreateWithFlags(&ctx->half_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_half_fork, hipEventDisableTiming) != hipSuccess ||
                               hipEventCreateWithFlags(&ctx->ev_half_join, hipEventDisableTiming) != hipSuccess)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
-    static const size_t split_pct = (size_t)env_long("NBLS_HALVES_SPLIT_PCT", 55);      // size of the first half in per cent: slightly unequal halves do not run phase-locked (profiles/round5_ab_split.txt: 16,384 pairs 6.25 -> 6.14 ms, 65,536 within noise)
+    static const size_t split_pct = (size_t)std::min<long>(99, std::max<long>(1, env_long("NBLS_HALVES_SPLIT_PCT", 55)));      // size of the first half in per cent (clamped to 1 .. 99): slightly unequal halves do not run phase-locked (profiles/round5_ab_split.txt: 16,384 pairs 6.25 -> 6.14 ms, 65,536 within noise)
     const size_t h = ((n * split_pct / 100) + 63) & ~(size_t)63;
-    HIPCHK(hipEventRecord(ctx->ev_half_fork, s)); HIPCHK(hipStreamWaitEvent(ctx->half_stream, ctx->ev_half_fork, 0));
-    ctx->in_halves = true;     // (round 4 compared each HALF with chain_max: calls of 8192..16383 pairs ran their halves chained, the configuration measured as slower)
-    r = pairing_core(ctx, h, d_g1, d_g2, with_final_exp, d_out, s, true);
-    if (!r) { ctx->ioff = h; r = pairing_core(ctx, n - h, d_g1, d_g2, with_final_exp, d_out, ctx->half_stream, true); ctx->ioff = 0; }
-    ctx->in_halves = false;
-    HIPCHK(hipEventRecord(ctx->ev_half_join, ctx->half_stream)); HIPCHK(hipStreamWaitEvent(s, ctx->ev_half_join, 0));
-    return r;
+    if (h > 0 && h < n) {      // (a split that leaves one side empty -- rounding at a small n -- falls through to the single-stream path)
+      HIPCHK(hipEventRecord(ctx->ev_half_fork, s)); HIPCHK(hipStreamWaitEvent(ctx->half_stream, ctx->ev_half_fork, 0));
+      ForkGuard fork_guard;
+      ctx->in_halves = true;     // (round 4 compared each HALF with chain_max: calls of 8192..16383 pairs ran their halves chained, the configuration measured as slower)
+      r = pairing_core(ctx, h, d_g1, d_g2, with_final_exp, d_out, s, true);
+      if (!r) { ctx->ioff = h; r = pairing_core(ctx, n - h, d_g1, d_g2, with_final_exp, d_out, ctx->half_stream, true); ctx->ioff = 0; }
+      ctx->in_halves = false;
+      HIPCHK(hipEventRecord(ctx->ev_half_join, ctx->half_stream)); HIPCHK(hipStreamWaitEvent(s, ctx->ev_half_join, 0));
+      if (!r) fork_guard.armed = false;      // joined into s; a failed half leaves work in flight on both streams: the guard waits for it
+      return r;
+    }
   }
   return pairing_core(ctx, n, d_g1, d_g2, with_final_exp, d_out, s, false);
 }
@@ -945,9 +955,19 @@ static int dev_point_sum(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, vo
 // Staging buffers on the device for one host-buffer call.  Round 5: taken from a pool the context keeps (best fit among the free blocks of at most four times the size; a miss
 // allocates) and handed back when the call returns -- every such call ends with a stream synchronisation and holds the context's mutex throughout, so a block is never reused while
 // the device still works on it.  The pool is capped (NBLS_IO_POOL_MB, default 1024): free blocks are released oldest first when it would grow past the cap.
+// Round 6: a call that fails half way may leave copies or kernels in flight on its stream, so the destructor synchronises the stream before the blocks
+// become free (on the success path the call has just synchronised: a query of an idle stream); buffers registered with secret() -- device copies of private keys -- are
+// zeroed on the call's stream before its last synchronisation (wipe()), or here when the call did not get that far: the pool hands blocks to later, unrelated calls.
 struct HostIO {
-  nbls_ctx* ctx; std::vector<size_t> mine;
-  ~HostIO() { for (size_t i : mine) ctx->io_pool[i].busy = false; }
+  nbls_ctx* ctx; std::vector<size_t> mine; hipStream_t s = nullptr; std::vector<std::pair<void*, size_t>> secrets; bool wiped = false;
+  ~HostIO() {
+    if (!mine.empty()) (void)hipStreamSynchronize(s ? s : ctx->stream);
+    if (!wiped) for (auto& k : secrets) (void)hipMemset(k.first, 0, k.second);
+    for (size_t i : mine) ctx->io_pool[i].busy = false;
+  }
+  void secret(void* p, size_t n) { if (p && n) secrets.push_back({p, n}); }
+  // enqueue the zeroing of the key buffers behind the work that reads them (call it before the call's final synchronisation)
+  int wipe(hipStream_t st) { for (auto& k : secrets) if (hipMemsetAsync(k.first, 0, k.second, st) != hipSuccess) return NBLS_EHIP; wiped = true; return NBLS_OK; }
   void* alloc(size_t n) {
     if (!n) n = 1;
     auto& pool = ctx->io_pool;
@@ -1086,7 +1106,7 @@ EXPORT const char* nbls_program_kernel(nbls_ctx* ctx, int prog) {
   std::lock_guard<std::recursive_mutex> g(ctx->mu);
   if (hipSetDevice(ctx->device) != hipSuccess || upload(ctx, (ProgId)prog)) return nullptr;
   const DevProgram& d = ctx->prog[prog];
-  return d.aot >= 0 ? nbls_aot_name(d.aot) : (d.p->lsplit > 1 ? "nbls_vm_kernel_ls4" : "nbls_vm_kernel");
+  return d.aot >= 0 ? nbls_aot_name(d.aot) : d.p->lsplit == 4 ? "nbls_vm_kernel_ls4" : d.p->lsplit == 1 ? "nbls_vm_kernel" : "none (two-lane programs have no interpreter form)";
 }
 EXPORT int nbls_program_count(void) { return (int)P_COUNT; }
 EXPORT const char* nbls_program_name(int prog) { return prog >= 0 && prog < P_COUNT ? get_program((ProgId)prog).name.c_str() : nullptr; }
@@ -1330,6 +1350,7 @@ static int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, si
     if (nbls_msm_decompose_launch((unsigned)n, 4, d_scalars, dig, s)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
     if ((r = run(ctx, P_G2_MUL_GLS, n, {B(1, d_pts, pt_stride), B(2, dig, 128), B(3, Pj, p), B(4, N, RAW)}, s))) return r;
     }
+    HIPCHK(hipMemsetAsync(dig, 0, n * 128, s));      // the recoded digits ARE the private keys: not left in a scratch slot that later calls reuse
   } else
   if (fixed) {
     if ((r = run(ctx, P_G1_MUL_FIXED, n, {B(2, d_scalars, 32), B(5, ctx->g1_fixed, 0), B(3, Pj, p), B(4, N, RAW)}, s))) return r;
@@ -1375,10 +1396,12 @@ static int mul_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* pts, const 
   const size_t a = g2 ? 192 : 96;
   LOCKED(ctx); HostIO io{ctx}; void *dp = pts ? io.alloc(n * a) : nullptr, *dk = io.alloc(n * 32), *o = io.alloc(n * a), *st = io.alloc(n);
   if ((pts && !dp) || !dk || !o || !st) return NBLS_EHIP;
+  io.secret(dk, n * 32);      // the scalars are private keys in getPublicKey / sign: zeroed before the staging block goes back to the pool
   if (pts) HIPCHK(hipMemcpyAsync(dp, pts, n * a, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(dk, scalars32, n * 32, hipMemcpyHostToDevice, s));
   int r = dev_point_mul(ctx, g2, n, pts ? dp : ctx->gen_g1, pts ? a : 0, dk, o, st, s); if (r) return r;
   std::vector<int8_t> tmp(n);
+  if ((r = io.wipe(s))) return r;
   HIPCHK(hipMemcpyAsync(out, o, n * a, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(tmp.data(), st, n, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
   for (size_t i = 0; i < n; i++) if (scalar_is_zero_mod_r(scalars32 + 32 * i)) tmp[i] = 5;
   if (status) memcpy(status, tmp.data(), n);
@@ -1502,10 +1525,12 @@ EXPORT int nbls_sign_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const u
   if (!ctx || (n && (!offsets || !out192 || !dst || !keys32))) return NBLS_EINVAL; if (!n) return NBLS_OK;
   LOCKED(ctx); HostIO io{ctx}; void *h = io.alloc(n * 192), *dk = io.alloc(n * 32), *o = io.alloc(n * 192), *st = io.alloc(n);
   if (!h || !dk || !o || !st) return NBLS_EHIP;
+  io.secret(dk, n * 32);
   uint8_t* d; int r = dev_expand(ctx, n, msgs, offsets, dst, dst_len, &d, s); if (r) return r;
   HIPCHK(hipMemcpyAsync(dk, keys32, n * 32, hipMemcpyHostToDevice, s));
   if ((r = sign_points(ctx, n, d, h, dk, o, st, s))) return r;
   std::vector<int8_t> tmp(n);
+  if ((r = io.wipe(s))) return r;
   HIPCHK(hipMemcpyAsync(out192, o, n * 192, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(tmp.data(), st, n, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
   for (size_t i = 0; i < n; i++) if (scalar_is_zero_mod_r(keys32 + 32 * i)) tmp[i] = 5;
   if (status) memcpy(status, tmp.data(), n);
@@ -1538,7 +1563,7 @@ EXPORT int nbls_sign_batch_dev(nbls_ctx* ctx, size_t n, const void* d_msgs, cons
   uint8_t* dd; int r;
   if ((r = dst_on_device(ctx, dst, &dst_len, s, &dd))) return r;
   StreamOrder order_(ctx, s);
-  HostIO io{ctx}; void* h = io.alloc(n * 192); if (!h) return NBLS_EHIP;
+  HostIO io{ctx}; io.s = s; void* h = io.alloc(n * 192); if (!h) return NBLS_EHIP;
   uint8_t* du;
   if ((r = need(ctx, 8, n * 256 + 16, &du))) return r;
   uint32_t* d_bad = (uint32_t*)(du + n * 256);
@@ -1621,6 +1646,7 @@ static int verify_pipeline(nbls_ctx* ctx, size_t n, const VerifyIn& in, int fina
   if (!ctx->ev_fork && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
   HIPCHK(hipMemsetAsync(d_bad, 0, 4, s));
   HIPCHK(hipEventRecord(ctx->ev_fork, s));
+  ForkGuard fork_guard;
   if (in.d_sig96) {
     // normP2: PointG2.fromSignature for the ONE signature, on the side stream with its own scratch (its Fp2 exponentiation on two lanes is pure latency)
     if (!ctx->side) {
@@ -1730,6 +1756,7 @@ static int verify_pipeline(nbls_ctx* ctx, size_t n, const VerifyIn& in, int fina
   HIPCHK(hipMemcpyAsync(st.data(), ST, ((np + 3) & ~(size_t)3) + 4, hipMemcpyDeviceToHost, s));
   if (final_exp) HIPCHK(hipMemcpyAsync(out, O, 576, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  fork_guard.armed = false;      // synchronised: every forked stream was joined into s
   uint32_t bad = 0; memcpy(&bad, st.data() + ((np + 3) & ~(size_t)3), 4);
   if (bad_offsets) *bad_offsets = bad != 0;
   st.resize(np);

@@ -75,7 +75,7 @@ enum ProgId {
   P_G1_MUL_W3, P_G2_MUL_W3,     // the ladders with 3-bit windows (85 instead of 128 additions: a shorter instruction stream, but a table that limits the wavefronts per CU): launches of at most one wavefront per SIMD
   P_MUL2S,             // A (buf 3) * B (buf 4) -> buf 5 (may alias buf 3): one level of the IN-PLACE product tree (round 5, reduce_product in nbls_api.cpp):
                        // level k multiplies F[i 2^(k+1)] by F[i 2^(k+1) + 2^k] into the former, so no level copies or pads anything
-  P_G1_MUL_FIXED,      // [k]G1.BASE by a fixed-base table (buf 5, shared by every item: 64 x 15 raw projective points), scalar 32 B (buf 2) -> projective (3), Z (4): getPublicKey without doublings (round 5, curve.h pt_mul_fixed_g1)
+  P_G1_MUL_FIXED,      // [k]G1.BASE by a fixed-base table (buf 5, shared by every item: 86 windows x 7 raw projective points with the default G1_FIXED_WIN = 3), scalar 32 B (buf 2) -> projective (3), Z (4): getPublicKey without doublings (round 5, curve.h pt_mul_fixed_g1)
   P_G2_MUL_GLS,        // [k]Q for Q in G2: affine Q (buf 1), the four base-|z| digits of k as 4 x 32 B big-endian (buf 2) -> projective (3), norm of Z (4): sign's ladder with the scalar split along psi (round 5, codec.h pt_mul_gls_g2)
   // two-lane split (round 5): launches of 1025 .. 2048 items, TWO items per wavefront, every K_DOT lane-op on two adjacent lanes (one DPP stage sums the columns)
   P_MILLER_BYTES_LS2, P_MILLER_RAW_LS2, P_MILLER_FE_LS2, P_EXPX_LS2,

@@ -139,7 +139,9 @@ static int emit_dot(Builder* B, std::vector<DotProduct> prods, int mult, std::ve
   if (offs > MAX_OFFS) { fprintf(stderr, "DOT offset %d: Vneg=%.1f Lneg=%.1f mult=%d\n", offs, Vneg, Lneg, mult); }
   assert(offs <= MAX_OFFS);
   n.offs = offs;
-  double T = mult * (Vpos * P_OVER_R + 1.0 + offs) + Lpos;
+  // lane-split programs (round 6, aot_exec.h aot_ls_presum_mask): every sub-lane that holds a product runs its own reduction, each adding less than p
+  const double redc_p = B->lane_split > 1 ? (double)std::min<size_t>((size_t)B->lane_split, std::max<size_t>(prods.size(), 1)) : 1.0;
+  double T = mult * (Vpos * P_OVER_R + redc_p + offs) + Lpos;
   if (wred) { assert(T < WRED_MAX_IN && mult + (int)lin.size() <= 7); n.wred = true; T = WRED_BOUND; }
   if (halve_it) T = T / 2 + 0.5;
   assert(T < 1000.0);

@@ -84,10 +84,10 @@ NBLS_AOT_KERNELS(SIM_TABLE)
 // g_ls_cols before it takes the sum, so the three partners of a sub-lane 0 are already there.
 static u64 g_ls_cols[64][2 * NL];
 static unsigned g_ls_lane = 0, g_ls_width = 4;
-static void sim_ls_sum(u64* acc) {
+static void sim_ls_sum(u64* acc, int nc) {
   const unsigned i = g_ls_lane;
-  memcpy(g_ls_cols[i], acc, sizeof g_ls_cols[i]);
-  for (unsigned k = 1; k < g_ls_width; k++) if (i + k < 64 && (i + k) / 16 == i / 16) for (int c = 0; c < 2 * NL; c++) acc[c] += g_ls_cols[i + k][c];
+  memcpy(g_ls_cols[i], acc, (size_t)nc * sizeof(u64));
+  for (unsigned k = 1; k < g_ls_width; k++) if (i + k < 64 && (i + k) / 16 == i / 16) for (int c = 0; c < nc; c++) acc[c] += g_ls_cols[i + k][c];
 }
 #undef SIM_CASE
 #define SIM_CASE(ID, KIND, P0, FLAGS, T, SH0, SH1, CNT) \
