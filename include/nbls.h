@@ -219,17 +219,23 @@ int nbls_miller_product_partial_into(nbls_ctx* ctx, size_t n, const uint8_t* g1_
 int nbls_verify_batch_partial_into(nbls_ctx* ctx, size_t n, const uint8_t* sig96 /* or NULL */, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
                                    const uint8_t* dst, size_t dst_len, void* d_dst576, int* zero_flag, int8_t* pk_status /* n, may be NULL */);
 const char* nbls_config_describe(void);   /* "NBLS_X=value(env|default) ...": every environment switch the library has read so far and the value in force -- print it next to an A/B result */
-/* 3 (round 5): nbls_program_kernel, nbls_pool_*, nbls_sign_batch_dev, NBLS_TUNE_VERIFY_* / _SAC_MAX / _PT_LS2_MAX (additions only); nbls_verify_batch_partial_dev writes d_out_fp12 even when it reports a zero point or a decode error
+/* 4 (round 6): nbls_hw_queues (addition only); the library sets GPU_MAX_HW_QUEUES = 22 at load when the variable is unset (see nbls_pool_init below).
+   3 (round 5): nbls_program_kernel, nbls_pool_*, nbls_sign_batch_dev, NBLS_TUNE_VERIFY_* / _SAC_MAX / _PT_LS2_MAX (additions only); nbls_verify_batch_partial_dev writes d_out_fp12 even when it reports a zero point or a decode error
    (contents then meaningless); 2: *_partial take *d_partial as OUT only, *_partial_into added, nbls_tower_op_batch, nbls_verify_batch_msgs_dev.  The bindings check it at load. */
-#define NBLS_ABI_VERSION 3
+#define NBLS_ABI_VERSION 4
 int nbls_abi_version(void);
 int nbls_context_device(nbls_ctx* ctx);
 
 /* ---- several calls in flight on ONE device (round 5): `depth` contexts, each with its own stream and scratch, fed round-robin (what noble-bls12-381_amd/pipeline.py does, for C
  * callers).  A 4096-pairing call alone fills the chip one wavefront deep and runs at ~0.27 of the multiply-add roofline; twelve overlapping calls (nbls_pool_*) reach ~0.45.
  * nbls_pool_pairing_batch_dev enqueues pairing(P_i, Q_i) (reference index.ts:715-722) for n device-resident pairs on the next context's stream and returns at once;
- * *slot (may be NULL) = the context used -- keep one output buffer per slot; nbls_pool_next_slot tells it in advance.  Set GPU_MAX_HW_QUEUES >= depth (and <= 22) in the
- * environment before the HIP runtime initialises: streams that share a hardware queue serialise. */
+ * *slot (may be NULL) = the context used -- keep one output buffer per slot; nbls_pool_next_slot tells it in advance.
+ * Hardware queues: the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read once when the runtime initialises; streams that share a queue
+ * serialise (a pool of twelve on four queues: 2.50 M instead of 2.98 M pairings/s, tests/c/pool_rate.c).  Round 6: libnbls.so sets GPU_MAX_HW_QUEUES = 22 when it is loaded and the variable is unset
+ * (NBLS_KEEP_HW_QUEUES=1: never), which is in time for every process that loads the library before its first HIP call -- a C program linked against it, the N-API addon, a Python
+ * process that imports the binding first.  A process that initialised HIP earlier sets the variable itself; nbls_pool_init warns on stderr when `depth` exceeds the value in force.
+ * nbls_hw_queues: the value in the environment (0 = unset: the runtime's default of 4); *set_by_library (may be NULL) = 1 when the library put it there. */
+int nbls_hw_queues(int* set_by_library);
 typedef struct nbls_pool nbls_pool;
 int nbls_pool_init(int device_id, int depth /* 1 .. 64 */, nbls_pool** out);
 void nbls_pool_destroy(nbls_pool* p);

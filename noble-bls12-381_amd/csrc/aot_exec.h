@@ -198,9 +198,37 @@ typedef void (*AotSimLsHook)(u64*, int);
 inline AotSimLsHook& aot_sim_ls_hook() { static AotSimLsHook h = nullptr; return h; }
 // Lane split: sum of NC 64-bit columns over the LS = 4 (2) adjacent lanes of a lane-op, result in the first of them.  Two DPP stages (lane i += lane i + 1, then
 // lane i += lane i + 2, inside rows of 16 lanes; groups of four never straddle a row) -- one stage for LS = 2.  On the host the simulator's hook does the same sum.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NBLS_LS_SUM_ASM)
+#define NBLS_LS_SUM_ASM 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// 64-bit add of the same column of a neighbouring lane as TWO instructions (v_add_co_u32_dpp + v_addc_co_u32_dpp): the compiler's form of `v += dpp(v)` is two
+// v_mov_b32_dpp and two adds (it folds a DPP move into a 32-bit add, not into a carry chain).  One block for all fourteen columns: a DPP operand must not have been
+// written by the two preceding VALU instructions, which only holds for certain inside a block (s_nop 1 covers whatever the compiler placed in front of it; inside, the
+// second stage reads a register written 27 instructions earlier).
+#define NBLS_DPP_ADD64(L, H, CTRL) "v_add_co_u32_dpp " L ", vcc, " L ", " L " " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_addc_co_u32_dpp " H ", vcc, " H ", " H ", vcc " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+#define NBLS_DPP_STAGE(CTRL) NBLS_DPP_ADD64("%0", "%1", CTRL) NBLS_DPP_ADD64("%2", "%3", CTRL) NBLS_DPP_ADD64("%4", "%5", CTRL) NBLS_DPP_ADD64("%6", "%7", CTRL) NBLS_DPP_ADD64("%8", "%9", CTRL) \
+  NBLS_DPP_ADD64("%10", "%11", CTRL) NBLS_DPP_ADD64("%12", "%13", CTRL) NBLS_DPP_ADD64("%14", "%15", CTRL) NBLS_DPP_ADD64("%16", "%17", CTRL) NBLS_DPP_ADD64("%18", "%19", CTRL) \
+  NBLS_DPP_ADD64("%20", "%21", CTRL) NBLS_DPP_ADD64("%22", "%23", CTRL) NBLS_DPP_ADD64("%24", "%25", CTRL) NBLS_DPP_ADD64("%26", "%27", CTRL)
+template <u32 LS>
+__device__ __forceinline__ void aot_acc_sum14_asm(u64* c) {
+  u32 l[NL], h[NL];
+#pragma unroll
+  for (int k = 0; k < NL; k++) { l[k] = (u32)c[k]; h[k] = (u32)(c[k] >> 32); }
+#define NBLS_DPP_OPS "+v"(l[0]), "+v"(h[0]), "+v"(l[1]), "+v"(h[1]), "+v"(l[2]), "+v"(h[2]), "+v"(l[3]), "+v"(h[3]), "+v"(l[4]), "+v"(h[4]), "+v"(l[5]), "+v"(h[5]), "+v"(l[6]), "+v"(h[6]), \
+  "+v"(l[7]), "+v"(h[7]), "+v"(l[8]), "+v"(h[8]), "+v"(l[9]), "+v"(h[9]), "+v"(l[10]), "+v"(h[10]), "+v"(l[11]), "+v"(h[11]), "+v"(l[12]), "+v"(h[12]), "+v"(l[13]), "+v"(h[13])
+  if (LS == 4) asm volatile("s_nop 1\n\t" NBLS_DPP_STAGE("row_shl:1") NBLS_DPP_STAGE("row_shl:2") : NBLS_DPP_OPS : : "vcc");
+  else asm volatile("s_nop 1\n\t" NBLS_DPP_STAGE("row_shl:1") : NBLS_DPP_OPS : : "vcc");
+#pragma unroll
+  for (int k = 0; k < NL; k++) c[k] = ((u64)h[k] << 32) | l[k];
+}
+#endif
 template <u32 LS, int NC>
 NBLS_HD void aot_acc_sum(u64* acc) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#if NBLS_LS_SUM_ASM
+  if (NC == NL) { aot_acc_sum14_asm<LS>(acc); return; }
+#endif
 #pragma unroll
   for (int c = 0; c < NC; c++) {
     u64 v = acc[c];

@@ -8,6 +8,8 @@
 // This layer uses only the public single-device ABI (include/nbls.h) plus HIP for the peer copies.
 #include <hip/hip_runtime.h>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <functional>
@@ -219,10 +221,37 @@ EXPORT int nbls_multi_verify_batch(nbls_multi* m, size_t n, const uint8_t* sig96
 // the same thing behind the C ABI: `depth` contexts, each with its own stream and scratch, tuned for overlapping calls (the two-program Miller loop at every size, the
 // final exponentiation's middle as seven launches: what counts with other calls' wavefronts on the SIMDs is the instruction count and fine launches), fed round-robin.
 // nbls_pool_pairing_batch_dev enqueues and returns; results are complete after nbls_pool_synchronize (or a synchronisation of the device by the caller).
+//
+// Hardware queues (round 6).  The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read ONCE when the runtime initialises; with fewer
+// queues than contexts in flight, streams share a queue and their kernels serialise: a pool of twelve on four queues runs at 2.50 M instead of 2.98 M pairings/s (tests/c/pool_rate.c).  Round 5 left
+// this to the caller (bench.py set the variable, the JS facade and a plain C caller did not).  Now the library sets GPU_MAX_HW_QUEUES = 22 when it is LOADED and the variable is
+// unset (a constructor: a program linked against libnbls.so, the N-API addon and a Python process that imports the binding before its first HIP call all get it without doing
+// anything; 22: above ~24 user queues the process oversubscribes the device's queue slots and every later stream pays a queue switch per launch, profiles/round4_ab_queues20.txt).
+// NBLS_KEEP_HW_QUEUES=1 leaves the environment alone.  A process that initialised HIP before loading the library keeps what it had: nbls_hw_queues() reports the value in the
+// environment (0 = unset, i.e. the runtime's 4) and whether the library put it there, and nbls_pool_init warns once on stderr when the depth asked for exceeds it.
+static int g_queues_set_by_library = 0;
+__attribute__((constructor)) static void nbls_on_load() {
+  if (getenv("NBLS_KEEP_HW_QUEUES")) return;
+  if (!getenv("GPU_MAX_HW_QUEUES")) { setenv("GPU_MAX_HW_QUEUES", "22", 0); g_queues_set_by_library = 1; }
+}
+EXPORT int nbls_hw_queues(int* set_by_library) {
+  if (set_by_library) *set_by_library = g_queues_set_by_library;
+  const char* v = getenv("GPU_MAX_HW_QUEUES");
+  return v && *v ? atoi(v) : 0;
+}
 struct nbls_pool { std::vector<nbls_ctx*> ctx; std::mutex mu; size_t next = 0; int device = 0; };
 EXPORT void nbls_pool_destroy(nbls_pool* p) { if (!p) return; for (nbls_ctx* c : p->ctx) nbls_destroy(c); delete p; }
 EXPORT int nbls_pool_init(int device_id, int depth, nbls_pool** out) {
   if (!out || depth < 1 || depth > 64) return NBLS_EINVAL;
+  {
+    const int q = nbls_hw_queues(nullptr), eff = q > 0 ? q : 4;
+    static bool warned = false;
+    if (depth > eff && !warned) {
+      warned = true;
+      fprintf(stderr, "nbls: pool of %d contexts on %d hardware queues (GPU_MAX_HW_QUEUES %s): streams will share queues and their kernels serialise; set GPU_MAX_HW_QUEUES >= depth (<= 22) before the first HIP call of the process\n",
+              depth, eff, q > 0 ? "as set" : "unset");
+    }
+  }
   nbls_pool* p = new nbls_pool(); p->device = device_id;
   for (int i = 0; i < depth; i++) {
     nbls_ctx* c = nullptr;

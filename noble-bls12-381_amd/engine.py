@@ -12,7 +12,7 @@ except ImportError:      # the binding itself needs only ctypes
     _np = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 3   # include/nbls.h NBLS_ABI_VERSION: checked at load (round 4's advisor: an ABI-1 caller of *_partial read stale bytes from an ABI-2 library with no error)
+ABI_VERSION = 4   # include/nbls.h NBLS_ABI_VERSION: checked at load (round 4's advisor: an ABI-1 caller of *_partial read stale bytes from an ABI-2 library with no error)
 PROGRAMS = []   # names of the step programs in the library's numbering (filled by load_library from nbls_program_name)
 DST_DEFAULT = b'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_'   # htfDefaults.DST, reference index.ts:64
 

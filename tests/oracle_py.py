@@ -52,6 +52,15 @@ class Oracle:
         self.lib.oracle_pairing_batch(C.c_size_t(n), g1s, g2s, C.c_int(int(final_exp)), C.c_int(int(validate)), out, st, C.c_int(threads))
         return out.raw, st.raw
 
+    def decompress_batch(self, comp, g2=False, threads=8):
+        """PointG1.fromHex (48 B) / PointG2.fromSignature (96 B) of every encoding -> (affine bytes, zeroed where the status is not 0; status bytes)"""
+        a = 96 if g2 else 48
+        n = len(comp) // a
+        out = self._out(2 * a * n)
+        st = self._out(n)
+        self.lib.oracle_decompress_batch(C.c_size_t(n), C.c_int(int(g2)), comp, out, st, C.c_int(threads))
+        return out.raw, st.raw
+
     def miller_product(self, g1s, g2s, final_exp=True):
         n = len(g1s) // 96
         out = self._out(576)

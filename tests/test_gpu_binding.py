@@ -42,7 +42,9 @@ eng = pkg.Engine(0)
 mode = sys.argv[1]
 b = eng.kernel_bindings()
 if mode == 'interp':
-    assert all(k.startswith('nbls_vm_kernel') for k in b.values()), [p for p, k in b.items() if not k.startswith('nbls_vm_kernel')]
+    # every program on the interpreter; the two-lane programs have no interpreter form and say so (round 6: they used to be reported as 'nbls_vm_kernel_ls4')
+    assert all(k.startswith('nbls_vm_kernel') or (p.endswith('_ls2') and k.startswith('none')) for p, k in b.items()), [p for p, k in b.items() if not k.startswith('nbls_vm_kernel')]
+    assert all(k.startswith('none') for p, k in b.items() if p.endswith('_ls2'))
 golden = goldenio.load('ref_vectors.json.gz')
 oracle = oracle_py.load()
 g1 = b''.join(hx(v['g1']) for v in golden['pairs']); g2 = b''.join(hx(v['g2']) for v in golden['pairs'])
