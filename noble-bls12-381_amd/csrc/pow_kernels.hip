@@ -5,6 +5,7 @@
 #include "consts_gen.h"
 #include "fp_inv.h"
 #include "pow_exec.h"
+#include "pow_wide.h"
 
 namespace nbls {
 
@@ -108,8 +109,60 @@ extern "C" __global__ void __launch_bounds__(64) nbls_fp2_pow_kernel(unsigned n,
   fp2_pow_seq(o, ops, nops, tail);
 }
 
+// ---- one limb per lane (pow_wide.h): one wavefront per element, rows 0 / 1 of the wavefront = the components of an Fp2 value (an Fp value: row 0)
+struct WideDev {
+  typedef u32 U; typedef u64 W;
+  u32 lane; const u32* in; u32* out; u32* tab; bool live;      // in / out: the lane's row of the element (16 words per component); tab: the wavefront's LDS table, [entry][64 lanes]
+  __device__ __forceinline__ bool row() const { return (lane & 16u) != 0; }
+  __device__ __forceinline__ U konst(const u32* t16) const { return t16[lane & 15u]; }
+  __device__ __forceinline__ U sel(U a, U b) const { return row() ? b : a; }
+  __device__ __forceinline__ U add(U a, U b) const { return a + b; }
+  __device__ __forceinline__ U sub(U a, U b) const { return a - b; }
+  __device__ __forceinline__ U and_(U a, u32 m) const { return a & m; }
+  __device__ __forceinline__ U shr(U a, int k) const { return a >> k; }
+  __device__ __forceinline__ U mul_lo(U a, u32 k) const { return a * k; }
+  __device__ __forceinline__ U lo(W w) const { return (u32)w; }
+  __device__ __forceinline__ W zero() const { return 0; }
+  __device__ __forceinline__ W mad(U a, U b, W acc) const { return acc + (u64)a * b; }
+  __device__ __forceinline__ W mad_s(U a, u32 s, W acc) const { return acc + (u64)a * s; }
+  __device__ __forceinline__ W shr28(W w) const { return w >> 28; }
+  __device__ __forceinline__ W add_lo(W w, U x) const { return (w & 0xffffffff00000000ull) | (u32)((u32)w + x); }
+  __device__ __forceinline__ U bcast(U v, int i) const {      // ds_swizzle, bit-mask mode: source lane = (lane & 0x10) | i inside every group of 32 lanes; the pattern is an immediate
+    switch (i) {
+#define NBLS_SWZ(I) case I: return (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x10 | (I << 5));
+      NBLS_SWZ(0) NBLS_SWZ(1) NBLS_SWZ(2) NBLS_SWZ(3) NBLS_SWZ(4) NBLS_SWZ(5) NBLS_SWZ(6) NBLS_SWZ(7) NBLS_SWZ(8) NBLS_SWZ(9) NBLS_SWZ(10) NBLS_SWZ(11) NBLS_SWZ(12) default: NBLS_SWZ(13)
+#undef NBLS_SWZ
+    }
+  }
+  __device__ __forceinline__ U xchg(U v) const { return (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (0x10 << 10)); }      // lane ^ 16
+  __device__ __forceinline__ U shl1(U v) const { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); }      // row_shl:1
+  __device__ __forceinline__ U shr1(U v) const { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }      // row_shr:1
+  __device__ __forceinline__ u32 lane_of(U v, int k) const { return (u32)__builtin_amdgcn_readlane((int)v, k); }
+  __device__ __forceinline__ U load() const { return (live && (lane & 15u) < (u32)NL) ? in[lane & 15u] : 0u; }
+  __device__ __forceinline__ void store(U v) const { if (live) out[lane & 15u] = (lane & 15u) < (u32)NL ? v : 0u; }
+  __device__ __forceinline__ void tab_put(int e, U v) const { tab[64 * e + lane] = v; }      // every lane its own word (the upper half of the wavefront idles, but it executes the stores)
+  __device__ __forceinline__ U tab_get(int e) const { return tab[64 * e + lane]; }
+};
+// tail: 0 = Fp (op list of the exponent itself), 7 / 8 = Fp2 with that tail (fp2_pow_seq)
+extern "C" __global__ void __launch_bounds__(64) nbls_pow_wide_kernel(unsigned n, const u32* __restrict__ in, u32* __restrict__ out, const unsigned char* __restrict__ ops, int nops, int tail, WideConsts consts) {
+  __shared__ u32 tab[POW_TAB * 64];
+  const unsigned i = blockIdx.x, lane = threadIdx.x;
+  const bool fp2 = tail != 0;
+  const bool live = i < n && lane < (fp2 ? 32u : 16u);
+  const size_t off = (size_t)i * (fp2 ? 32u : 16u) + (fp2 ? 16u * ((lane >> 4) & 1u) : 0u);
+  WideDev l{lane, in + off, out + off, tab, live};
+  if (fp2) { WideField<WideDev, true> f(l, consts); fp2_pow_seq(f, ops, nops, tail); }
+  else { WideField<WideDev, false> f(l, consts); fp_pow_seq(f, ops, nops); }
+}
+
 }  // namespace nbls
 
+extern "C" int nbls_pow_wide_launch(unsigned n, const void* in, void* out, const void* ops, int nops, int is_fp2, void* stream) {
+  if (n == 0) return 0;
+  static const nbls::WideConsts consts = nbls::wide_consts();
+  hipLaunchKernelGGL(nbls::nbls_pow_wide_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, n, (const nbls::u32*)in, (nbls::u32*)out, (const unsigned char*)ops, nops, is_fp2, consts);
+  return (int)hipGetLastError();
+}
 extern "C" int nbls_fp_pow_launch(unsigned n, const void* in, void* out, const void* ops, int nops, void* scratch, int is_fp2, void* stream) {   // ops: pow_exec.h op list (device memory); is_fp2: 0 Fp, 7 / 8: Fp2 with that tail (nbls_fp2_pow_kernel); scratch: POW_TAB raw elements per lane
   if (n == 0) return 0;
   if (is_fp2) hipLaunchKernelGGL(nbls::nbls_fp2_pow_kernel, dim3((2 * n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, (const nbls::u32*)in, (nbls::u32*)out, (const unsigned char*)ops, nops, (nbls::u32*)scratch, is_fp2);

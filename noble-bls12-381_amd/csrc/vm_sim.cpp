@@ -10,6 +10,7 @@
 #include "consts_gen.h"
 #include "fp_inv.h"
 #include "pow_exec.h"
+#include "pow_wide.h"
 #include "scalar_split.h"
 #include "aot_exec.h"
 #include "aot_layout.h"
@@ -137,6 +138,37 @@ static int sim_run_aot(int prog, unsigned n_items, const IOBuf* bufs) {
   return 0;
 }
 
+// The one-limb-per-lane form (pow_wide.h) on the host: a value of type U is the array of the 32 lanes of a wavefront's first two rows, every cross-lane move a loop.  The
+// arithmetic the device does in 32 / 64 bits is checked here for what the device silently assumes: no 64-bit column overflows, the low-word additions never carry.
+static unsigned long g_wide_violations = 0;
+struct WideHost {
+  struct U { u32 v[32]; };
+  struct W { u64 v[32]; };
+  const u32* in; u32* out; bool fp2; U tab[POW_TAB];
+  template <class F> static U map(F f) { U r; for (int k = 0; k < 32; k++) r.v[k] = f(k); return r; }
+  U konst(const u32* t16) const { return map([&](int k) { return t16[k & 15]; }); }
+  U sel(const U& a, const U& b) const { return map([&](int k) { return k >= 16 ? b.v[k] : a.v[k]; }); }
+  U add(const U& a, const U& b) const { return map([&](int k) { if ((u64)a.v[k] + b.v[k] > 0xffffffffull) g_wide_violations++; return a.v[k] + b.v[k]; }); }
+  U sub(const U& a, const U& b) const { return map([&](int k) { if (a.v[k] < b.v[k]) g_wide_violations++; return a.v[k] - b.v[k]; }); }
+  U and_(const U& a, u32 m) const { return map([&](int k) { return a.v[k] & m; }); }
+  U shr(const U& a, int s) const { return map([&](int k) { return a.v[k] >> s; }); }
+  U mul_lo(const U& a, u32 c) const { return map([&](int k) { return a.v[k] * c; }); }
+  U lo(const W& w) const { return map([&](int k) { return (u32)w.v[k]; }); }
+  W zero() const { W w; for (int k = 0; k < 32; k++) w.v[k] = 0; return w; }
+  W mad(const U& a, const U& b, const W& acc) const { W w; for (int k = 0; k < 32; k++) { const unsigned __int128 t = (unsigned __int128)acc.v[k] + (unsigned __int128)a.v[k] * b.v[k]; if (t >> 64) g_wide_violations++; w.v[k] = (u64)t; } return w; }
+  W mad_s(const U& a, u32 s, const W& acc) const { W w; for (int k = 0; k < 32; k++) { const unsigned __int128 t = (unsigned __int128)acc.v[k] + (unsigned __int128)a.v[k] * s; if (t >> 64) g_wide_violations++; w.v[k] = (u64)t; } return w; }
+  W shr28(const W& a) const { W w; for (int k = 0; k < 32; k++) w.v[k] = a.v[k] >> 28; return w; }
+  W add_lo(const W& a, const U& x) const { W w; for (int k = 0; k < 32; k++) { if ((a.v[k] >> 32) || (a.v[k] + x.v[k]) >> 32) g_wide_violations++; w.v[k] = (a.v[k] & 0xffffffff00000000ull) | (u32)((u32)a.v[k] + x.v[k]); } return w; }
+  U bcast(const U& a, int i) const { return map([&](int k) { return a.v[(k & 16) | i]; }); }
+  U xchg(const U& a) const { return map([&](int k) { return a.v[k ^ 16]; }); }
+  U shl1(const U& a) const { return map([&](int k) { return (k & 15) == 15 ? 0u : a.v[k + 1]; }); }
+  U shr1(const U& a) const { return map([&](int k) { return (k & 15) == 0 ? 0u : a.v[k - 1]; }); }
+  u32 lane_of(const U& a, int k) const { return a.v[k]; }
+  U load() const { return map([&](int k) { return (k & 15) < NL && (fp2 || k < 16) ? in[k] : 0u; }); }      // in: the element's 16 (Fp) or 32 (Fp2) words
+  void store(const U& a) { for (int k = 0; k < (fp2 ? 32 : 16); k++) out[k] = (k & 15) < NL ? a.v[k] : 0u; }
+  void tab_put(int e, const U& a) { tab[e] = a; }
+  U tab_get(int e) const { return tab[e]; }
+};
 extern "C" {
 // translated programs (aot.h) instead of the interpreter's semantics for the programs that have an ahead-of-time kernel: 0 off, 1 on
 __attribute__((visibility("default"))) void nbls_sim_set_aot(int on) { g_sim_aot = on; }
@@ -220,6 +252,24 @@ __attribute__((visibility("default"))) void nbls_sim_fp_pow(unsigned n, const u3
     if (which == 0 || which == 3) { FpHost o; o.in = in + 16 * k; o.out = out + 16 * k; fp_pow_seq(o, ops.data(), nops); }
     else { Fp2Host o; o.in = in + 32 * k; o.out = out + 32 * k; fp2_pow_seq(o, ops.data(), nops, which == 1 ? 8 : 7); }
   }
+}
+// out = in^e through the one-limb-per-lane chains (which as nbls_sim_fp_pow); returns the number of violated device assumptions (0 on a correct build)
+__attribute__((visibility("default"))) unsigned long nbls_sim_fp_pow_wide(unsigned n, const u32* in, u32* out, int which) {
+  std::vector<unsigned char> ops;
+  if (which == 1 || which == 2) {
+    uint64_t K[6]; for (int j = 0; j < 6; j++) K[j] = NBLS_EXP_P_MINUS_3_DIV_4[j];
+    K[0] -= 2;
+    for (int j = 0; j < 6; j++) K[j] = (K[j] >> 2) | (j < 5 ? K[j + 1] << 62 : 0);
+    ops = pow_make_ops(K, 377);
+  } else ops = which == 0 ? pow_make_ops(NBLS_EXP_P_PLUS_1_DIV_4, NBLS_P_PLUS_1_DIV_4_BITS) : pow_make_ops(NBLS_EXP_P_MINUS_3_DIV_4, NBLS_P_MINUS_3_DIV_4_BITS);
+  const int nops = (int)(ops.size() / 2);
+  const WideConsts consts = wide_consts();
+  g_wide_violations = 0;
+  for (unsigned k = 0; k < n; k++) {
+    if (which == 0 || which == 3) { WideHost l; l.in = in + 16 * k; l.out = out + 16 * k; l.fp2 = false; WideField<WideHost, false> f(l, consts); fp_pow_seq(f, ops.data(), nops); }
+    else { WideHost l; l.in = in + 32 * k; l.out = out + 32 * k; l.fp2 = true; WideField<WideHost, true> f(l, consts); fp2_pow_seq(f, ops.data(), nops, which == 1 ? 8 : 7); }
+  }
+  return g_wide_violations;
 }
 // op list statistics of an exponent (tests): squarings, multiplications
 __attribute__((visibility("default"))) void nbls_sim_pow_ops(int which, unsigned* out2) {

@@ -194,6 +194,26 @@ def test_pow_chains(sim):
             got = (_unraw(dst.raw, 2 * k), _unraw(dst.raw, 2 * k + 1))
             assert got[0] < 4 * p and got[1] < 4 * p
             assert (got[0] % p, got[1] % p) == ((want[0] * R) % p, (want[1] * R) % p), (which, k)
+    # round 6: the same four exponents through the one-limb-per-lane form (pow_wide.h; the host runs the device's sequences with the cross-lane moves as loops and counts every
+    # violated assumption -- a 64-bit column overflow, a carry out of a low-word addition, a borrow in a biased subtraction)
+    sim.nbls_sim_fp_pow_wide.restype = C.c_ulong
+    for which, e in ((0, (p + 1) // 4), (3, (p - 3) // 4)):
+        src = C.create_string_buffer(_raw(xs), 64 * len(xs)); dst = C.create_string_buffer(64 * len(xs))
+        assert sim.nbls_sim_fp_pow_wide(C.c_uint(len(xs)), src, dst, which) == 0
+        for k, x in enumerate(xs):
+            got = _unraw(dst.raw, k)
+            a = (x * pow(R, -1, p)) % p
+            assert got < 2 * p and got % p == (pow(a, e, p) * R) % p, ('wide', which, hex(x))
+            assert all(int.from_bytes(dst.raw[64 * k + 4 * i:64 * k + 4 * i + 4], 'little') < (1 << 28) for i in range(14)) and dst.raw[64 * k + 56:64 * k + 64] == bytes(8)     # stored limbs are exact
+    for which, e in ((1, (p * p + 7) // 16), (2, (p * p - 9) // 16)):
+        src = C.create_string_buffer(_raw(flat), 64 * len(flat)); dst = C.create_string_buffer(64 * len(flat))
+        assert sim.nbls_sim_fp_pow_wide(C.c_uint(len(pairs)), src, dst, which) == 0
+        ri = pow(R, -1, p)
+        for k, (x0, x1) in enumerate(pairs):
+            want = f2pow(((x0 * ri) % p, (x1 * ri) % p), e)
+            got = (_unraw(dst.raw, 2 * k), _unraw(dst.raw, 2 * k + 1))
+            assert got[0] < 2 * p and got[1] < 2 * p
+            assert (got[0] % p, got[1] % p) == ((want[0] * R) % p, (want[1] * R) % p), ('wide', which, k)
     # the chains are shorter than 4-bit fixed windows: squarings and multiplications of each op list
     for which, nbits in ((0, 379), (1, 377), (2, 377), (3, 379)):
         st = (C.c_uint * 2)()
