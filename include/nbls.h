@@ -283,6 +283,7 @@ int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks);
 #define NBLS_TUNE_SAC_MAX 8            /* keys up to which sign's ladder (points known to lie in G2) uses the sign-aligned recoding with one addition per bit (default 6144: every
                                         * wavefront of the launch resident at once; 0 = never: the windowed psi-split ladder at every size) */
 #define NBLS_TUNE_PT_LS2_MAX 9         /* items up to which the G2 point chains of verify / sign (clearCofactor's two ladders, sign's ladder) run in their two-lane forms (default 4096; 0 = never) */
+#define NBLS_TUNE_WIDE_MAX 10          /* round 6, experiment: items up to which the programs that allow it run on the one-limb-per-lane interpreter (one item per workgroup of three wavefronts, two barriers per step); bit-exact, measured slower than the four-lane forms (0.93 against 0.66 ms for a final exponentiation's five exponentiations), so the default is 0 = never */
 int nbls_set_tuning(nbls_ctx* ctx, int key, long long value);
 int nbls_program_count(void);                 /* number of step programs; timing slot nbls_program_count() = the inversion kernel */
 const char* nbls_program_name(int prog);

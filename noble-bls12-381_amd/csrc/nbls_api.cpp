@@ -17,6 +17,8 @@
 #include <thread>
 
 extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream);
+extern "C" int nbls_vm_wide_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream);
+#include "wide_exec.h"   // wide_step_supported
 #include "aot.h"
 #include <map>
 #include <tuple>
@@ -51,6 +53,7 @@ static const size_t EXPC_MIN_DEFAULT = (size_t)1 << 40;   // items from which th
 struct DevProgram {
   Step* steps = nullptr; u32* descs = nullptr; u32* consts = nullptr;
   const Program* p = nullptr;
+  bool wide_ok = false;   // every step is one the one-limb-per-lane interpreter implements (wide_exec.h): launches of at most ctx->wide_max items run on nbls_vm_kernel_wide
   int aot = -1; AotStep* aot_steps = nullptr; u32* aot_descs = nullptr; u32 aot_lds = 0;   // ahead-of-time kernel of this program (aot.h) and the translated program, when every step's signature is in the kernel's table
 };
 
@@ -93,6 +96,14 @@ struct nbls_ctx {
   size_t expc_min = (size_t)env_long("NBLS_EXPC_MIN", (long)EXPC_MIN_DEFAULT);   // nbls_set_tuning(NBLS_TUNE_EXPC_MIN)
   size_t pt_ls2_max = (size_t)env_long("NBLS_PT_LS2_MAX", 4096);                // nbls_set_tuning(NBLS_TUNE_PT_LS2_MAX): items up to which the G2 point chains run in their two-lane forms (pt_ls2_variant)
   size_t sac_max = (size_t)env_long("NBLS_G2_SAC_MAX", 6144);                   // nbls_set_tuning(NBLS_TUNE_SAC_MAX): keys up to which sign's ladder is the sign-aligned form (dev_point_mul)
+  // round 6: launches of at most wide_max items run the programs that allow it on the one-limb-per-lane interpreter (vm_wide_kernel.hip: one item per workgroup of ceil(W / 4)
+  // wavefronts, the Montgomery reduction spread over a row of lanes, two barriers per step) -- the multi-wavefront item form the round-5 review asked for.  Built, bit-exact
+  // (tests/test_wide_sim.py, test_gpu_pairing.py::test_one_limb_per_lane_forms) and MEASURED SLOWER than the four-lane forms: the five exponentiations of one final exponentiation
+  // take 0.93 ms against 0.66 ms (tools/wide_time.py, profiles/round6_wide_time.txt).  A step is 350 instructions in its rows + ~190 around them where the four-lane form has 660,
+  // but every one of them waits for its predecessor (one column per lane: no independent work), and a lone wavefront then pays ~9-11 clocks per instruction instead of ~5.  Off by
+  // default: NBLS_WIDE_MAX / NBLS_TUNE_WIDE_MAX (items; 0 = never), NBLS_WIDE_PROGS = 0: only the final exponentiation's programs.  The fixed-exponent powers, where the same
+  // idea removes a 196-multiply-add reduction per squaring from ONE lane, are the case that pays (pow_wide.h: 0.7 -> 0.3 ms).
+  size_t wide_max = (size_t)env_long("NBLS_WIDE_MAX", 0);
   size_t chain_max = (size_t)env_long("NBLS_CHAIN_MAX", 8192);                  // nbls_set_tuning(NBLS_TUNE_CHAIN_MAX); see run_chain
   u32* qp_table = nullptr;      // multiples of p for the weak reduction (vm_exec.h weak_reduce), device copy
   uint8_t* unit_lines = nullptr;   // a line table whose 68 lines are all 1 (c0 = 1, c1 = c2 = 0): the neutral partner of an odd last pair
@@ -150,8 +161,17 @@ static int upload_program(nbls_ctx* ctx, DevProgram& d, const Program& p, const 
       d.aot = k; d.aot_lds = ap.lds_bytes;
     } else fprintf(stderr, "nbls: %s: %s; running on the interpreter\n", p.name.c_str(), why.empty() ? "step signatures differ from the ahead-of-time kernel's table" : why.c_str());
   }
+  d.wide_ok = p.lsplit == 1 && p.W <= 16 && p.inst_base(0) + p.inst_bytes() <= 64 * 1024;
+  for (const Step& st : p.steps) if (!wide_step_supported(st, p.descs.data())) { d.wide_ok = false; break; }
   d.p = &p;
   return NBLS_OK;
+}
+// does a launch of n items of this (uploaded) program take the one-limb-per-lane form?
+static bool wide_applies(const nbls_ctx* ctx, const DevProgram& d, int id, size_t n) {
+  if (!d.wide_ok || n > ctx->wide_max || id < 0) return false;
+  static const long which = env_long("NBLS_WIDE_PROGS", 1);
+  if (which) return true;
+  return id == P_EXPX || id == P_FE_MID1 || id == P_FE_MID2 || id == P_FE_EASY || id == P_NORM_RAW || id == P_MUL2 || id == P_MUL2S;
 }
 
 static hipEvent_t timing_event(nbls_ctx* ctx) {
@@ -197,7 +217,8 @@ static int run_dev(nbls_ctx* ctx, const DevProgram& d, int id, size_t n, std::in
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->timing) { e0 = timing_event(ctx); e1 = timing_event(ctx); hipEventRecord(e0, s); }
   int e;
-  if (d.aot >= 0) {
+  if (wide_applies(ctx, d, id, n)) e = nbls_vm_wide_launch(&ka, d.p->inst_base(0) + d.p->inst_bytes(), s);
+  else if (d.aot >= 0) {
     AotArgs a; memset(&a, 0, sizeof a);
     aot_seg(a.seg[0], d, ka.bufs);
     a.nseg = 1; a.W = ka.W; a.G = ka.G; a.n_items = ka.n_items; a.qp_table = ka.qp_table; a.item_index = ka.item_index; a.n_items_dev = ka.n_items_dev;
@@ -361,6 +382,7 @@ static size_t ls_max() { static const size_t v = (size_t)env_long("NBLS_LS_MAX",
 // used only where the program is bound to its ahead-of-time kernel).  Measured (tools/ab_ls2.sh): 2048 pairings 1.9 against 2.17 ms.  NBLS_LS2_MAX = 0 switches them off.
 static size_t ls2_max() { static const size_t v = (size_t)env_long("NBLS_LS2_MAX", 2048); return v; }
 static ProgId ls_variant(nbls_ctx* ctx, ProgId id, size_t n) {
+  if (n <= ctx->wide_max && upload(ctx, id) == NBLS_OK && wide_applies(ctx, ctx->prog[id], (int)id, n)) return id;      // the one-limb-per-lane form runs the plain program
   if (n <= ls_max()) {
     switch (id) {
       case P_MILLER_BYTES: return P_MILLER_BYTES_LS;
@@ -386,6 +408,7 @@ static ProgId ls_variant(nbls_ctx* ctx, ProgId id, size_t n) {
 // The G2 point chains of a single verify / sign (the two ladders of clearCofactor, sign's own ladder) in their two-lane forms (round 5; nbls_aot_g2pt_ls2): four items per wavefront,
 // launches of at most 4096 items -- one wavefront per SIMD at most, where a shorter instruction stream is the whole gain.  NBLS_PT_LS2_MAX / NBLS_TUNE_PT_LS2_MAX (0 = never).
 static ProgId pt_ls2_variant(nbls_ctx* ctx, ProgId id, size_t n) {
+  if (n <= ctx->wide_max && upload(ctx, id) == NBLS_OK && wide_applies(ctx, ctx->prog[id], (int)id, n)) return id;
   if (n > ctx->pt_ls2_max) return id;
   const ProgId v = id == P_H2C_C1 ? P_H2C_C1_LS2 : id == P_H2C_C2 ? P_H2C_C2_LS2 : id == P_G2_MUL_SAC ? P_G2_MUL_SAC_LS2 : id;
   if (v != id && upload(ctx, v) == NBLS_OK && ctx->prog[v].aot >= 0) return v;   // (no interpreter form of the two-lane split exists)
@@ -435,7 +458,7 @@ static int final_exp_pipeline(nbls_ctx* ctx, size_t n, uint8_t* f_raw, void* d_o
   uint8_t** T = ctx->T;
   if ((r = run_inv(ctx, n, s))) return r;
   if ((r = run(ctx, P_FE_EASY, n, {B(3, f_raw, F12), B(4, ctx->NI, RAW), B(5, T[0], F12)}, s))) return r;
-  if (n < ctx->expc_min && n < ctx->chain_max && !ctx->in_halves && ls_variant(ctx, P_EXPX, n) == P_EXPX) {
+  if (n < ctx->expc_min && n < ctx->chain_max && !ctx->in_halves && ls_variant(ctx, P_EXPX, n) == P_EXPX && !wide_applies(ctx, ctx->prog[P_EXPX], (int)P_EXPX, n)) {
     // the seven launches between the easy part and the final product as one chain (math.ts:862-867): t2 = t1^x, t3 = conj(t1^2) t2, t4 = t3^x, t5 = t4^x,
     // t6' = t5^x, t6 = t6' t2^2, t7 = t6^x
     if ((r = run_chain(ctx, n, {{P_EXPX, {B(3, T[0], F12), B(5, T[1], F12)}},
@@ -1101,6 +1124,7 @@ EXPORT int nbls_set_tuning(nbls_ctx* ctx, int key, long long value) {
     case NBLS_TUNE_CHAIN_MAX: if (value < 0) return NBLS_EINVAL; ctx->chain_max = (size_t)value; return NBLS_OK;
     case NBLS_TUNE_SAC_MAX: if (value < 0) return NBLS_EINVAL; ctx->sac_max = (size_t)value; return NBLS_OK;
     case NBLS_TUNE_PT_LS2_MAX: if (value < 0) return NBLS_EINVAL; ctx->pt_ls2_max = (size_t)value; return NBLS_OK;
+    case NBLS_TUNE_WIDE_MAX: if (value < 0) return NBLS_EINVAL; ctx->wide_max = (size_t)value; return NBLS_OK;
     case NBLS_TUNE_VERIFY_CHUNKS: if (value < 0 || value > 16) return NBLS_EINVAL; ctx->verify_chunks = (long)value; return NBLS_OK;
     case NBLS_TUNE_VERIFY_LAST_PCT: if (value < 1 || value > 100) return NBLS_EINVAL; ctx->verify_last_pct = (long)value; return NBLS_OK;
     case NBLS_TUNE_VERIFY_PIPE_MIN: if (value < 0) return NBLS_EINVAL; ctx->verify_pipe_min = (long)value; return NBLS_OK;

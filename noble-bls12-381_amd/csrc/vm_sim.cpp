@@ -11,6 +11,7 @@
 #include "fp_inv.h"
 #include "pow_exec.h"
 #include "pow_wide.h"
+#include "wide_exec.h"
 #include "scalar_split.h"
 #include "aot_exec.h"
 #include "aot_layout.h"
@@ -169,7 +170,76 @@ struct WideHost {
   void tab_put(int e, const U& a) { tab[e] = a; }
   U tab_get(int e) const { return tab[e]; }
 };
+// ---- the one-limb-per-lane interpreter (wide_exec.h, vm_wide_kernel.hip) on the host: a value is the array of a row's sixteen lanes; every lane-op of a step reads,
+// then all results are committed (the device's two barriers).  The 32 / 64-bit assumptions of the device code are checked: g_wide_violations counts them.
+struct WideRowHost {
+  struct I { i32 v[16]; };
+  struct W { i64 v[16]; };
+  const char* lds; u32 base;
+  u32 addr(u32 f) const { return (f & 2u) ? base + f - 2u : f; }
+  template <class F> static I map(F f) { I r; for (int k = 0; k < 16; k++) r.v[k] = f(k); return r; }
+  static i32 chk32(i64 x) { if (x > 0x7fffffffll || x < -0x80000000ll) { g_wide_violations++; if (getenv("NBLS_SIM_WIDE_DEBUG")) fprintf(stderr, "wide: 32-bit overflow %lld\n", (long long)x); } return (i32)x; }
+  I zero() const { return map([](int) { return 0; }); }
+  void fence() const {}
+  bool skip_rows() const { return false; }
+  I konst(u32 c) const { return map([&](int) { return (i32)c; }); }
+  I add(const I& a, const I& b) const { return map([&](int k) { return chk32((i64)a.v[k] + b.v[k]); }); }
+  I sub(const I& a, const I& b) const { return map([&](int k) { return chk32((i64)a.v[k] - b.v[k]); }); }
+  I and_(const I& a, u32 m) const { return map([&](int k) { return (i32)((u32)a.v[k] & m); }); }
+  I low13(const I& a) const { return map([&](int k) { return k < 13 ? (i32)((u32)a.v[k] & LMASK) : a.v[k]; }); }
+  I carry13(const I& a) const { return map([&](int k) { return k < 13 ? a.v[k] : 0; }); }
+  I sar(const I& a, int s) const { return map([&](int k) { return a.v[k] >> s; }); }
+  I mul_lo(const I& a, u32 c) const { return map([&](int k) { return (i32)((u32)a.v[k] * c); }); }
+  I mul_small(const I& a, u32 c) const { return map([&](int k) { return chk32((i64)a.v[k] * (i64)c); }); }
+  I lo(const W& w) const { return map([&](int k) { return (i32)w.v[k]; }); }
+  W wzero() const { W w; for (int k = 0; k < 16; k++) w.v[k] = 0; return w; }
+  static i64 chk64(__int128 t) { if (t > (__int128)0x7fffffffffffffffll || t < -(__int128)0x7fffffffffffffffll - 1) { g_wide_violations++; if (getenv("NBLS_SIM_WIDE_DEBUG")) fprintf(stderr, "wide: 64-bit overflow\n"); } return (i64)t; }
+  W mad(const I& a, const I& b, const W& acc) const { W w; for (int k = 0; k < 16; k++) w.v[k] = chk64((__int128)acc.v[k] + (__int128)a.v[k] * b.v[k]); return w; }
+  W mad_p(const I& ml, const W& acc) const { const u32 P[NL] = NBLS_P28; W w; for (int k = 0; k < 16; k++) w.v[k] = chk64((__int128)acc.v[k] + (__int128)(k < NL ? P[k] : 0u) * ml.v[0]); return w; }
+  W mad_pq(const I& q, const W& acc) const { const u32 P[NL] = NBLS_P28; W w; for (int k = 0; k < 16; k++) w.v[k] = chk64((__int128)acc.v[k] + (__int128)(k < NL ? P[k] : 0u) * q.v[k]); return w; }
+  W sar28(const W& a) const { W w; for (int k = 0; k < 16; k++) w.v[k] = a.v[k] >> 28; return w; }
+  W addw(const W& a, const I& x) const { W w; for (int k = 0; k < 16; k++) w.v[k] = chk64((__int128)a.v[k] + x.v[k]); return w; }
+  W addww(const W& a, const W& b) const { W w; for (int k = 0; k < 16; k++) w.v[k] = chk64((__int128)a.v[k] + b.v[k]); return w; }
+  I wred_q(const I& top) const { return map([&](int k) { i32 t = top.v[k] - 9; t = t < 0 ? 0 : t; const u32 q = (u32)(((u64)(u32)t * 2642610142u) >> 48); return (i32)(q > (u32)(QP_TABLE_ENTRIES - 1) ? (u32)(QP_TABLE_ENTRIES - 1) : q); }); }
+  I bcast(const I& a, int i) const { return map([&](int) { return a.v[i]; }); }
+  I shl1(const I& a) const { return map([&](int k) { return k == 15 ? 0 : a.v[k + 1]; }); }
+  I shr1(const I& a) const { return map([&](int k) { return k == 0 ? 0 : a.v[k - 1]; }); }
+  I ld(u32 f) const { const u32 off = addr(f); return map([&](int k) { i32 x; memcpy(&x, lds + off + 4 * k, 4); return x; }); }
+  I gload(const u32* g, bool live) const { return map([&](int k) { return (live && k < NL) ? (i32)g[k] : 0; }); }
+  void gstore(u32* g, const I& v, bool live) const { if (live) for (int k = 0; k < 16; k++) g[k] = (u32)v.v[k]; }
+};
+struct WideDescHost { const u32* w; u32 operator()(int k) const { return w[k]; } };
+// 0: ran; -4: the program has a step the form does not implement (or shared constants / a lane split)
+static int sim_run_wide(const Program& p, unsigned n_items, const IOBuf* bufs) {
+  if (p.lsplit != 1 || p.W > 16) return -4;
+  for (auto& st : p.steps) if (!wide_step_supported(st, p.descs.data())) return -4;
+  const u32 base = p.inst_base(0);
+  std::vector<u32> image((size_t)(base + p.inst_bytes()) / 4 + 8);
+  char* lds = (char*)image.data();
+  for (unsigned item = 0; item < n_items; item++) {
+    std::fill(image.begin(), image.end(), 0u);
+    for (unsigned c = 0; c < p.nconst; c++) memcpy(lds + c * p.slot_bytes, p.consts.data() + c * RAW_WORDS, NL * 4);
+    for (auto& st : p.steps) {
+      struct Pending { u32 dst; WideRowHost::I v; };
+      std::vector<Pending> pend;
+      for (unsigned row = 0; row < st.nlanes; row++) {
+        WideRowHost l; l.lds = lds; l.base = base;
+        WideOps<WideRowHost> o(l);
+        WideDescHost d{p.descs.data() + st.desc_off + row * st.stride};
+        Pending pd;
+        if (wide_step(o, st, d, bufs, item, true, pd.dst, pd.v)) pend.push_back(pd);
+      }
+      for (auto& pd : pend) { const u32 a = (pd.dst & 2u) ? base + pd.dst - 2u : pd.dst; memcpy(lds + a, pd.v.v, 64); }
+    }
+  }
+  return 0;
+}
+static int g_sim_wide = 0;
 extern "C" {
+// the one-limb-per-lane form for the programs it implements (others run as usual): 0 off, 1 on; nbls_sim_wide_violations: device assumptions violated since the last call (0 on a correct build)
+__attribute__((visibility("default"))) void nbls_sim_set_wide(int on) { g_sim_wide = on; }
+__attribute__((visibility("default"))) unsigned long nbls_sim_wide_violations() { const unsigned long v = g_wide_violations; g_wide_violations = 0; return v; }
+__attribute__((visibility("default"))) int nbls_sim_wide_supported(int prog) { if (prog < 0 || prog >= (int)P_COUNT) return 0; const Program& p = get_program((ProgId)prog); if (p.lsplit != 1 || p.W > 16) return 0; for (auto& st : p.steps) if (!wide_step_supported(st, p.descs.data())) return 0; return 1; }
 // translated programs (aot.h) instead of the interpreter's semantics for the programs that have an ahead-of-time kernel: 0 off, 1 on
 __attribute__((visibility("default"))) void nbls_sim_set_aot(int on) { g_sim_aot = on; }
 __attribute__((visibility("default"))) int nbls_sim_has_aot(int prog) { if (prog < 0 || prog >= (int)P_COUNT) return 0; for (auto& k : g_sim_kernels) for (int j = 0; j < 4; j++) if (k.prog_id[j] == prog) return 1; return 0; }
@@ -178,6 +248,7 @@ __attribute__((visibility("default"))) int nbls_sim_run(int prog, unsigned n_ite
   if (prog < 0 || prog >= P_COUNT) return -1;
   IOBuf b[MAX_BUFS];
   for (int i = 0; i < MAX_BUFS; i++) { b[i].ptr = ptrs[i]; b[i].stride = strides[i]; }
+  if (g_sim_wide) { const int r = sim_run_wide(get_program((ProgId)prog), n_items, b); if (r != -4) return r; }
   if (g_sim_aot) { const int r = sim_run_aot(prog, n_items, b); if (r != -2) return r; }
   sim_run(get_program((ProgId)prog), n_items, b);
   return 0;

@@ -410,6 +410,10 @@ class Engine:
         """keys up to which sign's ladder is the sign-aligned one-addition-per-bit form (NBLS_TUNE_SAC_MAX; default 6144, 0: the windowed psi-split ladder at every size)"""
         self._chk(self.lib.nbls_set_tuning(self.h, 8, n))
 
+    def set_wide_max(self, n):
+        """items up to which the programs that allow it run on the one-limb-per-lane interpreter (NBLS_TUNE_WIDE_MAX; an experiment, measured slower than the lane-split forms: default 0 = never)"""
+        self._chk(self.lib.nbls_set_tuning(self.h, 10, n))
+
     def set_pt_ls2_max(self, n):
         """items up to which the G2 point chains of verify / sign run in their two-lane forms (NBLS_TUNE_PT_LS2_MAX; default 4096, 0: never)"""
         self._chk(self.lib.nbls_set_tuning(self.h, 9, n))

@@ -283,3 +283,37 @@ def test_two_lane_split_range(oracle, golden, n):
     refm, _ = oracle.pairing_batch(g1, g2, False, False, threads=32)
     assert ml == refm
     assert eng.miller_product(g1, g2, True)[0] == oracle.miller_product(g1, g2, True)
+
+
+def test_one_limb_per_lane_forms(oracle, golden):
+    """round 6: the one-limb-per-lane interpreter (nbls_vm_kernel_wide: one item per workgroup of three wavefronts, a lane-op per row of sixteen lanes, two barriers per step;
+    an experiment, off by default because it measured slower than the lane-split forms) switched on for launches of at most 128 items -- final exponentiation, Miller products
+    and verifyBatch on both sides of the switch against the oracle, and the same bytes with the form switched off"""
+    import hashlib
+    pkg = importlib.import_module('noble-bls12-381_amd')
+    eng = pkg.Engine(0)
+    pairs = golden['pairs']
+    for n in (1, 2, 5, 127, 128, 129):
+        g1 = b''.join(hx(pairs[(5 * i + 3) % len(pairs)]['g1']) for i in range(n)); g2 = b''.join(hx(pairs[(7 * i + n) % len(pairs)]['g2']) for i in range(n))
+        eng.set_wide_max(128)
+        out, _ = eng.pairing_batch(g1, g2, True, False)
+        prod = eng.miller_product(g1, g2, True)[0]
+        assert out == oracle.pairing_batch(g1, g2, True, False, threads=32)[0], n
+        assert prod == oracle.miller_product(g1, g2, True), n
+        eng.set_wide_max(0)
+        assert eng.pairing_batch(g1, g2, True, False)[0] == out and eng.miller_product(g1, g2, True)[0] == prod, n
+    eng.set_wide_max(128)
+    # raw Fp12 inputs through the final exponentiation alone: random elements, ONE, and the all-(p - 1) element
+    rnd = __import__("random").Random(128)
+    P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+    elems = [[rnd.randrange(P) for _ in range(12)] for _ in range(6)] + [[1] + [0] * 11, [P - 1] * 12]
+    blob = b''.join(b''.join(v.to_bytes(48, 'big') for v in e) for e in elems)
+    got = eng.final_exp_batch(blob)
+    for i in range(len(elems)):
+        assert got[576 * i:576 * i + 576] == oracle.un('fp12_final_exp', blob[576 * i:576 * i + 576], 576), i
+    # one verify and a small verifyBatch (their tails run the one-element final exponentiation)
+    sks = [(int.from_bytes(hashlib.sha256(b'wide-sk%d' % i).digest(), 'big') % (1 << 254) + 1).to_bytes(32, 'big') for i in range(9)]
+    msgs = [hashlib.sha256(b'wide-m%d' % i).digest() for i in range(9)]
+    pk, sig = oracle.aggregate_sign(msgs, sks, threads=8)
+    assert eng.verify_batch(sig, msgs, pk) is True and eng.verify_batch(sig, msgs[::-1], pk) is False
+    assert eng.verify_batch(oracle.sign(msgs[0], sks[0])[1], msgs[:1], pk[:1]) is True
