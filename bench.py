@@ -131,8 +131,10 @@ def main():
         t3 = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
         dist.all_reduce(t3, op=dist.ReduceOp.MAX)
         dist.barrier()
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {'rank': rank, 'local_rank': int(os.environ.get('LOCAL_RANK', '0')), 'device': 'cpu (dry launch)', 'value_region_ms': 1.0 + rank, 'config3_shard_ms': 1000.0 * 0.001 * (rank + 1), 'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES')})
         if rank == 0:
-            print(json.dumps({'dry_launch': True, 'n_gpus': world, 'gpus_flag': args.gpus, 'rank_sum': int(t.item()), 'backend': 'gloo',
+            print(json.dumps({'multi_gpu': {'per_rank': per_rank, 'rccl_ranks': None, 'backend': 'gloo', 'visible_devices': 0, 'peer_access': None}, 'dry_launch': True, 'n_gpus': world, 'gpus_flag': args.gpus, 'rank_sum': int(t.item()), 'backend': 'gloo',
                               'config3': {'pairings': args.config3_pairings, 'shards': shards, 'max_time_reduced': float(t3.item())},
                               'legs': ['value', 'product', 'verify_batch_sharded', 'config3'] + (['multi_one_process'] if world > 1 else [])}), flush=True)
         dist.destroy_process_group()
@@ -210,6 +212,8 @@ def main():
     for k in range(D):
         assert bytes(heads[k].tobytes()) == ref, 'bench parity check failed'
 
+    local_times = []      # this rank's own time of every timed region (the line's `value` uses the maximum over the ranks; the per-rank figures go into `multi_gpu`)
+
     def timed_region(mark_it):
         """W untimed warm-up steps, then exactly K timed steps bracketed by barrier + synchronize on both sides; the maximum over the ranks"""
         for i in range(args.warmup):
@@ -227,6 +231,7 @@ def main():
         if multi:
             dist.barrier()
         d_ = time.perf_counter() - t0
+        local_times.append(d_)
         if mark_it:
             mark.fill_(2.0); torch.cuda.synchronize()
         if multi:
@@ -250,7 +255,7 @@ def main():
     # strictly serial figure (one batch at a time on one stream) = per-batch latency, this rank
     torch.cuda.synchronize()
     eng.set_chain_max(8192)             # ... and the chained final exponentiation (6 launches per call; the in-flight contexts run it as seven launches, pipeline.py)
-    eng.set_split_miller_min(4097)      # the single-call legs use the library's default choice of Miller programs (SPLIT_MILLER_MIN in csrc/nbls_api.cpp: the fused program up to 4096 pairs; the in-flight contexts were set to 0)
+    eng.set_split_miller_min(4097)      # the single-call legs use the library's default choice of Miller programs (SPLIT_MILLER_MIN in csrc/nbls_internal.h: the fused program up to 4096 pairs; the in-flight contexts were set to 0)
     serial_steps = max(8, min(args.steps, 320))
     s0 = time.perf_counter()
     for _ in range(serial_steps):
@@ -363,6 +368,7 @@ def main():
     # ---- BASELINE configs[3] as written (all N): --config3-pairings independent pairings sharded contiguously over the ranks, every rank ONE nbls_pairing_batch_dev call on its
     # shard of SURVEY 8(d)'s item stream, barrier before and after, whole-node pairings/s over the slowest rank; no collective on the data path
     config3 = None
+    config3_local_ms = None
     try:
         if args.config3_pairings > 0:
             par = importlib.import_module('noble-bls12-381_amd.parallel')
@@ -387,6 +393,7 @@ def main():
             if multi:
                 dist.barrier()
             qdt = (time.perf_counter() - q0) / creps
+            config3_local_ms = qdt * 1e3
             if multi:
                 t = torch.tensor([qdt], dtype=torch.float64, device='cuda')
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -423,6 +430,19 @@ def main():
         except Exception as e:   # noqa: BLE001  -- no collective inside: rank 0 reaches the barrier either way
             multi1 = {'error': repr(e)}
         dist.barrier()
+
+    # ---- what an N-rank record needs to explain itself (round-5 review item 5): every rank's own device, its own times of the value region and of its configs[3] shard, how many
+    # ranks RCCL saw, and the peer-access matrix of the node as rank 0 sees it
+    multi_gpu = None
+    if multi:
+        mine = {'rank': rank, 'local_rank': local_rank, 'device': torch.cuda.get_device_name(local_rank), 'value_region_ms': round(local_times[0] * 1e3, 3) if local_times else None,
+                'config3_shard_ms': round(config3_local_ms, 3) if config3_local_ms is not None else None, 'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES')}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        ndev = torch.cuda.device_count()
+        multi_gpu = {'per_rank': per_rank, 'rccl_ranks': ranks_seen if args.dist_backend == 'nccl' else None, 'backend': args.dist_backend, 'visible_devices': ndev,
+                     'peer_access': [[int(i == j or torch.cuda.can_device_access_peer(i, j)) for j in range(ndev)] for i in range(ndev)] if rank == 0 else None,
+                     'note': 'value / config3 divide by the SLOWEST rank (max-reduced between barriers); per_rank shows every rank\'s own time'}
 
     # ---- roofline leg: per-kernel HIP-event durations of the same step (separate untimed passes)
     roof = None
@@ -537,7 +557,7 @@ def main():
             smp.join()
             assert bytes(louts[-1][:576 * 8].cpu().numpy().tobytes()) == ref, 'large-batch in-flight parity check failed'
             del louts
-            # the call runs as two halves on two streams from 8192 pairs (csrc/nbls_api.cpp): its kernels overlap, so achieved / frac are over the WALL time of the call
+            # the call runs as two halves on two streams from 8192 pairs (csrc/pipelines_pairing.cpp): its kernels overlap, so achieved / frac are over the WALL time of the call
             roof['large_batch'] = {'pairings': nl, 'pairings_per_s': round(nl / ldt, 2), 'ms_per_call': round(ldt * 1e3, 3),
                                    'achieved': round(nl * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL / ldt / 1e12, 4),
                                    'frac': round(nl * (FPMUL_MILLER + FPMUL_FINALEXP) * MAD_PER_FPMUL / ldt / 1e12 / PEAK_TMAD, 4),
@@ -809,7 +829,7 @@ def main():
             'single_stream': {'pairings_per_s': round(n * args.steps / dt_serial, 2), 'ms_per_batch': round(dt_serial / args.steps * 1e3, 4), 'note': 'alias of single_call (round-1 name)'},
             'rccl_ranks': ranks_seen if (multi and args.dist_backend == 'nccl') else None, 'ranks_in_all_gather': ranks_seen, 'dist_backend': args.dist_backend if multi else None,
             'roofline': roof, 'cpu_baseline': cpu, 'facade': facade, 'product': product, 'verify_batch': vbatch if vbatch is not None else vshard, 'verify_batch_sharded': vshard if vbatch is not None else None, 'sign': sleg, 'aggregate': aleg, 'msm': mleg,
-            'config3': config3, 'multi_one_process': multi1,
+            'config3': config3, 'multi_one_process': multi1, 'multi_gpu': multi_gpu,
             'pool': {'depth': D, 'entry_point': 'nbls_pool_pairing_batch_dev (include/nbls.h): `value` is measured through the C ABI pool; noble-bls12-381_amd/pipeline.py only forwards to it'},
         }
         out_line = json.dumps(line)

@@ -162,10 +162,10 @@ template <class F> static inline Pt<F> pt_mul_ladder(const Pt<F>& p, const SFp& 
 }
 // [k]G for the FIXED base point G1.BASE (getPublicKey, index.ts:738-740; PointG1.fromPrivateKey 350-353) with no doubling at all: k = sum_w d_w 2^(WIN w) over WIN-bit
 // digits, [k]G = sum_w [d_w 2^(WIN w)]G with the multiples [d 2^(WIN w)]G, d = 1 .. 2^WIN - 1, read from a table in HBM that every item shares (buffer `buf`, entry (2^WIN - 1) w + d - 1:
-// raw x, y, z = 1; built once per context on the device by the ladder above, nbls_api.cpp g1_fixed_table).  Per window: ALL entries are loaded and a binary tree of
+// raw x, y, z = 1; built once per context on the device by the ladder above, pipelines_codec.cpp ensure_g1_fixed).  Per window: ALL entries are loaded and a binary tree of
 // masked selects on the four scalar bits picks one (digit 0: the identity (0 : 1 : 0)), then one complete addition -- the instruction stream, the LDS accesses and the global
 // addresses are the same for every key, as in the ladder.  With 3-bit windows (the default: seven entries per window keep the LDS image small enough for seven workgroups per CU; 4-bit windows hold 35+ slots per item) 86 additions where the 2-bit-window ladder spends 256 doublings and 128 additions.
-static const int G1_FIXED_WIN = (int)env_long("NBLS_G1FIXED_WIN", 3);   // bits per window of the fixed-base table (nbls_api.cpp builds the table for the same value)
+static const int G1_FIXED_WIN = (int)env_long("NBLS_G1FIXED_WIN", 3);   // bits per window of the fixed-base table (pipelines_codec.cpp builds the table for the same value)
 static inline int g1_fixed_windows() { return (256 + G1_FIXED_WIN - 1) / G1_FIXED_WIN; }
 static inline int g1_fixed_entries() { return (1 << G1_FIXED_WIN) - 1; }
 static inline Pt<SFp> pt_mul_fixed_g1(const SFp& k_raw, int buf) {

@@ -25,9 +25,11 @@
 // bytes of result).  A call takes a free set (or allocates one) and returns it when it is done, so that calls racing on one handle -- the
 // N-API addon runs nbls_multi_verify_batch on libuv worker threads -- never see each other's partials: the contexts serialise the per-device
 // work themselves, and everything between a context's *_partial call and the end of finish() touches only the call's own set.
+struct GatherLanes;
 struct CallBuffers {
   std::vector<uint8_t*> part;   // part[g] on dev[g]
   uint8_t* gather = nullptr;    // on dev[0]
+  GatherLanes* lanes = nullptr; // copy streams / events of this set (created with it, on dev[0])
 };
 // One host thread per device for the LIFETIME of the handle (round 5; round 4 created G - 1 std::threads per call, which shows in the latency of a single verify on
 // eight GPUs): a call posts its per-device work to the workers of devices 1 .. G-1, runs device 0's share itself and waits on a latch.  Calls racing on one handle
@@ -54,10 +56,21 @@ struct nbls_multi {
   std::vector<CallBuffers*> free_sets;
   std::vector<CallBuffers*> all_sets;
 };
+// the gather of one product call (round 6): every device's partial travels on a stream of its own and the reduction waits for all of them through events -- the copies of an
+// eight-device node overlap instead of running one after the other (round 5: a loop of synchronous hipMemcpyPeer).  The streams live on the reducing device and belong to the
+// call's buffer set, so racing calls do not share them.
+struct GatherLanes { std::vector<hipStream_t> s; std::vector<hipEvent_t> e; hipStream_t fin = nullptr; };
 
 static void free_set(nbls_multi* m, CallBuffers* b) {
   for (size_t g = 0; g < b->part.size(); g++) if (b->part[g]) { hipSetDevice(m->dev[g]); hipFree(b->part[g]); }
-  if (b->gather) { hipSetDevice(m->dev[0]); hipFree(b->gather); }
+  hipSetDevice(m->dev[0]);
+  if (b->gather) hipFree(b->gather);
+  if (b->lanes) {
+    for (hipStream_t st : b->lanes->s) if (st) hipStreamDestroy(st);
+    for (hipEvent_t e : b->lanes->e) if (e) hipEventDestroy(e);
+    if (b->lanes->fin) hipStreamDestroy(b->lanes->fin);
+    delete b->lanes;
+  }
   delete b;
 }
 static CallBuffers* take_set(nbls_multi* m) {
@@ -71,6 +84,13 @@ static CallBuffers* take_set(nbls_multi* m) {
   bool ok = true;
   for (size_t g = 0; g < m->dev.size() && ok; g++) ok = hipSetDevice(m->dev[g]) == hipSuccess && hipMalloc(&b->part[g], 576) == hipSuccess;
   ok = ok && hipSetDevice(m->dev[0]) == hipSuccess && hipMalloc(&b->gather, 576 * (m->dev.size() + 1)) == hipSuccess;
+  if (ok) {
+    b->lanes = new GatherLanes();
+    b->lanes->s.assign(m->dev.size(), nullptr); b->lanes->e.assign(m->dev.size(), nullptr);
+    for (size_t g = 0; g < m->dev.size() && ok; g++) ok = hipStreamCreateWithFlags(&b->lanes->s[g], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&b->lanes->e[g],
+        hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&b->lanes->fin, hipStreamNonBlocking) == hipSuccess;
+  }
   hipSetDevice(prev);
   if (!ok) { free_set(m, b); (void)hipGetLastError(); return nullptr; }
   std::lock_guard<std::mutex> g(m->mu);
@@ -162,15 +182,18 @@ EXPORT int nbls_multi_pairing_batch(nbls_multi* m, size_t n, const uint8_t* g1, 
 // gather the partials of the first G devices on the first device (the call's own gather area), multiply, one shared final exponentiation, result to the host
 static int finish(nbls_multi* m, CallBuffers* b, size_t G, int final_exp, uint8_t* out) {
   if (hipSetDevice(m->dev[0]) != hipSuccess) return NBLS_EHIP;
+  GatherLanes* L = b->lanes;
+  // every partial on its own stream (the producers have synchronised: on_every_device returned), one event each, the reduction's stream waits for all of them
   for (size_t g = 0; g < G; g++) {
-    hipError_t e = g == 0 ? hipMemcpy(b->gather, b->part[0], 576, hipMemcpyDeviceToDevice) : hipMemcpyPeer(b->gather + 576 * g, m->dev[0], b->part[g], m->dev[g], 576);
-    if (e != hipSuccess) return NBLS_EHIP;
+    const hipError_t e = g == 0 || m->dev[g] == m->dev[0] ? hipMemcpyAsync(b->gather + 576 * g, b->part[g], 576, hipMemcpyDeviceToDevice, L->s[g])
+                                                           : hipMemcpyPeerAsync(b->gather + 576 * g, m->dev[0], b->part[g], m->dev[g], 576, L->s[g]);
+    if (e != hipSuccess || hipEventRecord(L->e[g], L->s[g]) != hipSuccess || hipStreamWaitEvent(L->fin, L->e[g], 0) != hipSuccess) { (void)hipDeviceSynchronize(); return NBLS_EHIP; }
   }
   uint8_t* res = b->gather + 576 * m->dev.size();
-  int r = nbls_fp12_product_final_dev(m->ctx[0], G, b->gather, final_exp, res, nullptr);
-  if (r) return r;
-  if (nbls_device_synchronize(m->ctx[0])) return NBLS_EHIP;
-  return hipMemcpy(out, res, 576, hipMemcpyDeviceToHost) == hipSuccess ? NBLS_OK : NBLS_EHIP;
+  int r = nbls_fp12_product_final_dev(m->ctx[0], G, b->gather, final_exp, res, L->fin);
+  if (r) { (void)hipDeviceSynchronize(); return r; }
+  if (hipMemcpyAsync(out, res, 576, hipMemcpyDeviceToHost, L->fin) != hipSuccess || hipStreamSynchronize(L->fin) != hipSuccess) return NBLS_EHIP;
+  return NBLS_OK;
 }
 
 // prod_i millerLoop(P_i, Q_i) with ONE shared final exponentiation (BASELINE configs[4]) -- the core of verify / verifyBatch, index.ts:763-766, 811-816
@@ -248,7 +271,8 @@ EXPORT int nbls_pool_init(int device_id, int depth, nbls_pool** out) {
     static bool warned = false;
     if (depth > eff && !warned) {
       warned = true;
-      fprintf(stderr, "nbls: pool of %d contexts on %d hardware queues (GPU_MAX_HW_QUEUES %s): streams will share queues and their kernels serialise; set GPU_MAX_HW_QUEUES >= depth (<= 22) before the first HIP call of the process\n",
+      fprintf(stderr, "nbls: pool of %d contexts on %d hardware queues (GPU_MAX_HW_QUEUES %s): streams will share queues and their kernels serialise; "
+                      "set GPU_MAX_HW_QUEUES >= depth (<= 22) before the first HIP call of the process\n",
               depth, eff, q > 0 ? "as set" : "unset");
     }
   }
@@ -258,7 +282,8 @@ EXPORT int nbls_pool_init(int device_id, int depth, nbls_pool** out) {
     const int r = nbls_init(device_id, &c);
     if (r) { nbls_pool_destroy(p); return r; }
     p->ctx.push_back(c);
-    if (depth > 1) { nbls_set_tuning(c, NBLS_TUNE_SPLIT_MILLER_MIN, 0); if (nbls::env_long("NBLS_PIPELINE_CHAIN", 0) != 1) nbls_set_tuning(c, NBLS_TUNE_CHAIN_MAX, 0); }   // NBLS_PIPELINE_CHAIN=1: A/B switch (tools/ab_pipeline.sh)
+    // NBLS_PIPELINE_CHAIN=1: A/B switch (tools/ab_pipeline.sh)
+    if (depth > 1) { nbls_set_tuning(c, NBLS_TUNE_SPLIT_MILLER_MIN, 0); if (nbls::env_long("NBLS_PIPELINE_CHAIN", 0) != 1) nbls_set_tuning(c, NBLS_TUNE_CHAIN_MAX, 0); }
   }
   *out = p;
   return NBLS_OK;

@@ -171,7 +171,7 @@ extern "C" int nbls_fp_pow_launch(unsigned n, const void* in, void* out, const v
 }
 
 // list[k] = index of the k-th item whose int8 flag is set, *count = their number (order irrelevant): the items of a compressed cyclotomic exponentiation that
-// met a zero denominator and are recomputed by the plain program over this index list (nbls_api.cpp expx)
+// met a zero denominator and are recomputed by the plain program over this index list (pipelines_pairing.cpp expx)
 namespace nbls {
 __global__ void nbls_flag_compact_kernel(unsigned n, const signed char* __restrict__ flags, u32* __restrict__ list, u32* __restrict__ count) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -35,7 +35,7 @@ enum ProgId {
   P_G1_CLEAR,           // projective point (3) -> clearCofactor -> projective point (6), Z (7)                            (index.ts:401-405)
   P_ENC2_A, P_ENC2_B,   // G2 encodeToCurve: 128 uniform bytes (0) -> u (3), SWU exponentiation input (4) ; u (3), power (5) -> projective point on E2 (6)
   P_G1_MUL, P_G2_MUL,            // [k]P for per-item 256-bit scalars: point (buf 0 / 1), scalar 32 B (buf 2) -> projective (3), norm of Z (4)   (getPublicKey / sign, index.ts:738-752)
-  // multi-scalar multiplication (bucket method, 12-bit windows; nbls_api.cpp dev_msm): points are raw projective (3 / 6 field elements)
+  // multi-scalar multiplication (bucket method, 12-bit windows; pipelines_codec.cpp dev_msm): points are raw projective (3 / 6 field elements)
   P_G1_ADD_AB, P_G2_ADD_AB,       // A[i] (buf 3) + B[i] (buf 4) -> buf 5 (may alias buf 3)
   P_G1_HORNER, P_G2_HORNER,       // T[0..11] of one window (buf 3) -> sum_t 2^t T[t] (buf 5)
   P_G1_SHIFTADD, P_G2_SHIFTADD,   // 2^12 * acc (buf 3) + S (buf 4) -> buf 5
@@ -68,12 +68,12 @@ enum ProgId {
   P_EXPC_SQ,           // A (buf 3) -> the compressed coordinates (g2, g3, g4, g5) of (3 A)^(2^k) for k = 16, 48, 57 (buf 5: 3 x 8 raw elements): 57 compressed squarings, 8 lanes per item
   P_EXPC_DEC_A,        // compressed powers (buf 3) -> product of the three |2 g2|^2 (buf 4: the element to invert), numerators times conj(g2), all-but-one products (and a third of them), the g1-free part of g0, zero flag (buf 5: 19 raw elements)
   P_EXPC_DEC_B,        // compressed powers (3), inverse (4), DEC_A scratch (6) -> conj(A^|x|) (buf 5), int8 status (buf 7): 1 = some g2 was zero, the item must be recomputed by P_EXPX
-  P_ACC8_RAW,          // eight folded line tables per item (buf 3) -> F (buf 5): one Fp12 squaring per bit for eight Miller loops (round 4: Miller products of 131,072 pairs and more, acc8_min in nbls_api.cpp)
+  P_ACC8_RAW,          // eight folded line tables per item (buf 3) -> F (buf 5): one Fp12 squaring per bit for eight Miller loops (round 4: Miller products of 131,072 pairs and more, acc8_min in nbls_internal.h)
   P_H2C_C0,            // clearCofactor, the part that does not depend on [x]P: projective P (3) -> v = psi(P) (6), u = psi^2(2P) - psi(P) - P (5), read back by P_H2C_C1 / C2 after their ladders
   P_H2C_B1,            // one SWU map per item (2 n items): t (buf 3: Fp2), its exponentiation (buf 5: Fp2) -> projective point on E2' (buf 6: 6 raw elements)
   P_H2C_B2,            // the two points of a message (buf 3: 12 raw elements) -> their sum mapped to E2 by the 3-isogeny (buf 6), index.ts:487-488
   P_G1_MUL_W3, P_G2_MUL_W3,     // the ladders with 3-bit windows (85 instead of 128 additions: a shorter instruction stream, but a table that limits the wavefronts per CU): launches of at most one wavefront per SIMD
-  P_MUL2S,             // A (buf 3) * B (buf 4) -> buf 5 (may alias buf 3): one level of the IN-PLACE product tree (round 5, reduce_product in nbls_api.cpp):
+  P_MUL2S,             // A (buf 3) * B (buf 4) -> buf 5 (may alias buf 3): one level of the IN-PLACE product tree (round 5, reduce_product in pipelines_pairing.cpp):
                        // level k multiplies F[i 2^(k+1)] by F[i 2^(k+1) + 2^k] into the former, so no level copies or pads anything
   P_G1_MUL_FIXED,      // [k]G1.BASE by a fixed-base table (buf 5, shared by every item: 86 windows x 7 raw projective points with the default G1_FIXED_WIN = 3), scalar 32 B (buf 2) -> projective (3), Z (4): getPublicKey without doublings (round 5, curve.h pt_mul_fixed_g1)
   P_G2_MUL_GLS,        // [k]Q for Q in G2: affine Q (buf 1), the four base-|z| digits of k as 4 x 32 B big-endian (buf 2) -> projective (3), norm of Z (4): sign's ladder with the scalar split along psi (round 5, codec.h pt_mul_gls_g2)

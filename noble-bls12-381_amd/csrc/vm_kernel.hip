@@ -142,7 +142,7 @@ extern "C" __global__ void __launch_bounds__(64) nbls_vm_kernel_ls4(KernelArgs k
 
 }  // namespace nbls
 
-// host-side launcher (C linkage, used by nbls_api.cpp)
+// host-side launcher (C linkage, used by runtime.cpp)
 extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream) {
   using namespace nbls;
   if (ka->n_items == 0) return 0;

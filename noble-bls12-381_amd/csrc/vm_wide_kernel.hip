@@ -1,6 +1,6 @@
 // vm_wide_kernel.hip -- the one-limb-per-lane interpreter (wide_exec.h): ONE item per workgroup, a lane-op per row of sixteen lanes, four rows per wavefront, ceil(W / 4)
 // wavefronts per workgroup; the compiled step program, its descriptors and the LDS slot layout are the plain interpreter's (vm.h).  Two barriers per step.
-// For launches of a few hundred items at most (nbls_api.cpp wide_max): the final exponentiation of a single verify / sign, the one-element tail of every verifyBatch.
+// For launches of a few hundred items at most (nbls_internal.h wide_max): the final exponentiation of a single verify / sign, the one-element tail of every verifyBatch.
 #include <hip/hip_runtime.h>
 #include "wide_exec.h"
 

@@ -48,6 +48,10 @@ def test_gpus_flag_eight_ranks():
     assert all(c3['shards'][i][1] == c3['shards'][i + 1][0] for i in range(7))
     assert abs(c3['max_time_reduced'] - 0.008) < 1e-9                     # the slowest rank's time is what every rank divides by
     assert 'config3' in d['legs'] and 'multi_one_process' in d['legs']
+    # round 6: the record explains itself -- one entry per rank with its own device and its own times (the real legs fill the same object and add the peer-access matrix)
+    pr = d['multi_gpu']['per_rank']
+    assert [e['rank'] for e in pr] == list(range(8)) and all({'local_rank', 'device', 'value_region_ms', 'config3_shard_ms', 'hw_queues'} <= set(e) for e in pr)
+    assert max(e['config3_shard_ms'] for e in pr) == 8.0 and abs(c3['max_time_reduced'] * 1e3 - 8.0) < 1e-6
 
 
 def test_driver_launcher_command_line():

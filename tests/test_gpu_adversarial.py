@@ -70,7 +70,7 @@ def test_final_exp_extremes(eng, oracle):
 
 @pytest.mark.parametrize('n', [1, 7, 8, 9, 41, 300])
 def test_final_exp_compressed_squarings(eng, oracle, n):
-    """The compressed-squaring form of the five cyclotomic exponentiations (Karabina; csrc/nbls_api.cpp expx, forced with NBLS_TUNE_EXPC_MIN = 0) on the
+    """The compressed-squaring form of the five cyclotomic exponentiations (Karabina; csrc/pipelines_pairing.cpp expx, forced with NBLS_TUNE_EXPC_MIN = 0) on the
     extremal Fp12 inputs, random ones, and the inputs whose compressed coordinates vanish (the unit element, elements of Fp6 and of Fp2: their easy
     part is 1) scattered over the batch -- those are flagged on the device and recomputed by the plain program.  Batch sizes around the wavefront fills
     (8 items per wavefront in the squaring program, 5 in the decompression).  Every result against the oracle (math.ts:856-874)."""

@@ -120,7 +120,7 @@ def test_sign_with_everything_resident_in_hbm(eng, testdata):
 
 
 def test_both_ladders_of_sign(eng, testdata, oracle):
-    """sign's two ladders for points of G2 (csrc/nbls_api.cpp dev_point_mul): the sign-aligned one-addition-per-bit form (up to 6144 keys) and the windowed psi-split form (above) on the
+    """sign's two ladders for points of G2 (csrc/pipelines_codec.cpp dev_point_mul): the sign-aligned one-addition-per-bit form (up to 6144 keys) and the windowed psi-split form (above) on the
     reference's 559 sign vectors and on structured keys -- even / odd low digit, digits rolling over at powers of |z|, r - 1, r + 1, 2^256 - 1 -- against the oracle"""
     vs = testdata['sign_vectors']
     Z = 0xd201000000010000

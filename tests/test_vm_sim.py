@@ -307,7 +307,7 @@ def test_sign_aligned_ladder_for_subgroup_points(sim, oracle, prog='G2_MUL_SAC')
 
 
 def test_msm_pipeline(sim, oracle):
-    """the bucket-method multi-scalar multiplication (dev_msm in csrc/nbls_api.cpp: sort by window digit, segmented sums,
+    """the bucket-method multi-scalar multiplication (dev_msm in csrc/pipelines_codec.cpp: sort by window digit, segmented sums,
     bit-sliced bucket weighting, Horner over the windows) with its step programs on the simulator, against the oracle's
     sum of scalar multiples; scalars with repeated digits (long runs in one bucket), zero digits and zero scalars"""
     import random
@@ -555,7 +555,7 @@ def test_lane_split_programs(sim, oracle, golden, suffix):
 
 
 def test_compressed_exponentiation(sim, golden, testdata):
-    """Karabina's compressed squarings (round 3; EXPC_SQ -> EXPC_DEC_A -> inversion -> EXPC_DEC_B, csrc/nbls_api.cpp expx): the same final exponentiation,
+    """Karabina's compressed squarings (round 3; EXPC_SQ -> EXPC_DEC_A -> inversion -> EXPC_DEC_B, csrc/pipelines_pairing.cpp expx): the same final exponentiation,
     bit for bit, on the reference's finalExponentiate known answer (test/pairing.test.ts:65-96), reference-run Fp12 values, and the inputs whose
     compressed coordinates vanish -- the unit element and an element of Fp6 (its easy part is 1): those are flagged and recomputed by the plain program"""
     one = (1).to_bytes(48, 'big') + bytes(528)

@@ -42,7 +42,7 @@ EXPC_SQ_BYTES, EXPC_DEC_BYTES = 24 * RAW, 19 * RAW
 
 
 def expx_compressed(lib, n, src, dst):
-    """expx_compressed() of csrc/nbls_api.cpp on the simulator: Karabina's compressed squarings (EXPC_SQ), decompression around one inversion
+    """the compressed branch of expx() in csrc/pipelines_pairing.cpp on the simulator: Karabina's compressed squarings (EXPC_SQ), decompression around one inversion
     (EXPC_DEC_A, fp_inv, EXPC_DEC_B), flagged items (a vanishing g2) recomputed by the plain program.  Returns the flags."""
     KS = C.create_string_buffer(EXPC_SQ_BYTES * n); KD = C.create_string_buffer(EXPC_DEC_BYTES * n)
     KN = C.create_string_buffer(RAW * n); KNI = C.create_string_buffer(RAW * n); st = C.create_string_buffer(n)
@@ -59,7 +59,7 @@ def expx_compressed(lib, n, src, dst):
 
 
 def final_exp(lib, n, F, N, out, expx='EXPX'):
-    """The launch sequence of final_exp_pipeline() in csrc/nbls_api.cpp, on the simulator (expx='EXPC': the compressed-squaring form of the five exponentiations)."""
+    """The launch sequence of final_exp_pipeline() in csrc/pipelines_pairing.cpp, on the simulator (expx='EXPC': the compressed-squaring form of the five exponentiations)."""
     NI = C.create_string_buffer(RAW * n)
     T = [C.create_string_buffer(F12 * n) for _ in range(7)]
     lib.nbls_sim_fp_inv(C.c_uint(n), N, NI)
@@ -116,11 +116,11 @@ def hash_to_g2(lib, uniform, ls2=False):
     run(lib, 'H2C_A', n, {0: (buf(uniform), 256), 3: (T, 4 * RAW), 4: (E, 4 * RAW), 5: (St, 24 * RAW)})
     lib.nbls_sim_fp_pow(C.c_uint(2 * n), E, Pw, 2)
     E2 = buf(6 * RAW * n)
-    # one SWU map per item (2 n items), then the two points of a message -> their sum on E2 (the launch sequence of dev_hash_to_g2 in csrc/nbls_api.cpp)
+    # one SWU map per item (2 n items), then the two points of a message -> their sum on E2 (the launch sequence of dev_hash_to_g2 in csrc/pipelines_codec.cpp)
     run(lib, 'H2C_B1', 2 * n, {3: (T, 2 * RAW), 5: (Pw, 2 * RAW), 4: (St, 12 * RAW), 6: (Pt2, 6 * RAW)})
     run(lib, 'H2C_B2', n, {3: (Pt2, 12 * RAW), 6: (E2, 6 * RAW)})
     # clearCofactor in three programs: the points that do not depend on [x]P, then one program around each multiplication by x (the launch sequence of dev_clear_g2
-    # in csrc/nbls_api.cpp, in place like there: C1 overwrites P with t1, C2 writes the result over t1)
+    # in csrc/pipelines_codec.cpp, in place like there: C1 overwrites P with t1, C2 writes the result over t1)
     S = buf(6 * RAW * n)
     run(lib, 'H2C_C0', n, {3: (E2, 6 * RAW), 6: (Q, 6 * RAW), 5: (S, 6 * RAW)})
     run(lib, 'H2C_C1_LS2' if ls2 else 'H2C_C1', n, {3: (E2, 6 * RAW), 6: (Q, 6 * RAW)})
@@ -156,7 +156,7 @@ def point_sum(lib, pts, g2=False):
 
 
 def point_mul(lib, pts, scalars32, g2=False, w3=False):
-    """dev_point_mul() of csrc/nbls_api.cpp on the simulator: ladder (2-bit windows; w3: the 3-bit form of small launches) -> inversion -> affine"""
+    """dev_point_mul() of csrc/pipelines_codec.cpp on the simulator: ladder (2-bit windows; w3: the 3-bit form of small launches) -> inversion -> affine"""
     sz, psz = (192, 6 * RAW) if g2 else (96, 3 * RAW)
     pre = 'G2' if g2 else 'G1'
     n = len(scalars32) // 32
@@ -171,7 +171,7 @@ G1_FIXED_WIN = 3     # csrc/curve.h G1_FIXED_WIN (NBLS_G1FIXED_WIN)
 
 
 def g1_fixed_table(lib, oracle):
-    """ensure_g1_fixed() of csrc/nbls_api.cpp with the oracle in place of the device ladder: raw projective multiples [d 2^(WIN w)]G1, d = 1 .. 2^WIN - 1, per window"""
+    """ensure_g1_fixed() of csrc/pipelines_codec.cpp with the oracle in place of the device ladder: raw projective multiples [d 2^(WIN w)]G1, d = 1 .. 2^WIN - 1, per window"""
     win = G1_FIXED_WIN; nw = (256 + win - 1) // win; ne = (1 << win) - 1
     g = oracle.g1_generator()
     aff = b''
@@ -273,7 +273,7 @@ def point_mul_sac(lib, pts192, scalars32, prog='G2_MUL_SAC'):
 
 
 def msm(lib, pts, scalars32, nbits, g2=False):
-    """dev_msm() of csrc/nbls_api.cpp on the simulator; the data-movement kernels of msm_kernels.hip (window digits, sort,
+    """dev_msm() of csrc/pipelines_codec.cpp on the simulator; the data-movement kernels of msm_kernels.hip (window digits, sort,
     gathers) are restated in Python, every group operation runs as a step program"""
     WB = 12
     sz, psz = (192, 6 * RAW) if g2 else (96, 3 * RAW)
@@ -362,7 +362,7 @@ def compress(lib, aff, g2=False):
 
 
 def hash_to_g1(lib, uniform, count):
-    """dev_hash_to_g1() of csrc/nbls_api.cpp on the simulator; uniform: n * 64 * count bytes of expand_message_xmd output"""
+    """dev_hash_to_g1() of csrc/pipelines_codec.cpp on the simulator; uniform: n * 64 * count bytes of expand_message_xmd output"""
     n = len(uniform) // (64 * count)
     us = count * RAW
     U, E, Pw, Q, Q2, N, NI, out, st = buf(us * n), buf(us * n), buf(us * n), buf(3 * RAW * n), buf(3 * RAW * n), buf(RAW * n), buf(RAW * n), buf(96 * n), buf(n)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of the compressed cyclotomic squarings (NBLS_EXPC_MIN: items from which expx() in csrc/nbls_api.cpp uses them; a huge value = never)
+# A/B of the compressed cyclotomic squarings (NBLS_EXPC_MIN: items from which expx() in csrc/pipelines_pairing.cpp uses them; a huge value = never)
 mkdir -p gpurun_out/r3e
 python -m pytest tests/test_gpu_adversarial.py tests/test_gpu_pairing.py -q -x -k "compressed or final_exp or kilic or batch_4096 or 131072" > gpurun_out/r3e/pytest.log 2>&1; tail -3 gpurun_out/r3e/pytest.log
 for m in 1000000000 0; do

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Round 5: wall time of verifyBatch(n) (inputs resident in HBM, expand_message_xmd inside) over the settings of the software pipeline
-(csrc/nbls_api.cpp verify_pipeline): chunks K x size of the last chunk, best and median of k calls each, one call at a time.  NBLS_VERIFY_PIPE=0 in the
+(csrc/pipelines_verify.cpp verify_pipeline): chunks K x size of the last chunk, best and median of k calls each, one call at a time.  NBLS_VERIFY_PIPE=0 in the
 environment times round 4's two-phase form with the same script (then the settings are ignored).  Usage: tools/verify_sweep.py [n] [k] [K,K,..] [pct,pct,..]"""
 import hashlib, importlib, os, statistics, sys, time
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '22')   # one hardware queue per stream of the call (the default of 4 would serialise sub-batches that share one)
