@@ -365,10 +365,12 @@ int mul_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* pts, const uint8_t
   if (pts) HIPCHK(hipMemcpyAsync(dp, pts, n * a, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(dk, scalars32, n * 32, hipMemcpyHostToDevice, s));
   int r = dev_point_mul(ctx, g2, n, pts ? dp : ctx->gen_g1, pts ? a : 0, dk, o, st, s); if (r) return r;
-  std::vector<int8_t> tmp(n);
+  std::vector<int8_t> tmp(n), zero(n, 0);
   if ((r = io.wipe(s))) return r;
-  HIPCHK(hipMemcpyAsync(out, o, n * a, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(tmp.data(), st, n, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
-  for (size_t i = 0; i < n; i++) if (scalar_is_zero_mod_r(scalars32 + 32 * i)) tmp[i] = 5;
+  HIPCHK(hipMemcpyAsync(out, o, n * a, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(tmp.data(), st, n, hipMemcpyDeviceToHost, s));
+  for (size_t i = 0; i < n; i++) if (scalar_is_zero_mod_r(scalars32 + 32 * i)) zero[i] = 1;      // host work under the device's (round 6: 0.3 ms at 8192 keys when it followed the synchronisation)
+  HIPCHK(hipStreamSynchronize(s));
+  for (size_t i = 0; i < n; i++) if (zero[i]) tmp[i] = 5;
   if (status) memcpy(status, tmp.data(), n);
   return NBLS_OK;
 }
@@ -491,16 +493,37 @@ EXPORT int nbls_msm_dev(nbls_ctx* ctx, int g2, size_t n, const void* d_pts, cons
 EXPORT int nbls_sign_batch(nbls_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* dst, size_t dst_len, const uint8_t* keys32, uint8_t* out192, int8_t* status) {
   std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);   // scratch and I/O staging buffers belong to this call until it returns
   if (!ctx || (n && (!offsets || !out192 || !dst || !keys32))) return NBLS_EINVAL; if (!n) return NBLS_OK;
-  LOCKED(ctx); HostIO io{ctx}; void *h = io.alloc(n * 192), *dk = io.alloc(n * 32), *o = io.alloc(n * 192), *st = io.alloc(n);
-  if (!h || !dk || !o || !st) return NBLS_EHIP;
-  io.secret(dk, n * 32);
-  uint8_t* d; int r = dev_expand(ctx, n, msgs, offsets, dst, dst_len, &d, s); if (r) return r;
-  HIPCHK(hipMemcpyAsync(dk, keys32, n * 32, hipMemcpyHostToDevice, s));
-  if ((r = sign_points(ctx, n, d, h, dk, o, st, s))) return r;
-  std::vector<int8_t> tmp(n);
+  // Round 6: ONE pinned staging block in, one out.  Round 5 made six copies from / to pageable memory (messages, offsets, tag, keys; signatures, statuses) with a
+  // synchronisation in the middle: 0.5 ms of a 4.4 ms call at 8192 keys (the same call on resident inputs: 3.85 ms).  Inputs are packed into the context's pinned buffer --
+  // [message bytes | n + 1 relative offsets | tag (256 B) | keys] -- and travel as one asynchronous copy; signatures and statuses come back the same way.
+  for (size_t i = 0; i < n; i++) if (offsets[i + 1] < offsets[i]) return NBLS_EINVAL;
+  const size_t total = offsets[n] - offsets[0];
+  uint8_t dst_hash[32];
+  if (dst_len > 255) { Sha256 c; c.update((const uint8_t*)"H2C-OVERSIZE-DST-", 17); c.update(dst, dst_len); c.final(dst_hash); dst = dst_hash; dst_len = 32; }
+  const size_t o_off = (total + 15) & ~(size_t)15, o_dst = o_off + (((n + 1) * 4 + 15) & ~(size_t)15), o_key = o_dst + 256, in_bytes = o_key + n * 32, out_bytes = n * 192 + n;
+  LOCKED(ctx); HostIO io{ctx};
+  uint8_t *h = (uint8_t*)io.alloc(n * 192), *din = (uint8_t*)io.alloc(in_bytes), *dout = (uint8_t*)io.alloc(out_bytes), *du;
+  if (!h || !din || !dout) return NBLS_EHIP;
+  io.secret(din + o_key, n * 32);
+  int r;
+  const size_t pin_out = (in_bytes + 63) & ~(size_t)63;      // the way back has its own part of the pinned block: nothing waits between the ladder and the copy out
+  if ((r = need(ctx, 8, n * 256, &du)) || (r = ensure_pinned(ctx, pin_out + out_bytes))) return r;
+  uint8_t* pin = ctx->pinned;
+  if (total) memcpy(pin, msgs + offsets[0], total);
+  { uint32_t* rel = (uint32_t*)(pin + o_off); for (size_t i = 0; i <= n; i++) rel[i] = offsets[i] - offsets[0]; }
+  memcpy(pin + o_dst, dst, dst_len); memcpy(pin + o_key, keys32, n * 32);
+  HIPCHK(hipMemcpyAsync(din, pin, in_bytes, hipMemcpyHostToDevice, s));
+  const int e = nbls_xmd_launch((unsigned)n, din, din + o_off, din + o_dst, (unsigned)dst_len, du, 256, nullptr, s);
+  if (e) { ctx->last_hip = e; return NBLS_EHIP; }
+  if ((r = sign_points(ctx, n, du, h, din + o_key, dout, dout + n * 192, s))) return r;
   if ((r = io.wipe(s))) return r;
-  HIPCHK(hipMemcpyAsync(out192, o, n * 192, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(tmp.data(), st, n, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
-  for (size_t i = 0; i < n; i++) if (scalar_is_zero_mod_r(keys32 + 32 * i)) tmp[i] = 5;
+  HIPCHK(hipMemcpyAsync(pin + pin_out, dout, out_bytes, hipMemcpyDeviceToHost, s));
+  std::vector<int8_t> tmp(n, 0);
+  for (size_t i = 0; i < n; i++) if (scalar_is_zero_mod_r(keys32 + 32 * i)) tmp[i] = 5;      // (host work under the device's: normalizePrivKey's rejection, index.ts:269-279)
+  HIPCHK(hipStreamSynchronize(s));
+  memset(pin + o_key, 0, n * 32);        // the host copy of the keys does not outlive the call either
+  memcpy(out192, pin + pin_out, n * 192);
+  for (size_t i = 0; i < n; i++) if (tmp[i] != 5) tmp[i] = (int8_t)pin[pin_out + n * 192 + i];
   if (status) memcpy(status, tmp.data(), n);
   return NBLS_OK;
 }

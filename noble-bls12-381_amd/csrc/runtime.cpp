@@ -205,6 +205,14 @@ int ensure_lines(nbls_ctx* ctx, size_t n) {
   ctx->cap_L = cap;
   return NBLS_OK;
 }
+int ensure_pinned(nbls_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->pinned_cap) return NBLS_OK;
+  if (ctx->pinned) { hipHostFree(ctx->pinned); ctx->pinned = nullptr; ctx->pinned_cap = 0; }
+  const size_t cap = bytes + bytes / 4 + 4096;
+  HIPCHK(hipHostMalloc((void**)&ctx->pinned, cap, hipHostMallocDefault));
+  ctx->pinned_cap = cap;
+  return NBLS_OK;
+}
 int need(nbls_ctx* ctx, int i, size_t bytes, uint8_t** out) {
   if (bytes > ctx->sb_cap[i]) {
     if (ctx->sb[i]) hipFree(ctx->sb[i]);
@@ -305,6 +313,7 @@ EXPORT void nbls_destroy(nbls_ctx* ctx) {
   for (uint8_t* p : ctx->sb) if (p) hipFree(p);
   for (auto& b : ctx->io_pool) if (b.p) hipFree(b.p);
   for (uint8_t* p : ctx->nib) if (p) hipFree(p);
+  if (ctx->pinned) hipHostFree(ctx->pinned);
   if (ctx->qp_table) hipFree(ctx->qp_table);
   for (uint8_t* p : {ctx->neg_g1, ctx->ident_g1, ctx->ident_g2}) if (p) hipFree(p);
   if (ctx->side) hipStreamDestroy(ctx->side);
