@@ -405,7 +405,9 @@ static Program build(ProgId id) {
     case P_MUL2S: {
       SFp12 a = inputw_fp12(3, 0), b = inputw_fp12(4, 0);
       outputw_fp12(mul(a, b), 5, 0);
-      return B.compile("fp12_mul2s", 16);
+      Program P = B.compile("fp12_mul2s", 16);
+      P.aliases.push_back({5, 3});      // reduce_product (pipelines_pairing.cpp) runs the tree in place: the output buffer IS the first input
+      return P;
     }
     case P_RAW_TO_BYTES: {
       output_fp12(inputw_fp12(3, 0), 2, 0);

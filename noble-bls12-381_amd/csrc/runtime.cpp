@@ -293,9 +293,10 @@ EXPORT int nbls_init(int device_id, nbls_ctx** out) {
         hipMalloc(&ctx->ident_g1, 3 * RAW) != hipSuccess || hipMemcpy(ctx->ident_g1, id1, 3 * RAW, hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc(&ctx->ident_g2, 6 * RAW) != hipSuccess || hipMemcpy(ctx->ident_g2, id2, 6 * RAW, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return NBLS_EHIP; }
   }
-  // the scalar-multiplication ladders are uploaded on first use
+  // the scalar-multiplication ladders are traced and uploaded on first use; so are (round 6) the programs of experiments and unit tests that no default path runs: the
+  // compressed-squaring exponentiation (off unless NBLS_TUNE_EXPC_MIN asks for it), round 3's one-program forms of hash-to-G2 and the test-only pieces of it
   for (int i = 0; i < P_COUNT; i++) { if (i == P_G1_MUL || i == P_G2_MUL || i == P_G1_MUL_W3 || i == P_G2_MUL_W3 || i == P_G1_MUL_FIXED || i == P_G2_MUL_GLS || i == P_G2_MUL_SAC
-      || i == P_G2_MUL_SAC_LS2) continue;
+      || i == P_G2_MUL_SAC_LS2 || i == P_EXPC_SQ || i == P_EXPC_DEC_A || i == P_EXPC_DEC_B || i == P_H2C_B || i == P_H2C_C || i == P_T_SWU || i == P_T_ISO || i == P_T_CLEAR) continue;
     int r = upload(ctx, (ProgId)i); if (r) { int e = ctx->last_hip; (void)e; nbls_destroy(ctx); return r; } }
   *out = ctx;
   return NBLS_OK;

@@ -647,6 +647,20 @@ std::string verify_program(const Program& p) {
     if (sh && !(f & 2u)) return o + 56 <= cbytes;
     return o + 56 <= ib;
   };
+  // declared aliases: no load of the input buffer after the first store to the output buffer (whatever the lanes: the items of a wavefront run in lock step, but a store of one
+  // lane-op and a later load of another would see the new bytes)
+  for (auto& al : p.aliases) {
+    bool stored = false;
+    for (size_t s = 0; s < p.steps.size(); s++) {
+      const Step& st = p.steps[s];
+      if (st.kind != K_LOAD && st.kind != K_LOADW && st.kind != K_STORE && st.kind != K_STOREW) continue;
+      for (unsigned l = 0; l < st.nlanes; l++) {
+        const u32 buf = (p.descs[st.desc_off + l * st.stride] >> 16) & 7u;
+        if ((st.kind == K_STORE || st.kind == K_STOREW) && (int)buf == al.first) stored = true;
+        if ((st.kind == K_LOAD || st.kind == K_LOADW) && (int)buf == al.second && stored) return bad(s, l, "load of an aliased input after the first store to its output", buf);
+      }
+    }
+  }
   for (size_t s = 0; s < p.steps.size(); s++) {
     const Step& st = p.steps[s];
     if (st.nlanes == 0 || st.nlanes > p.W) return bad(s, 0, "active lanes", st.nlanes);

@@ -37,6 +37,9 @@ struct Program {
   u32 n_dot_steps = 0, n_lin_steps = 0, n_other_steps = 0, n_dot_ops = 0, n_products = 0, n_prod_slots = 0, n_lin_ops = 0, n_lin_terms = 0, n_norm_operands = 0, n_neg_operands = 0, n_comb_operands = 0;
   u32 n_round_ops = 0, n_op_mode[4] = {0, 0, 0, 0}, n_op_norm = 0;   // product-round operands (two per round) by shape
   double est_valu = 0;       // cost-model estimate of VALU instructions per wave (see Builder::compile)
+  // buffers a caller may bind to the SAME memory (out, in): verify_program checks that every load of `in` precedes the first store to `out` (round 6; the in-place product tree
+  // binds buffer 5 of fp12_mul2s onto buffer 3 -- safe because every output coefficient depends on all inputs, and now checked instead of assumed)
+  std::vector<std::pair<int, int>> aliases;
   std::vector<u32> buf_extent = std::vector<u32>(MAX_BUFS, 0);   // per buffer index: bytes of one item the program touches (max offset + size); launch check in checked builds
   u32 lsplit = 1;            // lane split: every K_DOT lane-op is spread over `lsplit` adjacent lanes, each accumulating a share of the products; the columns are summed
                              // across them before the one reduction (latency variant for launches of at most one wavefront per SIMD).  W is the PHYSICAL lane count.

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Markdown rows of DESIGN.md section 6 from the committed bench JSON lines (profiles/roundN_bench_default.json, ..._bench_driver_args.json).  Usage: tools/design_numbers.py [round]"""
 import json, sys
-r = sys.argv[1] if len(sys.argv) > 1 else '5'
+r = sys.argv[1] if len(sys.argv) > 1 else '6'
 d = json.load(open('profiles/round%s_bench_default.json' % r)); a = json.load(open('profiles/round%s_bench_driver_args.json' % r))
 v = d['verify_batch']; f = d.get('facade') or {}; c = d['cpu_baseline']; j = c['js_bigint']
 print('| `value`: 4096-pairing batches, %d in flight (%d steps) | **%.3f M pairings/s** (%.3f ms per batch) | %.3f (`roofline.frac_at_value`) |' % (d['config']['batches_in_flight'], d['steps'], d['value'] / 1e6, d['ms_per_step'], d['roofline']['frac_at_value']))
-cs = a.get('cold_start') or {}
-print('| the same at the driver\'s %d steps (%d contexts; the 20 calls of a %.0f ms region, after %d untimed pre-warm steps) | %.3f M pairings/s (%.3f M for the same burst right after the idle phase: `cold_start`) | %.3f |' % (a['steps'], a['config']['batches_in_flight'], a['ms_per_step'] * a['steps'], a.get('prewarm_steps', 0), a['value'] / 1e6, (cs.get('pairings_per_s') or 0) / 1e6, a['roofline']['frac_at_value']))
+ss = a.get('steady_state') or {}
+print('| the same at the driver\'s arguments: %d warm-up + %d timed steps, nothing in front of them (%d contexts; a %.0f ms region on a chip that was idle a moment before) | %.3f M pairings/s (`value` of that line; %.3f M after %d further untimed steps: `steady_state`) | %.3f |' % (a['warmup'], a['steps'], a['config']['batches_in_flight'], a['ms_per_step'] * a['steps'], a['value'] / 1e6, (ss.get('pairings_per_s') or 0) / 1e6, ss.get('prewarm_steps', 0), a['roofline']['frac_at_value']))
 print('| `single_call`: one 4096-pairing call at a time | %.3f ms (%.2f M pairings/s) | **%.4f** (top-level `roofline.frac`) |' % (d['single_call']['ms_per_batch'], d['single_call']['pairings_per_s'] / 1e6, d['roofline']['frac']))
 lb = d['roofline']['large_batch']
 print('| `roofline.large_batch`: one 65,536-pairing call | %.2f ms (%.2f M pairings/s) | %.3f; three calls in flight %.3f |' % (lb['ms_per_call'], lb['pairings_per_s'] / 1e6, lb['frac'], lb['in_flight']['roofline_frac']))

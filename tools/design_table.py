@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Rows of the per-kernel table of DESIGN.md section 4 from the committed PMC summaries (profiles/roundN_pmc_b4096.json / _b65536.json, tools/pmc_percall.py; N = argv[1], default 5).
+"""Rows of the per-kernel table of DESIGN.md section 4 from the committed PMC summaries (profiles/roundN_pmc_b4096.json / _b65536.json, tools/pmc_percall.py; N = argv[1], default 6).
 Static columns: lanes x items per wavefront and the multiply-add share (196 x (product rounds + reductions) of the program's K_DOT steps / measured VALU instructions --
 instruction counts do not change from box to box); algorithmic Fp multiplications per item as in SURVEY 8(d).  Usage: tools/design_table4.py"""
 import json, os, sys
-RND = sys.argv[1] if len(sys.argv) > 1 else '5'
+RND = sys.argv[1] if len(sys.argv) > 1 else '6'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PEAK = 256 * 64 * 2.4e9
 K = [('nbls_aot_lines_pq', '10 × 6', '63 %', 2400), ('nbls_aot_acc_fe', '12 × 5', '79 %', 5156), ('nbls_fp_inv_kernel', '1 × 64', '–', None), ('nbls_aot_fe_easy', '16 × 4', '77 %', 374),
