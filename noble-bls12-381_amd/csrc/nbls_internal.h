@@ -120,6 +120,7 @@ struct nbls_ctx {
   uint8_t* L = nullptr; size_t cap_L = 0;   // line tables of the Miller loop (LINE_BYTES each), at most LINES_CHUNK of them
   // the scratch above is shared by every call on this context: a call that uses another stream than its predecessor waits for it (StreamOrder)
   hipStream_t last_stream = nullptr; hipEvent_t ev_last = nullptr; bool ev_last_set = false;
+  uint8_t* pinned_out = nullptr; size_t pinned_out_cap = 0;   // the same for the way back (a call's inputs may still be in flight from `pinned` when its outputs are copied)
   uint8_t* pinned = nullptr; size_t pinned_cap = 0;   // page-locked host staging of the host-buffer entry points that pack their inputs (ensure_pinned; nbls_sign_batch)
   int last_hip = 0;
   // optional per-kernel timing (HIP events on the launch stream); slot P_COUNT = inversion kernel
@@ -219,6 +220,7 @@ int ensure_io(nbls_ctx* ctx, size_t n);
 int ensure_lines(nbls_ctx* ctx, size_t n);
 int need(nbls_ctx* ctx, int i, size_t bytes, uint8_t** out);
 int ensure_pinned(nbls_ctx* ctx, size_t bytes);
+int ensure_pinned_out(nbls_ctx* ctx, size_t bytes);
 size_t pow_wide_max();
 int run_pow(nbls_ctx* ctx, int which, size_t n, const void* in, void* out, hipStream_t s, uint8_t* scratch = nullptr);
 int run_inv_buf(nbls_ctx* ctx, size_t n, const void* in, void* out, hipStream_t s);

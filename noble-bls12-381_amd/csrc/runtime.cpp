@@ -213,6 +213,14 @@ int ensure_pinned(nbls_ctx* ctx, size_t bytes) {
   ctx->pinned_cap = cap;
   return NBLS_OK;
 }
+int ensure_pinned_out(nbls_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->pinned_out_cap) return NBLS_OK;
+  if (ctx->pinned_out) { hipHostFree(ctx->pinned_out); ctx->pinned_out = nullptr; ctx->pinned_out_cap = 0; }
+  const size_t cap = bytes + bytes / 4 + 4096;
+  HIPCHK(hipHostMalloc((void**)&ctx->pinned_out, cap, hipHostMallocDefault));
+  ctx->pinned_out_cap = cap;
+  return NBLS_OK;
+}
 int need(nbls_ctx* ctx, int i, size_t bytes, uint8_t** out) {
   if (bytes > ctx->sb_cap[i]) {
     if (ctx->sb[i]) hipFree(ctx->sb[i]);
@@ -315,6 +323,7 @@ EXPORT void nbls_destroy(nbls_ctx* ctx) {
   for (auto& b : ctx->io_pool) if (b.p) hipFree(b.p);
   for (uint8_t* p : ctx->nib) if (p) hipFree(p);
   if (ctx->pinned) hipHostFree(ctx->pinned);
+  if (ctx->pinned_out) hipHostFree(ctx->pinned_out);
   if (ctx->qp_table) hipFree(ctx->qp_table);
   for (uint8_t* p : {ctx->neg_g1, ctx->ident_g1, ctx->ident_g2}) if (p) hipFree(p);
   if (ctx->side) hipStreamDestroy(ctx->side);
