@@ -219,6 +219,8 @@ int ensure_expc_scratch(nbls_ctx* ctx);
 int ensure_io(nbls_ctx* ctx, size_t n);
 int ensure_lines(nbls_ctx* ctx, size_t n);
 int need(nbls_ctx* ctx, int i, size_t bytes, uint8_t** out);
+int ensure_side(nbls_ctx* ctx);
+int ensure_side2(nbls_ctx* ctx);
 int ensure_pinned(nbls_ctx* ctx, size_t bytes);
 int ensure_pinned_out(nbls_ctx* ctx, size_t bytes);
 size_t pow_wide_max();

@@ -141,30 +141,76 @@ int pairing_core(nbls_ctx* ctx, size_t n, const void* d_g1, const void* d_g2, in
   return final_exp_pipeline(ctx, n, ctx->F, d_out, s);
 }
 
+// Host-buffer staging shared by nbls_pairing_batch and nbls_miller_product: the points go up ONCE (the validity programs read the same device copies the Miller
+// loop reads), small calls through the context's page-locked block (one pageable copy costs a staging pass inside the runtime and a synchronisation of its own).
+static const size_t PIN_STAGE_MAX = 1u << 20, VALIDATE_BESIDE_MAX = 1024;
+static int stage_points(nbls_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2, bool validate, void* d_st, hipStream_t s) {
+  int r;
+  if ((r = ensure_io(ctx, n ? n : 1)) || !n) return r;
+  const uint8_t *h1 = g1, *h2 = g2;
+  if (n * 288 <= PIN_STAGE_MAX) {
+    if ((r = ensure_pinned(ctx, n * 288))) return r;
+    memcpy(ctx->pinned, g1, n * 96); memcpy(ctx->pinned + n * 96, g2, n * 192);
+    h1 = ctx->pinned; h2 = ctx->pinned + n * 96;
+  }
+  HIPCHK(hipMemcpyAsync(ctx->io_g1, h1, n * 96, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(ctx->io_g2, h2, n * 192, hipMemcpyHostToDevice, s));
+  if (!validate) return NBLS_OK;
+  if (n > VALIDATE_BESIDE_MAX) {
+    if ((r = dev_validate(ctx, false, n, ctx->io_g1, d_st, s))) return r;
+    return dev_validate(ctx, true, n, ctx->io_g2, (uint8_t*)d_st + n, s);
+  }
+  // A small call leaves most of the device idle, and the validity programs (two 64-bit scalar multiplications and a curve equation each; they touch only the points and
+  // the status bytes) do not feed the Miller loop: they run BESIDE it on the context's two side streams; join_validation() makes `s` wait for them before the read-back.
+  if ((r = ensure_side(ctx)) || (r = ensure_side2(ctx))) return r;
+  HIPCHK(hipEventRecord(ctx->ev_fork, s));
+  HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));
+  if ((r = dev_validate(ctx, true, n, ctx->io_g2, (uint8_t*)d_st + n, ctx->side))) return r;
+  HIPCHK(hipEventRecord(ctx->ev_join, ctx->side));
+  if ((r = dev_validate(ctx, false, n, ctx->io_g1, d_st, ctx->side2))) return r;
+  HIPCHK(hipEventRecord(ctx->ev_join2, ctx->side2));
+  return NBLS_OK;
+}
+static int join_validation(nbls_ctx* ctx, size_t n, bool validate, hipStream_t s) {
+  if (!validate || n > VALIDATE_BESIDE_MAX) return NBLS_OK;
+  HIPCHK(hipStreamWaitEvent(s, ctx->ev_join, 0)); HIPCHK(hipStreamWaitEvent(s, ctx->ev_join2, 0));
+  return NBLS_OK;
+}
+// results (out_bytes from ctx->io_f12) and, when validating, the 2 n status bytes come back behind ONE synchronisation; codes as PointG1/G2.assertValidity order them
+static int fetch_results(nbls_ctx* ctx, size_t n, size_t out_bytes, uint8_t* out, bool validate, const void* d_st, int8_t* st12, hipStream_t s) {
+  int r;
+  const size_t stb = validate ? 2 * n : 0;
+  if (out_bytes + stb <= PIN_STAGE_MAX) {
+    if ((r = ensure_pinned_out(ctx, out_bytes + stb))) return r;
+    HIPCHK(hipMemcpyAsync(ctx->pinned_out, ctx->io_f12, out_bytes, hipMemcpyDeviceToHost, s));
+    if (stb) HIPCHK(hipMemcpyAsync(ctx->pinned_out + out_bytes, d_st, stb, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    memcpy(out, ctx->pinned_out, out_bytes); if (stb) memcpy(st12, ctx->pinned_out + out_bytes, stb);
+    return NBLS_OK;
+  }
+  HIPCHK(hipMemcpyAsync(out, ctx->io_f12, out_bytes, hipMemcpyDeviceToHost, s));
+  if (stb) HIPCHK(hipMemcpyAsync(st12, d_st, stb, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return NBLS_OK;
+}
+static inline int8_t pair_code(const int8_t* st12, size_t n, size_t i) { return st12[i] ? st12[i] : (st12[n + i] ? (int8_t)(10 + st12[n + i]) : 0); }
+
 EXPORT int nbls_pairing_batch(nbls_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2, int with_final_exp, int validate, uint8_t* out, int8_t* status) {
-  std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);   // scratch and I/O staging buffers belong to this call until it returns
   if (!ctx || (n && (!g1 || !g2 || !out))) return NBLS_EINVAL;
   if (n == 0) return NBLS_OK;
+  LOCKED(ctx);   // scratch and I/O staging buffers belong to this call until it returns
   int r;
-  std::vector<int8_t> st1, st2;
-  if (validate) {   // P.assertValidity(); Q.assertValidity()  (index.ts:717-718)
-    st1.resize(n); st2.resize(n);
-    if ((r = nbls_g1_validate_batch(ctx, n, g1, st1.data())) || (r = nbls_g2_validate_batch(ctx, n, g2, st2.data()))) return r;
-  }
-  {
-    std::lock_guard<std::recursive_mutex> g(ctx->mu);
-    HIPCHK(hipSetDevice(ctx->device));
-    if ((r = ensure_io(ctx, n))) return r;
-    HIPCHK(hipMemcpyAsync(ctx->io_g1, g1, n * 96, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->io_g2, g2, n * 192, hipMemcpyHostToDevice, ctx->stream));
-  }
-  if ((r = nbls_pairing_batch_dev(ctx, n, ctx->io_g1, ctx->io_g2, with_final_exp, ctx->io_f12, ctx->stream))) return r;
-  std::lock_guard<std::recursive_mutex> g(ctx->mu);
-  HIPCHK(hipMemcpyAsync(out, ctx->io_f12, n * 576, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HostIO io{ctx}; void* d_st = validate ? io.alloc(2 * n) : nullptr;   // P.assertValidity(); Q.assertValidity()  (index.ts:717-718)
+  if (validate && !d_st) return NBLS_EHIP;
+  std::vector<int8_t> st12(validate ? 2 * n : 0);
+  ForkGuard fork;   // an error return below must not leave the side streams running over buffers the next call reuses
+  if ((r = stage_points(ctx, n, g1, g2, validate, d_st, s))) return r;
+  if ((r = nbls_pairing_batch_dev(ctx, n, ctx->io_g1, ctx->io_g2, with_final_exp, ctx->io_f12, s)) || (r = join_validation(ctx, n, validate, s))) return r;
+  fork.armed = false;
+  if ((r = fetch_results(ctx, n, n * 576, out, validate, d_st, st12.data(), s))) return r;
   if (status) memset(status, 0, n);
   if (validate) for (size_t i = 0; i < n; i++) {
-    int8_t c = st1[i] ? st1[i] : (st2[i] ? (int8_t)(10 + st2[i]) : 0);
+    const int8_t c = pair_code(st12.data(), n, i);
     if (c) { memset(out + 576 * i, 0, 576); if (status) status[i] = c; }
   }
   return NBLS_OK;
@@ -239,28 +285,24 @@ EXPORT int nbls_miller_product_dev(nbls_ctx* ctx, size_t n, const void* d_g1, co
 }
 
 EXPORT int nbls_miller_product(nbls_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2, int final_exp, int validate, uint8_t* out, int8_t* status) {
-  std::lock_guard<std::recursive_mutex> whole_call_(ctx ? ctx->mu : g_null_mu);   // scratch and I/O staging buffers belong to this call until it returns
   if (!ctx || !out || (n && (!g1 || !g2))) return NBLS_EINVAL;
+  LOCKED(ctx);   // scratch and I/O staging buffers belong to this call until it returns
   int r;
-  if (validate && n) {
-    std::vector<int8_t> st1(n), st2(n); bool bad = false;
-    if ((r = nbls_g1_validate_batch(ctx, n, g1, st1.data())) || (r = nbls_g2_validate_batch(ctx, n, g2, st2.data()))) return r;
-    for (size_t i = 0; i < n; i++) { int8_t c = st1[i] ? st1[i] : (st2[i] ? (int8_t)(10 + st2[i]) : 0); if (status) status[i] = c; bad = bad || c; }
+  const bool val = validate && n;
+  HostIO io{ctx}; void* d_st = val ? io.alloc(2 * n) : nullptr;
+  if (val && !d_st) return NBLS_EHIP;
+  std::vector<int8_t> st12(val ? 2 * n : 0);
+  ForkGuard fork;
+  if ((r = stage_points(ctx, n, g1, g2, val, d_st, s))) return r;
+  // an invalid point fails the whole product (the facade throws before any arithmetic); here the product of a small call is formed beside the checks and dropped if one fails
+  if ((r = nbls_miller_product_dev(ctx, n, ctx->io_g1, ctx->io_g2, final_exp, ctx->io_f12, s)) || (r = join_validation(ctx, n, val, s))) return r;
+  fork.armed = false;
+  if ((r = fetch_results(ctx, n, 576, out, val, d_st, st12.data(), s))) return r;
+  if (val) {
+    bool bad = false;
+    for (size_t i = 0; i < n; i++) { const int8_t c = pair_code(st12.data(), n, i); if (status) status[i] = c; bad = bad || c; }
     if (bad) { memset(out, 0, 576); return NBLS_EDECODE; }
   }
-  {
-    std::lock_guard<std::recursive_mutex> g(ctx->mu);
-    HIPCHK(hipSetDevice(ctx->device));
-    if ((r = ensure_io(ctx, n ? n : 1))) return r;
-    if (n) {
-      HIPCHK(hipMemcpyAsync(ctx->io_g1, g1, n * 96, hipMemcpyHostToDevice, ctx->stream));
-      HIPCHK(hipMemcpyAsync(ctx->io_g2, g2, n * 192, hipMemcpyHostToDevice, ctx->stream));
-    }
-  }
-  if ((r = nbls_miller_product_dev(ctx, n, ctx->io_g1, ctx->io_g2, final_exp, ctx->io_f12, ctx->stream))) return r;
-  std::lock_guard<std::recursive_mutex> g(ctx->mu);
-  HIPCHK(hipMemcpyAsync(out, ctx->io_f12, 576, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
   if (status) memset(status, 0, n);
   return NBLS_OK;
 }

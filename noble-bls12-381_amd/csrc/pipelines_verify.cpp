@@ -75,10 +75,7 @@ int verify_pipeline(nbls_ctx* ctx, size_t n, const VerifyIn& in, int final_exp, 
   ForkGuard fork_guard;
   if (in.d_sig96) {
     // normP2: PointG2.fromSignature for the ONE signature, on the side stream with its own scratch (its Fp2 exponentiation on two lanes is pure latency)
-    if (!ctx->side) {
-      if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
-          hipMalloc(&ctx->side_scratch, (6 + 2 * POW_TAB) * RAW) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
-    }
+    if ((r = ensure_side(ctx))) return r;
     uint8_t *X = ctx->side_scratch, *Rr = X + 2 * RAW, *Cd = Rr + 2 * RAW, *pw = Cd + 2 * RAW;
     HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
     if ((r = run(ctx, P_G2_DEC_A, 1, {B(0, in.d_sig96, 96), B(3, X, 2 * RAW), B(4, Rr, 2 * RAW)}, ctx->side))) return r;
@@ -90,8 +87,7 @@ int verify_pipeline(nbls_ctx* ctx, size_t n, const VerifyIn& in, int final_exp, 
   size_t m_off = 0;
   if (K == 1) {
     // one sub-batch: keys on a second stream beside the hash chain (both contain a per-lane exponentiation kernel that leaves issue slots free), then the Miller loops of all pairs
-    if (!ctx->side2 && (hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join2,
-        hipEventDisableTiming) != hipSuccess)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+    if ((r = ensure_side2(ctx))) return r;
     HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));
     if ((r = dev_decompress(ctx, false, n, in.d_pk48, G1, ST, ctx->side2, 14, 17))) return r;      // normP1: PointG1.fromHex; scratch slots 14..16 / 17
     HIPCHK(hipEventRecord(ctx->ev_join2, ctx->side2));
@@ -134,8 +130,7 @@ int verify_pipeline(nbls_ctx* ctx, size_t n, const VerifyIn& in, int final_exp, 
       // NBLS_VERIFY_KEYS_SIDE=1
       static const bool keys_side = env_long("NBLS_VERIFY_KEYS_SIDE", 0) != 0;
       if (c == 0 && keys_side) {
-        if (!ctx->side2 && (hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join2,
-            hipEventDisableTiming) != hipSuccess)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+        if ((r = ensure_side2(ctx))) return r;
         HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));
         hipStream_t keep = sc; sc = ctx->side2;
         if ((r = keys())) return r;
@@ -285,11 +280,7 @@ int verify_stage(nbls_ctx* ctx, size_t n, const void* d_sig96, const void* d_uni
     // normP2: PointG2.fromSignature for the ONE signature, on the side stream with its own scratch (overlaps everything below).
     // The side stream is created on first use: HIP spreads streams over a few hardware queues in creation order, and contexts
     // that only run pairing batches (noble-bls12-381_amd/pipeline.py keeps several in flight) should each get a queue of their own.
-    if (!ctx->side) {
-      if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess || (!ctx->ev_fork && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) ||
-          hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess || hipMalloc(&ctx->side_scratch,
-              (6 + 2 * POW_TAB) * RAW) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
-    }
+    if ((r = ensure_side(ctx))) return r;
     uint8_t *X = ctx->side_scratch, *Rr = X + 2 * RAW, *Cd = Rr + 2 * RAW, *pw = Cd + 2 * RAW;
     HIPCHK(hipEventRecord(ctx->ev_fork, s)); HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
     if ((r = run(ctx, P_G2_DEC_A, 1, {B(0, d_sig96, 96), B(3, X, 2 * RAW), B(4, Rr, 2 * RAW)}, ctx->side))) return r;
@@ -303,9 +294,7 @@ int verify_stage(nbls_ctx* ctx, size_t n, const void* d_sig96, const void* d_uni
   // 7..9 / 12 hold the staged messages, keys and expand_message_xmd output of the host-buffer entry point).
   static const bool overlap = !env_set("NBLS_VERIFY_NO_OVERLAP");
   if (overlap) {
-    if (!ctx->side2 && (hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join2,
-        hipEventDisableTiming) != hipSuccess)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
-    if (!ctx->ev_fork && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+    if ((r = ensure_side2(ctx))) return r;
     HIPCHK(hipEventRecord(ctx->ev_fork, s)); HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));
     if ((r = dev_decompress(ctx, false, n, d_pk48, G1, ST, ctx->side2, 14, 17))) return r;
     HIPCHK(hipEventRecord(ctx->ev_join2, ctx->side2));

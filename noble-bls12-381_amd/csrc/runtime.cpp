@@ -205,6 +205,25 @@ int ensure_lines(nbls_ctx* ctx, size_t n) {
   ctx->cap_L = cap;
   return NBLS_OK;
 }
+// The side streams (verifyBatch's one-element chains and key decoding; the validity programs of a small validated pairing call) are created on first use: HIP spreads
+// streams over a few hardware queues in creation order, and contexts that only run pairing batches (pipeline.py keeps several in flight) should each get a queue of their own.
+static int ensure_fork_event(nbls_ctx* ctx) {
+  if (!ctx->ev_fork && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+  return NBLS_OK;
+}
+int ensure_side(nbls_ctx* ctx) {     // ctx->side, ev_fork, ev_join and the side stream's own scratch (PointG2.fromSignature of ONE signature)
+  int r = ensure_fork_event(ctx); if (r) return r;
+  if (!ctx->side && hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) { ctx->side = nullptr; ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+  if (!ctx->ev_join && hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+  if (!ctx->side_scratch && hipMalloc(&ctx->side_scratch, (6 + 2 * POW_TAB) * RAW) != hipSuccess) { ctx->side_scratch = nullptr; ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+  return NBLS_OK;
+}
+int ensure_side2(nbls_ctx* ctx) {    // ctx->side2, ev_fork, ev_join2
+  int r = ensure_fork_event(ctx); if (r) return r;
+  if (!ctx->side2 && hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking) != hipSuccess) { ctx->side2 = nullptr; ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+  if (!ctx->ev_join2 && hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming) != hipSuccess) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+  return NBLS_OK;
+}
 int ensure_pinned(nbls_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->pinned_cap) return NBLS_OK;
   if (ctx->pinned) { hipHostFree(ctx->pinned); ctx->pinned = nullptr; ctx->pinned_cap = 0; }

@@ -33,6 +33,40 @@ def test_pairing_with_validation(eng, oracle, golden):
         assert out[576 * i:576 * i + 576] == (ref if rst == 0 else bytes(576))
 
 
+def test_validation_beside_the_loop_and_in_line(eng, oracle, golden):
+    """nbls_pairing_batch / nbls_miller_product with validate = 1: up to 1024 pairs the validity programs run on the side streams beside the Miller loop, above that in
+    line before it; the points go up once either way.  Same statuses, same zeroed slots, the product refused (NBLS_EDECODE) when any point is invalid."""
+    pkg = importlib.import_module('noble-bls12-381_amd')
+    v1, v2 = golden['validity']['g1'], golden['validity']['g2']
+    bad1 = [hx(v['aff']) for v in v1 if STATUS[v['result']] != 0][:2]; bad2 = [hx(v['aff']) for v in v2 if STATUS[v['result']] != 0][:2]
+    ok1 = [hx(v['aff']) for v in v1 if STATUS[v['result']] == 0 and hx(v['aff']) != bytes(96)][:3]
+    ok2 = [hx(v['aff']) for v in v2 if STATUS[v['result']] == 0 and hx(v['aff']) != bytes(192)][:3]
+    assert bad1 and bad2 and ok1 and ok2
+    for n in (1, 5, 1024, 1025, 1500):
+        P = [ok1[i % len(ok1)] for i in range(n)]; Q = [ok2[(i // 3) % len(ok2)] for i in range(n)]
+        G1, G2 = b''.join(P), b''.join(Q)
+        out, st = eng.pairing_batch(G1, G2, True, True)
+        assert st == bytes(n) and out == eng.pairing_batch(G1, G2, True, False)[0]
+        if n <= 5:
+            assert out == oracle.pairing_batch(G1, G2, True, False)[0]
+        prod = eng.miller_product(G1, G2, True, True)
+        assert prod[1] == bytes(n) and prod[0] == eng.miller_product(G1, G2, True, False)[0]
+        if n == 1: continue
+        P[n // 2] = bad1[0]; Q[n - 1] = bad2[0]
+        if n > 4: P[3] = bad1[-1]; Q[3] = bad2[-1]
+        B1, B2 = b''.join(P), b''.join(Q)
+        out2, st2 = eng.pairing_batch(B1, B2, True, True)
+        for i in sorted({n // 2, n - 1, 3 if n > 4 else n - 1, 0}):
+            rst, ref = oracle.pairing(B1[96 * i:96 * i + 96], B2[192 * i:192 * i + 192], True, True)
+            assert st2[i] == rst, (n, i)
+            assert out2[576 * i:576 * i + 576] == (ref if rst == 0 else bytes(576)), (n, i)
+        assert sum(1 for c in st2 if c) == len({n // 2, n - 1} | ({3} if n > 4 else set()))
+        assert bytes(x for i, x in enumerate(out2) if st2[i // 576] == 0) == bytes(x for i, x in enumerate(out) if st2[i // 576] == 0)
+        with pytest.raises(pkg.NblsError):
+            eng.miller_product(B1, B2, True, True)
+        assert eng.miller_product(G1, G2, True, True)[0] == prod[0]      # the context is fine afterwards
+
+
 def test_decompress(eng, oracle, golden, testdata):
     for g2 in (False, True):
         vs = golden['codec']['g2' if g2 else 'g1']

@@ -28,6 +28,14 @@ res['sign_ms'] = med(lambda: eng.sign_batch_affine([msg], [sk]))
 res['hash_to_g2_ms'] = med(lambda: eng.hash_to_g2_batch([msg]))
 res['g2_decompress_ms'] = med(lambda: eng.decompress_batch(sig, g2=True))
 res['g1_decompress_ms'] = med(lambda: eng.decompress_batch(pk, g2=False))
+try:
+    g1a = eng.decompress_batch(pk, g2=False)[0]; g2a = eng.decompress_batch(sig, g2=True)[0]
+    res['pairing1_ms'] = med(lambda: eng.pairing_batch(g1a, g2a))
+    res['pairing1_validated_ms'] = med(lambda: eng.pairing_batch(g1a, g2a, validate=True))
+    res['miller_product2_validated_ms'] = med(lambda: eng.miller_product(g1a * 2, g2a * 2, validate=True))
+    assert eng.pairing_batch(g1a, g2a, validate=True)[0] == eng.pairing_batch(g1a, g2a)[0]
+except Exception as e:   # noqa: BLE001
+    res['pairing_legs_error'] = repr(e)
 eng.timing_enable(True); eng.verify_batch(sig, [msg], [pk]); tm = eng.timing_read(); eng.timing_enable(False)
 res['verify_kernels_ms'] = {k: round(v[0], 4) for k, v in sorted(tm.items(), key=lambda kv: -kv[1][0])[:12]}
 print('LATENCY_AB', tag, json.dumps(res), flush=True)
