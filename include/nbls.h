@@ -284,6 +284,7 @@ int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks);
                                         * wavefront of the launch resident at once; 0 = never: the windowed psi-split ladder at every size) */
 #define NBLS_TUNE_PT_LS2_MAX 9         /* items up to which the G2 point chains of verify / sign (clearCofactor's two ladders, sign's ladder) run in their two-lane forms (default 4096; 0 = never) */
 #define NBLS_TUNE_WIDE_MAX 10          /* round 6, experiment: items up to which the programs that allow it run on the one-limb-per-lane interpreter (one item per workgroup of three wavefronts, two barriers per step); bit-exact, measured slower than the four-lane forms (0.93 against 0.66 ms for a final exponentiation's five exponentiations), so the default is 0 = never */
+#define NBLS_TUNE_H2C_NORM_MIN 11     /* round 6: messages from which hash-to-G2 (also inside sign / verify / verifyBatch) takes the square root of its SWU map by the norm method -- two Fp exponentiations and a short program between them instead of one Fp2 exponentiation of twice the work; the same points; less work but two dependent exponentiations, so it pays where the device is full or the chain runs beside other work: the size compared is the whole call's (default 32768; 0 = always) */
 int nbls_set_tuning(nbls_ctx* ctx, int key, long long value);
 int nbls_program_count(void);                 /* number of step programs; timing slot nbls_program_count() = the inversion kernel */
 const char* nbls_program_name(int prog);

@@ -59,7 +59,8 @@
   X(6, from_raw, P_G1_FROM_RAW, P_G2_FROM_RAW, P_G1_COMPRESS, P_G2_COMPRESS) \
   X(7, h2c1, P_H2C1_A, P_H2C1_B, P_ENC1_A, P_ENC1_B)                         \
   X(7, g1_clear, P_G1_CLEAR, P_COUNT, P_COUNT, P_COUNT)                      \
-  X(7, enc2, P_ENC2_A, P_ENC2_B, P_COUNT, P_COUNT)
+  X(7, enc2, P_ENC2_A, P_ENC2_B, P_COUNT, P_COUNT)                            \
+  X(4, h2c_n, P_H2C_NA, P_H2C_NM, P_H2C_NB, P_COUNT)
 
 // Lane-split kernels (latency form for launches of at most one wavefront per SIMD): ONE item per wavefront, every K_DOT lane-op spread over four adjacent
 // lanes that each accumulate a share of its products; the 28 columns are summed across the four lanes (two DPP stages) before the one reduction on the first of them.

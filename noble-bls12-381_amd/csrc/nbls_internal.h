@@ -113,6 +113,11 @@ struct nbls_ctx {
   // default: NBLS_WIDE_MAX / NBLS_TUNE_WIDE_MAX (items; 0 = never), NBLS_WIDE_PROGS = 0: only the final exponentiation's programs.  The fixed-exponent powers, where the same
   // idea removes a 196-multiply-add reduction per squaring from ONE lane, are the case that pays (pow_wide.h: 0.7 -> 0.3 ms).
   size_t wide_max = (size_t)env_long("NBLS_WIDE_MAX", 0);
+  // round 6: messages from which hash-to-G2 takes its SWU square root by the norm method (two Fp exponentiations, programs P_H2C_NA / NM / NB) instead of one Fp2 exponentiation;
+  // nbls_set_tuning(NBLS_TUNE_H2C_NORM_MIN); 0 = always.  Less work (1.96 against 2.53 ms of exponentiation kernels per 65,536 roots) but two dependent exponentiations where
+  // there was one: a launch that does not fill the device pays their latency twice (sign of 8192 keys +0.09 ms), one that does, or that runs beside other work as the sub-batches
+  // of verifyBatch do (the size counted there is the whole call's), gains (sign of 65,536 keys -0.7 ms, verifyBatch -0.3 ms alone and -0.5 ms with three calls in flight)
+  size_t h2c_norm_min = (size_t)env_long("NBLS_H2C_NORM_MIN", 32768);
   size_t chain_max = (size_t)env_long("NBLS_CHAIN_MAX", 8192);                  // nbls_set_tuning(NBLS_TUNE_CHAIN_MAX); see run_chain
   u32* qp_table = nullptr;      // multiples of p for the weak reduction (vm_exec.h weak_reduce), device copy
   uint8_t* unit_lines = nullptr;   // a line table whose 68 lines are all 1 (c0 = 1, c1 = c2 = 0): the neutral partner of an odd last pair

@@ -37,17 +37,29 @@ int dev_clear_g2(nbls_ctx* ctx, size_t n, void* in, uint8_t* base, uint8_t* S, v
 int dev_hash_to_g2(nbls_ctx* ctx, size_t n, const void* d_uniform, void* d_out, hipStream_t s, size_t io, size_t ntot, uint8_t** proj) {
   if (ntot < io + n) ntot = io + n;
   uint8_t *T, *E, *Pw, *Q, *N, *NI, *st, *St, *Pt2, *S, *tab; int r;
+  const size_t ST = 32;   // raw elements of SWU state per message: 2 x 12 (P_H2C_A) or 2 x 16 (P_H2C_NA / NM)
   if ((r = need(ctx, 0, ntot * 4 * RAW, &T)) || (r = need(ctx, 1, ntot * 6 * RAW, &E)) || (r = need(ctx, 2, ntot * 4 * RAW, &Pw)) || (r = need(ctx, 3, ntot * 6 * RAW, &Q)) ||
-      (r = need(ctx, 4, ntot * RAW, &N)) || (r = need(ctx, 5, ntot * RAW, &NI)) || (r = need(ctx, 6, ntot, &st)) || (r = need(ctx, 18, ntot * 24 * RAW, &St)) || (r = need(ctx, 19,
+      (r = need(ctx, 4, ntot * RAW, &N)) || (r = need(ctx, 5, ntot * RAW, &NI)) || (r = need(ctx, 6, ntot, &st)) || (r = need(ctx, 18, ntot * ST * RAW, &St)) || (r = need(ctx, 19,
           ntot * 12 * RAW, &Pt2)) ||
       (r = need(ctx, 13, ntot * 6 * RAW, &S)) || (r = need(ctx, 11, ntot * 4 * POW_TAB * RAW, &tab))) return r;
-  T += io * 4 * RAW; E += io * 6 * RAW; Pw += io * 4 * RAW; Q += io * 6 * RAW; N += io * RAW; NI += io * RAW; st += io; St += io * 24 * RAW; Pt2 += io * 12 * RAW; S += io * 6 * RAW;
+  T += io * 4 * RAW; E += io * 6 * RAW; Pw += io * 4 * RAW; Q += io * 6 * RAW; N += io * RAW; NI += io * RAW; st += io; St += io * ST * RAW; Pt2 += io * 12 * RAW; S += io * 6 * RAW;
   tab += io * 4 * POW_TAB * RAW;
-  // H2C_A: per message the two field elements t (T), the exponentiation inputs (E) and the rest of the SWU state (St: twelve raw elements per map)
-  if ((r = run(ctx, P_H2C_A, n, {B(0, d_uniform, 256), B(3, T, 4 * RAW), B(4, E, 4 * RAW), B(5, St, 24 * RAW)}, s))) return r;
-  if ((r = run_pow(ctx, 2, 2 * n, E, Pw, s, tab))) return r;
-  // H2C_B1: one map per item (2 n items) -> its point on E2'; H2C_B2: the two points of a message -> their sum on E2 (round 3: one program, 62 slots, four workgroups per CU)
-  if ((r = run(ctx, P_H2C_B1, 2 * n, {B(3, T, 2 * RAW), B(5, Pw, 2 * RAW), B(4, St, 12 * RAW), B(6, Pt2, 6 * RAW)}, s))) return r;
+  if (ntot >= ctx->h2c_norm_min) {   // ntot: the messages of the whole call (verifyBatch hashes its sub-batches side by side)
+    // The SWU square root by the norm method (codec.h swu_norm_*): two Fp exponentiations with a short program between them where the Fp2 form spends one exponentiation of
+    // twice the work.  Same points (the root's sign is fixed by sgn0 afterwards); two more launches, so single messages keep the Fp2 form.
+    if ((r = run(ctx, P_H2C_NA, n, {B(0, d_uniform, 256), B(3, T, 4 * RAW), B(4, E, 2 * RAW), B(5, St, 32 * RAW)}, s))) return r;
+    if ((r = run_pow(ctx, 0, 2 * n, E, Pw, s, tab))) return r;                                        // n = N(a)^((p+1)/4)
+    if ((r = run(ctx, P_H2C_NM, 2 * n, {B(3, T, 2 * RAW), B(4, St, 16 * RAW), B(5, Pw, RAW), B(6, St + 9 * RAW, 16 * RAW), B(7, E, RAW)}, s))) return r;
+    if ((r = run_pow(ctx, 3, 2 * n, E, Pw, s, tab))) return r;                                        // e = (delta d^3)^((p-3)/4)
+    if ((r = run(ctx, P_H2C_NB, 2 * n, {B(3, T, 2 * RAW), B(4, St, 16 * RAW), B(5, Pw, RAW), B(6, Pt2, 6 * RAW)}, s))) return r;
+  } else {
+    // H2C_A: per message the two field elements t (T), the exponentiation inputs (E) and the rest of the SWU state (St: twelve raw elements per map)
+    if ((r = run(ctx, P_H2C_A, n, {B(0, d_uniform, 256), B(3, T, 4 * RAW), B(4, E, 4 * RAW), B(5, St, 24 * RAW)}, s))) return r;
+    if ((r = run_pow(ctx, 2, 2 * n, E, Pw, s, tab))) return r;
+    // H2C_B1: one map per item (2 n items) -> its point on E2'
+    if ((r = run(ctx, P_H2C_B1, 2 * n, {B(3, T, 2 * RAW), B(5, Pw, 2 * RAW), B(4, St, 12 * RAW), B(6, Pt2, 6 * RAW)}, s))) return r;
+  }
+  // H2C_B2: the two points of a message -> their sum on E2 (round 3: one program, 62 slots, four workgroups per CU)
   if ((r = run(ctx, P_H2C_B2, n, {B(3, Pt2, 12 * RAW), B(6, E, 6 * RAW)}, s))) return r;        // E is free again: reuse it for the E2 point
   if ((r = dev_clear_g2(ctx, n, E, Q, S, E, N, s))) return r;
   if (proj) { *proj = E; return NBLS_OK; }

@@ -464,6 +464,33 @@ static Program build(ProgId id) {
       outputw(q.x.c0, 6, 0); outputw(q.x.c1, 6, 48); outputw(q.y.c0, 6, 96); outputw(q.y.c1, 6, 144); outputw(q.z.c0, 6, 192); outputw(q.z.c1, 6, 240);
       return B.compile("h2c_b2", env_int("NBLS_H2C_B2_W", 8));
     }
+    case P_H2C_NA: {
+      for (int k = 0; k < 2; k++) {
+        SFp2 t = {field_elem_from_64(0, 128 * k), field_elem_from_64(0, 128 * k + 64)};
+        outputw(t.c0, 3, 96 * k); outputw(t.c1, 3, 96 * k + 48);
+        SwuNormState s = swu_norm_prepare(t);
+        outputw(s.na, 4, 48 * k);
+        const SFp2* f[4] = {&s.zt2, &s.num, &s.den, &s.a};
+        for (int j = 0; j < 4; j++) { outputw(f[j]->c0, 5, 768 * k + 96 * j); outputw(f[j]->c1, 5, 768 * k + 96 * j + 48); }
+        outputw(s.d, 5, 768 * k + 384);
+      }
+      B.store_batch = 8;
+      return B.compile("h2c_na", 8);
+    }
+    case P_H2C_NM: {
+      SFp2 t = {inputw(3, 0), inputw(3, 48)}, zt2 = {inputw(4, 0), inputw(4, 48)}, num = {inputw(4, 96), inputw(4, 144)}, a = {inputw(4, 288), inputw(4, 336)};
+      SwuNormMid m = swu_norm_mid(t, zt2, num, a, inputw(4, 384), inputw(5, 0));
+      outputw(m.num.c0, 6, 0); outputw(m.num.c1, 6, 48); outputw(m.a1h, 6, 96); outputw(m.delta, 6, 144);
+      outputw(m.g, 7, 0);
+      return B.compile("h2c_nm", env_int("NBLS_H2C_NM_W", 4));
+    }
+    case P_H2C_NB: {
+      // the state's slots 9..12 are P_H2C_NM's output (buffer 6 there): num, a1 / 2, delta
+      SFp2 t = {inputw(3, 0), inputw(3, 48)}, den = {inputw(4, 192), inputw(4, 240)}, num = {inputw(4, 432), inputw(4, 480)};
+      Pt<SFp2> q = swu_norm_finish(t, num, den, inputw(4, 528), inputw(4, 576), inputw(4, 384), inputw(5, 0));
+      outputw(q.x.c0, 6, 0); outputw(q.x.c1, 6, 48); outputw(q.y.c0, 6, 96); outputw(q.y.c1, 6, 144); outputw(q.z.c0, 6, 192); outputw(q.z.c1, 6, 240);
+      return B.compile("h2c_nb", env_int("NBLS_H2C_NB_W", 4));
+    }
     case P_H2C_C: {   // its own program: chained to H2C_B through HBM so that neither keeps more than ~40 slots live (LDS-limited occupancy)
       Pt<SFp2> p = {{inputw(3, 0), inputw(3, 48)}, {inputw(3, 96), inputw(3, 144)}, {inputw(3, 192), inputw(3, 240)}};
       Pt<SFp2> q = clear_cofactor_g2(p);                               // index.ts:489, 659-672

@@ -84,6 +84,10 @@ enum ProgId {
   // two-lane split of the G2 point chains (round 5): launches of at most 4096 items (four items per wavefront): the two ladders of clearCofactor and sign's ladder -- a single verify / sign is
   // a chain of one-item launches whose time is the length of their instruction streams
   P_H2C_C1_LS2, P_H2C_C2_LS2, P_G2_MUL_SAC_LS2,
+  // hash-to-G2 with the SWU square root by the norm method (round 6, codec.h swu_norm_*): two Fp exponentiations instead of one in Fp2, for calls of NBLS_H2C_NORM_MIN messages and more
+  P_H2C_NA,            // 256 uniform bytes (buf 0) -> t0, t1 (3), N(u conj(v)) of both maps (4: the first exponentiation's input), state (5: per map zt2, num, den, a = u conj(v), d = N(v): 9 raw elements of 16)
+  P_H2C_NM,            // one map per item: t (3), state (4), n = N(a)^((p+1)/4) (5) -> num of the chosen x, a1 / 2, delta (6: 4 raw elements), delta d^3 (7: the second exponentiation's input)
+  P_H2C_NB,            // one map per item: t (3), state (4), e = (delta d^3)^((p-3)/4) (5) -> projective point on E2' (6), what P_H2C_B1 produces
   P_COUNT
 };
 // |x| = 2^63 + 2^62 + 2^60 + 2^57 + 2^48 + 2^16: the compressed chain runs to 2^57 and its values at the set bits 16, 48, 57 are decompressed; the powers

@@ -414,6 +414,10 @@ class Engine:
         """items up to which the programs that allow it run on the one-limb-per-lane interpreter (NBLS_TUNE_WIDE_MAX; an experiment, measured slower than the lane-split forms: default 0 = never)"""
         self._chk(self.lib.nbls_set_tuning(self.h, 10, n))
 
+    def set_h2c_norm_min(self, n):
+        """messages from which hash-to-G2 takes its SWU square root by the norm method (NBLS_TUNE_H2C_NORM_MIN = 11; default 32768, 0: always)"""
+        self._chk(self.lib.nbls_set_tuning(self.h, 11, int(n)))
+
     def set_pt_ls2_max(self, n):
         """items up to which the G2 point chains of verify / sign run in their two-lane forms (NBLS_TUNE_PT_LS2_MAX; default 4096, 0: never)"""
         self._chk(self.lib.nbls_set_tuning(self.h, 9, n))

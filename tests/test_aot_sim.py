@@ -71,6 +71,10 @@ def test_decode_and_hash_programs_translated(sim, oracle, golden, testdata):
         assert sim.nbls_sim_has_aot(vmsim_py.P[name]) == 1, name
     T.test_decompress_programs(sim, golden)
     T.test_hash_to_g2_program(sim, oracle, golden, testdata)
+    for name in ('H2C_NA', 'H2C_NM', 'H2C_NB'):          # round 6: the SWU square root by the norm method
+        assert sim.nbls_sim_has_aot(vmsim_py.P[name]) == 1, name
+    T.test_hash_to_g2_norm_method(sim, oracle, golden, testdata)
+    T.test_norm_method_square_root_corner_cases(sim)
 
 
 def test_slot_placement_table_is_current_and_pays(sim):

@@ -168,6 +168,34 @@ def test_hash_to_g2_dispatch_threshold(eng, oracle):
         assert eng.hash_to_g2_batch(msgs[:m]) == ref[:192 * m], m
 
 
+def test_hash_to_g2_norm_method_threshold(eng, oracle, testdata):
+    """round 6: from 32,768 messages hash-to-G2 takes the square root of its SWU maps by the norm method (P_H2C_NA / NM / NB around two Fp exponentiations, csrc/codec.h swu_norm_*)
+    instead of the reference's one Fp2 exponentiation (math.ts:1195-1214) -- the same points, since map_to_curve fixes the root's sign itself (math.ts:1264).  Both sides of the
+    switch, each method forced at every size, the RFC 9380 vectors of test/hashToCurve.test.ts through the norm method, the oracle on a strided sample."""
+    import hashlib
+    from goldenio import hx
+    msgs = [hashlib.sha256(b'norm-h%d' % i).digest()[:1 + i % 40] for i in range(2100)]
+    try:
+        eng.set_h2c_norm_min(1 << 30); fp2 = eng.hash_to_g2_batch(msgs)
+        eng.set_h2c_norm_min(0); nrm = eng.hash_to_g2_batch(msgs)
+        assert nrm == fp2
+        for m in (1, 2, 3, 65):
+            assert eng.hash_to_g2_batch(msgs[:m]) == fp2[:192 * m], m
+        suite = testdata['h2c_g2_ro']
+        out = eng.hash_to_g2_batch([hx(v['msg']) for v in suite['vectors']], suite['dst'].encode())
+        for i, v in enumerate(suite['vectors']):
+            e = hx(v['x1x0y1y0'])
+            assert out[192 * i:192 * (i + 1)] == e[48:96] + e[0:48] + e[144:192] + e[96:144]
+        eng.set_h2c_norm_min(2048)
+        for m in (2047, 2048, 2049):
+            assert eng.hash_to_g2_batch(msgs[:m]) == fp2[:192 * m], m
+        assert eng.program_kernel('h2c_na') == 'nbls_aot_h2c_n' and eng.program_kernel('h2c_nb') == 'nbls_aot_h2c_n'
+    finally:
+        eng.set_h2c_norm_min(32768)
+    for i in list(range(0, 2100, 97)) + [2047, 2048, 2099]:
+        assert fp2[192 * i:192 * i + 192] == oracle.hash_to_g2(msgs[i])[1], i
+
+
 def test_wide_power_kernel_threshold(eng, oracle):
     """round 6: launches of at most 1024 elements run the fixed-exponent powers in their one-limb-per-lane form (nbls_pow_wide_kernel, csrc/pow_wide.h) -- the Fp2 exponent of
     hash-to-G2 (two elements per message: 512 / 513 messages straddle the switch), the Fp2 square root of a compressed signature and the Fp square root of a compressed key (1024 /

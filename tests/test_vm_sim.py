@@ -101,15 +101,15 @@ def test_decompress_programs(sim, golden):
             assert out[192 * i:192 * (i + 1)] == hx(v['aff'])
 
 
-def test_hash_to_g2_program(sim, oracle, golden, testdata, ls2=False):
+def test_hash_to_g2_program(sim, oracle, golden, testdata, ls2=False, norm=False):
     vs = golden['h2c']
     uni = b''.join(oracle.expand_message_xmd(hx(v['msg']), v['dst'].encode(), 256) for v in vs)
-    out = vmsim_py.hash_to_g2(sim, uni, ls2)
+    out = vmsim_py.hash_to_g2(sim, uni, ls2, norm)
     for i, v in enumerate(vs):
         assert out[192 * i:192 * (i + 1)] == hx(v['aff']), i
     suite = testdata['h2c_g2_ro']          # RFC 9380 vectors held by test/hashToCurve.test.ts
     uni = b''.join(oracle.expand_message_xmd(hx(v['msg']), suite['dst'].encode(), 256) for v in suite['vectors'])
-    out = vmsim_py.hash_to_g2(sim, uni, ls2)
+    out = vmsim_py.hash_to_g2(sim, uni, ls2, norm)
     for i, v in enumerate(suite['vectors']):
         e = hx(v['x1x0y1y0'])
         assert out[192 * i:192 * (i + 1)] == e[48:96] + e[0:48] + e[144:192] + e[96:144], i
@@ -623,3 +623,59 @@ def test_scalar_splits_as_the_device_runs_them(sim):
                 want = b''.join(x.to_bytes(32, 'big') for x in vmsim_py.sac_recode(k))
                 got = out.raw[128 * i:128 * i + 128]
             assert got == want, (dims, hex(k))
+
+
+def test_hash_to_g2_norm_method(sim, oracle, golden, testdata):
+    """hash-to-G2 with the SWU square root by the norm method (P_H2C_NA / NM / NB around two Fp exponentiations, codec.h swu_norm_*): the reference's points on its own
+    vectors (test/hashToCurve.test.ts) and on the generated ones -- the root's sign is fixed by sgn0 (math.ts:1264), so any method that finds a root finds the same point"""
+    test_hash_to_g2_program(sim, oracle, golden, testdata, False, True)
+    vs = golden['h2c_more']
+    uni = b''.join(oracle.expand_message_xmd(hx(v['msg']), v['dst'].encode(), 256) for v in vs)
+    assert vmsim_py.hash_to_g2(sim, uni, False, True) == vmsim_py.hash_to_g2(sim, uni, False, False)
+
+
+def test_norm_method_square_root_corner_cases(sim):
+    """P_H2C_NM / P_H2C_NB fed directly: values a = u conj(v) with a vanishing imaginary part, where delta = (a0 + n) / 2 is zero for the root n = -a0 of the norm and the
+    programs must fall back to n = a0; both characters of a0 / d (the root is real or purely imaginary); a = 0.  With num = den = 1 the point's Y coordinate is the
+    root y itself: y^2 d == a, and sgn0(y) == sgn0(t) (math.ts:1264)."""
+    import random
+    p = vmsim_py.P_MOD; R = 1 << 392; RAW = vmsim_py.RAW
+    rnd = random.Random(9380)
+    mont = lambda v: (v % p) * R % p
+    cases = []
+    for k in range(12):
+        a0 = rnd.randrange(1, p); d = rnd.randrange(1, p)
+        n = (p - a0) if k % 2 == 0 else a0                       # both roots of the norm a0^2: the first makes delta vanish
+        cases.append(((a0, 0), d, n))
+    cases.append(((0, 0), rnd.randrange(1, p), 0))
+    for k in range(6):                                          # ordinary values whose norm is a square, with its root given either sign
+        y = (rnd.randrange(p), rnd.randrange(p)); d = rnd.randrange(1, p)
+        a = ((y[0] * y[0] - y[1] * y[1]) * d % p, 2 * y[0] * y[1] * d % p)
+        n = pow((a[0] * a[0] + a[1] * a[1]) % p, (p + 1) // 4, p)
+        assert n * n % p == (a[0] * a[0] + a[1] * a[1]) % p
+        cases.append((a, d, n if k % 2 else p - n))
+    m = len(cases)
+    ts = [(rnd.randrange(p), rnd.randrange(p)) for _ in range(m)]
+    T = vmsim_py.buf(_raw([mont(x) for t in ts for x in t]))
+    st = []
+    for (a, d, n) in cases:
+        st += [mont(3), mont(5), mont(1), 0, mont(1), 0, mont(a[0]), mont(a[1]), mont(d)] + [0] * 7      # zt2 (unused: the norm is a square), num = 1, den = 1, a, d
+    St = vmsim_py.buf(_raw(st)); Nn = vmsim_py.buf(_raw([mont(n) for (_, _, n) in cases]))
+    E, Pw, Pt2 = vmsim_py.buf(RAW * m), vmsim_py.buf(RAW * m), vmsim_py.buf(6 * RAW * m)
+    St9 = (C.c_char * (16 * RAW * m - 9 * RAW)).from_buffer(St, 9 * RAW)
+    vmsim_py.run(sim, 'H2C_NM', m, {3: (T, 2 * RAW), 4: (St, 16 * RAW), 5: (Nn, RAW), 6: (St9, 16 * RAW), 7: (E, RAW)})
+    sim.nbls_sim_fp_pow(C.c_uint(m), E, Pw, 3)
+    vmsim_py.run(sim, 'H2C_NB', m, {3: (T, 2 * RAW), 4: (St, 16 * RAW), 5: (Pw, RAW), 6: (Pt2, 6 * RAW)})
+    Ri = pow(R, -1, p)
+    sgn0 = lambda x: (x[0] % 2) or (x[0] == 0 and x[1] % 2)
+    real = imag = 0
+    for k, ((a, d, n), t) in enumerate(zip(cases, ts)):
+        X = [_unraw(Pt2.raw, 6 * k + j) * Ri % p for j in range(6)]
+        assert X[0] == 1 and X[1] == 0 and X[4] == 1 and X[5] == 0, k
+        y = (X[2], X[3])
+        assert ((y[0] * y[0] - y[1] * y[1]) * d % p, 2 * y[0] * y[1] * d % p) == a, k
+        if a != (0, 0):
+            assert bool(sgn0(y)) == bool(sgn0(t)), k
+        if k < 12:
+            real += y[1] == 0; imag += y[0] == 0
+    assert real and imag and real + imag == 12

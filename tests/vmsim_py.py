@@ -17,7 +17,7 @@ def raw_elem(v):
 
 
 PROGS = ['MILLER_BYTES', 'MILLER_RAW', 'MILLER_FE', 'NORM_RAW', 'NORM_BYTES', 'FE_EASY', 'EXPX', 'FE_MID1', 'FE_MID2', 'FE_FINAL', 'MUL2', 'RAW_TO_BYTES', 'G1_VALIDATE', 'G2_VALIDATE', 'G1_DEC_A', 'G1_DEC_B', 'G2_DEC_A', 'G2_DEC_B', 'H2C_A', 'H2C_B',
-         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'G1_COMPRESS', 'G2_COMPRESS', 'H2C1_A', 'ENC1_A', 'H2C1_B', 'ENC1_B', 'G1_CLEAR', 'ENC2_A', 'ENC2_B', 'G1_MUL', 'G2_MUL', 'G1_ADD_AB', 'G2_ADD_AB', 'G1_HORNER', 'G2_HORNER', 'G1_SHIFTADD', 'G2_SHIFTADD', 'G1_MSM_PREP', 'G2_MSM_PREP', 'LINES_PQ', 'LINES_Q', 'LINES_BYTES', 'LINES_FROM_BYTES', 'ACC_BYTES', 'ACC_RAW', 'ACC_FE', 'ACC2_RAW', 'ACC_Q', 'G2_DEC_A192', 'G2_DEC_B192', 'G2_DEC_B_HEX', 'G1_FROM_RAW', 'G2_FROM_RAW', 'G2_SWAP', 'H2C_C1', 'H2C_C2', 'ACC4_RAW', 'MILLER_BYTES_LS', 'MILLER_RAW_LS', 'MILLER_FE_LS', 'EXPX_LS', 'EXPC_SQ', 'EXPC_DEC_A', 'EXPC_DEC_B', 'ACC8_RAW', 'H2C_C0', 'H2C_B1', 'H2C_B2', 'G1_MUL_W3', 'G2_MUL_W3', 'MUL2S', 'G1_MUL_FIXED', 'G2_MUL_GLS', 'MILLER_BYTES_LS2', 'MILLER_RAW_LS2', 'MILLER_FE_LS2', 'EXPX_LS2', 'G2_MUL_SAC', 'H2C_C1_LS2', 'H2C_C2_LS2', 'G2_MUL_SAC_LS2']
+         'G1_TO_PROJ', 'G1_ADD2', 'G1_NORM', 'G1_TO_AFFINE', 'G2_TO_PROJ', 'G2_ADD2', 'G2_NORM', 'G2_TO_AFFINE', 'T_SWU', 'T_ISO', 'T_CLEAR', 'H2C_C', 'MILLER_RAW2', 'G1_COMPRESS', 'G2_COMPRESS', 'H2C1_A', 'ENC1_A', 'H2C1_B', 'ENC1_B', 'G1_CLEAR', 'ENC2_A', 'ENC2_B', 'G1_MUL', 'G2_MUL', 'G1_ADD_AB', 'G2_ADD_AB', 'G1_HORNER', 'G2_HORNER', 'G1_SHIFTADD', 'G2_SHIFTADD', 'G1_MSM_PREP', 'G2_MSM_PREP', 'LINES_PQ', 'LINES_Q', 'LINES_BYTES', 'LINES_FROM_BYTES', 'ACC_BYTES', 'ACC_RAW', 'ACC_FE', 'ACC2_RAW', 'ACC_Q', 'G2_DEC_A192', 'G2_DEC_B192', 'G2_DEC_B_HEX', 'G1_FROM_RAW', 'G2_FROM_RAW', 'G2_SWAP', 'H2C_C1', 'H2C_C2', 'ACC4_RAW', 'MILLER_BYTES_LS', 'MILLER_RAW_LS', 'MILLER_FE_LS', 'EXPX_LS', 'EXPC_SQ', 'EXPC_DEC_A', 'EXPC_DEC_B', 'ACC8_RAW', 'H2C_C0', 'H2C_B1', 'H2C_B2', 'G1_MUL_W3', 'G2_MUL_W3', 'MUL2S', 'G1_MUL_FIXED', 'G2_MUL_GLS', 'MILLER_BYTES_LS2', 'MILLER_RAW_LS2', 'MILLER_FE_LS2', 'EXPX_LS2', 'G2_MUL_SAC', 'H2C_C1_LS2', 'H2C_C2_LS2', 'G2_MUL_SAC_LS2', 'H2C_NA', 'H2C_NM', 'H2C_NB']
 P = {n: i for i, n in enumerate(PROGS)}
 
 
@@ -108,16 +108,25 @@ def g2_decompress(lib, comp, mode='sig'):
     return out.raw, list(st.raw)
 
 
-def hash_to_g2(lib, uniform, ls2=False):
-    """uniform: n * 256 bytes of expand_message_xmd output; ls2: the two ladders of clearCofactor in their two-lane forms (launches of at most 4096 messages)"""
+def hash_to_g2(lib, uniform, ls2=False, norm=False):
+    """uniform: n * 256 bytes of expand_message_xmd output; ls2: the two ladders of clearCofactor in their two-lane forms (launches of at most 4096 messages);
+    norm: the SWU square root by the norm method (two Fp exponentiations; launches of NBLS_H2C_NORM_MIN messages and more)"""
     n = len(uniform) // 256
     T, E, Pw, Q, N, NI, out, st = buf(4 * RAW * n), buf(4 * RAW * n), buf(4 * RAW * n), buf(6 * RAW * n), buf(RAW * n), buf(RAW * n), buf(192 * n), buf(n)
-    St, Pt2 = buf(24 * RAW * n), buf(12 * RAW * n)
-    run(lib, 'H2C_A', n, {0: (buf(uniform), 256), 3: (T, 4 * RAW), 4: (E, 4 * RAW), 5: (St, 24 * RAW)})
-    lib.nbls_sim_fp_pow(C.c_uint(2 * n), E, Pw, 2)
+    St, Pt2 = buf(32 * RAW * n), buf(12 * RAW * n)
     E2 = buf(6 * RAW * n)
     # one SWU map per item (2 n items), then the two points of a message -> their sum on E2 (the launch sequence of dev_hash_to_g2 in csrc/pipelines_codec.cpp)
-    run(lib, 'H2C_B1', 2 * n, {3: (T, 2 * RAW), 5: (Pw, 2 * RAW), 4: (St, 12 * RAW), 6: (Pt2, 6 * RAW)})
+    if norm:
+        run(lib, 'H2C_NA', n, {0: (buf(uniform), 256), 3: (T, 4 * RAW), 4: (E, 2 * RAW), 5: (St, 32 * RAW)})
+        lib.nbls_sim_fp_pow(C.c_uint(2 * n), E, Pw, 0)
+        St9 = (C.c_char * (32 * RAW * n - 9 * RAW)).from_buffer(St, 9 * RAW)
+        run(lib, 'H2C_NM', 2 * n, {3: (T, 2 * RAW), 4: (St, 16 * RAW), 5: (Pw, RAW), 6: (St9, 16 * RAW), 7: (E, RAW)})
+        lib.nbls_sim_fp_pow(C.c_uint(2 * n), E, Pw, 3)
+        run(lib, 'H2C_NB', 2 * n, {3: (T, 2 * RAW), 4: (St, 16 * RAW), 5: (Pw, RAW), 6: (Pt2, 6 * RAW)})
+    else:
+        run(lib, 'H2C_A', n, {0: (buf(uniform), 256), 3: (T, 4 * RAW), 4: (E, 4 * RAW), 5: (St, 24 * RAW)})
+        lib.nbls_sim_fp_pow(C.c_uint(2 * n), E, Pw, 2)
+        run(lib, 'H2C_B1', 2 * n, {3: (T, 2 * RAW), 5: (Pw, 2 * RAW), 4: (St, 12 * RAW), 6: (Pt2, 6 * RAW)})
     run(lib, 'H2C_B2', n, {3: (Pt2, 12 * RAW), 6: (E2, 6 * RAW)})
     # clearCofactor in three programs: the points that do not depend on [x]P, then one program around each multiplication by x (the launch sequence of dev_clear_g2
     # in csrc/pipelines_codec.cpp, in place like there: C1 overwrites P with t1, C2 writes the result over t1)

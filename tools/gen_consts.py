@@ -231,6 +231,10 @@ def _fp_sqrt(a):
 
 G1_SWU_C2 = _fp_sqrt(pow(P - G1_SWU_Z, 3, P))      # sqrt((-Z)^3), math.ts:1281 (the root Fp.sqrt returns: a^((p+1)/4))
 assert G1_SWU_C2 is not None
+# hash-to-G2 by the norm method (codec.h swu_norm_*): when u / v is not a square the root of Z^3 t^6 u / v is taken, and the root of ITS norm is sqrt(-N(Z)^3) N(t)^3 n with
+# n^2 = -N(u conj(v)) -- N(Z) = 5 is a non-residue (Z is a non-square of Fp2), so -125 is a square of Fp
+SWU_SQRT_M125 = _fp_sqrt(P - 125)
+assert SWU_SQRT_M125 is not None and (SWU_Z[0] ** 2 + SWU_Z[1] ** 2) % P == 5
 
 
 def _g1_iso_check():
@@ -373,6 +377,7 @@ def emit(path, bits, fp_t, guard, qual, rbits=RBITS):
     fp2('NBLS_SWU_Z', SWU_Z)
     fp2('NBLS_SWU_A', SWU_A)
     fp2('NBLS_SWU_B', SWU_B)
+    fp('NBLS_SWU_SQRT_M125', SWU_SQRT_M125)
     fp2arr('NBLS_ISO_XNUM', ISO_XNUM)
     fp2arr('NBLS_ISO_XDEN', ISO_XDEN)
     fp2arr('NBLS_ISO_YNUM', ISO_YNUM)
