@@ -278,7 +278,7 @@ int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks);
 #define NBLS_TUNE_CHAIN_MAX 4          /* items below which EXPX, FE_MID1, EXPX x 3, FE_MID2, EXPX of a final exponentiation are ONE launch (default 8192; 0 = seven launches:
                                           what a caller that keeps several calls in flight on other contexts wants, csrc/runtime.cpp run_chain) */
 #define NBLS_TUNE_VERIFY_CHUNKS 5      /* verifyBatch as concurrent sub-batches (csrc/pipelines_verify.cpp verify_pipeline): number of sub-batches the signatures are cut into (default 2; 0 or 1 = one) */
-#define NBLS_TUNE_VERIFY_LAST_PCT 6    /* ... size of the last sub-batch in per cent of the batch (default 12; the sizes fall linearly from the first to the last) */
+#define NBLS_TUNE_VERIFY_LAST_PCT 6    /* ... size of the last sub-batch in per cent of the batch (default 25; the sizes fall linearly from the first to the last) */
 #define NBLS_TUNE_VERIFY_PIPE_MIN 7    /* ... signatures from which a call is cut at all (default 32768) */
 #define NBLS_TUNE_SAC_MAX 8            /* keys up to which sign's ladder (points known to lie in G2) uses the sign-aligned recoding with one addition per bit (default 6144: every
                                         * wavefront of the launch resident at once; 0 = never: the windowed psi-split ladder at every size) */

@@ -91,7 +91,7 @@ struct nbls_ctx {
   // verifyBatch as a software pipeline (round 5, verify_pipeline): events of the chunks (two each), the "xmd met non-monotonic offsets" flag lives behind the statuses
   std::vector<hipEvent_t> pipe_ev; hipEvent_t ev_pipe_done = nullptr; std::vector<hipStream_t> pipe_streams;
   // nbls_set_tuning(NBLS_TUNE_VERIFY_*)
-  long verify_chunks = env_long("NBLS_VERIFY_CHUNKS", 2), verify_last_pct = env_long("NBLS_VERIFY_LAST_PCT", 12), verify_pipe_min = env_long("NBLS_VERIFY_PIPE_MIN", 32768);
+  long verify_chunks = env_long("NBLS_VERIFY_CHUNKS", 2), verify_last_pct = env_long("NBLS_VERIFY_LAST_PCT", 25), verify_pipe_min = env_long("NBLS_VERIFY_PIPE_MIN", 32768);
   hipStream_t side2 = nullptr; hipEvent_t ev_join2 = nullptr;   // verifyBatch: key decoding runs beside message hashing (their exponentiation kernels are latency-bound and leave issue slots free)
   uint8_t* ident_g1 = nullptr; uint8_t* ident_g2 = nullptr;   // projective identity (0 : 1 : 0), raw
   size_t cap_F = 0, cap_io = 0;
