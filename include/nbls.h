@@ -219,7 +219,7 @@ int nbls_miller_product_partial_into(nbls_ctx* ctx, size_t n, const uint8_t* g1_
 int nbls_verify_batch_partial_into(nbls_ctx* ctx, size_t n, const uint8_t* sig96 /* or NULL */, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
                                    const uint8_t* dst, size_t dst_len, void* d_dst576, int* zero_flag, int8_t* pk_status /* n, may be NULL */);
 const char* nbls_config_describe(void);   /* "NBLS_X=value(env|default) ...": every environment switch the library has read so far and the value in force -- print it next to an A/B result */
-/* 4 (round 6): nbls_hw_queues (addition only); the library sets GPU_MAX_HW_QUEUES = 22 at load when the variable is unset (see nbls_pool_init below).
+/* 4 (round 6): nbls_hw_queues, NBLS_TUNE_WIDE_MAX, NBLS_TUNE_H2C_NORM_MIN (additions only); the library sets GPU_MAX_HW_QUEUES = 22 at load when the variable is unset (see nbls_pool_init below).
    3 (round 5): nbls_program_kernel, nbls_pool_*, nbls_sign_batch_dev, NBLS_TUNE_VERIFY_* / _SAC_MAX / _PT_LS2_MAX (additions only); nbls_verify_batch_partial_dev writes d_out_fp12 even when it reports a zero point or a decode error
    (contents then meaningless); 2: *_partial take *d_partial as OUT only, *_partial_into added, nbls_tower_op_batch, nbls_verify_batch_msgs_dev.  The bindings check it at load. */
 #define NBLS_ABI_VERSION 4
