@@ -462,10 +462,18 @@ int dev_msm(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, const void* d_s
     std::swap(src, dst);
   }
   uint8_t* S = A;   // per-window sums
-  if ((r = run(ctx, g2 ? P_G2_HORNER : P_G1_HORNER, nwin, {B(3, src, C * p), B(5, S, p)}, s))) return r;
-  HIPCHK(hipMemcpyAsync(acc, S + (size_t)(nwin - 1) * p, p, hipMemcpyDeviceToDevice, s));
-  for (int w = (int)nwin - 2; w >= 0; w--)
-    if ((r = run(ctx, g2 ? P_G2_SHIFTADD : P_G1_SHIFTADD, 1, {B(3, acc, p), B(4, S + (size_t)w * p, p), B(5, acc, p)}, s))) return r;
+  static const bool wide_combine = env_long("NBLS_MSM_WIDE", 1) != 0;
+  // Horner over the bit-slices t of every window (sum_t 2^t T_t, one sum per window), then over the windows (below).  G1 (round 6): both with one limb per lane, a wavefront per
+  // sum, the four products of a doubling level on its four rows (g1_wide.h: 0.74 -> 0.25 ms of a 65,536-point call); G2 and NBLS_MSM_WIDE=0: the step programs
+  if (!g2 && wide_combine) MSMCHK(nbls_g1_wide_combine_launch(src, (int)C, 1, S, nwin, s));
+  else if ((r = run(ctx, g2 ? P_G2_HORNER : P_G1_HORNER, nwin, {B(3, src, C * p), B(5, S, p)}, s))) return r;
+  // acc <- 2^12 acc + S_w from the top window down: (nwin - 1) x (12 doublings + 1 addition) on ONE point
+  if (!g2 && wide_combine) MSMCHK(nbls_g1_wide_combine_launch(S, (int)nwin, (int)C, acc, 1, s));
+  else {
+    HIPCHK(hipMemcpyAsync(acc, S + (size_t)(nwin - 1) * p, p, hipMemcpyDeviceToDevice, s));
+    for (int w = (int)nwin - 2; w >= 0; w--)
+      if ((r = run(ctx, g2 ? P_G2_SHIFTADD : P_G1_SHIFTADD, 1, {B(3, acc, p), B(4, S + (size_t)w * p, p), B(5, acc, p)}, s))) return r;
+  }
   if ((r = run(ctx, g2 ? P_G2_NORM : P_G1_NORM, 1, {B(3, acc, p), B(4, N, RAW)}, s))) return r;
   if ((r = run_inv_buf(ctx, 1, N, NI, s))) return r;
   return run(ctx, g2 ? P_G2_TO_AFFINE : P_G1_TO_AFFINE, 1, {B(3, acc, p), B(4, NI, RAW), B(2, d_out, a), B(7, d_status, 1)}, s);

@@ -12,6 +12,7 @@
 #include "pow_exec.h"
 #include "pow_wide.h"
 #include "wide_exec.h"
+#include "g1_wide.h"
 #include "scalar_split.h"
 #include "aot_exec.h"
 #include "aot_layout.h"
@@ -191,6 +192,7 @@ struct WideRowHost {
   I sar(const I& a, int s) const { return map([&](int k) { return a.v[k] >> s; }); }
   I mul_lo(const I& a, u32 c) const { return map([&](int k) { return (i32)((u32)a.v[k] * c); }); }
   I mul_small(const I& a, u32 c) const { return map([&](int k) { return chk32((i64)a.v[k] * (i64)c); }); }
+  I muls(const I& a, int c) const { return map([&](int k) { return chk32((i64)a.v[k] * (i64)c); }); }
   I lo(const W& w) const { return map([&](int k) { return (i32)w.v[k]; }); }
   W wzero() const { W w; for (int k = 0; k < 16; k++) w.v[k] = 0; return w; }
   static i64 chk64(__int128 t) { if (t > (__int128)0x7fffffffffffffffll || t < -(__int128)0x7fffffffffffffffll - 1) { g_wide_violations++; if (getenv("NBLS_SIM_WIDE_DEBUG")) fprintf(stderr, "wide: 64-bit overflow\n"); } return (i64)t; }
@@ -234,10 +236,42 @@ static int sim_run_wide(const Program& p, unsigned n_items, const IOBuf* bufs) {
   }
   return 0;
 }
+// g1_wide.h on the host: the rows of a round one after the other, their results written once all of them have read (the device: one wavefront, LDS in program order)
+static const u32 GW_TABLE_HOST[GW_TABLE_WORDS] = GW_TABLE_INIT;
+static void sim_g1_wide_combine(const u32* S, int nwin, int shift, u32* out) {
+  std::vector<u32> image((size_t)GW_SLOTS * 16, 0u);
+  char* lds = (char*)image.data();
+  auto fetch = [&](const u32* pt, int s0, int s1, int s2) { const int sl[3] = {s0, s1, s2}; for (int r = 0; r < 3; r++) { memset(lds + sl[r] * 64, 0, 64); memcpy(lds + sl[r] * 64, pt + r * RAW_WORDS, NL * 4); } };
+  auto run_round = [&](int q, int p0) {
+    WideRowHost::I res[4];
+    for (int row = 0; row < 4; row++) {
+      WideRowHost l; l.lds = lds; l.base = 0;
+      WideOps<WideRowHost> o(l); WideG1<WideRowHost> g(o);
+      const u32* d = GW_TABLE_HOST + (4 * q + row) * GW_ROW_WORDS;
+      res[row] = p0 == 1 ? g.round<1>(d) : g.round<2>(d);
+    }
+    for (int row = 0; row < 4; row++) memcpy(lds + GW_TABLE_HOST[(4 * q + row) * GW_ROW_WORDS + 4] * 64, res[row].v, 64);
+  };
+  fetch(S + (size_t)(nwin - 1) * 3 * RAW_WORDS, GW_X, GW_U, GW_Z);
+  for (int w = nwin - 2; w >= 0; w--) {
+    fetch(S + (size_t)w * 3 * RAW_WORDS, GW_X2, GW_Y2, GW_Z2);
+    for (int i = 0; i < shift; i++) { run_round(0, 1); run_round(1, 1); }
+    for (int q = 0; q < GW_ADD_ROUNDS; q++) run_round(GW_DBL_ROUNDS + q, 2);
+  }
+  for (int row = 0; row < 3; row++) {
+    WideRowHost l; l.lds = lds; l.base = 0;
+    WideOps<WideRowHost> o(l); WideG1<WideRowHost> g(o);
+    const WideRowHost::I v = row == 0 ? l.ld(GW_X * 64u) : row == 1 ? l.sub(l.ld(GW_U * 64u), l.ld(GW_V * 64u)) : l.ld(GW_Z * 64u);
+    const WideRowHost::I e = g.leave(v, row == 1 ? 2u : 1u);
+    for (int k = 0; k < 16; k++) { if (e.v[k] < 0 || (k < NL - 1 && e.v[k] > (i32)LMASK)) g_wide_violations++; out[row * RAW_WORDS + k] = (u32)e.v[k]; }
+  }
+}
 static int g_sim_wide = 0;
 extern "C" {
 // the one-limb-per-lane form for the programs it implements (others run as usual): 0 off, 1 on; nbls_sim_wide_violations: device assumptions violated since the last call (0 on a correct build)
 __attribute__((visibility("default"))) void nbls_sim_set_wide(int on) { g_sim_wide = on; }
+// the window combination of the G1 MSM with one limb per lane (g1_wide.h): S = nwin projective points of 3 raw elements, out = sum_w 2^(shift w) S_w (3 raw elements)
+__attribute__((visibility("default"))) void nbls_sim_g1_wide_combine(const u32* S, int nwin, int shift, u32* out) { sim_g1_wide_combine(S, nwin, shift, out); }
 __attribute__((visibility("default"))) unsigned long nbls_sim_wide_violations() { const unsigned long v = g_wide_violations; g_wide_violations = 0; return v; }
 __attribute__((visibility("default"))) int nbls_sim_wide_supported(int prog) { if (prog < 0 || prog >= (int)P_COUNT) return 0; const Program& p = get_program((ProgId)prog); if (p.lsplit != 1 || p.W > 16) return 0; for (auto& st : p.steps) if (!wide_step_supported(st, p.descs.data())) return 0; return 1; }
 // translated programs (aot.h) instead of the interpreter's semantics for the programs that have an ahead-of-time kernel: 0 off, 1 on

@@ -3,6 +3,7 @@
 // For launches of a few hundred items at most (nbls_internal.h wide_max): the final exponentiation of a single verify / sign, the one-element tail of every verifyBatch.
 #include <hip/hip_runtime.h>
 #include "wide_exec.h"
+#include "g1_wide.h"
 
 namespace nbls {
 
@@ -24,6 +25,7 @@ struct WideLane {
   __device__ __forceinline__ I sar(I a, int k) const { return a >> k; }
   __device__ __forceinline__ I mul_lo(I a, u32 k) const { return (i32)((u32)a * k); }
   __device__ __forceinline__ I mul_small(I a, u32 k) const { return a * (i32)k; }
+  __device__ __forceinline__ I muls(I a, int k) const { return a * k; }
   __device__ __forceinline__ I lo(W w) const { return (i32)w; }
   __device__ __forceinline__ W wzero() const { return 0; }
   __device__ __forceinline__ W mad(I a, I b, W acc) const { return acc + (i64)a * (i64)b; }
@@ -132,6 +134,52 @@ extern "C" __global__ void __launch_bounds__(256) nbls_vm_kernel_wide(KernelArgs
     st = nst; nst = nnst; d = nd; settle(d);
   }
 }
+
+// ---- the window combination of the G1 MSM (g1_wide.h): ONE wavefront, the four products of a doubling level on its four rows, the state in LDS slots
+__constant__ u32 GW_TABLE_DEV[GW_TABLE_WORDS] = GW_TABLE_INIT;
+// S: nwin projective points (3 raw elements each: the per-window sums, window 0 first); out: sum_w 2^(12 w) S_w as a projective point (3 raw elements, exact limbs, below 8 p)
+// One workgroup (= one wavefront) per sum: workgroup b reads its nwin points at S + b * nwin * 3 raw elements and writes out + b * 3 raw elements (dev_msm: first the Horner sum
+// over the twelve bit-slices of every window, shift 1, a workgroup per window; then the combination of the windows, shift 12, one workgroup)
+extern "C" __global__ void __launch_bounds__(64) nbls_g1_wide_combine_kernel(const u32* __restrict__ S, int nwin, int shift, u32* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) char lds[GW_SLOTS * 64];
+  S += (size_t)blockIdx.x * (size_t)nwin * 3 * RAW_WORDS; out += (size_t)blockIdx.x * 3 * RAW_WORDS;
+  const u32 tid = threadIdx.x, row = tid >> 4, j = tid & 15u;
+  for (u32 i = tid; i < (u32)GW_SLOTS * 16u; i += 64u) ((u32*)lds)[i] = 0;
+  const u32 P[NL] = NBLS_P28;
+  u32 pj = 0;
+#pragma unroll
+  for (int k = 0; k < NL; k++) pj = j == (u32)k ? P[k] : pj;
+  WideLane l{lds, 4 * j, j, 0u, row == 0 ? (i32)pj : 0, row == 1 ? (i32)pj : 0, row == 2 ? (i32)pj : 0, row == 3 ? (i32)pj : 0, (i32)pj, j < 13u ? LMASK : 0xffffffffu, j < 13u ? 0xffffffffu : 0u};
+  WideOps<WideLane> o(l);
+  WideG1<WideLane> g(o);
+  u32 d[GW_DBL_ROUNDS + GW_ADD_ROUNDS][GW_ROW_WORDS];      // this row's part of every round: loop invariant, in registers
+#pragma unroll
+  for (int q = 0; q < GW_DBL_ROUNDS + GW_ADD_ROUNDS; q++) {
+#pragma unroll
+    for (int k = 0; k < GW_ROW_WORDS; k++) d[q][k] = GW_TABLE_DEV[(4 * q + row) * GW_ROW_WORDS + k];
+  }
+  auto put = [&](u32 slot, i32 v) __attribute__((always_inline)) { *(i32*)(lds + slot * 64u + 4u * j) = v; };
+  // a point from HBM: row r < 3 reads coordinate r into slot s0 / s1 / s2
+  auto fetch = [&](const u32* pt, u32 s0, u32 s1, u32 s2) __attribute__((always_inline)) {
+    const i32 v = (row < 3u && j < (u32)NL) ? (i32)pt[row * RAW_WORDS + j] : 0;
+    put(row == 0 ? s0 : row == 1 ? s1 : row == 2 ? s2 : (u32)GW_JUNK, v);
+  };
+  fetch(S + (size_t)(nwin - 1) * 3 * RAW_WORDS, GW_X, GW_U, GW_Z);
+  for (int w = nwin - 2; w >= 0; w--) {
+    fetch(S + (size_t)w * 3 * RAW_WORDS, GW_X2, GW_Y2, GW_Z2);
+#pragma unroll 1
+    for (int i = 0; i < shift; i++) {
+      i32 r = g.round<1>(d[0]); put(d[0][4], r);
+      r = g.round<1>(d[1]); put(d[1][4], r);
+    }
+#pragma unroll
+    for (int q = 0; q < GW_ADD_ROUNDS; q++) { const i32 r = g.round<2>(d[GW_DBL_ROUNDS + q]); put(d[GW_DBL_ROUNDS + q][4], r); }
+  }
+  // leave: x + p, (U - V) + 2 p, z + p with exact limbs
+  const i32 v = row == 0 ? l.ld(GW_X * 64u) : row == 1 ? l.sub(l.ld(GW_U * 64u), l.ld(GW_V * 64u)) : l.ld(GW_Z * 64u);
+  const i32 e = g.leave(v, row == 1 ? 2u : 1u);
+  if (row < 3u) out[row * RAW_WORDS + j] = (u32)e;
+}
 }  // namespace nbls
 
 extern "C" int nbls_vm_wide_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream) {
@@ -140,5 +188,11 @@ extern "C" int nbls_vm_wide_launch(const nbls::KernelArgs* ka, unsigned lds_byte
   if (ka->lsplit != 1 || ka->W > 16 || lds_bytes > 64 * 1024) return -1;
   const unsigned waves = (ka->W + 3) / 4;
   hipLaunchKernelGGL(nbls_vm_kernel_wide, dim3(ka->n_items), dim3(64 * waves), lds_bytes, (hipStream_t)stream, *ka);
+  return (int)hipGetLastError();
+}
+extern "C" int nbls_g1_wide_combine_launch(const void* S, int nwin, int shift, void* out, unsigned sums, void* stream) {
+  if (nwin < 1) return -1;
+  if (sums == 0) return 0;
+  hipLaunchKernelGGL(nbls::nbls_g1_wide_combine_kernel, dim3(sums), dim3(64), 0, (hipStream_t)stream, (const nbls::u32*)S, nwin, shift, (nbls::u32*)out);
   return (int)hipGetLastError();
 }

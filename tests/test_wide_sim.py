@@ -56,3 +56,78 @@ def test_wide_expx_agrees_with_the_interpreter_on_extreme_elements(sim):
         a = sum(x << (28 * i) for i, x in enumerate(wa[:14])); b = sum(x << (28 * i) for i, x in enumerate(wb[:14]))
         assert (a - b) % p == 0 and 0 <= a < 8 * p, k
     assert sim.nbls_sim_wide_violations() == 0
+
+
+def test_g1_window_combination_with_one_limb_per_lane(sim):
+    """csrc/g1_wide.h (device: nbls_g1_wide_combine_kernel, one wavefront): sum_w 2^(12 w) S_w over eleven projective window sums -- the tail of the G1 multi-scalar
+    multiplication -- against plain affine arithmetic on y^2 = x^3 + 4 in Python, for ordinary points, a window sum that is the identity, equal and opposite neighbours (the
+    formulas are the complete ones), raw inputs at the top of the range scratch elements may have; outputs exact and below 8 p; no 32 / 64-bit assumption violated."""
+    import random
+    p = vmsim_py.P_MOD; R = 1 << 392; RAW = vmsim_py.RAW
+    rnd = random.Random(1212)
+
+    def add(P1, P2):
+        if P1 is None: return P2
+        if P2 is None: return P1
+        (x1, y1), (x2, y2) = P1, P2
+        if x1 == x2:
+            if (y1 + y2) % p == 0: return None
+            lam = 3 * x1 * x1 * pow(2 * y1, -1, p) % p
+        else:
+            lam = (y2 - y1) * pow(x2 - x1, -1, p) % p
+        x3 = (lam * lam - x1 - x2) % p
+        return (x3, (lam * (x1 - x3) - y1) % p)
+
+    def mul(k, P1):
+        acc = None
+        while k:
+            if k & 1: acc = add(acc, P1)
+            P1 = add(P1, P1); k >>= 1
+        return acc
+
+    def point():
+        while True:
+            x = rnd.randrange(p); y2 = (x * x * x + 4) % p; y = pow(y2, (p + 1) // 4, p)
+            if y * y % p == y2: return (x, y)
+
+    def raw_proj(P1, big=False):
+        # a projective representative with a random Z; `big`: coordinates as non-canonical representatives up to 7.9 p (what a program may leave in scratch)
+        if P1 is None: c = [0, rnd.randrange(1, p), 0]
+        else:
+            z = rnd.randrange(1, p); c = [P1[0] * z % p, P1[1] * z % p, z]
+        vals = [(v * R) % p + (rnd.randrange(7) * p if big else 0) for v in c]
+        assert all(v < (1 << 392) for v in vals)
+        return b''.join(b''.join(((v >> (28 * i)) & 0xfffffff).to_bytes(4, 'little') for i in range(13)) + (v >> 364).to_bytes(4, 'little') + bytes(8) for v in vals)
+
+    def unraw(buf):
+        out = []
+        for k in range(3):
+            o = buf[64 * k:64 * k + 64]
+            limbs = [int.from_bytes(o[4 * i:4 * i + 4], 'little') for i in range(16)]
+            assert all(l < (1 << 28) for l in limbs[:13]) and limbs[14] == 0 and limbs[15] == 0
+            v = sum(l << (28 * i) for i, l in enumerate(limbs[:14]))
+            assert v < 8 * p
+            out.append(v * pow(R, -1, p) % p)
+        return out
+
+    nwin, shift = 11, 12
+    for trial in range(6):
+        W = [point() for _ in range(nwin)]
+        if trial == 1: W[3] = None; W[10] = None                 # identity window sums, also the top one
+        if trial == 2: W[5] = W[6]; W[7] = (W[8][0], (-W[8][1]) % p)
+        if trial == 3: W = [None] * nwin
+        if trial == 4:                                           # the running sum meets its own negative: 2^12 acc + S = 0 at window 4
+            acc = None
+            for w in range(nwin - 1, 4, -1): acc = add(mul(1 << shift, acc), W[w]) if acc is not None else W[w]
+            t = mul(1 << shift, acc); W[4] = (t[0], (-t[1]) % p)
+        S = vmsim_py.buf(b''.join(raw_proj(Q, big=(trial == 5)) for Q in W))
+        out = vmsim_py.buf(3 * RAW)
+        sim.nbls_sim_g1_wide_combine(S, nwin, shift, out)
+        X, Y, Z = unraw(out.raw)
+        exp = None
+        for w in range(nwin - 1, -1, -1): exp = add(mul(1 << shift, exp), W[w])
+        if exp is None:
+            assert X == 0 and Z == 0 and Y != 0, trial
+        else:
+            assert Z != 0 and X * pow(Z, -1, p) % p == exp[0] and Y * pow(Z, -1, p) % p == exp[1], trial
+    assert sim.nbls_sim_wide_violations() == 0
