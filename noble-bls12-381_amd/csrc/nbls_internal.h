@@ -19,6 +19,7 @@
 
 extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream);
 extern "C" int nbls_vm_wide_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream);
+extern "C" int nbls_fp_inv_wide_launch(unsigned n, const void* in, void* out, void* stream);   // fp_inv_wide.h: four elements per wavefront, one limb per lane
 extern "C" int nbls_g1_wide_combine_launch(const void* S, int nwin, int shift, void* out, unsigned sums, void* stream);   // g1_wide.h: `sums` times sum_w 2^(shift w) S_w over nwin points, one wavefront each
 #include "wide_exec.h"   // wide_step_supported
 #include "aot.h"

@@ -13,6 +13,7 @@
 #include "pow_wide.h"
 #include "wide_exec.h"
 #include "g1_wide.h"
+#include "fp_inv_wide.h"
 #include "scalar_split.h"
 #include "aot_exec.h"
 #include "aot_layout.h"
@@ -193,6 +194,15 @@ struct WideRowHost {
   I mul_lo(const I& a, u32 c) const { return map([&](int k) { return (i32)((u32)a.v[k] * c); }); }
   I mul_small(const I& a, u32 c) const { return map([&](int k) { return chk32((i64)a.v[k] * (i64)c); }); }
   I muls(const I& a, int c) const { return map([&](int k) { return chk32((i64)a.v[k] * (i64)c); }); }
+  // fp_inv_wide.h
+  I or_(const I& a, const I& b) const { return map([&](int k) { return a.v[k] | b.v[k]; }); }
+  I spread(i32 s) const { return map([&](int) { return s; }); }
+  i32 first(const I& a) const { for (int k = 1; k < 16; k++) if (a.v[k] != a.v[0]) g_wide_violations++; return a.v[0]; }      // (must be row-uniform)
+  I plimbs() const { const u32 P[NL] = NBLS_P28; return map([&](int k) { return k < NL ? (i32)P[k] : 0; }); }
+  u32 nonzero_mask(const I& a) const { u32 m = 0; for (int k = 0; k < 16; k++) if (a.v[k] != 0) m |= 1u << k; return m; }
+  I gather(const I& a, u32 j) const { return map([&](int) { return a.v[j & 15u]; }); }
+  I pick(u32 lanebit, const I& a, const I& b) const { return map([&](int k) { return ((lanebit >> k) & 1u) ? a.v[k] : b.v[k]; }); }
+  I lane_eq(u32 j, const I& a, const I& b) const { return map([&](int k) { return (u32)k == j ? a.v[k] : b.v[k]; }); }
   I lo(const W& w) const { return map([&](int k) { return (i32)w.v[k]; }); }
   W wzero() const { W w; for (int k = 0; k < 16; k++) w.v[k] = 0; return w; }
   static i64 chk64(__int128 t) { if (t > (__int128)0x7fffffffffffffffll || t < -(__int128)0x7fffffffffffffffll - 1) { g_wide_violations++; if (getenv("NBLS_SIM_WIDE_DEBUG")) fprintf(stderr, "wide: 64-bit overflow\n"); } return (i64)t; }
@@ -288,6 +298,18 @@ __attribute__((visibility("default"))) int nbls_sim_run(int prog, unsigned n_ite
   return 0;
 }
 // out = in^-1 on raw elements (16 words each): the same fp_mont_inverse routine the inversion kernel runs per lane
+// the same inverse with one limb per lane (fp_inv_wide.h), one element after the other
+__attribute__((visibility("default"))) void nbls_sim_fp_inv_wide(unsigned n, const u32* in, u32* out) {
+  const u32 R3[NL] = NBLS_R3_INIT;
+  for (unsigned e = 0; e < n; e++) {
+    WideRowHost l; l.lds = nullptr; l.base = 0;
+    WideOps<WideRowHost> o(l); WideInv<WideRowHost> w(o);
+    WideRowHost::I y, r3;
+    for (int k = 0; k < 16; k++) { y.v[k] = k < NL ? (i32)in[SLOT_WORDS * e + k] : 0; r3.v[k] = k < NL ? (i32)R3[k] : 0; }
+    const WideRowHost::I r = w.invert(y, r3);
+    for (int k = 0; k < 16; k++) { if (k < NL && (r.v[k] < 0 || (k < NL - 1 && r.v[k] > (i32)LMASK))) g_wide_violations++; out[SLOT_WORDS * e + k] = k < NL ? (u32)r.v[k] : 0u; }
+  }
+}
 __attribute__((visibility("default"))) void nbls_sim_fp_inv(unsigned n, const u32* in, u32* out) {
   for (unsigned k = 0; k < n; k++) { u32 r[NL]; fp_mont_inverse(r, in + SLOT_WORDS * k); memcpy(out + SLOT_WORDS * k, r, NL * 4); out[SLOT_WORDS * k + 14] = out[SLOT_WORDS * k + 15] = 0; }
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include "wide_exec.h"
 #include "g1_wide.h"
+#include "fp_inv_wide.h"
 
 namespace nbls {
 
@@ -14,6 +15,7 @@ struct WideLane {
   i32 pr0, pr1, pr2, pr3, pj;      // p_j on row k of the wavefront (0 on the other rows) ; p_j
   __device__ __forceinline__ bool skip_rows() const { return false; }
   u32 lmask13, cmask13;            // lane < 13: 2^28 - 1 / all ones ; lane 13 and above: all ones / zero (the top limb keeps the rest)
+  u32 rowshift = 0;                // 16 * (row inside the wavefront): the first lane of this lane's row (fp_inv_wide.h)
   __device__ __forceinline__ I low13(I a) const { return (i32)((u32)a & lmask13); }
   __device__ __forceinline__ I carry13(I a) const { return (i32)((u32)a & cmask13); }
   __device__ __forceinline__ I zero() const { return 0; }
@@ -26,6 +28,15 @@ struct WideLane {
   __device__ __forceinline__ I mul_lo(I a, u32 k) const { return (i32)((u32)a * k); }
   __device__ __forceinline__ I mul_small(I a, u32 k) const { return a * (i32)k; }
   __device__ __forceinline__ I muls(I a, int k) const { return a * k; }
+  // fp_inv_wide.h: row-uniform scalars and lane picks
+  __device__ __forceinline__ I or_(I a, I b) const { return a | b; }
+  __device__ __forceinline__ I spread(i32 s) const { return s; }
+  __device__ __forceinline__ i32 first(I v) const { return v; }
+  __device__ __forceinline__ I plimbs() const { return pj; }
+  __device__ __forceinline__ u32 nonzero_mask(I v) const { const u64 m = __builtin_amdgcn_ballot_w64(v != 0); return (u32)(m >> (rowshift)) & 0xffffu; }
+  __device__ __forceinline__ I gather(I v, u32 k) const { return __builtin_amdgcn_ds_bpermute((int)((rowshift + k) << 2), v); }
+  __device__ __forceinline__ I pick(u32 lanebit, I a, I b) const { return ((lanebit >> j) & 1u) ? a : b; }
+  __device__ __forceinline__ I lane_eq(u32 k, I a, I b) const { return j == k ? a : b; }
   __device__ __forceinline__ I lo(W w) const { return (i32)w; }
   __device__ __forceinline__ W wzero() const { return 0; }
   __device__ __forceinline__ W mad(I a, I b, W acc) const { return acc + (i64)a * (i64)b; }
@@ -180,6 +191,24 @@ extern "C" __global__ void __launch_bounds__(64) nbls_g1_wide_combine_kernel(con
   const i32 e = g.leave(v, row == 1 ? 2u : 1u);
   if (row < 3u) out[row * RAW_WORDS + j] = (u32)e;
 }
+
+// ---- the modular inverse with one limb per lane (fp_inv_wide.h): four elements per wavefront, one per row
+extern "C" __global__ void __launch_bounds__(64) nbls_fp_inv_wide_kernel(unsigned n, const u32* __restrict__ in, u32* __restrict__ out) {
+  const u32 tid = threadIdx.x, row = tid >> 4, j = tid & 15u;
+  const u32 P[NL] = NBLS_P28, R3[NL] = NBLS_R3_INIT;
+  u32 pj = 0, r3 = 0;
+#pragma unroll
+  for (int k = 0; k < NL; k++) { pj = j == (u32)k ? P[k] : pj; r3 = j == (u32)k ? R3[k] : r3; }
+  WideLane l{nullptr, 4 * j, j, 0u, row == 0 ? (i32)pj : 0, row == 1 ? (i32)pj : 0, row == 2 ? (i32)pj : 0, row == 3 ? (i32)pj : 0, (i32)pj, j < 13u ? LMASK : 0xffffffffu, j < 13u ? 0xffffffffu : 0u};
+  l.rowshift = 16u * row;
+  WideOps<WideLane> o(l);
+  WideInv<WideLane> w(o);
+  const u32 e = blockIdx.x * 4u + row;
+  const bool live = e < n;
+  const i32 y = (live && j < (u32)NL) ? (i32)in[(size_t)e * SLOT_WORDS + j] : 0;
+  const i32 r = w.invert(y, (i32)r3);
+  if (live) out[(size_t)e * SLOT_WORDS + j] = j < (u32)NL ? (u32)r : 0u;
+}
 }  // namespace nbls
 
 extern "C" int nbls_vm_wide_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream) {
@@ -194,5 +223,10 @@ extern "C" int nbls_g1_wide_combine_launch(const void* S, int nwin, int shift, v
   if (nwin < 1) return -1;
   if (sums == 0) return 0;
   hipLaunchKernelGGL(nbls::nbls_g1_wide_combine_kernel, dim3(sums), dim3(64), 0, (hipStream_t)stream, (const nbls::u32*)S, nwin, shift, (nbls::u32*)out);
+  return (int)hipGetLastError();
+}
+extern "C" int nbls_fp_inv_wide_launch(unsigned n, const void* in, void* out, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(nbls::nbls_fp_inv_wide_kernel, dim3((n + 3) / 4), dim3(64), 0, (hipStream_t)stream, n, (const nbls::u32*)in, (nbls::u32*)out);
   return (int)hipGetLastError();
 }

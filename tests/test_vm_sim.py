@@ -144,6 +144,20 @@ def test_fp_inverse_edge_cases(sim):
         got = sum(int.from_bytes(o[4 * i:4 * i + 4], 'little') << (28 * i) for i in range(14))
         assert got < 2 * p
         assert got % p == ((pow(x % p, -1, p) * R * R) % p if x % p else 0), hex(x)
+    # round 6: the same algorithm with one limb per lane (fp_inv_wide.h; device: nbls_fp_inv_wide_kernel, launches of a few thousand elements at most): the same inverses,
+    # exact limbs, below 2.1 p, and no violated 32 / 64-bit assumption or non-uniform "row-uniform" value in the host model
+    sim.nbls_sim_wide_violations.restype = C.c_ulong
+    sim.nbls_sim_wide_violations()
+    dst2 = C.create_string_buffer(len(inp))
+    sim.nbls_sim_fp_inv_wide(C.c_uint(len(xs)), src, dst2)
+    for k, x in enumerate(xs):
+        o = dst2.raw[64 * k:64 * k + 64]
+        limbs = [int.from_bytes(o[4 * i:4 * i + 4], 'little') for i in range(16)]
+        assert all(l < (1 << 28) for l in limbs[:14]) and limbs[14] == 0 and limbs[15] == 0, hex(x)
+        got = sum(l << (28 * i) for i, l in enumerate(limbs[:14]))
+        assert got < 21 * p // 10
+        assert got % p == ((pow(x % p, -1, p) * R * R) % p if x % p else 0), hex(x)
+    assert sim.nbls_sim_wide_violations() == 0
 
 
 def _raw(xs):
