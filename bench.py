@@ -255,6 +255,7 @@ def main():
     # strictly serial figure (one batch at a time on one stream) = per-batch latency, this rank
     torch.cuda.synchronize()
     eng.set_chain_max(8192)             # ... and the chained final exponentiation (6 launches per call; the in-flight contexts run it as seven launches, pipeline.py)
+    eng.set_inv_wide_max(4096)          # ... and the library's default for the inversion (nbls_pool_init set 256 on the in-flight contexts)
     eng.set_split_miller_min(4097)      # the single-call legs use the library's default choice of Miller programs (SPLIT_MILLER_MIN in csrc/nbls_internal.h: the fused program up to 4096 pairs; the in-flight contexts were set to 0)
     serial_steps = max(8, min(args.steps, 320))
     s0 = time.perf_counter()

@@ -20,7 +20,8 @@
 extern "C" int nbls_vm_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream);
 extern "C" int nbls_vm_wide_launch(const nbls::KernelArgs* ka, unsigned lds_bytes, void* stream);
 extern "C" int nbls_fp_inv_wide_launch(unsigned n, const void* in, void* out, void* stream);   // fp_inv_wide.h: four elements per wavefront, one limb per lane
-extern "C" int nbls_g1_wide_combine_launch(const void* S, int nwin, int shift, void* out, unsigned sums, void* stream);   // g1_wide.h: `sums` times sum_w 2^(shift w) S_w over nwin points, one wavefront each
+// g1_wide.h: `sums` times sum_w 2^(shift w) S_w over nwin points, one wavefront each
+extern "C" int nbls_g1_wide_combine_launch(const void* S, int nwin, int shift, void* out, unsigned sums, void* stream);
 #include "wide_exec.h"   // wide_step_supported
 #include "aot.h"
 #include <map>
@@ -120,6 +121,10 @@ struct nbls_ctx {
   // there was one: a launch that does not fill the device pays their latency twice (sign of 8192 keys +0.09 ms), one that does, or that runs beside other work as the sub-batches
   // of verifyBatch do (the size counted there is the whole call's), gains (sign of 65,536 keys -0.7 ms, verifyBatch -0.3 ms alone and -0.5 ms with three calls in flight)
   size_t h2c_norm_min = (size_t)env_long("NBLS_H2C_NORM_MIN", 32768);
+  // round 6: elements up to which an inversion launch runs with one limb per lane (fp_inv_wide.h; nbls_set_tuning(NBLS_TUNE_INV_WIDE_MAX)).  The form shortens ONE call (a 4096-pairing
+  // call 2.19 -> 2.165 ms, one verify 2.76 -> 2.67 ms) at eight times the instructions per element: contexts that are kept busy side by side (nbls_pool_init) lower it to 256
+  // (twelve 4096-pairing calls in flight: 3.03 M pairings/s against 2.97 M with 4096)
+  size_t inv_wide_max = (size_t)env_long("NBLS_INV_WIDE_MAX", 4096);
   size_t chain_max = (size_t)env_long("NBLS_CHAIN_MAX", 8192);                  // nbls_set_tuning(NBLS_TUNE_CHAIN_MAX); see run_chain
   u32* qp_table = nullptr;      // multiples of p for the weak reduction (vm_exec.h weak_reduce), device copy
   uint8_t* unit_lines = nullptr;   // a line table whose 68 lines are all 1 (c0 = 1, c1 = c2 = 0): the neutral partner of an odd last pair

@@ -283,7 +283,11 @@ EXPORT int nbls_pool_init(int device_id, int depth, nbls_pool** out) {
     if (r) { nbls_pool_destroy(p); return r; }
     p->ctx.push_back(c);
     // NBLS_PIPELINE_CHAIN=1: A/B switch (tools/ab_pipeline.sh)
-    if (depth > 1) { nbls_set_tuning(c, NBLS_TUNE_SPLIT_MILLER_MIN, 0); if (nbls::env_long("NBLS_PIPELINE_CHAIN", 0) != 1) nbls_set_tuning(c, NBLS_TUNE_CHAIN_MAX, 0); }
+    if (depth > 1) {
+      nbls_set_tuning(c, NBLS_TUNE_SPLIT_MILLER_MIN, 0);
+      if (nbls::env_long("NBLS_PIPELINE_CHAIN", 0) != 1) nbls_set_tuning(c, NBLS_TUNE_CHAIN_MAX, 0);
+      nbls_set_tuning(c, NBLS_TUNE_INV_WIDE_MAX, 256);      // contexts kept busy side by side: instructions count, not one call's latency (nbls_internal.h inv_wide_max)
+    }
   }
   *out = p;
   return NBLS_OK;

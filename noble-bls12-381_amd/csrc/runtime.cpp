@@ -115,13 +115,13 @@ int run_dev(nbls_ctx* ctx, const DevProgram& d, int id, size_t n, std::initializ
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
   return NBLS_OK;
 }
-// Launches of at most inv_wide_max elements run the inversion with one limb per lane, four elements per wavefront (fp_inv_wide.h: the same binary GCD, ~25 k instead of ~48 k
-// wave-instructions on the critical path of every single call); above, one element per lane.  NBLS_INV_WIDE_MAX (0 = never).
-size_t inv_wide_max() { static const size_t v = (size_t)env_long("NBLS_INV_WIDE_MAX", 4096); return v; }
+// Launches of at most ctx->inv_wide_max elements run the inversion with one limb per lane, four elements per wavefront (fp_inv_wide.h: the same binary GCD, ~25 k instead of ~48 k
+// wave-instructions on the critical path of every single call); above, one element per lane.  NBLS_INV_WIDE_MAX / NBLS_TUNE_INV_WIDE_MAX (0 = never).
 int run_inv(nbls_ctx* ctx, size_t n, hipStream_t s) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->timing) { e0 = timing_event(ctx); e1 = timing_event(ctx); hipEventRecord(e0, s); }
-  int e = n <= inv_wide_max() ? nbls_fp_inv_wide_launch((unsigned)n, ctx->N + ctx->ioff * RAW, ctx->NI + ctx->ioff * RAW, s) : nbls_fp_inv_launch((unsigned)n, ctx->N + ctx->ioff * RAW, ctx->NI + ctx->ioff * RAW, s);
+  const uint8_t* in = ctx->N + ctx->ioff * RAW; uint8_t* out = ctx->NI + ctx->ioff * RAW;
+  int e = n <= ctx->inv_wide_max ? nbls_fp_inv_wide_launch((unsigned)n, in, out, s) : nbls_fp_inv_launch((unsigned)n, in, out, s);
   if (ctx->timing) { hipEventRecord(e1, s); ctx->tev.push_back({(int)P_COUNT, {e0, e1}}); }
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
   return NBLS_OK;
@@ -270,7 +270,7 @@ int run_pow(nbls_ctx* ctx, int which, size_t n, const void* in, void* out, hipSt
   return NBLS_OK;
 }
 int run_inv_buf(nbls_ctx* ctx, size_t n, const void* in, void* out, hipStream_t s) {
-  int e = n <= inv_wide_max() ? nbls_fp_inv_wide_launch((unsigned)n, in, out, s) : nbls_fp_inv_launch((unsigned)n, in, out, s);
+  int e = n <= ctx->inv_wide_max ? nbls_fp_inv_wide_launch((unsigned)n, in, out, s) : nbls_fp_inv_launch((unsigned)n, in, out, s);
   if (e) { ctx->last_hip = e; return NBLS_EHIP; }
   return NBLS_OK;
 }

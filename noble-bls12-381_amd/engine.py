@@ -414,6 +414,10 @@ class Engine:
         """items up to which the programs that allow it run on the one-limb-per-lane interpreter (NBLS_TUNE_WIDE_MAX; an experiment, measured slower than the lane-split forms: default 0 = never)"""
         self._chk(self.lib.nbls_set_tuning(self.h, 10, n))
 
+    def set_inv_wide_max(self, n):
+        """elements up to which an Fp inversion launch runs with one limb per lane (NBLS_TUNE_INV_WIDE_MAX = 12; default 4096, pool contexts 256, 0: never)"""
+        self._chk(self.lib.nbls_set_tuning(self.h, 12, int(n)))
+
     def set_h2c_norm_min(self, n):
         """messages from which hash-to-G2 takes its SWU square root by the norm method (NBLS_TUNE_H2C_NORM_MIN = 11; default 32768, 0: always)"""
         self._chk(self.lib.nbls_set_tuning(self.h, 11, int(n)))
