@@ -255,8 +255,9 @@ int need(nbls_ctx* ctx, int i, size_t bytes, uint8_t** out) {
   return NBLS_OK;
 }
 // Launches of at most pow_wide_max elements -- a wavefront or two per SIMD -- run the one-limb-per-lane form (pow_wide.h, nbls_pow_wide_kernel: one wavefront per element, no scratch
-// table): one verify / sign spends 0.3 instead of 0.7 ms in the Fp2 exponentiation of hash-to-G2.  NBLS_POW_WIDE_MAX (0 = never).
-size_t pow_wide_max() { static const size_t v = (size_t)env_long("NBLS_POW_WIDE_MAX", 1024); return v; }
+// table): one verify / sign spends 0.3 instead of 0.7 ms in the Fp2 exponentiation of hash-to-G2.  NBLS_POW_WIDE_MAX (0 = never); 3072 since the end of round 6 (1024 before:
+// hash-to-G2 of 1024 messages 1.65 -> 1.40 ms, 2048 compressed signatures 1.10 -> 0.86 ms; from 4096 elements the one-lane kernels win, profiles/round6_ab_pow_wide_max.txt).
+size_t pow_wide_max() { static const size_t v = (size_t)env_long("NBLS_POW_WIDE_MAX", 3072); return v; }
 int run_pow(nbls_ctx* ctx, int which, size_t n, const void* in, void* out, hipStream_t s, uint8_t* scratch) {
   int is_fp2 = which == 1 || which == 2;
   if (n <= pow_wide_max()) {

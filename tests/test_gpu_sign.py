@@ -197,24 +197,24 @@ def test_hash_to_g2_norm_method_threshold(eng, oracle, testdata):
 
 
 def test_wide_power_kernel_threshold(eng, oracle):
-    """round 6: launches of at most 1024 elements run the fixed-exponent powers in their one-limb-per-lane form (nbls_pow_wide_kernel, csrc/pow_wide.h) -- the Fp2 exponent of
-    hash-to-G2 (two elements per message: 512 / 513 messages straddle the switch), the Fp2 square root of a compressed signature and the Fp square root of a compressed key (1024 /
-    1025 encodings): both sides against the oracle, item by item on a strided sample and in full against each other"""
+    """round 6: launches of at most 3072 elements run the fixed-exponent powers in their one-limb-per-lane form (nbls_pow_wide_kernel, csrc/pow_wide.h) -- the Fp2 exponent of
+    hash-to-G2 (two elements per message: 1536 / 1537 messages straddle the switch), the Fp2 square root of a compressed signature and the Fp square root of a compressed key (3072 /
+    3073 encodings): both sides against the oracle, item by item on a strided sample and in full against each other"""
     import hashlib
-    msgs = [hashlib.sha256(b'wide-h%d' % i).digest()[:1 + i % 32] for i in range(520)]
-    small = eng.hash_to_g2_batch(msgs[:512]); big = eng.hash_to_g2_batch(msgs)
-    assert big[:192 * 512] == small
-    for i in list(range(0, 520, 41)) + [511, 512, 513, 519]:
+    msgs = [hashlib.sha256(b'wide-h%d' % i).digest()[:1 + i % 32] for i in range(1545)]
+    small = eng.hash_to_g2_batch(msgs[:1536]); big = eng.hash_to_g2_batch(msgs)
+    assert big[:192 * 1536] == small
+    for i in list(range(0, 1545, 97)) + [1535, 1536, 1537, 1544]:
         assert big[192 * i:192 * i + 192] == oracle.hash_to_g2(msgs[i])[1], i
     g1, g2 = oracle.g1_generator(), oracle.g2_generator()
-    ks = [(int.from_bytes(hashlib.sha256(b'wide-k%d' % i).digest(), 'big') % (1 << 250) + 1).to_bytes(32, 'big') for i in range(1030)]
+    ks = [(int.from_bytes(hashlib.sha256(b'wide-k%d' % i).digest(), 'big') % (1 << 250) + 1).to_bytes(32, 'big') for i in range(3080)]
     P1, st = eng.point_mul_batch(ks); assert not any(st)
     P2, st = eng.point_mul_batch(ks, pts=g2 * len(ks), g2=True); assert not any(st)
     for is_g2, aff, a in ((False, P1, 96), (True, P2, 192)):
         comp = eng.compress_batch(aff, g2=is_g2)
         bad = bytearray(comp[:a // 2]); bad[-1] ^= 3      # one encoding without a square root or outside the subgroup among them
         comp = bytes(bad) + comp[a // 2:]
-        for m in (1, 2, 1024, 1025, 1030):
+        for m in (1, 2, 3072, 3073, 3080):
             out, st = eng.decompress_batch(comp[:a // 2 * m], g2=is_g2)
             ro, rs = oracle.decompress_batch(comp[:a // 2 * m], is_g2, 32)
             assert bytes(st) == rs and out == ro, (is_g2, m)
