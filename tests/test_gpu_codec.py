@@ -145,7 +145,8 @@ def test_hash_to_g2_message_and_dst_lengths(eng, oracle):
     """device expand_message_xmd (xmd_kernel.hip): every message length across the SHA-256 block boundaries of b_0 and a
     few DST lengths incl. an oversize DST (> 255 bytes is replaced by its digest, RFC 9380 5.3.3) against the oracle"""
     msgs = [bytes((7 * i + j) & 0xff for j in range(i)) for i in range(0, 200)] + [b'\xff' * 1000, b'\x00' * 4096]
-    for dst in (b'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_', b'QUUX-V01-CS02-with-BLS12381G2_XMD:SHA-256_SSWU_RO_', b'd', b'x' * 255, b'y' * 300):
+    # (round 6: for DSTs of up to 85 bytes the blocks of b_1 .. b_8 are laid out once -- one block up to 21 bytes, two from 22: both sides of both switches)
+    for dst in (b'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_', b'QUUX-V01-CS02-with-BLS12381G2_XMD:SHA-256_SSWU_RO_', b'd', b'a' * 21, b'b' * 22, b'c' * 85, b'e' * 86, b'x' * 255, b'y' * 300):
         sub = msgs if len(dst) == 43 else msgs[::17]
         out = eng.hash_to_g2_batch(sub, dst)
         for i, m in enumerate(sub):
