@@ -267,7 +267,7 @@ int decode_host(nbls_ctx* ctx, int kind /* 0 g1.fromHex, 1 g2.fromHex, 2 g2.from
 int encode_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* aff, const int8_t* zero, int compressed, uint8_t* out);
 int clear_host(nbls_ctx* ctx, bool g2, size_t n, const uint8_t* aff, uint8_t* out, int8_t* status);
 int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, size_t pt_stride, const void* d_scalars, void* d_out, void* d_status, hipStream_t s, bool allow_fixed = true,
-    bool in_subgroup = false);
+    bool in_subgroup = false, uint8_t* recoded = nullptr);
 int ensure_g1_fixed(nbls_ctx* ctx, hipStream_t s);
 int sign_points(nbls_ctx* ctx, size_t n, const void* d_uniform, void* h, const void* d_keys32, void* d_out192, void* d_status, hipStream_t s);
 bool scalar_is_zero_mod_r(const uint8_t* k32);

@@ -300,7 +300,8 @@ int ensure_g1_fixed(nbls_ctx* ctx, hipStream_t s) {
   ctx->g1_fixed = tab;
   return NBLS_OK;
 }
-int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, size_t pt_stride, const void* d_scalars, void* d_out, void* d_status, hipStream_t s, bool allow_fixed, bool in_subgroup) {
+int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, size_t pt_stride, const void* d_scalars, void* d_out, void* d_status, hipStream_t s, bool allow_fixed, bool in_subgroup,
+                  uint8_t* recoded) {   // recoded: the sign-aligned digits of the scalars, made by the caller (sign_points: beside the hash chain), or NULL
   const size_t a = g2 ? 192 : 96, p = g2 ? 6 * RAW : 3 * RAW;
   uint8_t *Pj, *N, *NI; int r;
   // getPublicKey (the base point is G1.BASE for every item): no doublings, the multiples of the generator come from a table (round 5: 86 additions instead of 256 doublings + 128
@@ -315,13 +316,13 @@ int dev_point_mul(nbls_ctx* ctx, bool g2, size_t n, const void* d_pts, size_t pt
   if (g2 && in_subgroup && gls_on) {
     // up to sac_max keys d_pts are RAW PROJECTIVE points (six raw elements each, pt_stride = 6 * RAW: sign_points() below) -- the hash points as cofactor clearing leaves them in
     // scratch slot 1, so the digits go to slot 2; above, affine wire points as everywhere else
-    uint8_t* dig;
-    if ((r = need(ctx, n <= ctx->sac_max ? 2 : 1, n * 128, &dig))) return r;
+    uint8_t* dig = recoded;
+    if (!dig && (r = need(ctx, n <= ctx->sac_max ? 2 : 1, n * 128, &dig))) return r;
     // while every wavefront of the launch is resident at once the length of ONE wavefront's instruction stream is the time: the sign-aligned recoding with one addition per bit
     // (codec.h pt_mul_sac_g2: 65 doublings + 73 additions; its table of eight points takes 101 slots = three workgroups per CU = 768 wavefronts of 8 keys); above 6144 keys the
     // windowed form, whose table of four leaves room for six workgroups per CU (NBLS_G2_SAC_MAX / NBLS_TUNE_SAC_MAX; 0 = never)
     if (n <= ctx->sac_max) {
-      if (nbls_msm_sac_launch((unsigned)n, d_scalars, dig, s)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+      if (!recoded && nbls_msm_sac_launch((unsigned)n, d_scalars, dig, s)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
       if ((r = run(ctx, pt_ls2_variant(ctx, P_G2_MUL_SAC, n), n, {B(1, d_pts, pt_stride), B(2, dig, 128), B(3, Pj, p), B(4, N, RAW)}, s))) return r;
     } else {
     if (nbls_msm_decompose_launch((unsigned)n, 4, d_scalars, dig, s)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
@@ -348,9 +349,17 @@ int sign_points(nbls_ctx* ctx, size_t n, const void* d_uniform, void* h, const v
   int r;
   static const bool gls_on = env_long("NBLS_G2_GLS", 1) != 0;
   if (gls_on && n <= ctx->sac_max) {
-    uint8_t* pj;
+    // the recoding of the keys (0.045 ms for one key: a branch-free long division) does not need the hash points: it runs beside the hash chain on a side stream (round 6)
+    uint8_t *pj, *dig;
+    if ((r = need(ctx, 7, n * 128, &dig)) || (r = ensure_side2(ctx))) return r;      // slot 7: used by neither the hash chain nor the ladder
+    HIPCHK(hipEventRecord(ctx->ev_fork, s)); HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));
+    ForkGuard fork;
+    if (nbls_msm_sac_launch((unsigned)n, d_keys32, dig, ctx->side2)) { ctx->last_hip = (int)hipGetLastError(); return NBLS_EHIP; }
+    HIPCHK(hipEventRecord(ctx->ev_join2, ctx->side2));
     if ((r = dev_hash_to_g2(ctx, n, d_uniform, nullptr, s, 0, 0, &pj))) return r;
-    return dev_point_mul(ctx, true, n, pj, 6 * RAW, d_keys32, d_out192, d_status, s, true, true);
+    HIPCHK(hipStreamWaitEvent(s, ctx->ev_join2, 0));
+    fork.armed = false;
+    return dev_point_mul(ctx, true, n, pj, 6 * RAW, d_keys32, d_out192, d_status, s, true, true, dig);
   }
   if ((r = dev_hash_to_g2(ctx, n, d_uniform, h, s))) return r;
   return dev_point_mul(ctx, true, n, h, 192, d_keys32, d_out192, d_status, s, true, true);      // H(m) is in G2: the ladder may split the key along psi
