@@ -11,6 +11,7 @@ K = [('nbls_aot_lines_pq', '10 × 6', '63 %', 2400), ('nbls_aot_acc_fe', '12 × 
 for b in (4096, 65536):
     j = json.load(open(os.path.join(ROOT, 'profiles', 'round%s_pmc_b%d.json' % (RND, b))))['kernels']
     for name, shape, share, alg in K:
+        if name == 'nbls_fp_inv_kernel' and name not in j: name, shape = 'nbls_fp_inv_wide_kernel', '16 × 4'      # launches of at most 4096 elements: one limb per lane (fp_inv_wide.h)
         v = j[name]; L = v['launches_per_call']; us = v['avg_us_under_pmc'] * L; valu = v['valu_per_wave'] * L
         label = name + (' (chain)' if name == 'nbls_aot_expx' and L == 1 else ' (%d launches)' % L if L > 1 else '')
         frac = '%.3f' % (alg * 300 * b / (us * 1e-6) / PEAK) if alg else '–'
