@@ -9,7 +9,7 @@ s = open(p).read()
 a = s.index('**Numbers on one MI355X'); b = s.index('What round 6 changed:')
 lb = d['roofline']['large_batch']; vb = d['verify_batch']; sg = d['sign']; fc = d['facade']; cl = lb['in_flight']; ss = d['steady_state']
 new = """**Numbers on one MI355X, measured as the driver measures them** (`python bench.py --gpus 1 --steps 20 --warmup 5`, `profiles/round6_bench_driver_args.json`; that box ran
-saturated at %.2f GHz / %d W; most boxes of the pool are within ±3 %% of these saturated figures, one met this round sustains only 2.13 GHz at the same power and is 9 %% slower (`profiles/round6_box_spread.txt`); round 5's driver record in brackets):
+saturated at %.2f GHz / %d W; the boxes of the pool sustain 2.13 - 2.26 GHz at the same ~1300 W, and saturated figures follow: 21.1 - 23.2 ms for one 65,536-pairing call (`profiles/round6_box_spread.txt`); round 5's driver record in brackets):
 
 | | round 6 | |
 |---|---|---|
