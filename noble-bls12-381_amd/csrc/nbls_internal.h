@@ -101,7 +101,8 @@ struct nbls_ctx {
   size_t split_min = SPLIT_MILLER_MIN;   // nbls_set_tuning(NBLS_TUNE_SPLIT_MILLER_MIN)
   // pairs per product call from which eight line tables share an accumulator (below: four).  Measured (tools/ab_acc8.sh): at 65,537 pairs the halves have 4096 groups of eight = 820
   // wavefronts, less than one per SIMD, and the call is slower (24.5 against 23.4 ms); at 2^18 terms 33.2 against 33.8 ms
-  size_t acc8_min = (size_t)env_long("NBLS_ACC8_MIN", 131072);
+  // (round 6, on the kernels as they are now: four per accumulator is faster at 2^17 and 2^18 terms as well -- 16.35 against 16.89 ms, 30.9 against 32.2 ms: never by default)
+  size_t acc8_min = (size_t)env_long("NBLS_ACC8_MIN", (long)1 << 40);
   // cyclotomic exponentiation with compressed squarings (expx): scratch per item -- compressed powers, decompression scratch, redo flags and list -- and two redo counters (one per half)
   uint8_t *KS = nullptr, *KD = nullptr, *Kflag = nullptr; uint32_t *Klist = nullptr, *Kcount = nullptr;
   size_t expc_min = (size_t)env_long("NBLS_EXPC_MIN", (long)EXPC_MIN_DEFAULT);   // nbls_set_tuning(NBLS_TUNE_EXPC_MIN)

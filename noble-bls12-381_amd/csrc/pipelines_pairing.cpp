@@ -236,9 +236,15 @@ int miller_values(nbls_ctx* ctx, size_t n, const void* d_g1, const void* d_g2, s
       // four pairs per item with ONE accumulator: f <- (f l1 l2 l3 l4)^2 per bit, a single Fp12 squaring for four Miller loops (16 % fewer
       // products per pair than two per item).  A last group of fewer than four pairs is filled up with the unit table (every line = 1:
       // multiplying by it changes nothing) instead of getting a launch -- and the latency of a whole Miller loop -- of its own.
-      // round 4: EIGHT pairs per accumulator from acc8_min pairs per call (one squaring per eight line tables: 1,921 instead of 2,196 instructions per pair and bit)
-      const size_t GR = n >= ctx->acc8_min ? 8 : 4;
-      const ProgId acc = GR == 8 ? P_ACC8_RAW : P_ACC4_RAW;
+      // round 4: EIGHT pairs per accumulator from acc8_min pairs per call (one squaring per eight line tables: 1,921 instead of 2,196 instructions per pair and bit) -- off since round 6
+      // round 6: FEWER pairs per accumulator where a launch is too small to fill the device with four: the accumulation program's instruction stream grows with the pairs per
+      // item (four: 1.46 ms for one wavefront), and 4097 pairs in groups of four are 205 wavefronts on 1024 SIMDs.  By the pairs of ONE launch (a call of 8192 pairs and more
+      // runs as two halves): one pair per item below acc2_min, two below acc4_min, four above; eight no longer pays at any size (profiles/round6_ab_acc_width.txt: 4098 pairs
+      // 2.91 -> 2.13 ms, 8192 4.01 -> 2.77, 16,384 4.54 -> 3.79, 49,152 8.59 -> 7.85, 2^18 32.2 -> 30.9 ms)
+      static const size_t acc2_min = (size_t)env_long("NBLS_ACC2_MIN", 6144), acc4_min = (size_t)env_long("NBLS_ACC4_MIN", 28672);
+      const size_t chunk = n < LINES_CHUNK ? n : LINES_CHUNK, part = (chunk >= ctx->halves_min && ctx->ioff == 0) ? chunk / 2 : chunk;
+      const size_t GR = n >= ctx->acc8_min ? 8 : part >= acc4_min ? 4 : part >= acc2_min ? 2 : 1;
+      const ProgId acc = GR == 8 ? P_ACC8_RAW : GR == 4 ? P_ACC4_RAW : GR == 2 ? P_ACC2_RAW : P_ACC_RAW;
       if ((r = ensure_lines(ctx, n + GR - 1))) return r;
       m = 0;
       for (size_t o = 0; o < n; o += LINES_CHUNK) {   // LINES_CHUNK is a multiple of eight: a chunk boundary never splits a group

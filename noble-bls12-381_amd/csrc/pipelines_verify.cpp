@@ -147,7 +147,9 @@ int verify_pipeline(nbls_ctx* ctx, size_t n, const VerifyIn& in, int final_exp, 
         cc++;
       }
       // line tables per accumulator: four where a quarter of the sub-batch's pairs still are thousands of items, fewer where only the length of one wavefront's instruction stream counts
-      const size_t GR = cc >= 8192 ? 4 : cc >= 2048 ? 2 : 1;
+      // (round 6: four from 32,768 pairs instead of 8192 -- verifyBatch(32,768) 13.2 -> 12.0 ms, (65,536) unchanged; profiles/round6_ab_acc_width.txt)
+      static const size_t v_acc4_min = (size_t)env_long("NBLS_VERIFY_ACC4_MIN", 32768), v_acc2_min = (size_t)env_long("NBLS_VERIFY_ACC2_MIN", 2048);
+      const size_t GR = cc >= v_acc4_min ? 4 : cc >= v_acc2_min ? 2 : 1;
       const ProgId acc = GR == 4 ? P_ACC4_RAW : GR == 2 ? P_ACC2_RAW : P_ACC_RAW;
       const size_t gg = (cc + GR - 1) / GR;
       uint8_t* Lc = ctx->L + (o + 4 * c) * LINE_BYTES;      // its own line tables (+ up to three unit tables behind them)
