@@ -272,7 +272,7 @@ int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks);
 /* Tuning knobs of a context (defaults are the measured optimum; tests use them to force a code path).
  * NBLS_TUNE_SPLIT_MILLER_MIN: number of pairs from which the Miller loop runs as two programs (line tables through HBM) instead of one. */
 #define NBLS_TUNE_SPLIT_MILLER_MIN 1
-#define NBLS_TUNE_HALVES_MIN 2         /* pairs from which nbls_pairing_batch_dev runs a batch as two halves on two streams (default 8192; 0 = never) */
+#define NBLS_TUNE_HALVES_MIN 2         /* pairs from which nbls_pairing_batch_dev runs a batch as two halves on two streams (default 16384 since the end of round 6, 8192 before; 0 = never) */
 #define NBLS_TUNE_EXPC_MIN 3           /* items from which the cyclotomic exponentiations of the final exponentiation use Karabina's compressed squarings
                                           (default: never -- 15 % fewer instructions but no faster as measured, see csrc/pipelines_pairing.cpp expx; 0 = always) */
 #define NBLS_TUNE_CHAIN_MAX 4          /* items below which EXPX, FE_MID1, EXPX x 3, FE_MID2, EXPX of a final exponentiation are ONE launch (default 8192; 0 = seven launches:

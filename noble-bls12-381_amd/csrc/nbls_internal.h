@@ -90,7 +90,9 @@ struct nbls_ctx {
   // large pairing batches run as two halves on two streams (nbls_pairing_batch_dev): item offset applied to every per-item buffer of a launch, second stream, events
   bool in_halves = false;   // the running pairing call is one of two halves on two streams: their launches fill each other's tails, so the final exponentiation's middle is NOT chained (run_chain)
   size_t ioff = 0; hipStream_t half_stream = nullptr; hipEvent_t ev_half_fork = nullptr, ev_half_join = nullptr;
-  size_t halves_min = env_long("NBLS_HALVES_MIN", 8192) > 0 ? (size_t)env_long("NBLS_HALVES_MIN", 8192) : (size_t)-1;   // NBLS_HALVES_MIN=0: never (profiles of kernels running alone)
+  // pairs from which a call runs as two halves on two streams.  16,384 since the end of round 6 (8192 before): on today's kernels one stream is faster up to 15,360 pairs
+  // (10,240: 3.91 against 4.73 ms; 12,800 - 15,360: 5.05 - 5.24 against 5.67 - 5.9), the halves from 16,384 (6.1 against 6.45; profiles/round6_ab_halves.txt)
+  size_t halves_min = env_long("NBLS_HALVES_MIN", 16384) > 0 ? (size_t)env_long("NBLS_HALVES_MIN", 16384) : (size_t)-1;   // NBLS_HALVES_MIN=0: never (profiles of kernels running alone)
   // verifyBatch as a software pipeline (round 5, verify_pipeline): events of the chunks (two each), the "xmd met non-monotonic offsets" flag lives behind the statuses
   std::vector<hipEvent_t> pipe_ev; hipEvent_t ev_pipe_done = nullptr; std::vector<hipStream_t> pipe_streams;
   // nbls_set_tuning(NBLS_TUNE_VERIFY_*)

@@ -399,7 +399,7 @@ class Engine:
         self._chk(self.lib.nbls_set_tuning(self.h, 1, n))
 
     def set_halves_min(self, n):
-        """pairs from which pairing_batch_dev runs a batch as two halves on two streams (default 8192; 0: never)"""
+        """pairs from which pairing_batch_dev runs a batch as two halves on two streams (default 16384; 0: never)"""
         self._chk(self.lib.nbls_set_tuning(self.h, 2, n))
 
     def set_chain_max(self, n):

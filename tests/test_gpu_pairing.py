@@ -207,7 +207,7 @@ def test_batches_in_flight(oracle):
 
 
 def test_two_halves_execution(oracle, golden):
-    """nbls_pairing_batch_dev runs batches from 8192 pairs as two halves on two streams sharing the caller's scratch through an item offset; forced here at a
+    """nbls_pairing_batch_dev runs batches from 16,384 pairs as two halves on two streams sharing the caller's scratch through an item offset; forced here at a
     size the oracle can check: same bytes as the one-stream execution, with and without the final exponentiation, odd and even sizes."""
     pkg = importlib.import_module('noble-bls12-381_amd')
     eng = pkg.Engine(0)
@@ -221,7 +221,7 @@ def test_two_halves_execution(oracle, golden):
             assert got == ref
             exp, _ = oracle.pairing_batch(g1, g2, fe, False, threads=16)
             assert got == exp
-    eng.set_halves_min(8192)
+    eng.set_halves_min(16384)
 
 
 def test_chained_and_separate_final_exponentiation(oracle, golden):
