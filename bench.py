@@ -256,6 +256,7 @@ def main():
     torch.cuda.synchronize()
     eng.set_chain_max(8192)             # ... and the chained final exponentiation (6 launches per call; the in-flight contexts run it as seven launches, pipeline.py)
     eng.set_inv_wide_max(4096)          # ... and the library's default for the inversion (nbls_pool_init set 256 on the in-flight contexts)
+    eng.set_ls_max(1024, 2048)          # ... and for the lane-split forms (0 / 0 on the in-flight contexts)
     eng.set_split_miller_min(4097)      # the single-call legs use the library's default choice of Miller programs (SPLIT_MILLER_MIN in csrc/nbls_internal.h: the fused program up to 4096 pairs; the in-flight contexts were set to 0)
     serial_steps = max(8, min(args.steps, 320))
     s0 = time.perf_counter()
@@ -458,7 +459,7 @@ def main():
         tm = eng.timing_read()
         eng.timing_enable(False)
         per_step = {k: v[0] / reps for k, v in tm.items()}          # ms per bench step, summed over that program's launches
-        MILLER_PROGS = ('miller_fe', 'miller_fe_ls', 'lines_pq', 'acc_fe')   # one fused program, or LINES_PQ -> ACC_FE through line tables in HBM (which one ran is read off the timing slots below)
+        MILLER_PROGS = ('miller_fe', 'miller_fe_ls', 'miller_fe_ls2', 'lines_pq', 'acc_fe')   # one fused program, or LINES_PQ -> ACC_FE through line tables in HBM (which one ran is read off the timing slots below)
         ms_miller = sum(v for k, v in per_step.items() if k in MILLER_PROGS)
         ms_inv = per_step['fp_inv']
         ms_hard = sum(v for k, v in per_step.items() if k not in MILLER_PROGS + ('fp_inv',))
@@ -493,8 +494,8 @@ def main():
             'frac_note': 'achieved/frac: the kernels of ONE %d-pairing call running alone (algorithmic multiply-adds over the sum of the HIP-event durations of ALL its launches, the inversion kernel included; profiles/ holds the rocprofv3 kernel trace of the same command); frac_at_value: the same algorithmic work at the rate of `value` (%d calls overlapping on %d streams; profiles/ holds a kernel trace taken with the same --inflight)' % (n, D, D),
             'clock_note': 'peak is priced at 2.4 GHz; under saturated load (value, large_batch) this engine is power-limited: 2.21-2.22 GHz at 1330-1360 W of the 1400 W package limit (profiles/round4_clocks_under_load.txt), and a pure stream of its multiply-add sustains 30.6 T/s at 2.32 GHz (profiles/round4_ubench_mad_power.txt); one call at a time runs at 2.39 GHz',
             'kernel_ms': {k: round(v, 4) for k, v in per_step.items()},
-            'miller_frac': round(n * FPMUL_MILLER * MAD_PER_FPMUL / (ms_miller * 1e-3) / 1e12 / PEAK_TMAD, 4),
-            'final_exp_frac': round(n * FPMUL_FINALEXP * MAD_PER_FPMUL / (ms_hard * 1e-3) / 1e12 / PEAK_TMAD, 4),
+            'miller_frac': round(n * FPMUL_MILLER * MAD_PER_FPMUL / (ms_miller * 1e-3) / 1e12 / PEAK_TMAD, 4) if ms_miller > 0 else None,      # (None: a batch size whose Miller program is not in MILLER_PROGS)
+            'final_exp_frac': round(n * FPMUL_FINALEXP * MAD_PER_FPMUL / (ms_hard * 1e-3) / 1e12 / PEAK_TMAD, 4) if ms_hard > 0 else None,
             'hbm': {'algorithmic_bytes_per_launch': hbm_bytes, 'achieved_GBps': round(hbm_bytes / (call_ms * 1e-3) / 1e9, 3),
                     'peak_GBps': HBM_PEAK_GBPS, 'frac': round(hbm_bytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
                     'algorithmic_bytes_8d': 864 * n, 'traffic_ratio_vs_8d': round(traffic / (864.0 * n), 1) if traffic else None,
@@ -673,6 +674,7 @@ def main():
             VF = max(2, args.verify_inflight)
             vengs = [eng] + [pipe.engines[i] if i < D else pkg.Engine(local_rank) for i in range(1, VF)]
             for e in vengs[1:]:
+                e.set_ls_max(1024, 2048); e.set_inv_wide_max(4096)      # in-flight contexts of the pairing leg: the library's defaults for the one-item tail of a verifyBatch call
                 assert vcall(e) is True
             preps = max(2, vreps)
             def _loop(e):

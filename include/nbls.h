@@ -219,7 +219,7 @@ int nbls_miller_product_partial_into(nbls_ctx* ctx, size_t n, const uint8_t* g1_
 int nbls_verify_batch_partial_into(nbls_ctx* ctx, size_t n, const uint8_t* sig96 /* or NULL */, const uint8_t* msgs, const uint32_t* offsets, const uint8_t* pk48,
                                    const uint8_t* dst, size_t dst_len, void* d_dst576, int* zero_flag, int8_t* pk_status /* n, may be NULL */);
 const char* nbls_config_describe(void);   /* "NBLS_X=value(env|default) ...": every environment switch the library has read so far and the value in force -- print it next to an A/B result */
-/* 4 (round 6): nbls_hw_queues, NBLS_TUNE_WIDE_MAX, NBLS_TUNE_H2C_NORM_MIN, NBLS_TUNE_INV_WIDE_MAX (additions only); the library sets GPU_MAX_HW_QUEUES = 22 at load when the variable is unset (see nbls_pool_init below).
+/* 4 (round 6): nbls_hw_queues, NBLS_TUNE_WIDE_MAX, NBLS_TUNE_H2C_NORM_MIN, NBLS_TUNE_INV_WIDE_MAX, NBLS_TUNE_LS_MAX / _LS2_MAX (additions only); the library sets GPU_MAX_HW_QUEUES = 22 at load when the variable is unset (see nbls_pool_init below).
    3 (round 5): nbls_program_kernel, nbls_pool_*, nbls_sign_batch_dev, NBLS_TUNE_VERIFY_* / _SAC_MAX / _PT_LS2_MAX (additions only); nbls_verify_batch_partial_dev writes d_out_fp12 even when it reports a zero point or a decode error
    (contents then meaningless); 2: *_partial take *d_partial as OUT only, *_partial_into added, nbls_tower_op_batch, nbls_verify_batch_msgs_dev.  The bindings check it at load. */
 #define NBLS_ABI_VERSION 4
@@ -286,6 +286,8 @@ int nbls_placement_probe(nbls_ctx* ctx, size_t n, uint64_t* out_blocks);
 #define NBLS_TUNE_WIDE_MAX 10          /* round 6, experiment: items up to which the programs that allow it run on the one-limb-per-lane interpreter (one item per workgroup of three wavefronts, two barriers per step); bit-exact, measured slower than the four-lane forms (0.93 against 0.66 ms for a final exponentiation's five exponentiations), so the default is 0 = never */
 #define NBLS_TUNE_H2C_NORM_MIN 11     /* round 6: messages from which hash-to-G2 (also inside sign / verify / verifyBatch) takes the square root of its SWU map by the norm method -- two Fp exponentiations and a short program between them instead of one Fp2 exponentiation of twice the work; the same points; less work but two dependent exponentiations, so it pays where the device is full or the chain runs beside other work: the size compared is the whole call's (default 32768; 0 = always) */
 #define NBLS_TUNE_INV_WIDE_MAX 12     /* round 6: elements up to which an Fp inversion launch runs with one limb per lane, four elements per wavefront (shorter for ONE call, eight times the instructions per element: default 4096; nbls_pool_init sets 256 on its contexts; 0 = never) */
+#define NBLS_TUNE_LS_MAX 13           /* items up to which the pairing programs run in their four-lane forms (default 1024; nbls_pool_init sets 0 on its contexts: the forms shorten ONE call at up to four times the instructions per item) */
+#define NBLS_TUNE_LS2_MAX 14          /* ... in their two-lane forms, above LS_MAX (default 2048; pool contexts 0) */
 int nbls_set_tuning(nbls_ctx* ctx, int key, long long value);
 int nbls_program_count(void);                 /* number of step programs; timing slot nbls_program_count() = the inversion kernel */
 const char* nbls_program_name(int prog);

@@ -65,6 +65,8 @@ struct DevProgram {
   int aot = -1; AotStep* aot_steps = nullptr; u32* aot_descs = nullptr; u32 aot_lds = 0;
 };
 
+size_t ls_max();      // defaults of the lane-split thresholds (NBLS_LS_MAX / NBLS_LS2_MAX), tuning.cpp
+size_t ls2_max();
 struct nbls_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -128,6 +130,9 @@ struct nbls_ctx {
   // call 2.19 -> 2.165 ms, one verify 2.76 -> 2.67 ms) at eight times the instructions per element: contexts that are kept busy side by side (nbls_pool_init) lower it to 256
   // (twelve 4096-pairing calls in flight: 3.03 M pairings/s against 2.97 M with 4096)
   size_t inv_wide_max = (size_t)env_long("NBLS_INV_WIDE_MAX", 4096);
+  // items up to which the pairing programs run in their four-lane / two-lane forms (tuning.cpp ls_variant; nbls_set_tuning(NBLS_TUNE_LS_MAX / _LS2_MAX)).  Latency forms as well:
+  // shorter for ONE call, up to four times the instructions per item -- nbls_pool_init sets both to 0 on its contexts (twelve 1024-pairing calls in flight: 1.52 -> 1.95 M pairings/s)
+  size_t ls_max = ::ls_max(), ls2_max = ::ls2_max();
   size_t chain_max = (size_t)env_long("NBLS_CHAIN_MAX", 8192);                  // nbls_set_tuning(NBLS_TUNE_CHAIN_MAX); see run_chain
   u32* qp_table = nullptr;      // multiples of p for the weak reduction (vm_exec.h weak_reduce), device copy
   uint8_t* unit_lines = nullptr;   // a line table whose 68 lines are all 1 (c0 = 1, c1 = c2 = 0): the neutral partner of an odd last pair
@@ -241,8 +246,6 @@ int ensure_pinned_out(nbls_ctx* ctx, size_t bytes);
 size_t pow_wide_max();
 int run_pow(nbls_ctx* ctx, int which, size_t n, const void* in, void* out, hipStream_t s, uint8_t* scratch = nullptr);
 int run_inv_buf(nbls_ctx* ctx, size_t n, const void* in, void* out, hipStream_t s);
-size_t ls_max();
-size_t ls2_max();
 ProgId ls_variant(nbls_ctx* ctx, ProgId id, size_t n);
 ProgId pt_ls2_variant(nbls_ctx* ctx, ProgId id, size_t n);
 int reduce_product(nbls_ctx* ctx, size_t n, uint8_t** result, hipStream_t s);

@@ -286,6 +286,7 @@ EXPORT int nbls_pool_init(int device_id, int depth, nbls_pool** out) {
     if (depth > 1) {
       nbls_set_tuning(c, NBLS_TUNE_SPLIT_MILLER_MIN, 0);
       if (nbls::env_long("NBLS_PIPELINE_CHAIN", 0) != 1) nbls_set_tuning(c, NBLS_TUNE_CHAIN_MAX, 0);
+      nbls_set_tuning(c, NBLS_TUNE_LS_MAX, 0); nbls_set_tuning(c, NBLS_TUNE_LS2_MAX, 0);      // the lane-split forms too: with calls side by side the plain programs carry more (1024-pair calls: 1.52 -> 1.95 M pairings/s)
       nbls_set_tuning(c, NBLS_TUNE_INV_WIDE_MAX, 256);      // contexts kept busy side by side: instructions count, not one call's latency (nbls_internal.h inv_wide_max)
     }
   }

@@ -12,7 +12,7 @@ size_t ls_max() { static const size_t v = (size_t)env_long("NBLS_LS_MAX", 1024);
 size_t ls2_max() { static const size_t v = (size_t)env_long("NBLS_LS2_MAX", 2048); return v; }
 ProgId ls_variant(nbls_ctx* ctx, ProgId id, size_t n) {
   if (n <= ctx->wide_max && upload(ctx, id) == NBLS_OK && wide_applies(ctx, ctx->prog[id], (int)id, n)) return id;      // the one-limb-per-lane form runs the plain program
-  if (n <= ls_max()) {
+  if (n <= ctx->ls_max) {
     switch (id) {
       case P_MILLER_BYTES: return P_MILLER_BYTES_LS;
       case P_MILLER_RAW: return P_MILLER_RAW_LS;
@@ -21,7 +21,7 @@ ProgId ls_variant(nbls_ctx* ctx, ProgId id, size_t n) {
       default: return id;
     }
   }
-  if (n <= ls2_max()) {
+  if (n <= ctx->ls2_max) {
     ProgId v = id;
     switch (id) {
       case P_MILLER_BYTES: v = P_MILLER_BYTES_LS2; break;
@@ -112,6 +112,8 @@ EXPORT int nbls_set_tuning(nbls_ctx* ctx, int key, long long value) {
     case NBLS_TUNE_WIDE_MAX: if (value < 0) return NBLS_EINVAL; ctx->wide_max = (size_t)value; return NBLS_OK;
     case NBLS_TUNE_H2C_NORM_MIN: if (value < 0) return NBLS_EINVAL; ctx->h2c_norm_min = (size_t)value; return NBLS_OK;
     case NBLS_TUNE_INV_WIDE_MAX: if (value < 0) return NBLS_EINVAL; ctx->inv_wide_max = (size_t)value; return NBLS_OK;
+    case NBLS_TUNE_LS_MAX: if (value < 0) return NBLS_EINVAL; ctx->ls_max = (size_t)value; return NBLS_OK;
+    case NBLS_TUNE_LS2_MAX: if (value < 0) return NBLS_EINVAL; ctx->ls2_max = (size_t)value; return NBLS_OK;
     case NBLS_TUNE_VERIFY_CHUNKS: if (value < 0 || value > 16) return NBLS_EINVAL; ctx->verify_chunks = (long)value; return NBLS_OK;
     case NBLS_TUNE_VERIFY_LAST_PCT: if (value < 1 || value > 100) return NBLS_EINVAL; ctx->verify_last_pct = (long)value; return NBLS_OK;
     case NBLS_TUNE_VERIFY_PIPE_MIN: if (value < 0) return NBLS_EINVAL; ctx->verify_pipe_min = (long)value; return NBLS_OK;

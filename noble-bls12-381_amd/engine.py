@@ -414,6 +414,11 @@ class Engine:
         """items up to which the programs that allow it run on the one-limb-per-lane interpreter (NBLS_TUNE_WIDE_MAX; an experiment, measured slower than the lane-split forms: default 0 = never)"""
         self._chk(self.lib.nbls_set_tuning(self.h, 10, n))
 
+    def set_ls_max(self, ls_max=None, ls2_max=None):
+        """items up to which the pairing programs run in their four-lane / two-lane forms (NBLS_TUNE_LS_MAX = 13, NBLS_TUNE_LS2_MAX = 14; defaults 1024 / 2048, pool contexts 0 / 0)"""
+        if ls_max is not None: self._chk(self.lib.nbls_set_tuning(self.h, 13, int(ls_max)))
+        if ls2_max is not None: self._chk(self.lib.nbls_set_tuning(self.h, 14, int(ls2_max)))
+
     def set_inv_wide_max(self, n):
         """elements up to which an Fp inversion launch runs with one limb per lane (NBLS_TUNE_INV_WIDE_MAX = 12; default 4096, pool contexts 256, 0: never)"""
         self._chk(self.lib.nbls_set_tuning(self.h, 12, int(n)))
